@@ -1,0 +1,70 @@
+"""ctypes loader for libefgh_hip.so (the C-ABI declared in include/efgh_hip.h).
+
+There is no CPU fallback: if the library is missing, or a call fails, this raises."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, 'lib', 'libefgh_hip.so')
+_lib = None
+
+c_void_p, c_int, c_int32, c_int64, c_float = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int32,
+                                              ctypes.c_int64, ctypes.c_float)
+
+
+class EfghError(RuntimeError):
+    pass
+
+
+class GemmDesc(ctypes.Structure):
+    """mirror of efgh_gemm_desc (include/efgh_hip.h)"""
+    _fields_ = [
+        ('A', c_void_p), ('lda', c_int64), ('C', c_int32), ('T', c_int32), ('mode', c_int32),
+        ('B', c_int32), ('Hin', c_int32), ('Win', c_int32), ('Hv', c_int32), ('Wv', c_int32),
+        ('sh', c_int32), ('sw', c_int32),
+        ('dh', ctypes.c_int8 * 16), ('dw', ctypes.c_int8 * 16),
+        ('Ho', c_int32), ('Wo', c_int32), ('osh', c_int32), ('osw', c_int32), ('oh0', c_int32),
+        ('ow0', c_int32),
+        ('table', c_void_p), ('W', c_void_p), ('N', c_int32), ('M', c_int64), ('M_dev', c_void_p),
+        ('bias', c_void_p), ('scale', c_void_p), ('shift', c_void_p),
+        ('residual', c_void_p), ('ldr', c_int64),
+        ('act', c_int32), ('slope', c_float), ('out', c_void_p), ('ldo', c_int64),
+        ('stats', c_void_p),
+    ]
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise EfghError(f'{SO_PATH} is missing: run `python -c "import __graft_entry__ as g; '
+                            f'g.build()"` (hipcc, gfx950). There is no CPU fallback.')
+        import torch  # noqa: F401  (load torch's HIP runtime first so both share one runtime)
+        _lib = ctypes.CDLL(SO_PATH)
+        _lib.efgh_last_error.restype = ctypes.c_char_p
+        for name in ('efgh_lattice_workspace_bytes', 'efgh_lattice_hash_capacity'):
+            getattr(_lib, name).restype = c_int64
+            getattr(_lib, name).argtypes = [c_int32]
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise EfghError(f'libefgh_hip: rc={rc}: {lib().efgh_last_error().decode()}')
+
+
+def ptr(t):
+    """device pointer of a torch tensor (None -> NULL)"""
+    return c_void_p(0 if t is None else t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise EfghError('efgh_amd runs on the GPU through libefgh_hip.so only (got a CPU tensor); '
+                            'there is no CPU fallback')

@@ -1,0 +1,130 @@
+/* libefgh_hip.so — C-ABI of the MI355X-native EFGHNet hot path.
+ *
+ * Conventions: every entry point returns int (0 = ok, <0 = EFGH_E_*);
+ * `efgh_last_error()` returns a thread-local message.  Tensor arguments are raw DEVICE pointers
+ * with explicit sizes/strides; dtypes are fixed per argument (float = fp32, int32_t indices).
+ * The caller owns all memory including workspaces; nothing is allocated, freed or synchronised
+ * inside; the last argument is the hipStream_t (as void*) the work is enqueued on.
+ *
+ * The reference has exactly one native interface (the cffi module `_khash_ffi`,
+ * lib/khash_int2int.h:8-33, called from nets/transforms.py:149-183); everything else on the hot
+ * path is python/torch.  Each entry point below cites the reference code it replaces.
+ *
+ * Layouts: image activations are channels-last  [B][H][W][C]  (C contiguous);
+ * point/vertex features are row-major  [N][C];  the reference's (B,C,H,W)/(B,C,N) tensors are
+ * converted at the model boundary only.
+ */
+#ifndef EFGH_HIP_H
+#define EFGH_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EFGH_OK 0
+#define EFGH_E_INVALID (-1)   /* bad argument / unsupported shape */
+#define EFGH_E_LAUNCH (-2)    /* hip launch error */
+
+const char *efgh_last_error(void);
+int efgh_version(void);
+
+/* ------------------------------------------------------------------ lattice (K1, K2) ------
+ * replaces GenerateData.get_keys_and_barycentric  nets/generate_data.py:56-112,
+ *          key2int / build_it                     nets/transforms.py:62-77, 125-184,
+ *          the khash map                          lib/khash_int2int.h:8-33
+ * for ONE pyramid level.  Bit-exact w.r.t. the reference for bary/emg (fp32 bits),
+ * lattice_offset and blur_neighbors (integers).                                             */
+
+/* bytes of scratch needed by efgh_lattice_build for n_in points */
+int64_t efgh_lattice_workspace_bytes(int32_t n_in);
+/* entries of hash_keys / hash_vals (power of two >= 8*n_in) */
+int64_t efgh_lattice_hash_capacity(int32_t n_in);
+
+/* pts: 3 coordinates, pts[c*pts_cstride + p]; positions are multiplied by `scale32` first
+ *      (generate_data.py:130), `div32` = float32(expected_std*scale) (:177).
+ * out: bary  [4][n_in] f32            (pc1_barycentric)
+ *      emg   emg[p*emg_pstride + r*emg_rstride] f32   (pc1_el_minus_gr; strides let the caller
+ *            write straight into channels 0..3 of the next BCL input feature rows)
+ *      off   [4][n_in] i32            (pc1_lattice_offset, in [0,H))
+ *      vkeys [cap][4] i32             (lattice coordinates of vertex h, first-seen order)
+ *      pts_next[c*cap + h] f32        (next level's points, generate_data.py:176-178)
+ *      minmax[8] i32                  (key_mins[4], key_maxs[4])
+ *      hash_keys[hcap] i64, hash_vals[hcap] i32       (open-addressing map key-int -> h; kept
+ *            for efgh_lattice_neighbors)
+ *      H_out[1] i32                   (pc1_hash_cnt), device memory
+ * cap = 4*n_in (upper bound on H); hcap = power of two >= 8*n_in.                          */
+int efgh_lattice_build(const float *pts, int64_t pts_cstride, int32_t n_in, float scale32,
+                       float div32, float *bary, float *emg, int64_t emg_pstride,
+                       int64_t emg_rstride, int32_t *off, int32_t *vkeys, float *pts_next,
+                       int32_t *minmax, int64_t *hash_keys, int32_t *hash_vals, int64_t hcap,
+                       int32_t *H_out, void *workspace, void *stream);
+
+/* blur neighbours (transforms.py:168-180): nbr[h*16 + t] = index of vertex key(h)+offset_t, or
+ * -1; t<15, column 15 is padding (-1).  H is read from H_dev on the device; `h_bound` (>= H,
+ * e.g. cap) only sizes the grid.                                                            */
+int efgh_lattice_neighbors(const int32_t *vkeys, const int32_t *minmax, const int64_t *hash_keys,
+                           const int32_t *hash_vals, int64_t hcap, const int32_t *H_dev,
+                           int32_t h_bound, int32_t *nbr, void *stream);
+
+/* ------------------------------------------------------------------ BCL splat (K3) ---------
+ * replaces SparseSum + density normalisation, nets/bilateralNN.py:6-40, 179-211.
+ * feat [n_in][ldf] (first C columns used), bary [4][n_in], off [4][n_in]  ->
+ * splat [H][C]  (row h = reference row h+1; the reference's all-zero row 0 is represented by
+ * neighbour index -1), already multiplied by 1/(sum_bary + 1e-5).  wsum [H] scratch.
+ * Contributions are summed in point order per vertex -> run-to-run deterministic.          */
+int efgh_splat_fwd(const float *feat, int64_t ldf, int32_t C, const float *bary,
+                   const int32_t *off, int32_t n_in, int32_t H, float *splat, float *wsum,
+                   void *stream);
+/* backward of the above w.r.t. feat: gfeat[p][c] = sum_r bary[r][p]*norm[off]*gsplat[off][c] */
+int efgh_splat_bwd(const float *gsplat, const float *wsum, int32_t C, const float *bary,
+                   const int32_t *off, int32_t n_in, int32_t H, float *gfeat, int64_t ldg,
+                   void *stream);
+
+/* ------------------------------------------------------------------ gather-GEMM (K4,K6,K8) -
+ * One implicit-GEMM kernel family on fp32 MFMA (v_mfma_f32_32x32x2_f32):
+ *     out[m][n] = act( scale[n]*(sum_{t<T,c<C} A[row(m,t)][c] * W[n][t*C+c] + bias[n])
+ *                      + shift[n] + residual[m][n] )
+ * replaces  Conv2d / ConvTranspose2d / Conv1d / Linear as used by nets/vgg.py:69-83,
+ *           nets/resnet.py:55-71, nets/net_utils.py:35-98, nets/gnet.py, nets/fnet.py and the
+ *           neighbour gather + blur_conv of nets/bilateralNN.py:240-246.                     */
+typedef struct {
+    /* A operand */
+    const float *A;        /* rows of lda floats, first C used (channel slice = pointer offset) */
+    int64_t lda;
+    int32_t C;             /* channels per tap, multiple of 4 */
+    int32_t T;             /* taps (<= 16) */
+    int32_t mode;          /* 0 = direct rows (row = m), 1 = conv geometry, 2 = neighbour table */
+    /* mode 1: m = (b*Hv + i)*Wv + j ;  input pixel (i*sh + dh[t], j*sw + dw[t]) of image b */
+    int32_t B, Hin, Win, Hv, Wv, sh, sw;
+    int8_t dh[16], dw[16];
+    /* output pixel (i*osh + oh0, j*osw + ow0) of a [B][Ho][Wo] image (transposed conv classes) */
+    int32_t Ho, Wo, osh, osw, oh0, ow0;
+    /* mode 2: row = table[m*16 + t] (or -1 -> zeros) */
+    const int32_t *table;
+    /* W operand: packed [N][K], K = T*C */
+    const float *W;
+    int32_t N;
+    int64_t M;
+    const int32_t *M_dev;  /* optional: M read on device (grid sized by the M above) */
+    /* epilogue */
+    const float *bias, *scale, *shift;   /* each optional, [N] */
+    const float *residual; int64_t ldr;  /* optional [M][ldr] */
+    int32_t act;           /* 0 none, 1 relu, 2 leaky */
+    float slope;
+    float *out; int64_t ldo;
+    float *stats;          /* optional [gridM][2][N] per-block column sum / sum of squares of the
+                              pre-activation value (train-mode BatchNorm statistics) */
+} efgh_gemm_desc;
+
+int efgh_gather_gemm(const efgh_gemm_desc *d, void *stream);
+int32_t efgh_gather_gemm_grid_m(int64_t M, int32_t N);      /* rows of `stats` */
+
+/* Wp[n][t][c] = W[n*sn + c*sc + tapidx[t]*st]   (weight re-layout for the kernel above) */
+int efgh_pack_weight(const float *W, float *Wp, int32_t N, int32_t T, int32_t C, int64_t sn,
+                     int64_t sc, int64_t st, const int32_t *tapidx_host, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

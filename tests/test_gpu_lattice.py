@@ -1,0 +1,76 @@
+"""HIP lattice build (through the C-ABI) vs the oracle and the reference's golden arrays: bit-exact."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from efgh_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+SCALES = (1.0, 0.75, 0.5, 0.25, 0.125)
+
+
+def sha16(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]
+
+
+def _gpu(pc):
+    from efgh_amd import lattice
+    lv = lattice.build_pyramid(torch.from_numpy(pc).cuda(), SCALES)
+    out = []
+    for d in lv:
+        out.append({'H': d.H, 'bary': d.bary.cpu().numpy(), 'emg': d.emg.cpu().numpy(),
+                    'off': d.off.cpu().numpy().astype(np.int64),
+                    'nbr': d.nbr.cpu().numpy()[:, :15].T.astype(np.int64).copy(),
+                    'pts_next': d.pts_next[:, :d.H].cpu().numpy()})
+    return out
+
+
+@pytest.mark.parametrize('n', [512, 4096])
+def test_vs_golden(golden_dir, n):
+    g = np.load(os.path.join(golden_dir, f'lattice_n{n}.npz'))
+    out = _gpu(syn.lidar_sweep(n, 0))
+    for l, d in enumerate(out):
+        assert d['H'] == int(g[f'H{l}'])
+        assert np.array_equal(d['bary'].view(np.uint32), g[f'bary{l}'].view(np.uint32)), l
+        assert np.array_equal(d['emg'].view(np.uint32), g[f'emg{l}'].view(np.uint32)), l
+        assert np.array_equal(d['off'], g[f'off{l}']), l
+        assert np.array_equal(d['nbr'], g[f'nbr{l}']), l
+
+
+@pytest.mark.parametrize('n', [65536, 131072])
+def test_full_size_known_answers(golden_dir, n):
+    kat = json.load(open(os.path.join(golden_dir, 'lattice_kat.json')))[str(n)]
+    out = _gpu(syn.lidar_sweep(n, 0))
+    for d, k in zip(out, kat['levels']):
+        assert d['H'] == k['H']
+        assert sha16(d['off'][None]) == k['offset_sha16']
+        assert sha16(d['nbr'][None]) == k['neighbors_sha16']
+        assert sha16(d['bary'][None]) == k['bary_sha16']
+        assert sha16(d['emg'][None]) == k['emg_sha16']
+
+
+@pytest.mark.parametrize('seed,n', [(1, 1024), (5, 20000), (9, 131072)])
+def test_vs_oracle_random_scenes(seed, n):
+    from oracle import lattice as olat
+    rs = np.random.RandomState(seed)
+    pc = (rs.randn(3, n) * np.array([[20.], [20.], [2.]])).astype(np.float32)
+    ref = olat.generate_data(pc)
+    out = _gpu(pc)
+    for l, (d, r) in enumerate(zip(out, ref)):
+        assert d['H'] == r['H']
+        for k in ('bary', 'emg', 'pts_next'):
+            assert np.array_equal(d[k].view(np.uint32), r[k].view(np.uint32)), (l, k)
+        assert np.array_equal(d['off'], r['off']) and np.array_equal(d['nbr'], r['nbr']), l
+
+
+def test_degenerate_inputs():
+    from oracle import lattice as olat
+    for pc in (np.zeros((3, 1), np.float32), np.zeros((3, 7), np.float32)):
+        ref = olat.generate_data(pc)
+        out = _gpu(pc)
+        for d, r in zip(out, ref):
+            assert d['H'] == r['H'] and np.array_equal(d['off'], r['off']) and np.array_equal(d['nbr'], r['nbr'])
