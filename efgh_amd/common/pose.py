@@ -1,0 +1,85 @@
+"""Batched pose-head algebra without host synchronisation (replaces the per-sample python loops
+with .item()/.tolist() of common/torch_utils.py:105-146, 170-233, 256-296).  These are O(B) scalar
+formulas on (B,3)/(B,4,4) tensors; they stay as device tensor expressions (no kernel of their own).
+Differentiability mirrors the reference: the skew matrix K is built from detached values, only
+(1-c)/s^2 carries gradient (torch_utils.py:184,194); translation matrices are detached (:229)."""
+import math
+
+import torch
+
+
+def softmax_l2(x):
+    """softmax(dim=1) then L2-normalise (enet.py:161-164, hnet.py:59-63) -> (B,C,1)"""
+    a = torch.softmax(x, 1)
+    return (a / torch.sqrt(torch.sum(a * a, 1, keepdim=True))).unsqueeze(-1)
+
+
+def normal_from_abs_sign(abs_, sign_logits, ndim):
+    """torch_utils.py:105-146: class = first argmax; bits MSB-first -> +-1; normal = abs*sign"""
+    cls = torch.argmax(sign_logits, dim=1)                              # softmax is monotone
+    shifts = torch.arange(ndim - 1, -1, -1, device=cls.device)
+    bits = (cls[:, None] >> shifts[None, :]) & 1
+    sgn = (bits * 2 - 1).to(abs_.dtype)
+    return abs_ * sgn[:, :, None]
+
+
+def rotation_between(srce, dest):
+    """torch_utils.py:170-200.  srce (B,3,1), dest (3,) constant -> (B,4,4)"""
+    B = srce.size(0)
+    v1 = srce[:, :, 0]
+    v2 = dest.to(v1)[None, :].expand(B, -1)
+    v = torch.linalg.cross(v1, v2, dim=1)
+    c = torch.sum(v1 * v2, 1)
+    s2 = torch.sum(v * v, 1)                                            # s**2
+    vd = v.detach()
+    z = torch.zeros_like(vd[:, 0])
+    K = torch.stack([torch.stack([z, -vd[:, 2], vd[:, 1]], 1),
+                     torch.stack([vd[:, 2], z, -vd[:, 0]], 1),
+                     torch.stack([-vd[:, 1], vd[:, 0], z], 1)], 1)      # (B,3,3)
+    eye3 = torch.eye(3, device=v1.device, dtype=v1.dtype)[None]
+    s = torch.sqrt(s2)
+    coef = (1 - c) / (s * s)
+    rot3 = eye3 + K + torch.bmm(K, K) * coef[:, None, None]
+    same = (1 - c) == 0
+    opp = (1 + c) == 0
+    neg = -eye3.expand(B, -1, -1).clone()
+    fix0 = (v1[:, 0] == 0) & (v2[:, 0] == 0)
+    fix2 = (v1[:, 2] == 0) & (v2[:, 2] == 0) & ~fix0
+    neg[:, 0, 0] = torch.where(fix0, torch.ones_like(c), neg[:, 0, 0])
+    neg[:, 2, 2] = torch.where(fix2, torch.ones_like(c), neg[:, 2, 2])
+    rot3 = torch.where(opp[:, None, None], neg, rot3)
+    rot3 = torch.where(same[:, None, None], eye3.expand(B, -1, -1), rot3)
+    R = torch.zeros((B, 4, 4), device=v1.device, dtype=v1.dtype)
+    R[:, 3, 3] = 1
+    # the reference's -I case also negates [3,3]
+    R[:, 3, 3] = torch.where(opp & ~same, -torch.ones_like(c), R[:, 3, 3])
+    R = R.clone()
+    R[:, :3, :3] = rot3
+    return R
+
+
+def translation_matrix(vec):
+    """torch_utils.py:220-233 (detached)"""
+    B = vec.size(0)
+    t = torch.eye(4, device=vec.device, dtype=vec.dtype)[None].repeat(B, 1, 1)
+    t[:, :3, 3] = vec[:, :3, 0].detach()
+    return t
+
+
+def compute_cam_T_velo(c_T, l_T, calib, A):
+    """torch_utils.py:256-269"""
+    m = torch.bmm(calib, l_T)
+    m = torch.bmm(A, m)
+    m = torch.bmm(c_T, m)
+    return torch.bmm(torch.inverse(A), m)
+
+
+def yaw_rotation_from_scores(f_score):
+    """fnet.py:87-91: argmax -> yaw -> (cos,sin,0) -> rotation onto e1"""
+    n = f_score.size(-1)
+    f_idx = torch.argmax(f_score, dim=1, keepdim=True).float()
+    f_rad = -(f_idx / (n - 1)) * 2 * math.pi + math.pi
+    rad = f_rad[:, 0].double()                       # python math.cos/sin operate in double
+    f_fwd = torch.stack([torch.cos(rad), torch.sin(rad), torch.zeros_like(rad)], 1).float()[:, :, None]
+    e1 = torch.tensor([1., 0., 0.], device=f_score.device)
+    return rotation_between(f_fwd, e1)

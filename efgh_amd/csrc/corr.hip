@@ -1,0 +1,143 @@
+// F-net cross-modal correlation head (K11 of SURVEY.md §2a), nets/fnet.py:57,64,78-81:
+//   cam_n = cam / (max(cam)-min(cam));  rng_n = rng / (max(rng)-min(rng))
+//   rng_p = [mirror(last W/8 cols) | rng_n | first W/8 cols]          (torch_utils.py:271-284)
+//   score[j] = sigmoid( (1/C) * sum_{c,y,x} rng_p[y][j+x][c] * cam_n[y][x][c] )
+// Feature maps are channels-last [B][h][w][C] with C = 16.
+#include "common.h"
+
+namespace {
+constexpr int TPB = 256;
+
+// ---- global min / max per sample: x [B][n] -> mm[B][2] ----------------------------------------
+__global__ void __launch_bounds__(TPB)
+k_minmax_part(const float *__restrict__ x, long long n, int G, float *__restrict__ part) {
+    int b = blockIdx.y, g = blockIdx.x;
+    const float *p = x + (long long)b * n;
+    float mn = INFINITY, mx = -INFINITY;
+    for (long long i = (long long)g * TPB + threadIdx.x; i < n; i += (long long)G * TPB) {
+        float v = p[i]; mn = fminf(mn, v); mx = fmaxf(mx, v);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { mn = fminf(mn, __shfl_xor(mn, o)); mx = fmaxf(mx, __shfl_xor(mx, o)); }
+    __shared__ float smn[TPB / 64], smx[TPB / 64];
+    if ((threadIdx.x & 63) == 0) { smn[threadIdx.x >> 6] = mn; smx[threadIdx.x >> 6] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < TPB / 64; ++i) { mn = fminf(mn, smn[i]); mx = fmaxf(mx, smx[i]); }
+        part[((long long)b * G + g) * 2] = mn; part[((long long)b * G + g) * 2 + 1] = mx;
+    }
+}
+__global__ void k_minmax_final(const float *__restrict__ part, int G, float *__restrict__ mm) {
+    int b = blockIdx.x;
+    float mn = INFINITY, mx = -INFINITY;
+    for (int g = threadIdx.x; g < G; g += 64) { mn = fminf(mn, part[((long long)b * G + g) * 2]); mx = fmaxf(mx, part[((long long)b * G + g) * 2 + 1]); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { mn = fminf(mn, __shfl_xor(mn, o)); mx = fmaxf(mx, __shfl_xor(mx, o)); }
+    if (threadIdx.x == 0) { mm[b * 2] = mn; mm[b * 2 + 1] = mx; }
+}
+
+// ---- normalise + pad: rng [B][h][w][C] -> rp [B][h][w+2*off][C] -----------------------------------
+__global__ void __launch_bounds__(TPB)
+k_norm_pad(const float *__restrict__ x, const float *__restrict__ mm, int B, int h, int w, int C, int off,
+           float *__restrict__ y) {
+    const int wp = w + 2 * off, c4n = C >> 2;
+    long long total = (long long)B * h * wp * c4n;
+    for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
+        int cq = (int)(i % c4n); long long r = i / c4n;
+        int xp = (int)(r % wp); r /= wp;
+        int yy = (int)(r % h); int b = (int)(r / h);
+        int xs = xp < off ? (w - 1 - xp) : (xp < off + w ? xp - off : xp - off - w);
+        float d = mm[b * 2 + 1] - mm[b * 2];
+        float4 v = *reinterpret_cast<const float4 *>(x + (((long long)b * h + yy) * w + xs) * C + cq * 4);
+        v.x /= d; v.y /= d; v.z /= d; v.w /= d;
+        reinterpret_cast<float4 *>(y)[i] = v;
+    }
+}
+
+// ---- correlation partials: part[b][y][j] = sum_{x,c} rp[b][y][j+x][c] * cam[b][y][x][c]/(max-min) ----
+// one block = one (b, y, tile of 256 j); the normalised camera row lives in LDS.
+__global__ void __launch_bounds__(TPB)
+k_corr_rows(const float *__restrict__ rp, const float *__restrict__ cam, const float *__restrict__ cam_mm,
+            int h, int wc, int wp, int nj, float *__restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) float srow[];      // wc*16 floats
+    const int b = blockIdx.z, y = blockIdx.y, j = blockIdx.x * TPB + threadIdx.x;
+    const float d = cam_mm[b * 2 + 1] - cam_mm[b * 2];
+    const float4 *crow = reinterpret_cast<const float4 *>(cam + (((long long)b * h + y) * wc) * 16);
+    for (int i = threadIdx.x; i < wc * 4; i += TPB) {
+        float4 v = crow[i];
+        v.x /= d; v.y /= d; v.z /= d; v.w /= d;
+        reinterpret_cast<float4 *>(srow)[i] = v;
+    }
+    __syncthreads();
+    if (j >= nj) return;
+    const float4 *r = reinterpret_cast<const float4 *>(rp + (((long long)b * h + y) * wp + j) * 16);
+    const float4 *s = reinterpret_cast<const float4 *>(srow);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int x = 0; x < wc * 4; x += 4) {
+        float4 r0 = r[x], r1 = r[x + 1], r2 = r[x + 2], r3 = r[x + 3];
+        float4 s0 = s[x], s1 = s[x + 1], s2 = s[x + 2], s3 = s[x + 3];
+        a0 += r0.x * s0.x + r0.y * s0.y + r0.z * s0.z + r0.w * s0.w;
+        a1 += r1.x * s1.x + r1.y * s1.y + r1.z * s1.z + r1.w * s1.w;
+        a2 += r2.x * s2.x + r2.y * s2.y + r2.z * s2.z + r2.w * s2.w;
+        a3 += r3.x * s3.x + r3.y * s3.y + r3.z * s3.z + r3.w * s3.w;
+    }
+    part[((long long)b * h + y) * nj + j] = (a0 + a1) + (a2 + a3);
+}
+
+// ---- reduce over rows, scale by 1/C, sigmoid -------------------------------------------------------
+__global__ void __launch_bounds__(TPB)
+k_corr_finish(const float *__restrict__ part, int B, int h, int nj, float invC, float *__restrict__ logit,
+              float *__restrict__ score) {
+    long long total = (long long)B * nj;
+    for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
+        int b = (int)(i / nj), j = (int)(i - (long long)b * nj);
+        float a = 0.f;
+        for (int y = 0; y < h; ++y) a += part[((long long)b * h + y) * nj + j];
+        a *= invC;
+        if (logit) logit[i] = a;
+        score[i] = 1.0f / (1.0f + expf(-a));
+    }
+}
+
+int grid_for(long long total) {
+    long long g = (total + TPB - 1) / TPB;
+    return (int)(g > 16384 ? 16384 : (g < 1 ? 1 : g));
+}
+}  // namespace
+
+extern "C" int32_t efgh_minmax_groups(int64_t n) {
+    long long g = (n + TPB * 8 - 1) / (TPB * 8);
+    return (int32_t)(g > 1024 ? 1024 : (g < 1 ? 1 : g));
+}
+
+extern "C" int efgh_minmax(const float *x, int32_t B, int64_t n, float *part, float *mm, void *stream_) {
+    hipStream_t st = (hipStream_t)stream_;
+    EFGH_CHECK_ARG(x && part && mm && B > 0 && n > 0);
+    int G = efgh_minmax_groups(n);
+    k_minmax_part<<<dim3(G, B), TPB, 0, st>>>(x, n, G, part);
+    k_minmax_final<<<B, 64, 0, st>>>(part, G, mm);
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}
+
+extern "C" int efgh_corr_pad(const float *rng, const float *rng_mm, int32_t B, int32_t h, int32_t w, int32_t C,
+                             int32_t off, float *rp, void *stream_) {
+    EFGH_CHECK_ARG(rng && rng_mm && rp && B > 0 && h > 0 && w > 0 && C % 4 == 0 && off >= 0 && off <= w);
+    k_norm_pad<<<grid_for((long long)B * h * (w + 2 * off) * (C / 4)), TPB, 0, (hipStream_t)stream_>>>(
+        rng, rng_mm, B, h, w, C, off, rp);
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}
+
+extern "C" int efgh_corr1d(const float *rp, const float *cam, const float *cam_mm, int32_t B, int32_t h,
+                           int32_t wc, int32_t wp, float *part, float *logit, float *score, void *stream_) {
+    hipStream_t st = (hipStream_t)stream_;
+    EFGH_CHECK_ARG(rp && cam && cam_mm && part && score && B > 0 && h > 0 && wc > 0 && wp >= wc);
+    EFGH_CHECK_ARG(wc * 16 * 4 <= 64 * 1024);
+    int nj = wp - wc + 1;
+    dim3 grid(cdiv(nj, TPB), h, B);
+    k_corr_rows<<<grid, TPB, (size_t)wc * 16 * 4, st>>>(rp, cam, cam_mm, h, wc, wp, nj, part);
+    k_corr_finish<<<grid_for((long long)B * nj), TPB, 0, st>>>(part, B, h, nj, 1.0f / 16.0f, logit, score);
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}

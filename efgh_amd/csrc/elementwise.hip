@@ -1,0 +1,262 @@
+// HBM-bound helper kernels around the gather-GEMM: BatchNorm statistics / apply, activation,
+// residual add, 2x2 max-pool, layout changes at the model boundary, column reductions.
+// All image tensors are channels-last [rows][ld] with the channel axis contiguous; every kernel
+// moves 16 B per lane where the channel count allows it.
+#include "common.h"
+
+namespace {
+constexpr int TPB = 256;
+
+__device__ __forceinline__ float act_f(float v, int act, float slope) {
+    if (act == 1) return v > 0.f ? v : 0.f;
+    if (act == 2) return v > 0.f ? v : v * slope;
+    return v;
+}
+
+// stats: [G][2][C] per-block partial (sum, sumsq) from the GEMM epilogue.
+// -> scale/shift for y = x*scale + shift, running stats update (nn.BatchNorm, momentum form).
+__global__ void k_bn_finalize(const float *__restrict__ stats, int G, int C, double count,
+                              const float *__restrict__ gamma, const float *__restrict__ beta,
+                              float *__restrict__ rmean, float *__restrict__ rvar, float momentum, float eps,
+                              float *__restrict__ scale, float *__restrict__ shift,
+                              float *__restrict__ save_mean, float *__restrict__ save_invstd) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int g = 0; g < G; ++g) { s += stats[((long long)g * 2) * C + c]; q += stats[((long long)g * 2 + 1) * C + c]; }
+    double mean = s / count;
+    double var = q / count - mean * mean;
+    if (var < 0) var = 0;
+    float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    float sc = gamma[c] * invstd;
+    scale[c] = sc;
+    shift[c] = beta[c] - (float)mean * sc;
+    if (save_mean) { save_mean[c] = (float)mean; save_invstd[c] = invstd; }
+    if (rmean) {
+        double unb = count > 1 ? var * count / (count - 1) : var;
+        rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+    }
+}
+
+// per-column (sum, sumsq) partials of a [M][ld] matrix (used when the producer is not the GEMM)
+__global__ void __launch_bounds__(TPB)
+k_col_stats(const float *__restrict__ x, long long M, int C, long long ld, int rows_per_block,
+            float *__restrict__ stats) {
+    // blockDim = (C rounded to 32 lanes?) simple version: each thread owns one column, loops rows
+    int c = blockIdx.x * TPB + threadIdx.x;
+    long long r0 = (long long)blockIdx.y * rows_per_block, r1 = r0 + rows_per_block;
+    if (r1 > M) r1 = M;
+    if (c >= C) return;
+    float s = 0.f, q = 0.f;
+    for (long long r = r0; r < r1; ++r) { float v = x[r * ld + c]; s += v; q += v * v; }
+    stats[((long long)blockIdx.y * 2) * C + c] = s;
+    stats[((long long)blockIdx.y * 2 + 1) * C + c] = q;
+}
+
+// y[r][c] = act(x[r][c]*scale[c] + shift[c] + res[r][c]); vector of 4 channels per thread
+__global__ void __launch_bounds__(TPB)
+k_scale_shift_act(const float *__restrict__ x, long long ldx, const float *__restrict__ scale,
+                  const float *__restrict__ shift, const float *__restrict__ res, long long ldr,
+                  float *__restrict__ y, long long ldy, long long M, int C, int act, float slope) {
+    const int c4 = C >> 2;
+    long long total = M * c4;
+    for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
+        long long r = i / c4; int c = (int)(i - r * c4) * 4;
+        float4 v = *reinterpret_cast<const float4 *>(x + r * ldx + c);
+        float4 s = scale ? *reinterpret_cast<const float4 *>(scale + c) : make_float4(1.f, 1.f, 1.f, 1.f);
+        float4 h = shift ? *reinterpret_cast<const float4 *>(shift + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        v.x = v.x * s.x + h.x; v.y = v.y * s.y + h.y; v.z = v.z * s.z + h.z; v.w = v.w * s.w + h.w;
+        if (res) {
+            float4 q = *reinterpret_cast<const float4 *>(res + r * ldr + c);
+            v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+        }
+        v.x = act_f(v.x, act, slope); v.y = act_f(v.y, act, slope);
+        v.z = act_f(v.z, act, slope); v.w = act_f(v.w, act, slope);
+        *reinterpret_cast<float4 *>(y + r * ldy + c) = v;
+    }
+}
+
+// scalar-channel fallback (C % 4 != 0)
+__global__ void __launch_bounds__(TPB)
+k_scale_shift_act1(const float *__restrict__ x, long long ldx, const float *__restrict__ scale,
+                   const float *__restrict__ shift, const float *__restrict__ res, long long ldr,
+                   float *__restrict__ y, long long ldy, long long M, int C, int act, float slope) {
+    long long total = M * C;
+    for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
+        long long r = i / C; int c = (int)(i - r * C);
+        float v = x[r * ldx + c] * (scale ? scale[c] : 1.f) + (shift ? shift[c] : 0.f);
+        if (res) v += res[r * ldr + c];
+        y[r * ldy + c] = act_f(v, act, slope);
+    }
+}
+
+// 2x2/2 max pool, [B][H][W][C] -> [B][H/2][W/2][C]  (nn.MaxPool2d(2,2): floor)
+__global__ void __launch_bounds__(TPB)
+k_maxpool2(const float *__restrict__ x, float *__restrict__ y, int B, int H, int W, int C) {
+    const int Ho = H / 2, Wo = W / 2, c4 = C >> 2;
+    long long total = (long long)B * Ho * Wo * c4;
+    for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
+        int c = (int)(i % c4) * 4; long long r = i / c4;
+        int ow = (int)(r % Wo); r /= Wo;
+        int oh = (int)(r % Ho); long long b = r / Ho;
+        const float *p = x + (((b * H + oh * 2) * W) + ow * 2) * (long long)C + c;
+        float4 a = *reinterpret_cast<const float4 *>(p);
+        float4 b4 = *reinterpret_cast<const float4 *>(p + C);
+        float4 c4v = *reinterpret_cast<const float4 *>(p + (long long)W * C);
+        float4 d = *reinterpret_cast<const float4 *>(p + (long long)W * C + C);
+        float4 m;
+        m.x = fmaxf(fmaxf(a.x, b4.x), fmaxf(c4v.x, d.x)); m.y = fmaxf(fmaxf(a.y, b4.y), fmaxf(c4v.y, d.y));
+        m.z = fmaxf(fmaxf(a.z, b4.z), fmaxf(c4v.z, d.z)); m.w = fmaxf(fmaxf(a.w, b4.w), fmaxf(c4v.w, d.w));
+        *reinterpret_cast<float4 *>(y + (((b * Ho + oh) * Wo) + ow) * (long long)C + c) = m;
+    }
+}
+
+// (B,Cs,H,W) planar -> [B][H][W][Cd] channels-last, Cd >= Cs, extra channels zero
+__global__ void __launch_bounds__(TPB)
+k_nchw_to_nhwc(const float *__restrict__ x, float *__restrict__ y, int B, int Cs, long long HW, int Cd) {
+    long long total = (long long)B * HW;
+    for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
+        long long b = i / HW, p = i - b * HW;
+        for (int c = 0; c < Cd; ++c)
+            y[i * Cd + c] = c < Cs ? x[(b * Cs + c) * HW + p] : 0.f;
+    }
+}
+
+// [B][H][W][ld] (first Cs channels) -> (B,Cs,H,W) planar
+__global__ void __launch_bounds__(TPB)
+k_nhwc_to_nchw(const float *__restrict__ x, long long ld, float *__restrict__ y, int B, int Cs, long long HW) {
+    long long total = (long long)B * Cs * HW;
+    for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
+        long long p = i % HW; long long r = i / HW;
+        int c = (int)(r % Cs); long long b = r / Cs;
+        y[i] = x[(b * HW + p) * ld + c];
+    }
+}
+
+// per-segment column max: x [M][ld], segment s = rows [seg[s], seg[s+1])  -> y[s][C]
+__global__ void __launch_bounds__(TPB)
+k_segment_colmax(const float *__restrict__ x, long long ld, int C, const int *__restrict__ seg,
+                 float *__restrict__ y, int *__restrict__ argrow) {
+    int s = blockIdx.y, c = blockIdx.x * TPB + threadIdx.x;
+    if (c >= C) return;
+    int r0 = seg[s], r1 = seg[s + 1];
+    float m = -INFINITY; int am = r0;
+    for (int r = r0; r < r1; ++r) { float v = x[(long long)r * ld + c]; if (v > m) { m = v; am = r; } }
+    y[(long long)s * C + c] = m;
+    if (argrow) argrow[(long long)s * C + c] = am;
+}
+
+// per-segment column mean
+__global__ void __launch_bounds__(TPB)
+k_segment_colmean(const float *__restrict__ x, long long ld, int C, int rows_per_seg, float *__restrict__ y) {
+    int s = blockIdx.y, c = blockIdx.x * TPB + threadIdx.x;
+    if (c >= C) return;
+    double a = 0.0;
+    for (int r = 0; r < rows_per_seg; ++r) a += x[((long long)s * rows_per_seg + r) * ld + c];
+    y[(long long)s * C + c] = (float)(a / rows_per_seg);
+}
+
+// softmax over the first 2 channels of [rows][ld] -> planar (B,2,HW)  (g_mask, gnet.py:124)
+__global__ void __launch_bounds__(TPB)
+k_softmax2_to_nchw(const float *__restrict__ x, long long ld, float *__restrict__ y, int B, long long HW) {
+    long long total = (long long)B * HW;
+    for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
+        long long b = i / HW, p = i - b * HW;
+        float a = x[i * ld], c = x[i * ld + 1];
+        float m = fmaxf(a, c);
+        float ea = expf(a - m), ec = expf(c - m), inv = 1.f / (ea + ec);
+        y[(b * 2) * HW + p] = ea * inv;
+        y[(b * 2 + 1) * HW + p] = ec * inv;
+    }
+}
+
+int grid_for(long long total) {
+    long long g = (total + TPB - 1) / TPB;
+    return (int)(g > 16384 ? 16384 : (g < 1 ? 1 : g));
+}
+}  // namespace
+
+extern "C" int efgh_bn_finalize(const float *stats, int32_t G, int32_t C, double count, const float *gamma,
+                                const float *beta, float *rmean, float *rvar, float momentum, float eps,
+                                float *scale, float *shift, float *save_mean, float *save_invstd,
+                                void *stream) {
+    EFGH_CHECK_ARG(stats && gamma && beta && scale && shift && C > 0 && G > 0 && count > 0);
+    k_bn_finalize<<<cdiv(C, 64), 64, 0, (hipStream_t)stream>>>(stats, G, C, count, gamma, beta, rmean, rvar,
+                                                               momentum, eps, scale, shift, save_mean,
+                                                               save_invstd);
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}
+
+extern "C" int32_t efgh_col_stats_groups(int64_t M) { return (int32_t)((M + 511) / 512); }
+
+extern "C" int efgh_col_stats(const float *x, int64_t M, int32_t C, int64_t ld, float *stats, void *stream) {
+    EFGH_CHECK_ARG(x && stats && M > 0 && C > 0);
+    dim3 grid(cdiv(C, TPB), efgh_col_stats_groups(M));
+    k_col_stats<<<grid, TPB, 0, (hipStream_t)stream>>>(x, M, C, ld, 512, stats);
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}
+
+extern "C" int efgh_scale_shift_act(const float *x, int64_t ldx, const float *scale, const float *shift,
+                                    const float *res, int64_t ldr, float *y, int64_t ldy, int64_t M,
+                                    int32_t C, int32_t act, float slope, void *stream) {
+    EFGH_CHECK_ARG(x && y && M > 0 && C > 0);
+    bool vec = (C % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && (!res || ldr % 4 == 0) &&
+               ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)res) | ((uintptr_t)scale) | ((uintptr_t)shift)) & 15) == 0;
+    if (vec)
+        k_scale_shift_act<<<grid_for(M * (C / 4)), TPB, 0, (hipStream_t)stream>>>(x, ldx, scale, shift, res, ldr,
+                                                                               y, ldy, M, C, act, slope);
+    else
+        k_scale_shift_act1<<<grid_for(M * C), TPB, 0, (hipStream_t)stream>>>(x, ldx, scale, shift, res, ldr, y,
+                                                                           ldy, M, C, act, slope);
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}
+
+extern "C" int efgh_maxpool2(const float *x, float *y, int32_t B, int32_t H, int32_t W, int32_t C, void *stream) {
+    EFGH_CHECK_ARG(x && y && B > 0 && H >= 2 && W >= 2 && C % 4 == 0);
+    k_maxpool2<<<grid_for((long long)B * (H / 2) * (W / 2) * (C / 4)), TPB, 0, (hipStream_t)stream>>>(x, y, B, H, W, C);
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}
+
+extern "C" int efgh_nchw_to_nhwc(const float *x, float *y, int32_t B, int32_t Cs, int64_t HW, int32_t Cd, void *stream) {
+    EFGH_CHECK_ARG(x && y && B > 0 && Cs > 0 && Cd >= Cs && HW > 0);
+    k_nchw_to_nhwc<<<grid_for((long long)B * HW), TPB, 0, (hipStream_t)stream>>>(x, y, B, Cs, HW, Cd);
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}
+
+extern "C" int efgh_nhwc_to_nchw(const float *x, int64_t ld, float *y, int32_t B, int32_t Cs, int64_t HW, void *stream) {
+    EFGH_CHECK_ARG(x && y && B > 0 && Cs > 0 && ld >= Cs && HW > 0);
+    k_nhwc_to_nchw<<<grid_for((long long)B * Cs * HW), TPB, 0, (hipStream_t)stream>>>(x, ld, y, B, Cs, HW);
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}
+
+extern "C" int efgh_segment_colmax(const float *x, int64_t ld, int32_t C, const int32_t *seg, int32_t nseg,
+                                   float *y, int32_t *argrow, void *stream) {
+    EFGH_CHECK_ARG(x && seg && y && C > 0 && nseg > 0);
+    dim3 grid(cdiv(C, TPB), nseg);
+    k_segment_colmax<<<grid, TPB, 0, (hipStream_t)stream>>>(x, ld, C, seg, y, argrow);
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}
+
+extern "C" int efgh_segment_colmean(const float *x, int64_t ld, int32_t C, int32_t rows_per_seg, int32_t nseg,
+                                    float *y, void *stream) {
+    EFGH_CHECK_ARG(x && y && C > 0 && nseg > 0 && rows_per_seg > 0);
+    dim3 grid(cdiv(C, TPB), nseg);
+    k_segment_colmean<<<grid, TPB, 0, (hipStream_t)stream>>>(x, ld, C, rows_per_seg, y);
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}
+
+extern "C" int efgh_softmax2_to_nchw(const float *x, int64_t ld, float *y, int32_t B, int64_t HW, void *stream) {
+    EFGH_CHECK_ARG(x && y && B > 0 && HW > 0 && ld >= 2);
+    k_softmax2_to_nchw<<<grid_for((long long)B * HW), TPB, 0, (hipStream_t)stream>>>(x, ld, y, B, HW);
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}

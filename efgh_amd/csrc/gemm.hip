@@ -1,0 +1,317 @@
+// Gather-GEMM on fp32 MFMA (v_mfma_f32_32x32x2_f32) for gfx950 — K4 / K6 / K8 of SURVEY.md §2a.
+//
+//   out[m][n] = act( scale[n]*(sum_{t<T,c<C} A[row(m,t)][c] * W[n][t*C+c] + bias[n]) + shift[n]
+//                    + residual[m][n] )
+//
+// One kernel family serves every dense contraction of the reference:
+//   Conv2d 3x3 / 1x1 / (1,2), stride 1|2          nets/vgg.py:77, nets/resnet.py:22-30, net_utils.py:49
+//   ConvTranspose2d k3 s2 (as 4 output-parity classes)               nets/net_utils.py:72-79
+//   Conv1d k1 / Linear                                               nets/enet.py:85-97, hnet.py:19-31
+//   neighbour gather + Conv2d(C,C',(15,1))  (BCL blur)               nets/bilateralNN.py:240-246
+// A rows are gathered on the fly (implicit GEMM): `row(m,t)` is an input pixel (mode 1), a lattice
+// neighbour (mode 2) or m itself (mode 0); out-of-image / missing rows contribute zeros.
+//
+// Tiling: 256 threads = 4 waves; block tile BM x BN x 32; each wave owns (BM/WM) x (BN/WN) as
+// 32x32 MFMA tiles with fp32 accumulators.  Global -> registers -> LDS staging (16-B vectors
+// along the channel axis, 128-B rows), LDS rows padded to 36 floats so that both the
+// ds_write_b128 of the staging pass and the ds_read_b128 fragment reads are bank-conflict free.
+// One ds_read_b128 feeds four MFMAs: lanes 0-31 hold k = g*8+j, lanes 32-63 hold k = g*8+4+j.
+// Numerics: exact fp32 products, fp32 accumulation (a k-ordered fma chain per output).
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 32;
+constexpr int LDS_LD = BK + 4;
+
+struct KArgs {
+    const float *A; int64_t lda;
+    int C, T, K;
+    unsigned magicC;          // ceil(2^32 / C)
+    int Hin, Win, Hv, Wv, sh, sw;
+    unsigned long long dhpack, dwpack;   // 16 taps x 4 bits, value + 8
+    int Ho, Wo, osh, osw, oh0, ow0;
+    const int *table;
+    const float *W; int N;
+    long long M; const int *M_dev;
+    const float *bias, *scale, *shift, *residual; int64_t ldr;
+    int act; float slope;
+    float *out; int64_t ldo;
+    float *stats;
+};
+
+template <int MODE, int BM, int BN, int WM, int WN>
+__global__ void __launch_bounds__(256)
+k_gather_gemm(const KArgs p) {
+    constexpr int MI = BM / WM / 32, NI = BN / WN / 32;
+    constexpr int NA = BM / 32, NB = BN / 32;
+    __shared__ __attribute__((aligned(16))) float As[BM * LDS_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[BN * LDS_LD];
+    __shared__ long long rowout[BM];          // output row (pixel) index per tile row, -1 = masked
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, lh = lane >> 5;
+    long long M = p.M;
+    if (p.M_dev) { long long md = *p.M_dev; M = md < M ? md : M; }
+    const long long m0 = (long long)blockIdx.y * BM;
+    const int n0 = blockIdx.x * BN;
+    if (m0 >= M) return;
+
+    // ---- per-thread row state for the staging loads --------------------------------------
+    const int arow = tid >> 3, kv = (tid & 7) * 4;
+    long long abase[NA];     // mode 0: row offset (floats) | mode 1: pixel base of image b | mode 2: m*16
+    int aih[NA], aiw[NA];
+    bool aval[NA];
+#pragma unroll
+    for (int q = 0; q < NA; ++q) {
+        long long m = m0 + q * 32 + arow;
+        aval[q] = m < M;
+        aih[q] = aiw[q] = 0;
+        abase[q] = 0;
+        if (aval[q]) {
+            if (MODE == 0) abase[q] = m * p.lda;
+            else if (MODE == 2) abase[q] = m * 16;
+            else {
+                int j = (int)(m % p.Wv); long long r = m / p.Wv;
+                int i = (int)(r % p.Hv); long long b = r / p.Hv;
+                aih[q] = i * p.sh; aiw[q] = j * p.sw;
+                abase[q] = b * p.Hin * p.Win;
+            }
+        }
+    }
+    for (int r = tid; r < BM; r += 256) {
+        long long m = m0 + r, o = -1;
+        if (m < M) {
+            if (MODE == 1) {
+                int j = (int)(m % p.Wv); long long rr = m / p.Wv;
+                int i = (int)(rr % p.Hv); long long b = rr / p.Hv;
+                o = (b * p.Ho + (i * p.osh + p.oh0)) * p.Wo + (j * p.osw + p.ow0);
+            } else o = m;
+        }
+        rowout[r] = o;
+    }
+    long long bbase[NB]; bool bval[NB];
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+        int n = n0 + q * 32 + arow;
+        bval[q] = n < p.N;
+        bbase[q] = (long long)n * p.K;
+    }
+
+    float4 ra[NA], rb[NB];
+    auto load_chunk = [&](int k0) {
+        const int kk = k0 + kv;
+        const bool kin = kk < p.K;
+        int t = (int)(((unsigned long long)kk * p.magicC) >> 32);
+        int c = kk - t * p.C;
+        int dh = (int)((p.dhpack >> (4 * t)) & 15) - 8, dw = (int)((p.dwpack >> (4 * t)) & 15) - 8;
+#pragma unroll
+        for (int q = 0; q < NA; ++q) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (aval[q] && kin) {
+                if (MODE == 0) {
+                    v = *reinterpret_cast<const float4 *>(p.A + abase[q] + kk);
+                } else if (MODE == 1) {
+                    int ih = aih[q] + dh, iw = aiw[q] + dw;
+                    if ((unsigned)ih < (unsigned)p.Hin && (unsigned)iw < (unsigned)p.Win)
+                        v = *reinterpret_cast<const float4 *>(
+                            p.A + (abase[q] + (long long)ih * p.Win + iw) * p.lda + c);
+                } else {
+                    int r = p.table[abase[q] + t];
+                    if (r >= 0) v = *reinterpret_cast<const float4 *>(p.A + (long long)r * p.lda + c);
+                }
+            }
+            ra[q] = v;
+        }
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (bval[q] && kin) v = *reinterpret_cast<const float4 *>(p.W + bbase[q] + kk);
+            rb[q] = v;
+        }
+    };
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nchunks = (p.K + BK - 1) / BK;
+    load_chunk(0);
+    for (int ch = 0; ch < nchunks; ++ch) {
+#pragma unroll
+        for (int q = 0; q < NA; ++q)
+            *reinterpret_cast<float4 *>(&As[(q * 32 + arow) * LDS_LD + kv]) = ra[q];
+#pragma unroll
+        for (int q = 0; q < NB; ++q)
+            *reinterpret_cast<float4 *>(&Bs[(q * 32 + arow) * LDS_LD + kv]) = rb[q];
+        __syncthreads();
+        if (ch + 1 < nchunks) load_chunk((ch + 1) * BK);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float4 a[MI], b[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+                a[i] = *reinterpret_cast<const float4 *>(
+                    &As[((wm * MI + i) * 32 + l31) * LDS_LD + g * 8 + lh * 4]);
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+                b[j] = *reinterpret_cast<const float4 *>(
+                    &Bs[((wn * NI + j) * 32 + l31) * LDS_LD + g * 8 + lh * 4]);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue -----------------------------------------------------------------------
+    float *ssum = As;            // [WM][BN] column sums, [WM][BN] sums of squares (LDS reuse)
+    float *ssq = As + WM * BN;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int coll = (wn * NI + j) * 32 + l31, col = n0 + coll;
+        const bool cok = col < p.N;
+        const float bi = (p.bias && cok) ? p.bias[col] : 0.f;
+        const float sc = (p.scale && cok) ? p.scale[col] : 1.f;
+        const float sf = (p.shift && cok) ? p.shift[col] : 0.f;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rl = (wm * MI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const long long orow = rowout[rl];
+                if (orow < 0 || !cok) continue;
+                float v = acc[i][j][r] + bi;
+                s1 += v; s2 += v * v;
+                v = v * sc + sf;
+                if (p.residual) v += p.residual[orow * p.ldr + col];
+                if (p.act == 1) v = v > 0.f ? v : 0.f;
+                else if (p.act == 2) v = v > 0.f ? v : v * p.slope;
+                p.out[orow * p.ldo + col] = v;
+            }
+        }
+        if (p.stats) {
+            s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+            if (lh == 0) { ssum[wm * BN + coll] = s1; ssq[wm * BN + coll] = s2; }
+        }
+    }
+    if (p.stats) {
+        __syncthreads();
+        for (int c = tid; c < BN; c += 256) {
+            if (n0 + c < p.N) {
+                float a = 0.f, b = 0.f;
+#pragma unroll
+                for (int w = 0; w < WM; ++w) { a += ssum[w * BN + c]; b += ssq[w * BN + c]; }
+                p.stats[((long long)blockIdx.y * 2 + 0) * p.N + n0 + c] = a;
+                p.stats[((long long)blockIdx.y * 2 + 1) * p.N + n0 + c] = b;
+            }
+        }
+    }
+}
+
+__global__ void k_pack_weight(const float *__restrict__ W, float *__restrict__ Wp, int N, int T, int C,
+                              long long sn, long long sc, long long st, const int4 taps0,
+                              const int4 taps1, const int4 taps2, const int4 taps3) {
+    const int tp[16] = {taps0.x, taps0.y, taps0.z, taps0.w, taps1.x, taps1.y, taps1.z, taps1.w,
+                        taps2.x, taps2.y, taps2.z, taps2.w, taps3.x, taps3.y, taps3.z, taps3.w};
+    long long total = (long long)N * T * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        int c = (int)(i % C); long long r = i / C;
+        int t = (int)(r % T); int n = (int)(r / T);
+        int ti = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) if (q == t) ti = tp[q];
+        Wp[i] = W[n * sn + c * sc + ti * st];
+    }
+}
+
+template <int MODE, int BM, int BN, int WM, int WN>
+void launch(const KArgs &a, hipStream_t st) {
+    dim3 grid((a.N + BN - 1) / BN, (unsigned)((a.M + BM - 1) / BM));
+    k_gather_gemm<MODE, BM, BN, WM, WN><<<grid, 256, 0, st>>>(a);
+}
+
+template <int MODE>
+void dispatch(const KArgs &a, hipStream_t st) {
+    if (a.N > 64) launch<MODE, 128, 128, 2, 2>(a, st);
+    else if (a.N > 32) launch<MODE, 256, 64, 4, 1>(a, st);
+    else launch<MODE, 256, 32, 4, 1>(a, st);
+}
+
+int tile_m(int N) { return N > 64 ? 128 : 256; }
+
+}  // namespace
+
+extern "C" int32_t efgh_gather_gemm_grid_m(int64_t M, int32_t N) {
+    int bm = tile_m(N);
+    return (int32_t)((M + bm - 1) / bm);
+}
+
+extern "C" int efgh_gather_gemm(const efgh_gemm_desc *d, void *stream_) {
+    hipStream_t st = (hipStream_t)stream_;
+    EFGH_CHECK_ARG(d && d->A && d->W && d->out);
+    EFGH_CHECK_ARG(d->C > 0 && d->C % 4 == 0 && d->T >= 1 && d->T <= 16);
+    EFGH_CHECK_ARG(d->N >= 1 && d->M >= 1 && d->lda % 4 == 0);
+    EFGH_CHECK_ARG((((uintptr_t)d->A) & 15) == 0 && (((uintptr_t)d->W) & 15) == 0);
+    EFGH_CHECK_ARG(d->mode >= 0 && d->mode <= 2);
+    EFGH_CHECK_ARG((int64_t)d->T * d->C < 65536);
+    KArgs a;
+    a.A = d->A; a.lda = d->lda; a.C = d->C; a.T = d->T; a.K = d->T * d->C;
+    a.magicC = (unsigned)((0x100000000ULL + d->C - 1) / d->C);
+    a.Hin = d->Hin; a.Win = d->Win; a.Hv = d->Hv; a.Wv = d->Wv; a.sh = d->sh; a.sw = d->sw;
+    a.dhpack = 0; a.dwpack = 0;
+    for (int t = 0; t < 16; ++t) {
+        int dh = t < d->T ? d->dh[t] : 0, dw = t < d->T ? d->dw[t] : 0;
+        if (d->mode == 1) EFGH_CHECK_ARG(dh >= -8 && dh <= 7 && dw >= -8 && dw <= 7);
+        a.dhpack |= (unsigned long long)((dh + 8) & 15) << (4 * t);
+        a.dwpack |= (unsigned long long)((dw + 8) & 15) << (4 * t);
+    }
+    a.Ho = d->Ho; a.Wo = d->Wo; a.osh = d->osh; a.osw = d->osw; a.oh0 = d->oh0; a.ow0 = d->ow0;
+    a.table = d->table; a.W = d->W; a.N = d->N; a.M = d->M; a.M_dev = d->M_dev;
+    a.bias = d->bias; a.scale = d->scale; a.shift = d->shift; a.residual = d->residual; a.ldr = d->ldr;
+    a.act = d->act; a.slope = d->slope; a.out = d->out; a.ldo = d->ldo; a.stats = d->stats;
+    if (d->mode == 1) {
+        EFGH_CHECK_ARG(d->B > 0 && d->Hin > 0 && d->Win > 0 && d->Hv > 0 && d->Wv > 0);
+        EFGH_CHECK_ARG(d->M == (int64_t)d->B * d->Hv * d->Wv);
+        EFGH_CHECK_ARG(d->osh >= 1 && d->osw >= 1 && d->Ho > 0 && d->Wo > 0);
+    }
+    if (d->mode == 2) EFGH_CHECK_ARG(d->table != nullptr);
+    if (d->mode == 0) EFGH_CHECK_ARG(d->T == 1);
+    if (d->mode == 0) dispatch<0>(a, st);
+    else if (d->mode == 1) dispatch<1>(a, st);
+    else dispatch<2>(a, st);
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}
+
+extern "C" int efgh_pack_weight(const float *W, float *Wp, int32_t N, int32_t T, int32_t C, int64_t sn,
+                                int64_t sc, int64_t stt, const int32_t *tapidx, void *stream_) {
+    hipStream_t st = (hipStream_t)stream_;
+    EFGH_CHECK_ARG(W && Wp && N > 0 && T > 0 && T <= 16 && C > 0);
+    int tp[16];
+    for (int t = 0; t < 16; ++t) tp[t] = (tapidx && t < T) ? tapidx[t] : (t < T ? t : 0);
+    long long total = (long long)N * T * C;
+    int grid = (int)((total + 255) / 256);
+    if (grid > 8192) grid = 8192;
+    k_pack_weight<<<grid, 256, 0, st>>>(W, Wp, N, T, C, sn, sc, stt, make_int4(tp[0], tp[1], tp[2], tp[3]),
+                                        make_int4(tp[4], tp[5], tp[6], tp[7]),
+                                        make_int4(tp[8], tp[9], tp[10], tp[11]),
+                                        make_int4(tp[12], tp[13], tp[14], tp[15]));
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}

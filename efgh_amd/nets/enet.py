@@ -1,0 +1,93 @@
+"""E-net: ground normal from the point cloud (reference nets/enet.py) on the HIP path."""
+import torch
+import torch.nn as nn
+
+from .. import lattice, ops
+from ..common import pose
+from ..ops import ACT_LEAKY, ACT_RELU
+from . import layers as L
+from .builders import BilateralConvFlex, conv_1x1
+
+
+class Enet(nn.Module):
+    def __init__(self, args):
+        super().__init__()
+        dim = args['dim']
+        self.scale_map = args['scale_map']
+        assert dim == 3 and all(int(r) == 1 for _, r in self.scale_map), 'd=3, radius-1 BCL only'
+        assert args['use_leaky'] and args['bcn_use_norm'] and not args['last_relu']
+        self.device = args['DEVICE']
+        self.conv_in = nn.Sequential(conv_1x1(dim, 32, True), conv_1x1(32, 32, True), conv_1x1(32, 32, True))
+        self.bcn1 = BilateralConvFlex(32 + dim + 1, [32, 32])          # enet.py:30-83
+        self.bcn2 = BilateralConvFlex(32 + dim + 1, [64, 64])
+        self.bcn3 = BilateralConvFlex(64 + dim + 1, [128, 128])
+        self.bcn4 = BilateralConvFlex(128 + dim + 1, [256, 256])
+        self.bcn5 = BilateralConvFlex(256 + dim + 1, [256, 256])
+        self.conv_gn_1 = nn.Conv1d(256, 128, 1)
+        self.conv_gn_2 = nn.Conv1d(128, 128, 1)
+        self.conv_gn_3 = nn.Conv1d(128, 128, 1)
+        self.bn_gn_1 = nn.BatchNorm1d(128)
+        self.bn_gn_2 = nn.BatchNorm1d(128)
+        self.bn_gn_3 = nn.BatchNorm1d(128)
+        self.lin_gn_1 = nn.Linear(128, 128)
+        self.lin_gn_2 = nn.Linear(128, 128)
+        self.lin_gn_3 = nn.Linear(128, 32)
+        self.lin_gn_abs = nn.Linear(32, 3)
+        self.lin_gn_sgn = nn.Linear(32, 8)
+
+    def forward(self, pc, check=False, keep=None):
+        """pc (B,3,N) -> dict as reference enet.py:179-187 (every sample gets its own lattice)."""
+        ops._C.require_cuda(pc)
+        ctx = L.Ctx(self.training)
+        B, _, N = pc.shape
+        dev = pc.device
+        bcns = [self.bcn1, self.bcn2, self.bcn3, self.bcn4, self.bcn5]
+        scales = [s for s, _ in self.scale_map]
+        outs, segs = [], [0]
+        for b in range(B):
+            pts = pc[b].contiguous()
+            cins = [m.num_input for m in bcns]
+            feats = [None] * 5
+
+            def mk(l):
+                def alloc(n):
+                    feats[l] = torch.empty((n, cins[l]), dtype=torch.float32, device=dev)
+                    return feats[l]
+                return alloc
+            lv = lattice.build_pyramid(pts, scales, feat_bufs=[mk(l) for l in range(5)])
+            if keep is not None:
+                keep.setdefault('lattice', []).append(lv)
+            # conv_in on [N][4] (x,y,z,0) -> channels 4..35 of the level-0 feature rows
+            x = ops.nchw_to_nhwc(pts[None], 4)[0]                        # (N,4)
+            for i in range(3):
+                conv = self.conv_in[i][0]
+                last = i == 2
+                x = L.linear_rows(ctx, x, N, conv.in_channels, conv.weight, conv.bias, act=ACT_LEAKY, slope=0.1,
+                                  out=(feats[0], 4) if last else None)
+            cur = feats[0]
+            for l in range(5):
+                d = lv[l]
+                splat, _ = ops.splat_fwd(cur, cins[l], d.bary, d.off, d.H)
+                tgt = (feats[l + 1], 4) if l < 4 else None
+                cur = L.blur_conv(ctx, splat, d.H, cins[l], d.nbr, bcns[l].blur_conv[0], bcns[l].blur_conv[2],
+                                  out=tgt)
+                if l < 4:
+                    cur = feats[l + 1]
+            outs.append(cur)                                             # (H5, 256)
+            segs.append(segs[-1] + lv[4].H)
+        x = torch.cat(outs, 0) if B > 1 else outs[0]
+        M = x.shape[0]
+        for conv, bn in ((self.conv_gn_1, self.bn_gn_1), (self.conv_gn_2, self.bn_gn_2),
+                         (self.conv_gn_3, self.bn_gn_3)):
+            x = L.linear_rows(ctx, x, M, conv.in_channels, conv.weight, conv.bias, bn=bn, act=ACT_RELU)
+        seg = torch.tensor(segs, dtype=torch.int32, device=dev)
+        x, _ = ops.segment_colmax(x, x.shape[-1], 128, seg, B)           # torch.max over vertices (:154)
+        for lin in (self.lin_gn_1, self.lin_gn_2, self.lin_gn_3):
+            x = L.linear_rows(ctx, x, B, lin.in_features, lin.weight, lin.bias, act=ACT_RELU)
+        gn_sgn = L.linear_rows(ctx, x, B, 32, self.lin_gn_sgn.weight, self.lin_gn_sgn.bias)[:, :8]
+        gn_abs0 = L.linear_rows(ctx, x, B, 32, self.lin_gn_abs.weight, self.lin_gn_abs.bias)[:, :3]
+        gn_abs = pose.softmax_l2(gn_abs0)
+        e_gn = pose.normal_from_abs_sign(gn_abs, gn_sgn, 3)
+        e_T = pose.rotation_between(e_gn, torch.tensor([0., 0., 1.], device=dev))
+        return {'e_gn_abs': gn_abs, 'e_gn_sgn': gn_sgn.contiguous(), 'e_gn': e_gn, 'e_l': e_T,
+                'sensor2_T_sensor1': e_T, 'network': 'E'}

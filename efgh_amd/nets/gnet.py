@@ -1,0 +1,89 @@
+"""G-net: translation + dense depth / mask (reference nets/gnet.py) on the HIP path."""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..common import pose
+from ..ops import ACT_LEAKY
+from . import layers as L
+from .builders import conv_bn_relu, convt_bn_relu, resnet18_layers
+
+
+class Gnet(nn.Module):
+    def __init__(self, args):
+        super().__init__()
+        self.device = args['DEVICE']
+        self.raw_cam_img_size = args['raw_cam_img_size']
+        self.conv_i0 = conv_bn_relu(3, 64, 3, 1, 1)
+        self.conv_img2, self.conv_img3, self.conv_img4, self.conv_img5 = resnet18_layers()
+        self.convt_img4 = convt_bn_relu(512, 256, 3, 2, 1, 1)
+        self.convt_img3 = convt_bn_relu(512, 128, 3, 2, 1, 1)
+        self.convt_img2 = convt_bn_relu(256, 64, 3, 2, 1, 1)
+        self.convt_dimg = convt_bn_relu(128, 1, 3, 2, 1, 1)
+        self.convt_mask = convt_bn_relu(128, 2, 3, 2, 1, 1)
+        self.conv_i1 = conv_bn_relu(64, 32, 1, 1, 0)
+        self.conv_d1 = conv_bn_relu(4, 32, 3, 2, 1)
+        self.conv2, self.conv3, self.conv4, self.conv5 = resnet18_layers()
+        self.conv_trs_1 = conv_bn_relu(512, 512, 1)
+        self.conv_trs_2 = conv_bn_relu(512, 512, 1)
+        self.conv_trs_3 = conv_bn_relu(512, 512, 1)
+        self.conv_trs_4 = nn.Conv1d(512, 3, 1)
+
+    def forward(self, pc, img, ret, check=False, img_nhwc=None, keep=None):
+        ctx = L.Ctx(self.training)
+        dev = img.device
+        x = img_nhwc if img_nhwc is not None else ops.nchw_to_nhwc(img, 4)
+        B, H, W, _ = x.shape
+
+        def buf(h, w, c):
+            return torch.empty((B, h, w, c), dtype=torch.float32, device=dev)
+        # concat targets (torch.cat / concat_tensors of gnet.py:117-121 become channel slices)
+        cat3 = buf(H // 4, W // 4, 512)       # [conv_img4 | convt_img4]
+        cat2 = buf(H // 2, W // 2, 256)       # [conv_img3 | convt_img3]
+        cat1 = buf(H, W, 128)                 # [convt_img2 | conv_img2]
+        assert H % 8 == 0 and W % 8 == 0, 'reference needs (W/2)%8==0 (SURVEY 8a-17); H likewise here'
+        c1 = L.run_conv_bn_relu(ctx, self.conv_i0, x)                              # gnet.py:103
+        L.run_resnet_layer(ctx, self.conv_img2, c1, out=(cat1, 64))
+        # layer2 reads the conv_img2 slice of cat1 (channel offset 64)
+        _layer_from_slice(ctx, self.conv_img3, cat1, 64, 64, out=(cat2, 0))
+        _layer_from_slice(ctx, self.conv_img4, cat2, 0, 128, out=(cat3, 0))
+        c5 = _layer_from_slice(ctx, self.conv_img5, cat3, 0, 256, out=None)
+        L.run_convt_bn_relu(ctx, self.convt_img4, c5, out=(cat3, 256))             # :116
+        L.run_convt_bn_relu(ctx, self.convt_img3, cat3, out=(cat2, 128))
+        L.run_convt_bn_relu(ctx, self.convt_img2, cat2, out=(cat1, 0))
+        dimg = L.run_convt_bn_relu(ctx, self.convt_dimg, cat1)                     # (B,2H,2W,4) ch0
+        mask = L.run_convt_bn_relu(ctx, self.convt_mask, cat1)                     # (B,2H,2W,4) ch0,1
+        g_depth = ops.nhwc_to_nchw(dimg, 1)
+        g_mask = ops.softmax2_to_nchw(mask)
+        rawH, rawW = self.raw_cam_img_size
+        f_depth, pix = ops.depth_image(pc, ret['efh_cam_T_velo'], rawH, rawW)      # :136
+        cat0 = buf(H, W, 64)                  # [conv_i1 | conv_d1]
+        L.run_conv_bn_relu(ctx, self.conv_i1, cat1, out=(cat0, 0), in_ch=(0, 64))
+        L.run_conv_bn_relu(ctx, self.conv_d1, f_depth, out=(cat0, 32))
+        y = L.run_resnet_layer(ctx, self.conv2, cat0)
+        y = L.run_resnet_layer(ctx, self.conv3, y)
+        y = L.run_resnet_layer(ctx, self.conv4, y)
+        y = L.run_resnet_layer(ctx, self.conv5, y)
+        for seq in (self.conv_trs_1, self.conv_trs_2, self.conv_trs_3):
+            y = L.run_conv_bn_relu(ctx, seq, y)
+        P = y.shape[1] * y.shape[2]
+        t4 = L.linear_rows(ctx, y.view(B * P, 512), B * P, 512, self.conv_trs_4.weight, self.conv_trs_4.bias)
+        trs = ops.segment_colmean(t4, t4.shape[-1], 3, P, B)[:, :, None]          # :165
+        g_T = pose.translation_matrix(trs)
+        if keep is not None:
+            keep.update({'f_depth': f_depth})
+        ret = dict(ret)
+        ret.update({'g_depth': g_depth, 'g_mask': g_mask, 'g_trs': trs, 'g_l': g_T})
+        ret['sensor2_T_sensor1'] = torch.bmm(g_T, ret['sensor2_T_sensor1'])        # :180
+        ret['network'] = ret['network'] + 'G'
+        return ret
+
+
+def _layer_from_slice(ctx, layer, src, coff, C, out):
+    """run a resnet layer whose input is the channel slice [coff, coff+C) of a concat buffer"""
+    blocks = list(layer.children())
+    blk = blocks[0]
+    y = L.conv2d(ctx, src, blk.conv1, blk.bn1, L.ACT_RELU, in_ch=(coff, C))
+    idt = L.conv2d(ctx, src, blk.downsample[0], blk.downsample[1], L.ACT_NONE, in_ch=(coff, C))
+    x = L.conv2d(ctx, y, blk.conv2, blk.bn2, L.ACT_RELU, residual=idt)
+    return L.run_basic_block(ctx, blocks[1], x, out=out)

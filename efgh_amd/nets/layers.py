@@ -1,0 +1,246 @@
+"""Layer executors: run torch.nn parameter containers (Conv2d, ConvTranspose2d, BatchNorm, Linear,
+Conv1d) through the HIP gather-GEMM.  Activations are channels-last [B][H][W][C] fp32 tensors.
+
+The nn.Module objects only hold parameters/buffers (so that state_dict keys and shapes equal the
+reference's); their own forward() is never called.
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..ops import ACT_LEAKY, ACT_NONE, ACT_RELU, ceil4
+
+
+class Ctx:
+    """Per-forward execution context."""
+
+    def __init__(self, train):
+        self.train = bool(train)
+
+
+def _bn_eval_affine(bn, Np):
+    """eval-mode BatchNorm as y = x*scale + shift, cached on the buffers' versions."""
+    key = (id(bn), 'bn_eval', Np)
+    vers = (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version)
+
+    def make():
+        with torch.no_grad():
+            scale = bn.weight.detach() * torch.rsqrt(bn.running_var + bn.eps)
+            shift = bn.bias.detach() - bn.running_mean * scale
+        return ops.pad_vec(scale, Np), ops.pad_vec(shift, Np)
+
+    return ops._cached(key, vers, make)
+
+
+def _bias_vec(bias, Np):
+    if bias is None:
+        return None
+    if bias.numel() == Np:
+        return bias.detach()
+    return ops._cached((id(bias), 'bias', Np), bias._version, lambda: ops.pad_vec(bias, Np))
+
+
+def _bn_train(ctx, bn, stats, G, Np, count):
+    """finalize batch statistics -> (scale, shift); updates running stats in place."""
+    N = bn.num_features
+    bn.num_batches_tracked += 1
+    momentum = bn.momentum if bn.momentum is not None else 0.1
+    if Np == N:
+        scale, shift, _, _ = ops.bn_finalize(stats, G, N, count, bn.weight.detach(), bn.bias.detach(),
+                                             bn.running_mean, bn.running_var, momentum, bn.eps)
+        return scale, shift
+    # padded channel count (tiny layers): run on padded temporaries, copy the real part back
+    g, b = ops.pad_vec(bn.weight, Np), ops.pad_vec(bn.bias, Np)
+    rm, rv = ops.pad_vec(bn.running_mean, Np), ops.pad_vec(bn.running_var, Np, 1.0)
+    if rm is bn.running_mean:
+        rm, rv = rm.clone(), rv.clone()
+    scale, shift, _, _ = ops.bn_finalize(stats, G, Np, count, g, b, rm, rv, momentum, bn.eps)
+    bn.running_mean.copy_(rm[:N])
+    bn.running_var.copy_(rv[:N])
+    return scale, shift
+
+
+def _epilogue_plan(ctx, bias, bn, Np):
+    """returns (bias, scale, shift, fused) for the GEMM epilogue; fused=False means BN needs batch stats."""
+    b = _bias_vec(bias, Np)
+    if bn is None:
+        return b, None, None, True
+    if not ctx.train:
+        sc, sh = _bn_eval_affine(bn, Np)
+        return b, sc, sh, True
+    return b, None, None, False
+
+
+def _alloc_out(x, shape_rows, N, out):
+    """out = None -> fresh [rows..][Np] buffer; or (tensor, coff): write into channels coff.. of an
+    existing channels-last buffer (concat fusion)."""
+    Np = ceil4(N)
+    if out is None:
+        t = torch.empty(tuple(shape_rows) + (Np,), dtype=torch.float32, device=x.device)
+        return t, Np, 0
+    t, coff = out
+    assert tuple(t.shape[:-1]) == tuple(shape_rows) and coff + N <= t.shape[-1] and N % 4 == 0
+    return t, t.shape[-1], coff
+
+
+def _run(ctx, x, lda, C, T, Wp, N, M, mode, geoms, out_t, ldo, coff, bias, bn, act, slope, residual=None,
+         res_ld=0, res_off=0, table=None, a_off=0, count=None):
+    """One logical layer = one or more GEMM launches (`geoms`: list of (geom, Wp, M_launch)), then the
+    BatchNorm finalize/apply pass when batch statistics are needed."""
+    Np = N if N % 4 == 0 else ceil4(N)
+    b, sc, sh, fused = _epilogue_plan(ctx, bias, bn, Np)
+    if fused:
+        for geom, wp, m in geoms:
+            ops.gather_gemm(x, lda, C, T if geom is None else len(geom[7]), wp, Np, m, out_t, ldo, mode=mode,
+                            geom=geom, table=table, bias=b, scale=sc, shift=sh, residual=residual, ldr=res_ld,
+                            act=act, slope=slope, a_off=a_off, out_off=coff, res_off=res_off)
+        return
+    # train-mode BatchNorm: raw conv output + per-block column statistics, then normalise in place
+    gs = [ops.gemm_grid_m(m, Np) for _, _, m in geoms]
+    stats = torch.empty((sum(gs), 2, Np), dtype=torch.float32, device=x.device)
+    g0 = 0
+    for (geom, wp, m), g in zip(geoms, gs):
+        ops.gather_gemm(x, lda, C, T if geom is None else len(geom[7]), wp, Np, m, out_t, ldo, mode=mode, geom=geom,
+                        table=table, bias=b, act=ACT_NONE, stats=stats[g0:g0 + g], a_off=a_off, out_off=coff)
+        g0 += g
+    cnt = count if count is not None else M
+    scale, shift = _bn_train(ctx, bn, stats, sum(gs), Np, float(cnt))
+    ops.scale_shift_act(out_t, ldo, scale, shift, out_t, ldo, M, Np, act, slope, res=residual, ldr=res_ld,
+                        x_off=coff, y_off=coff, res_off=res_off)
+
+
+# ----------------------------------------------------------------------------------------------
+def conv2d(ctx, x, conv, bn=None, act=ACT_NONE, slope=0.0, residual=None, out=None, in_ch=None):
+    """nn.Conv2d (+BatchNorm2d) (+residual) (+activation) on [B][H][W][Cx].
+    in_ch: (coff, C) selects a channel slice of x.  Returns the output buffer [B][Ho][Wo][ld]."""
+    B, H, W, ldx = x.shape
+    Cw, O = conv.in_channels, conv.out_channels
+    kh, kw = conv.kernel_size
+    sh, sw = conv.stride
+    ph, pw = conv.padding
+    a_off, Cx = in_ch if in_ch is not None else (0, ldx)
+    Cp = ceil4(Cw)
+    assert Cx == Cp, (Cx, Cw)
+    Ho, Wo = (H + 2 * ph - kh) // sh + 1, (W + 2 * pw - kw) // sw + 1
+    T = kh * kw
+    Np = ceil4(O)
+    Wp = ops.pack_weight(conv.weight, O, T, Cw, Cw * T, T, 1, list(range(T)), Np=Np, Cp=Cp, key=('conv', Np, Cp))
+    dh = [i // kw - ph for i in range(T)]
+    dw = [i % kw - pw for i in range(T)]
+    geom = (B, H, W, Ho, Wo, sh, sw, dh, dw, Ho, Wo, 1, 1, 0, 0)
+    out_t, ldo, coff = _alloc_out(x, (B, Ho, Wo), O, out)
+    M = B * Ho * Wo
+    res_ld = residual.shape[-1] if residual is not None else 0
+    _run(ctx, x, ldx, Cp, T, Wp, O, M, 1, [(geom, Wp, M)], out_t, ldo, coff, conv.bias, bn, act, slope,
+         residual=residual, res_ld=res_ld, a_off=a_off)
+    return out_t
+
+
+def conv_transpose2d(ctx, x, convt, bn=None, act=ACT_NONE, slope=0.0, out=None):
+    """nn.ConvTranspose2d(k=3, s=2) as four stride-1 sub-convolutions, one per output parity class."""
+    B, H, W, ldx = x.shape
+    Cw, O = convt.in_channels, convt.out_channels
+    assert convt.kernel_size == (3, 3) and convt.stride == (2, 2) and ldx == Cw and Cw % 4 == 0
+    ph, pw = convt.padding
+    oph, opw = convt.output_padding
+    Ho, Wo = (H - 1) * 2 - 2 * ph + 3 + oph, (W - 1) * 2 - 2 * pw + 3 + opw
+    Np = ceil4(O)
+    out_t, ldo, coff = _alloc_out(x, (B, Ho, Wo), O, out)
+    geoms = []
+    for cy in range(2):
+        for cx in range(2):
+            khs = [k for k in range(3) if (cy + ph - k) % 2 == 0]
+            kws = [k for k in range(3) if (cx + pw - k) % 2 == 0]
+            taps = [(a, b) for a in khs for b in kws]
+            Hv, Wv = (Ho - cy + 1) // 2, (Wo - cx + 1) // 2
+            if Hv <= 0 or Wv <= 0:
+                continue
+            dh = [(cy + ph - a) // 2 for a, _ in taps]
+            dw = [(cx + pw - b) // 2 for _, b in taps]
+            tapidx = [a * 3 + b for a, b in taps]
+            # ConvTranspose2d weight is (in, out, kh, kw)
+            Wp = ops.pack_weight(convt.weight, O, len(taps), Cw, 9, O * 9, 1, tapidx, Np=Np,
+                                 key=('convt', cy, cx, ph, pw, Np))
+            geom = (B, H, W, Hv, Wv, 1, 1, dh, dw, Ho, Wo, 2, 2, cy, cx)
+            geoms.append((geom, Wp, B * Hv * Wv))
+    _run(ctx, x, ldx, Cw, 0, None, O, B * Ho * Wo, 1, geoms, out_t, ldo, coff, convt.bias, bn, act, slope)
+    return out_t
+
+
+def linear_rows(ctx, x, M, C, weight, bias, bn=None, act=ACT_NONE, slope=0.0, out=None, lda=None, a_off=0,
+                count=None):
+    """rows [M][lda] x (O, C[,1]) weight -> [M][ld]: nn.Linear / nn.Conv1d(k=1) (+BatchNorm1d) (+act)."""
+    O = weight.shape[0]
+    Cp = ceil4(C)
+    lda = lda if lda is not None else x.shape[-1]
+    Np = ceil4(O)
+    Wp = ops.pack_weight(weight, O, 1, C, C, 1, 1, [0], Np=Np, Cp=Cp, key=('lin', Np, Cp))
+    if out is None:
+        out_t = torch.empty((M, Np), dtype=torch.float32, device=x.device)
+        ldo, coff = Np, 0
+    else:
+        out_t, coff = out
+        ldo = out_t.shape[-1]
+    _run(ctx, x, lda, Cp, 1, Wp, O, M, 0, [(None, Wp, M)], out_t, ldo, coff, bias, bn, act, slope, a_off=a_off,
+         count=count)
+    return out_t
+
+
+def blur_conv(ctx, splat, H, C, table, conv0, conv1, out=None):
+    """BCL blur: gather 15 neighbour rows + Conv2d(C,C0,(15,1)) + ReLU + Conv2d(C0,C1,1)
+    (nets/bilateralNN.py:240-246).  splat [H][C], table [H][16] -> [H][ld]."""
+    C0, C1 = conv0.out_channels, conv1.out_channels
+    Wp0 = ops.pack_weight(conv0.weight, C0, 15, C, C * 15, 15, 1, list(range(15)), key=('blur0',))
+    mid = torch.empty((H, C0), dtype=torch.float32, device=splat.device)
+    ops.gather_gemm(splat, C, C, 15, Wp0, C0, H, mid, C0, mode=2, table=table, bias=conv0.bias.detach(),
+                    act=ACT_RELU)
+    return linear_rows(ctx, mid, H, C0, conv1.weight, conv1.bias, out=out)
+
+
+def maxpool2(ctx, x):
+    return ops.maxpool2(x)
+
+
+# ----------------------------------------------------------------------------------------------
+def run_vgg(ctx, features, x):
+    """nets/vgg.py:69-83: [Conv2d, BatchNorm2d, ReLU]* with 'M' = MaxPool2d(2,2)."""
+    mods = list(features.children())
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, nn.MaxPool2d):
+            x = maxpool2(ctx, x)
+            i += 1
+        else:
+            assert isinstance(m, nn.Conv2d) and isinstance(mods[i + 1], nn.BatchNorm2d)
+            x = conv2d(ctx, x, m, mods[i + 1], ACT_RELU)
+            i += 3
+    return x
+
+
+def run_conv_bn_relu(ctx, seq, x, out=None, in_ch=None):
+    """nets/net_utils.py:45-64: Conv2d(no bias) + BN + LeakyReLU(0.2)."""
+    return conv2d(ctx, x, seq[0], seq[1], ACT_LEAKY, 0.2, out=out, in_ch=in_ch)
+
+
+def run_convt_bn_relu(ctx, seq, x, out=None):
+    """nets/net_utils.py:66-98: ConvT+BN+LeakyReLU(0.2) then Conv3x3+BN+LeakyReLU(0.2)."""
+    y = conv_transpose2d(ctx, x, seq[0], seq[1], ACT_LEAKY, 0.2)
+    return conv2d(ctx, y, seq[3], seq[4], ACT_LEAKY, 0.2, out=out)
+
+
+def run_basic_block(ctx, blk, x, out=None):
+    """nets/resnet.py:55-71."""
+    y = conv2d(ctx, x, blk.conv1, blk.bn1, ACT_RELU)
+    if blk.downsample is not None:
+        idt = conv2d(ctx, x, blk.downsample[0], blk.downsample[1], ACT_NONE)
+    else:
+        idt = x
+    return conv2d(ctx, y, blk.conv2, blk.bn2, ACT_RELU, residual=idt, out=out)
+
+
+def run_resnet_layer(ctx, layer, x, out=None):
+    blocks = list(layer.children())
+    for i, blk in enumerate(blocks):
+        x = run_basic_block(ctx, blk, x, out=out if i == len(blocks) - 1 else None)
+    return x

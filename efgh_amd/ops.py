@@ -1,0 +1,288 @@
+"""Tensor-level wrappers over the C-ABI (include/efgh_hip.h).  torch is used for device memory and
+the stream only; every arithmetic op below runs in libefgh_hip.so.  No CPU fallback."""
+import ctypes
+
+import torch
+
+from . import _C
+from ._C import c_float, c_int32, c_int64, ptr
+
+ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
+
+
+def _L():
+    return _C.lib()
+
+
+def _st():
+    return _C.stream_ptr()
+
+
+def ceil4(n):
+    return (n + 3) // 4 * 4
+
+
+# ----------------------------------------------------------------------------------------------
+# weight packing (cached on the parameter's version counter)
+# ----------------------------------------------------------------------------------------------
+_pack_cache = {}
+
+
+def _cached(key, versions, fn):
+    ent = _pack_cache.get(key)
+    if ent is not None and ent[0] == versions:
+        return ent[1]
+    val = fn()
+    _pack_cache[key] = (versions, val)
+    return val
+
+
+def clear_caches():
+    _pack_cache.clear()
+
+
+def pack_weight(w, N, T, C, sn, sc, st, taps=None, Np=None, Cp=None, key=None):
+    """Wp[n][t][c] = w.flat[n*sn + c*sc + taps[t]*st]; optionally zero-padded to (Np, T, Cp)."""
+    Np = Np or N
+    Cp = Cp or C
+
+    def make():
+        wd = w.detach()
+        _C.require_cuda(wd)
+        wd = wd.contiguous()
+        out = torch.empty((N, T, C), dtype=torch.float32, device=wd.device)
+        tp = (ctypes.c_int32 * 16)(*([int(t) for t in taps] + [0] * (16 - len(taps)))) if taps is not None else None
+        _C.check(_L().efgh_pack_weight(ptr(wd), ptr(out), c_int32(N), c_int32(T), c_int32(C), c_int64(sn),
+                                       c_int64(sc), c_int64(st), tp, _st()))
+        if Np != N or Cp != C:
+            full = torch.zeros((Np, T, Cp), dtype=torch.float32, device=wd.device)
+            full[:N, :, :C] = out
+            out = full
+        return out
+
+    if key is None:
+        return make()
+    return _cached((id(w),) + tuple(key), w._version, make)
+
+
+def pad_vec(v, Np, fill=0.0):
+    if v is None or v.numel() == Np:
+        return v
+    out = torch.full((Np,), fill, dtype=torch.float32, device=v.device)
+    out[:v.numel()] = v.detach()
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# gather-GEMM
+# ----------------------------------------------------------------------------------------------
+def gemm_grid_m(M, N):
+    return _L().efgh_gather_gemm_grid_m(c_int64(M), c_int32(N))
+
+
+def gather_gemm(A, lda, C, T, Wp, N, M, out, ldo, mode=0, geom=None, table=None, bias=None, scale=None,
+                shift=None, residual=None, ldr=0, act=ACT_NONE, slope=0.0, stats=None, a_off=0, out_off=0,
+                res_off=0, M_dev=None):
+    """See efgh_gemm_desc.  A/out/residual may be addressed with an element offset (channel slices)."""
+    d = _C.GemmDesc()
+    es = 4
+    d.A = A.data_ptr() + a_off * es
+    d.lda, d.C, d.T, d.mode = lda, C, T, mode
+    if geom is not None:
+        (d.B, d.Hin, d.Win, d.Hv, d.Wv, d.sh, d.sw, dh, dw, d.Ho, d.Wo, d.osh, d.osw, d.oh0, d.ow0) = geom
+        for i, (a, b) in enumerate(zip(dh, dw)):
+            d.dh[i], d.dw[i] = a, b
+    d.table = 0 if table is None else table.data_ptr()
+    d.W, d.N, d.M = Wp.data_ptr(), N, M
+    d.M_dev = 0 if M_dev is None else M_dev.data_ptr()
+    d.bias = 0 if bias is None else bias.data_ptr()
+    d.scale = 0 if scale is None else scale.data_ptr()
+    d.shift = 0 if shift is None else shift.data_ptr()
+    d.residual = 0 if residual is None else residual.data_ptr() + res_off * es
+    d.ldr, d.act, d.slope = ldr, act, slope
+    d.out = out.data_ptr() + out_off * es
+    d.ldo = ldo
+    d.stats = 0 if stats is None else stats.data_ptr()
+    _C.check(_L().efgh_gather_gemm(ctypes.byref(d), _st()))
+
+
+# ----------------------------------------------------------------------------------------------
+# BatchNorm / elementwise
+# ----------------------------------------------------------------------------------------------
+def bn_finalize(stats, G, C, count, gamma, beta, rmean, rvar, momentum, eps, save=False):
+    dev = stats.device
+    scale = torch.empty(C, dtype=torch.float32, device=dev)
+    shift = torch.empty(C, dtype=torch.float32, device=dev)
+    sm = torch.empty(C, dtype=torch.float32, device=dev) if save else None
+    si = torch.empty(C, dtype=torch.float32, device=dev) if save else None
+    _C.check(_L().efgh_bn_finalize(ptr(stats), c_int32(G), c_int32(C), ctypes.c_double(count), ptr(gamma), ptr(beta),
+                                   ptr(rmean), ptr(rvar), c_float(momentum), c_float(eps), ptr(scale), ptr(shift),
+                                   ptr(sm), ptr(si), _st()))
+    return scale, shift, sm, si
+
+
+def col_stats(x, M, C, ld, x_off=0):
+    G = _L().efgh_col_stats_groups(c_int64(M))
+    stats = torch.empty((G, 2, C), dtype=torch.float32, device=x.device)
+    _C.check(_L().efgh_col_stats(_C.c_void_p(x.data_ptr() + 4 * x_off), c_int64(M), c_int32(C), c_int64(ld),
+                                 ptr(stats), _st()))
+    return stats, G
+
+
+def scale_shift_act(x, ldx, scale, shift, y, ldy, M, C, act=ACT_NONE, slope=0.0, res=None, ldr=0, x_off=0,
+                    y_off=0, res_off=0):
+    _C.check(_L().efgh_scale_shift_act(
+        _C.c_void_p(x.data_ptr() + 4 * x_off), c_int64(ldx), ptr(scale), ptr(shift),
+        _C.c_void_p(0 if res is None else res.data_ptr() + 4 * res_off), c_int64(ldr),
+        _C.c_void_p(y.data_ptr() + 4 * y_off), c_int64(ldy), c_int64(M), c_int32(C), c_int32(act), c_float(slope),
+        _st()))
+
+
+def maxpool2(x):
+    B, H, W, C = x.shape
+    y = torch.empty((B, H // 2, W // 2, C), dtype=torch.float32, device=x.device)
+    _C.check(_L().efgh_maxpool2(ptr(x), ptr(y), c_int32(B), c_int32(H), c_int32(W), c_int32(C), _st()))
+    return y
+
+
+def nchw_to_nhwc(x, Cd=None):
+    _C.require_cuda(x)
+    x = x.contiguous()
+    B, Cs = x.shape[0], x.shape[1]
+    sp = tuple(x.shape[2:])
+    HW = 1
+    for s in sp:
+        HW *= s
+    Cd = Cd or Cs
+    y = torch.empty((B,) + sp + (Cd,), dtype=torch.float32, device=x.device)
+    _C.check(_L().efgh_nchw_to_nhwc(ptr(x), ptr(y), c_int32(B), c_int32(Cs), c_int64(HW), c_int32(Cd), _st()))
+    return y
+
+
+def nhwc_to_nchw(x, Cs=None):
+    B, ld = x.shape[0], x.shape[-1]
+    sp = tuple(x.shape[1:-1])
+    HW = 1
+    for s in sp:
+        HW *= s
+    Cs = Cs or ld
+    y = torch.empty((B, Cs) + sp, dtype=torch.float32, device=x.device)
+    _C.check(_L().efgh_nhwc_to_nchw(ptr(x), c_int64(ld), ptr(y), c_int32(B), c_int32(Cs), c_int64(HW), _st()))
+    return y
+
+
+def segment_colmax(x, ld, C, seg, nseg, want_arg=False):
+    y = torch.empty((nseg, C), dtype=torch.float32, device=x.device)
+    arg = torch.empty((nseg, C), dtype=torch.int32, device=x.device) if want_arg else None
+    _C.check(_L().efgh_segment_colmax(ptr(x), c_int64(ld), c_int32(C), ptr(seg), c_int32(nseg), ptr(y), ptr(arg),
+                                      _st()))
+    return y, arg
+
+
+def segment_colmean(x, ld, C, rows_per_seg, nseg):
+    y = torch.empty((nseg, C), dtype=torch.float32, device=x.device)
+    _C.check(_L().efgh_segment_colmean(ptr(x), c_int64(ld), c_int32(C), c_int32(rows_per_seg), c_int32(nseg),
+                                       ptr(y), _st()))
+    return y
+
+
+def softmax2_to_nchw(x):
+    B, H, W, ld = x.shape
+    y = torch.empty((B, 2, H, W), dtype=torch.float32, device=x.device)
+    _C.check(_L().efgh_softmax2_to_nchw(ptr(x), c_int64(ld), ptr(y), c_int32(B), c_int64(H * W), _st()))
+    return y
+
+
+# ----------------------------------------------------------------------------------------------
+# BCL splat
+# ----------------------------------------------------------------------------------------------
+def splat_fwd(feat, C, bary, off, H):
+    n = feat.shape[0]
+    splat = torch.empty((H, C), dtype=torch.float32, device=feat.device)
+    wsum = torch.empty((H,), dtype=torch.float32, device=feat.device)
+    _C.check(_L().efgh_splat_fwd(ptr(feat), c_int64(feat.stride(0)), c_int32(C), ptr(bary), ptr(off), c_int32(n),
+                                 c_int32(H), ptr(splat), ptr(wsum), _st()))
+    return splat, wsum
+
+
+def splat_bwd(gsplat, wsum, C, bary, off, n, H, gfeat):
+    _C.check(_L().efgh_splat_bwd(ptr(gsplat), ptr(wsum), c_int32(C), ptr(bary), ptr(off), c_int32(n), c_int32(H),
+                                 ptr(gfeat), c_int64(gfeat.stride(0)), _st()))
+
+
+# ----------------------------------------------------------------------------------------------
+# rasterisers, rotate
+# ----------------------------------------------------------------------------------------------
+def range_image(pc, e_l, H, W, fov_up, fov_down):
+    """pc (B,3,N), e_l (B,4,4) -> img [B][H][W][4], pix (B,N)"""
+    _C.require_cuda(pc, e_l)
+    pc, e_l = pc.contiguous(), e_l.detach().contiguous()
+    B, _, N = pc.shape
+    dev = pc.device
+    pix = torch.empty((B, N), dtype=torch.int32, device=dev)
+    vals = torch.empty((B, N, 4), dtype=torch.float32, device=dev)
+    win = torch.empty((B, H * W), dtype=torch.int32, device=dev)
+    img = torch.empty((B, H, W, 4), dtype=torch.float32, device=dev)
+    _C.check(_L().efgh_range_image(ptr(pc), ptr(e_l), c_int32(B), c_int32(N), c_int32(H), c_int32(W),
+                                   ctypes.c_double(fov_up), ctypes.c_double(fov_down), ptr(pix), ptr(vals),
+                                   ptr(win), ptr(img), _st()))
+    return img, pix
+
+
+def depth_image(pc, cam_T_velo, H, W):
+    _C.require_cuda(pc, cam_T_velo)
+    pc, P = pc.contiguous(), cam_T_velo.detach().contiguous()
+    B, _, N = pc.shape
+    dev = pc.device
+    pix = torch.empty((B, N), dtype=torch.int32, device=dev)
+    vals = torch.empty((B, N, 4), dtype=torch.float32, device=dev)
+    win = torch.empty((B, H * W), dtype=torch.int32, device=dev)
+    img = torch.empty((B, H, W, 4), dtype=torch.float32, device=dev)
+    _C.check(_L().efgh_depth_image(ptr(pc), ptr(P), c_int32(B), c_int32(N), c_int32(H), c_int32(W), ptr(pix),
+                                   ptr(vals), ptr(win), ptr(img), _st()))
+    return img, pix
+
+
+def rotate_nearest_u8(img, rot_deg, want_nchw=True, want_nhwc4=True):
+    _C.require_cuda(img, rot_deg)
+    img = img.detach().contiguous()
+    B, _, H, W = img.shape
+    o1 = torch.empty((B, 3, H, W), dtype=torch.float32, device=img.device) if want_nchw else None
+    o2 = torch.empty((B, H, W, 4), dtype=torch.float32, device=img.device) if want_nhwc4 else None
+    _C.check(_L().efgh_rotate_nearest_u8(ptr(img), ptr(rot_deg.detach().contiguous().float()), c_int32(B), c_int32(H),
+                                         c_int32(W), ptr(o1), ptr(o2), _st()))
+    return o1, o2
+
+
+# ----------------------------------------------------------------------------------------------
+# F correlation head
+# ----------------------------------------------------------------------------------------------
+def minmax(x):
+    """x [B][...] -> (B,2) per-sample (min,max)"""
+    B = x.shape[0]
+    n = x.numel() // B
+    G = _L().efgh_minmax_groups(c_int64(n))
+    part = torch.empty((B, G, 2), dtype=torch.float32, device=x.device)
+    mm = torch.empty((B, 2), dtype=torch.float32, device=x.device)
+    _C.check(_L().efgh_minmax(ptr(x), c_int32(B), c_int64(n), ptr(part), ptr(mm), _st()))
+    return mm
+
+
+def corr_head(cam, rng, want_logit=False):
+    """cam [B][h][wc][16], rng [B][h][wr][16] -> f_score (B, wr + 2*(wr//8) - wc + 1)"""
+    B, h, wc, C = cam.shape
+    wr = rng.shape[2]
+    assert C == 16 and rng.shape[1] == h
+    off = int(wr / 8)
+    wp = wr + 2 * off
+    cam_mm, rng_mm = minmax(cam), minmax(rng)
+    rp = torch.empty((B, h, wp, C), dtype=torch.float32, device=cam.device)
+    _C.check(_L().efgh_corr_pad(ptr(rng), ptr(rng_mm), c_int32(B), c_int32(h), c_int32(wr), c_int32(C),
+                                c_int32(off), ptr(rp), _st()))
+    nj = wp - wc + 1
+    part = torch.empty((B, h, nj), dtype=torch.float32, device=cam.device)
+    score = torch.empty((B, nj), dtype=torch.float32, device=cam.device)
+    logit = torch.empty((B, nj), dtype=torch.float32, device=cam.device) if want_logit else None
+    _C.check(_L().efgh_corr1d(ptr(rp), ptr(cam), ptr(cam_mm), c_int32(B), c_int32(h), c_int32(wc), c_int32(wp),
+                              ptr(part), ptr(logit), ptr(score), _st()))
+    return score, logit

@@ -71,8 +71,8 @@ int efgh_lattice_neighbors(const int32_t *vkeys, const int32_t *minmax, const in
  * replaces SparseSum + density normalisation, nets/bilateralNN.py:6-40, 179-211.
  * feat [n_in][ldf] (first C columns used), bary [4][n_in], off [4][n_in]  ->
  * splat [H][C]  (row h = reference row h+1; the reference's all-zero row 0 is represented by
- * neighbour index -1), already multiplied by 1/(sum_bary + 1e-5).  wsum [H] scratch.
- * Contributions are summed in point order per vertex -> run-to-run deterministic.          */
+ * neighbour index -1), already multiplied by 1/(sum_bary + 1e-5).  wsum [H] holds the density
+ * (kept for backward).                                                                     */
 int efgh_splat_fwd(const float *feat, int64_t ldf, int32_t C, const float *bary,
                    const int32_t *off, int32_t n_in, int32_t H, float *splat, float *wsum,
                    void *stream);
@@ -123,6 +123,69 @@ int32_t efgh_gather_gemm_grid_m(int64_t M, int32_t N);      /* rows of `stats` *
 /* Wp[n][t][c] = W[n*sn + c*sc + tapidx[t]*st]   (weight re-layout for the kernel above) */
 int efgh_pack_weight(const float *W, float *Wp, int32_t N, int32_t T, int32_t C, int64_t sn,
                      int64_t sc, int64_t st, const int32_t *tapidx_host, void *stream);
+
+/* ------------------------------------------------------------------ BatchNorm / elementwise --
+ * replaces nn.BatchNorm1d/2d + ReLU/LeakyReLU + residual add + nn.MaxPool2d(2,2) as composed in
+ * nets/vgg.py:69-83, nets/resnet.py:55-71, nets/net_utils.py:45-98, nets/enet.py:150-152.     */
+
+/* reduce the GEMM epilogue's per-block (sum,sumsq) partials [G][2][C] to the affine
+ * y = x*scale + shift of train-mode BatchNorm; updates running_mean/var (momentum form, unbiased
+ * variance) when rmean != NULL; save_mean/save_invstd (optional) are kept for backward.       */
+int efgh_bn_finalize(const float *stats, int32_t G, int32_t C, double count, const float *gamma,
+                     const float *beta, float *rmean, float *rvar, float momentum, float eps,
+                     float *scale, float *shift, float *save_mean, float *save_invstd, void *stream);
+/* same partials for a matrix that was not produced by the GEMM: stats [groups(M)][2][C] */
+int32_t efgh_col_stats_groups(int64_t M);
+int efgh_col_stats(const float *x, int64_t M, int32_t C, int64_t ld, float *stats, void *stream);
+/* y[r][c] = act(x[r][c]*scale[c] + shift[c] + res[r][c]); scale/shift/res optional */
+int efgh_scale_shift_act(const float *x, int64_t ldx, const float *scale, const float *shift,
+                         const float *res, int64_t ldr, float *y, int64_t ldy, int64_t M, int32_t C,
+                         int32_t act, float slope, void *stream);
+int efgh_maxpool2(const float *x, float *y, int32_t B, int32_t H, int32_t W, int32_t C, void *stream);
+/* model-boundary layout changes: (B,Cs,H,W) <-> [B][H][W][Cd] (extra channels zero) */
+int efgh_nchw_to_nhwc(const float *x, float *y, int32_t B, int32_t Cs, int64_t HW, int32_t Cd, void *stream);
+int efgh_nhwc_to_nchw(const float *x, int64_t ld, float *y, int32_t B, int32_t Cs, int64_t HW, void *stream);
+/* torch.max(x, 2) over ragged segments of rows (enet.py:154, hnet.py:53): y[s][c], argrow opt. */
+int efgh_segment_colmax(const float *x, int64_t ld, int32_t C, const int32_t *seg, int32_t nseg,
+                        float *y, int32_t *argrow, void *stream);
+/* torch.mean(x, 2) over equal segments (gnet.py:165) */
+int efgh_segment_colmean(const float *x, int64_t ld, int32_t C, int32_t rows_per_seg, int32_t nseg,
+                         float *y, void *stream);
+/* nn.Softmax(dim=1) over 2 channels, written planar (B,2,H,W) (gnet.py:124) */
+int efgh_softmax2_to_nchw(const float *x, int64_t ld, float *y, int32_t B, int64_t HW, void *stream);
+
+/* ------------------------------------------------------------------ rasterisers / rotate ----
+ * range image: common/torch_utils.py:11-59 applied to e_l.[pc;1] (nets/fnet.py:43-45).
+ * pc [B][3][N], e_l [B][4][4] -> img [B][H][W][4] = (x,y,z,r); duplicates: last point wins.
+ * pix [B][N] (pixel of each point or -1), vals [B][N][4] and winner [B][H*W] are caller scratch;
+ * pix is what efgh_raster_bwd needs.                                                          */
+int efgh_range_image(const float *pc, const float *e_l, int32_t B, int32_t N, int32_t H, int32_t W,
+                     double fov_up, double fov_down, int32_t *pix, float *vals, int32_t *winner,
+                     float *img, void *stream);
+/* depth image: common/torch_utils.py:61-103; cam_T_velo [B][3][4]; img = (px,py,pz,w) */
+int efgh_depth_image(const float *pc, const float *cam_T_velo, int32_t B, int32_t N, int32_t H,
+                     int32_t W, int32_t *pix, float *vals, int32_t *winner, float *img, void *stream);
+/* d(values)/d(img): gvals[b][i] = gimg[b][pix[b][i]] for every rasterised point */
+int efgh_raster_bwd(const int32_t *pix, const float *gimg, int32_t B, int32_t N, int64_t HW,
+                    float *gvals, void *stream);
+/* PIL.Image.rotate(angle) NEAREST on uint8 (common/torch_utils.py:235-254): img (B,3,H,W) float
+ * holding 0..255, rot_deg [B] degrees (fp32, as torch_utils.py:245 computes it);
+ * out_nchw (B,3,H,W) and/or out_nhwc4 [B][H][W][4] (4th channel 0).                           */
+int efgh_rotate_nearest_u8(const float *img, const float *rot_deg, int32_t B, int32_t H, int32_t W,
+                           float *out_nchw, float *out_nhwc4, void *stream);
+
+/* ------------------------------------------------------------------ F correlation head ------
+ * nets/fnet.py:57,64,78-81 and circular_assign_torch, common/torch_utils.py:271-284.         */
+int32_t efgh_minmax_groups(int64_t n);
+/* per-sample global (min,max): x [B][n] -> mm [B][2]; part [B][groups][2] scratch */
+int efgh_minmax(const float *x, int32_t B, int64_t n, float *part, float *mm, void *stream);
+/* rp [B][h][w+2*off][C] = pad(rng / (max-min)) : mirror on the left, circular on the right */
+int efgh_corr_pad(const float *rng, const float *rng_mm, int32_t B, int32_t h, int32_t w, int32_t C,
+                  int32_t off, float *rp, void *stream);
+/* score [B][wp-wc+1] = sigmoid(corr / 16); cam [B][h][wc][16] is divided by (max-min) on the fly;
+ * part [B][h][wp-wc+1] scratch; logit optional (pre-sigmoid, for tests / backward)           */
+int efgh_corr1d(const float *rp, const float *cam, const float *cam_mm, int32_t B, int32_t h,
+                int32_t wc, int32_t wp, float *part, float *logit, float *score, void *stream);
 
 #ifdef __cplusplus
 }

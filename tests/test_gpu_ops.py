@@ -1,0 +1,188 @@
+"""Unit parity of the HIP ops (through the C-ABI) against torch fp32 CPU references."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def _rel(a, b):
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+@pytest.fixture(scope='module')
+def L():
+    from efgh_amd.nets import layers
+    return layers
+
+
+@pytest.mark.parametrize('cin,cout,k,s,p,hw', [
+    (64, 64, 3, 1, 1, (24, 40)), (64, 128, 3, 2, 1, (24, 40)), (64, 128, 1, 2, 0, (24, 40)),
+    (3, 64, 3, 1, 1, (16, 24)), (128, 256, 3, 1, 1, (9, 13)), (4, 32, 3, 2, 1, (20, 28)),
+    (512, 512, 1, 1, 0, (6, 10)), (16, 16, 3, 1, 1, (29, 61)), (1, 1, 3, 1, 1, (16, 24)),
+    (260, 72, 3, 1, 1, (7, 9)),
+])
+@pytest.mark.parametrize('train', [False, True])
+def test_conv_bn_act(L, cin, cout, k, s, p, hw, train):
+    torch.manual_seed(0)
+    conv = nn.Conv2d(cin, cout, k, s, p, bias=True)
+    bn = nn.BatchNorm2d(cout)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.2)
+        bn.running_mean.normal_(0, 0.2); bn.running_var.uniform_(0.5, 1.5)
+    x = torch.randn(2, cin, *hw)
+    bn.train(train)
+    ref = F.leaky_relu(bn(conv(x)), 0.2)
+    rm_ref, rv_ref = bn.running_mean.clone(), bn.running_var.clone()
+    # reset running stats, run ours
+    conv_g, bn_g = nn.Conv2d(cin, cout, k, s, p, bias=True).cuda(), nn.BatchNorm2d(cout).cuda()
+    conv_g.load_state_dict(conv.state_dict())
+    torch.manual_seed(0)
+    bn2 = nn.BatchNorm2d(cout)
+    with torch.no_grad():
+        nn.Conv2d(cin, cout, k, s, p, bias=True)       # consume the same RNG stream
+        bn2.weight.uniform_(0.5, 1.5); bn2.bias.normal_(0, 0.2)
+        bn2.running_mean.normal_(0, 0.2); bn2.running_var.uniform_(0.5, 1.5)
+    bn_g.load_state_dict(bn2.state_dict())
+    bn_g.train(train)
+    from efgh_amd import ops
+    xg = ops.nchw_to_nhwc(x.cuda(), (cin + 3) // 4 * 4)
+    y = L.conv2d(L.Ctx(train), xg, conv_g, bn_g, L.ACT_LEAKY, 0.2)
+    got = y[..., :cout].permute(0, 3, 1, 2).cpu()
+    assert _rel(got, ref) < 2e-5
+    if train:
+        assert _rel(bn_g.running_mean.cpu(), rm_ref) < 1e-5 and _rel(bn_g.running_var.cpu(), rv_ref) < 1e-5
+
+
+@pytest.mark.parametrize('cin,cout,pad,opad,hw', [(512, 128, 1, 0, (4, 8)), (128, 32, 0, 0, (7, 15)),
+                                                  (32, 16, 1, 0, (15, 31)), (512, 256, 1, 1, (6, 10)),
+                                                  (128, 1, 1, 1, (12, 20)), (128, 2, 1, 1, (12, 20))])
+@pytest.mark.parametrize('train', [False, True])
+def test_conv_transpose(L, cin, cout, pad, opad, hw, train):
+    torch.manual_seed(1)
+    ct = nn.ConvTranspose2d(cin, cout, 3, 2, pad, opad, bias=False)
+    bn = nn.BatchNorm2d(cout)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.2)
+        bn.running_mean.normal_(0, 0.2); bn.running_var.uniform_(0.5, 1.5)
+    sd_bn = {k: v.clone() for k, v in bn.state_dict().items()}
+    x = torch.randn(2, cin, *hw)
+    bn.train(train)
+    ref = F.leaky_relu(bn(ct(x)), 0.2)
+    ct_g, bn_g = nn.ConvTranspose2d(cin, cout, 3, 2, pad, opad, bias=False).cuda(), nn.BatchNorm2d(cout).cuda()
+    ct_g.load_state_dict(ct.state_dict()); bn_g.load_state_dict(sd_bn); bn_g.train(train)
+    y = L.conv_transpose2d(L.Ctx(train), _nhwc(x).cuda(), ct_g, bn_g, L.ACT_LEAKY, 0.2)
+    got = y[..., :cout].permute(0, 3, 1, 2).cpu()
+    assert got.shape == ref.shape
+    assert _rel(got, ref) < 2e-5
+
+
+def test_conv_1x2_and_residual_and_concat(L):
+    torch.manual_seed(2)
+    from efgh_amd import ops
+    conv = nn.Conv2d(4, 3, (1, 2), 1, 0, bias=False)
+    x = torch.randn(1, 4, 8, 33)
+    ref = conv(x)
+    y = L.conv2d(L.Ctx(False), _nhwc(x).cuda(), conv.cuda(), None)
+    assert _rel(y[..., :3].permute(0, 3, 1, 2).cpu(), ref) < 1e-5
+    assert float(y[..., 3].abs().max()) == 0.0
+    # residual + relu into a channel slice of a wider buffer, reading a channel slice
+    c2 = nn.Conv2d(64, 64, 3, 1, 1, bias=False)
+    xin, res = torch.randn(2, 128, 10, 12), torch.randn(2, 64, 10, 12)
+    ref = F.relu(c2(xin[:, 64:]) + res)
+    buf = torch.full((2, 10, 12, 192), 7.0).cuda()
+    L.conv2d(L.Ctx(False), _nhwc(xin).cuda(), c2.cuda(), None, L.ACT_RELU, residual=_nhwc(res).cuda(),
+             out=(buf, 64), in_ch=(64, 64))
+    assert _rel(buf[..., 64:128].permute(0, 3, 1, 2).cpu(), ref) < 1e-5
+    assert float((buf[..., :64] - 7).abs().max()) == 0 and float((buf[..., 128:] - 7).abs().max()) == 0
+
+
+def test_maxpool_linear_colmax(L):
+    from efgh_amd import ops
+    torch.manual_seed(3)
+    x = torch.randn(2, 8, 10, 14)
+    assert torch.equal(ops.maxpool2(_nhwc(x).cuda()).permute(0, 3, 1, 2).cpu(), F.max_pool2d(x, 2, 2))
+    lin = nn.Linear(128, 32)
+    a = torch.randn(5, 128)
+    y = L.linear_rows(L.Ctx(False), a.cuda(), 5, 128, lin.cuda().weight, lin.bias, act=L.ACT_RELU)
+    assert _rel(y.cpu(), F.relu(F.linear(a, lin.weight.cpu(), lin.bias.cpu()))) < 1e-5
+    m = torch.randn(37, 128)
+    seg = torch.tensor([0, 10, 37], dtype=torch.int32).cuda()
+    mx, _ = ops.segment_colmax(m.cuda(), 128, 128, seg, 2)
+    assert torch.equal(mx.cpu(), torch.stack([m[:10].max(0)[0], m[10:].max(0)[0]]))
+
+
+def test_splat_and_blur(golden_dir):
+    """BCL level: splat + normalise + neighbour gather + blur conv vs the oracle's bcl()."""
+    from efgh_amd import lattice, ops, synthetic as syn
+    from efgh_amd.nets import layers as L
+    from efgh_amd.nets.builders import BilateralConvFlex
+    from oracle import efgh_oracle as O, lattice as olat
+    torch.manual_seed(4)
+    pc = syn.lidar_sweep(2048, 2)
+    ref_lv = olat.generate_data(pc)[0]
+    lv = lattice.build_pyramid(torch.from_numpy(pc).cuda(), (1.0,))[0]
+    C = 36
+    feat = torch.randn(2048, C)
+    m = BilateralConvFlex(C, [32, 48])
+    with torch.no_grad():
+        for p in m.parameters():
+            p.normal_(0, 0.2)
+    P = {'b.' + k: v for k, v in m.state_dict().items()}
+    ref = O.bcl(P, 'b', feat.t().contiguous(), torch.from_numpy(ref_lv['bary']), torch.from_numpy(ref_lv['off']),
+                torch.from_numpy(ref_lv['nbr']))
+    m = m.cuda()
+    splat, _ = ops.splat_fwd(feat.cuda(), C, lv.bary, lv.off, lv.H)
+    out = L.blur_conv(L.Ctx(False), splat, lv.H, C, lv.nbr, m.blur_conv[0], m.blur_conv[2])
+    assert _rel(out[:, :48].t().cpu(), ref) < 2e-5
+
+
+def test_rotate_golden(golden_dir):
+    import os
+    from efgh_amd import ops
+    R = np.load(os.path.join(golden_dir, 'rotate_cases.npz'))
+    for i in range(int(R['count'])):
+        img = torch.from_numpy(R[f'img{i}'].astype(np.float32)).cuda()
+        mat = torch.from_numpy(R[f'mat{i}'])
+        rot_deg = torch.rad2deg(torch.atan2(mat[:, 1, 0], mat[:, 0, 0]))        # CPU fp32, as the reference
+        o1, o2 = ops.rotate_nearest_u8(img, rot_deg.cuda())
+        assert np.array_equal(o1.cpu().numpy().astype(np.uint8), R[f'out{i}']), i
+        assert np.array_equal(o2[..., :3].permute(0, 3, 1, 2).cpu().numpy().astype(np.uint8), R[f'out{i}']), i
+
+
+def test_rasterisers_golden(golden_dir):
+    import os
+    from efgh_amd import ops
+    R = np.load(os.path.join(golden_dir, 'raster_cases.npz'))
+    epc = torch.from_numpy(R['range.pc'])                                      # already e_l-rotated, (1,4,N)
+    eye = torch.eye(4)[None]
+    img, pix = ops.range_image(epc[:, :3].cuda(), eye.cuda(), 32, 256, 0.125 * math.pi, -0.125 * math.pi)
+    got = img.permute(0, 3, 1, 2).cpu().numpy()
+    bad = (np.abs(got - R['range.out']).max(1) > 1e-5).mean()
+    assert bad < 2e-3, bad
+    dep, _ = ops.depth_image(torch.from_numpy(R['depth.pc']).cuda(), torch.from_numpy(R['depth.calib']).cuda(), 64, 128)
+    got = dep.permute(0, 3, 1, 2).cpu().numpy()
+    bad = (np.abs(got - R['depth.out']).max(1) > 1e-5).mean()
+    assert bad < 2e-3, bad
+
+
+def test_corr_head():
+    from efgh_amd import ops
+    from oracle import efgh_oracle as O
+    torch.manual_seed(5)
+    cam, rng = torch.randn(2, 16, 29, 61), torch.randn(2, 16, 29, 245)
+    score, logit = ops.corr_head(_nhwc(cam).cuda(), _nhwc(rng).cuda(), want_logit=True)
+    for b in range(2):
+        c = cam[b:b + 1] / (cam[b].max() - cam[b].min())
+        r = rng[b:b + 1] / (rng[b].max() - rng[b].min())
+        ref = F.conv2d(O.circular_assign(r, int(245 / 8)), c).view(-1) / 16
+        assert _rel(logit[b].cpu(), ref) < 2e-5
+        assert _rel(score[b].cpu(), torch.sigmoid(ref)) < 2e-5
