@@ -20,8 +20,8 @@ class Ctx:
 
 def _bn_eval_affine(bn, Np):
     """eval-mode BatchNorm as y = x*scale + shift, cached on the buffers' versions."""
-    key = (id(bn), 'bn_eval', Np)
-    vers = (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version)
+    key = ('bn_eval', Np)
+    vers = ops._ver(bn.weight, bn.bias, bn.running_mean, bn.running_var)
 
     def make():
         with torch.no_grad():
@@ -29,7 +29,7 @@ def _bn_eval_affine(bn, Np):
             shift = bn.bias.detach() - bn.running_mean * scale
         return ops.pad_vec(scale, Np), ops.pad_vec(shift, Np)
 
-    return ops._cached(key, vers, make)
+    return ops._cached(bn, key, vers, make)
 
 
 def _bias_vec(bias, Np):
@@ -37,7 +37,7 @@ def _bias_vec(bias, Np):
         return None
     if bias.numel() == Np:
         return bias.detach()
-    return ops._cached((id(bias), 'bias', Np), bias._version, lambda: ops.pad_vec(bias, Np))
+    return ops._cached(bias, ('bias', Np), ops._ver(bias), lambda: ops.pad_vec(bias, Np))
 
 
 def _bn_train(ctx, bn, stats, G, Np, count):

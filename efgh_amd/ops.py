@@ -25,20 +25,19 @@ def ceil4(n):
 # ----------------------------------------------------------------------------------------------
 # weight packing (cached on the parameter's version counter)
 # ----------------------------------------------------------------------------------------------
-_pack_cache = {}
-
-
-def _cached(key, versions, fn):
-    ent = _pack_cache.get(key)
+def _cached(owner, key, versions, fn):
+    """memoise `fn()` on the owning tensor / module itself (never on id(): ids are recycled)"""
+    store = owner.__dict__.setdefault('_efgh_cache', {})
+    ent = store.get(key)
     if ent is not None and ent[0] == versions:
         return ent[1]
     val = fn()
-    _pack_cache[key] = (versions, val)
+    store[key] = (versions, val)
     return val
 
 
-def clear_caches():
-    _pack_cache.clear()
+def _ver(*tensors):
+    return tuple((t._version, t.data_ptr()) for t in tensors)
 
 
 def pack_weight(w, N, T, C, sn, sc, st, taps=None, Np=None, Cp=None, key=None):
@@ -62,7 +61,7 @@ def pack_weight(w, N, T, C, sn, sc, st, taps=None, Np=None, Cp=None, key=None):
 
     if key is None:
         return make()
-    return _cached((id(w),) + tuple(key), w._version, make)
+    return _cached(w, tuple(key), _ver(w), make)
 
 
 def pad_vec(v, Np, fill=0.0):
