@@ -84,16 +84,20 @@ def _alloc_out(x, shape_rows, N, out):
 
 
 def _run(ctx, x, lda, C, T, Wp, N, M, mode, geoms, out_t, ldo, coff, bias, bn, act, slope, residual=None,
-         res_ld=0, res_off=0, table=None, a_off=0, count=None):
+         res_ld=0, res_off=0, table=None, a_off=0, count=None, c_real=None):
     """One logical layer = one or more GEMM launches (`geoms`: list of (geom, Wp, M_launch)), then the
     BatchNorm finalize/apply pass when batch statistics are needed."""
     Np = N if N % 4 == 0 else ceil4(N)
     b, sc, sh, fused = _epilogue_plan(ctx, bias, bn, Np)
+    cr = c_real if c_real is not None else C
+
+    def fl(geom, m):       # algorithmic FLOPs of one launch: real (unpadded) channel counts
+        return 2.0 * m * N * (T if geom is None else len(geom[7])) * cr
     if fused:
         for geom, wp, m in geoms:
             ops.gather_gemm(x, lda, C, T if geom is None else len(geom[7]), wp, Np, m, out_t, ldo, mode=mode,
                             geom=geom, table=table, bias=b, scale=sc, shift=sh, residual=residual, ldr=res_ld,
-                            act=act, slope=slope, a_off=a_off, out_off=coff, res_off=res_off)
+                            act=act, slope=slope, a_off=a_off, out_off=coff, res_off=res_off, flops=fl(geom, m))
         return
     # train-mode BatchNorm: raw conv output + per-block column statistics, then normalise in place
     gs = [ops.gemm_grid_m(m, Np) for _, _, m in geoms]
@@ -101,7 +105,8 @@ def _run(ctx, x, lda, C, T, Wp, N, M, mode, geoms, out_t, ldo, coff, bias, bn, a
     g0 = 0
     for (geom, wp, m), g in zip(geoms, gs):
         ops.gather_gemm(x, lda, C, T if geom is None else len(geom[7]), wp, Np, m, out_t, ldo, mode=mode, geom=geom,
-                        table=table, bias=b, act=ACT_NONE, stats=stats[g0:g0 + g], a_off=a_off, out_off=coff)
+                        table=table, bias=b, act=ACT_NONE, stats=stats[g0:g0 + g], a_off=a_off, out_off=coff,
+                        flops=fl(geom, m))
         g0 += g
     cnt = count if count is not None else M
     scale, shift = _bn_train(ctx, bn, stats, sum(gs), Np, float(cnt))
@@ -132,7 +137,7 @@ def conv2d(ctx, x, conv, bn=None, act=ACT_NONE, slope=0.0, residual=None, out=No
     M = B * Ho * Wo
     res_ld = residual.shape[-1] if residual is not None else 0
     _run(ctx, x, ldx, Cp, T, Wp, O, M, 1, [(geom, Wp, M)], out_t, ldo, coff, conv.bias, bn, act, slope,
-         residual=residual, res_ld=res_ld, a_off=a_off)
+         residual=residual, res_ld=res_ld, a_off=a_off, c_real=Cw)
     return out_t
 
 
@@ -182,7 +187,7 @@ def linear_rows(ctx, x, M, C, weight, bias, bn=None, act=ACT_NONE, slope=0.0, ou
         out_t, coff = out
         ldo = out_t.shape[-1]
     _run(ctx, x, lda, Cp, 1, Wp, O, M, 0, [(None, Wp, M)], out_t, ldo, coff, bias, bn, act, slope, a_off=a_off,
-         count=count)
+         count=count, c_real=C)
     return out_t
 
 

@@ -79,10 +79,16 @@ def gemm_grid_m(M, N):
     return _L().efgh_gather_gemm_grid_m(c_int64(M), c_int32(N))
 
 
+PROFILE = None          # bench.py sets this to a list: (start_event, end_event, algorithmic_flops) per launch
+
+
 def gather_gemm(A, lda, C, T, Wp, N, M, out, ldo, mode=0, geom=None, table=None, bias=None, scale=None,
                 shift=None, residual=None, ldr=0, act=ACT_NONE, slope=0.0, stats=None, a_off=0, out_off=0,
-                res_off=0, M_dev=None):
+                res_off=0, M_dev=None, flops=None):
     """See efgh_gemm_desc.  A/out/residual may be addressed with an element offset (channel slices)."""
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     d = _C.GemmDesc()
     es = 4
     d.A = A.data_ptr() + a_off * es
@@ -103,6 +109,9 @@ def gather_gemm(A, lda, C, T, Wp, N, M, out, ldo, mode=0, geom=None, table=None,
     d.ldo = ldo
     d.stats = 0 if stats is None else stats.data_ptr()
     _C.check(_L().efgh_gather_gemm(ctypes.byref(d), _st()))
+    if PROFILE is not None:
+        e1.record()
+        PROFILE.append((e0, e1, float(flops) if flops is not None else 2.0 * M * N * T * C))
 
 
 # ----------------------------------------------------------------------------------------------
