@@ -1,0 +1,297 @@
+// Backward passes of the HBM-bound layers (autograd of BatchNorm + activation + residual,
+// MaxPool2d, max/mean over positions, the 2-channel softmax and the F correlation head).
+// Each kernel is one streaming pass with 16-B accesses along the channel axis.
+#include "common.h"
+
+namespace {
+constexpr int TPB = 256;
+
+__device__ __forceinline__ float dact(float y, int act, float slope) {
+    if (act == 1) return y > 0.f ? 1.f : 0.f;
+    if (act == 2) return y > 0.f ? 1.f : slope;
+    return 1.f;
+}
+
+// per-column partial sums of  dpre = dy*act'(y)  and  dpre*xhat,  xhat = (raw-mean)*invstd
+// (mean == NULL: xhat := 0, only sum dpre is meaningful -> bias gradient)
+__global__ void __launch_bounds__(TPB)
+k_act_bn_bwd_reduce(const float *__restrict__ dy, long long lddy, const float *__restrict__ y, long long ldy,
+                    const float *__restrict__ raw, long long ldraw, const float *__restrict__ mean,
+                    const float *__restrict__ invstd, long long M, int C, int act, float slope, int rows_per_block,
+                    float *__restrict__ part) {
+    int c = blockIdx.x * TPB + threadIdx.x;
+    if (c >= C) return;
+    long long r0 = (long long)blockIdx.y * rows_per_block, r1 = r0 + rows_per_block;
+    if (r1 > M) r1 = M;
+    float mu = mean ? mean[c] : 0.f, is = mean ? invstd[c] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+    for (long long r = r0; r < r1; ++r) {
+        float g = dy[r * lddy + c] * dact(y[r * ldy + c], act, slope);
+        s1 += g;
+        if (mean) s2 += g * ((raw[r * ldraw + c] - mu) * is);
+    }
+    part[((long long)blockIdx.y * 2) * C + c] = s1;
+    part[((long long)blockIdx.y * 2 + 1) * C + c] = s2;
+}
+
+__global__ void k_bwd_finalize(const float *__restrict__ part, int G, int C, double count,
+                               float *__restrict__ sum_dpre, float *__restrict__ sum_dpre_xhat,
+                               float *__restrict__ mean_dpre, float *__restrict__ mean_dpre_xhat) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double a = 0.0, b = 0.0;
+    for (int g = 0; g < G; ++g) { a += part[((long long)g * 2) * C + c]; b += part[((long long)g * 2 + 1) * C + c]; }
+    sum_dpre[c] = (float)a; sum_dpre_xhat[c] = (float)b;
+    if (mean_dpre) { mean_dpre[c] = (float)(a / count); mean_dpre_xhat[c] = (float)(b / count); }
+}
+
+// draw = coef[c] * (dpre - m1[c] - xhat*m2[c])   (train BN; coef = gamma*invstd)
+//      = coef[c] * dpre                          (eval BN / no BN: mean == NULL, coef optional)
+// dres (optional) = dpre
+__global__ void __launch_bounds__(TPB)
+k_act_bn_bwd_apply(const float *__restrict__ dy, long long lddy, const float *__restrict__ y, long long ldy,
+                   const float *__restrict__ raw, long long ldraw, const float *__restrict__ mean,
+                   const float *__restrict__ invstd, const float *__restrict__ coef,
+                   const float *__restrict__ m1, const float *__restrict__ m2, long long M, int C, int act,
+                   float slope, float *__restrict__ draw, long long lddraw, float *__restrict__ dres,
+                   long long lddres) {
+    const int c4n = C >> 2;
+    long long total = M * c4n;
+    for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
+        long long r = i / c4n; int c = (int)(i - r * c4n) * 4;
+        float4 g = *reinterpret_cast<const float4 *>(dy + r * lddy + c);
+        float4 yy = *reinterpret_cast<const float4 *>(y + r * ldy + c);
+        float gv[4] = {g.x * dact(yy.x, act, slope), g.y * dact(yy.y, act, slope), g.z * dact(yy.z, act, slope),
+                       g.w * dact(yy.w, act, slope)};
+        if (dres) *reinterpret_cast<float4 *>(dres + r * lddres + c) = make_float4(gv[0], gv[1], gv[2], gv[3]);
+        float o[4];
+        if (mean) {
+            float4 rw = *reinterpret_cast<const float4 *>(raw + r * ldraw + c);
+            float rv[4] = {rw.x, rw.y, rw.z, rw.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float xh = (rv[q] - mean[c + q]) * invstd[c + q];
+                o[q] = coef[c + q] * (gv[q] - m1[c + q] - xh * m2[c + q]);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q] = coef ? coef[c + q] * gv[q] : gv[q];
+        }
+        if (draw) *reinterpret_cast<float4 *>(draw + r * lddraw + c) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// MaxPool2d(2,2) backward: gradient goes to the first maximal element in (h,w) scan order
+__global__ void __launch_bounds__(TPB)
+k_maxpool2_bwd(const float *__restrict__ x, const float *__restrict__ dy, float *__restrict__ dx, int B, int H,
+               int W, int C) {
+    const int Ho = H / 2, Wo = W / 2, c4 = C >> 2;
+    long long total = (long long)B * Ho * Wo * c4;
+    for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
+        int c = (int)(i % c4) * 4; long long r = i / c4;
+        int ow = (int)(r % Wo); r /= Wo;
+        int oh = (int)(r % Ho); long long b = r / Ho;
+        long long base = (((b * H + oh * 2) * W) + ow * 2) * (long long)C + c;
+        const long long offs[4] = {0, C, (long long)W * C, (long long)W * C + C};
+        float4 v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const float4 *>(x + base + offs[q]);
+        float4 g = *reinterpret_cast<const float4 *>(dy + (((b * Ho + oh) * Wo) + ow) * (long long)C + c);
+        float o[4][4];
+        const float gg[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) {
+            float e[4] = {((float *)&v[0])[ch], ((float *)&v[1])[ch], ((float *)&v[2])[ch], ((float *)&v[3])[ch]};
+            int best = 0;
+#pragma unroll
+            for (int q = 1; q < 4; ++q) if (e[q] > e[best]) best = q;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q][ch] = (q == best) ? gg[ch] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4 *>(dx + base + offs[q]) = make_float4(o[q][0], o[q][1], o[q][2], o[q][3]);
+    }
+    // odd trailing rows / columns (floor pooling) receive no gradient: caller zero-fills dx when H or W is odd
+}
+
+// dx[argrow[s][c]][c] = dy[s][c], dx pre-zeroed
+__global__ void k_segment_colmax_bwd(const float *__restrict__ dy, const int *__restrict__ argrow, int nseg, int C,
+                                     float *__restrict__ dx, long long ld) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nseg * C) return;
+    int c = i % C;
+    dx[(long long)argrow[i] * ld + c] = dy[i];
+}
+
+// dx[s*P + r][c] = dy[s][c] / P
+__global__ void __launch_bounds__(TPB)
+k_segment_colmean_bwd(const float *__restrict__ dy, int P, int nseg, int C, float *__restrict__ dx, long long ld) {
+    long long total = (long long)nseg * P * C;
+    for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
+        int c = (int)(i % C); long long r = i / C;
+        int s = (int)(r / P);
+        dx[r * ld + c] = dy[(long long)s * C + c] / (float)P;
+    }
+}
+
+// softmax over 2 channels: y planar (B,2,HW), dy planar -> dx [B*HW][ld] channels 0,1 (others 0)
+__global__ void __launch_bounds__(TPB)
+k_softmax2_bwd(const float *__restrict__ y, const float *__restrict__ dy, int B, long long HW,
+               float *__restrict__ dx, long long ld) {
+    long long total = (long long)B * HW;
+    for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
+        long long b = i / HW, p = i - b * HW;
+        float y0 = y[(b * 2) * HW + p], y1 = y[(b * 2 + 1) * HW + p];
+        float g0 = dy[(b * 2) * HW + p], g1 = dy[(b * 2 + 1) * HW + p];
+        float dot = g0 * y0 + g1 * y1;
+        for (int c = 0; c < (int)ld; ++c) dx[i * ld + c] = 0.f;
+        dx[i * ld] = y0 * (g0 - dot);
+        dx[i * ld + 1] = y1 * (g1 - dot);
+    }
+}
+
+// ---- correlation backward -------------------------------------------------------------------------
+// dcam_n[b][y][x][c] = sum_j dl[b][j] * rp[b][y][j+x][c]
+__global__ void __launch_bounds__(TPB)
+k_corr_bwd_cam(const float *__restrict__ rp, const float *__restrict__ dl, int h, int wc, int wp, int nj,
+               float *__restrict__ dcam) {
+    const int b = blockIdx.z, y = blockIdx.y;
+    int i = blockIdx.x * TPB + threadIdx.x;           // over wc*4 float4 slots of the row
+    if (i >= wc * 4) return;
+    const float4 *r = reinterpret_cast<const float4 *>(rp + (((long long)b * h + y) * wp) * 16) + i;
+    const float *g = dl + (long long)b * nj;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < nj; ++j) {
+        float w = g[j]; float4 v = r[(long long)j * 4];
+        a.x += w * v.x; a.y += w * v.y; a.z += w * v.z; a.w += w * v.w;
+    }
+    reinterpret_cast<float4 *>(dcam + (((long long)b * h + y) * wc) * 16)[i] = a;
+}
+
+// drp[b][y][xp][c] = sum_{x: 0<=xp-x<nj... } dl[b][xp-x] * cam_n[b][y][x][c]
+__global__ void __launch_bounds__(TPB)
+k_corr_bwd_rng(const float *__restrict__ cam, const float *__restrict__ cam_mm, const float *__restrict__ dl,
+               int h, int wc, int wp, int nj, float *__restrict__ drp) {
+    const int b = blockIdx.z, y = blockIdx.y;
+    int i = blockIdx.x * TPB + threadIdx.x;           // over wp*4
+    if (i >= wp * 4) return;
+    int xp = i >> 2, cq = i & 3;
+    const float d = cam_mm[b * 2 + 1] - cam_mm[b * 2];
+    const float4 *cr = reinterpret_cast<const float4 *>(cam + (((long long)b * h + y) * wc) * 16);
+    const float *g = dl + (long long)b * nj;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    int x0 = xp - (nj - 1); if (x0 < 0) x0 = 0;
+    int x1 = xp < wc - 1 ? xp : wc - 1;
+    for (int x = x0; x <= x1; ++x) {
+        float w = g[xp - x]; float4 v = cr[x * 4 + cq];
+        a.x += w * (v.x / d); a.y += w * (v.y / d); a.z += w * (v.z / d); a.w += w * (v.w / d);
+    }
+    reinterpret_cast<float4 *>(drp + (((long long)b * h + y) * wp) * 16)[i] = a;
+}
+
+// fold the padded gradient back: drng_n[b][y][xs][c] = drp[xs+off] (+ drp[w-1-xs] if w-1-xs < off) (+ drp[xs+off+w] if xs < off)
+__global__ void __launch_bounds__(TPB)
+k_corr_unpad(const float *__restrict__ drp, int B, int h, int w, int C, int off, float *__restrict__ dx) {
+    const int wp = w + 2 * off, c4n = C >> 2;
+    long long total = (long long)B * h * w * c4n;
+    for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
+        int cq = (int)(i % c4n); long long r = i / c4n;
+        int xs = (int)(r % w); r /= w;                 // r = b*h + y
+        const float4 *row = reinterpret_cast<const float4 *>(drp + (r * wp) * C) ;
+        float4 a = row[(long long)(xs + off) * c4n + cq];
+        int xm = w - 1 - xs;
+        if (xm < off) { float4 v = row[(long long)xm * c4n + cq]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+        if (xs < off) { float4 v = row[(long long)(xs + off + w) * c4n + cq]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+        reinterpret_cast<float4 *>(dx)[i] = a;
+    }
+}
+
+int grid_for(long long total) {
+    long long g = (total + TPB - 1) / TPB;
+    return (int)(g > 16384 ? 16384 : (g < 1 ? 1 : g));
+}
+}  // namespace
+
+extern "C" int32_t efgh_bwd_groups(int64_t M) { return (int32_t)((M + 511) / 512); }
+
+extern "C" int efgh_act_bn_bwd_reduce(const float *dy, int64_t lddy, const float *y, int64_t ldy, const float *raw,
+                                      int64_t ldraw, const float *mean, const float *invstd, int64_t M, int32_t C,
+                                      int32_t act, float slope, float *part, float *sum_dpre, float *sum_dpre_xhat,
+                                      float *mean_dpre, float *mean_dpre_xhat, void *stream_) {
+    hipStream_t st = (hipStream_t)stream_;
+    EFGH_CHECK_ARG(dy && y && part && sum_dpre && sum_dpre_xhat && M > 0 && C > 0);
+    EFGH_CHECK_ARG(!mean || (raw && invstd));
+    int G = efgh_bwd_groups(M);
+    k_act_bn_bwd_reduce<<<dim3(cdiv(C, TPB), G), TPB, 0, st>>>(dy, lddy, y, ldy, raw, ldraw, mean, invstd, M, C, act,
+                                                              slope, 512, part);
+    k_bwd_finalize<<<cdiv(C, 64), 64, 0, st>>>(part, G, C, (double)M, sum_dpre, sum_dpre_xhat, mean_dpre,
+                                               mean_dpre_xhat);
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}
+
+extern "C" int efgh_act_bn_bwd_apply(const float *dy, int64_t lddy, const float *y, int64_t ldy, const float *raw,
+                                     int64_t ldraw, const float *mean, const float *invstd, const float *coef,
+                                     const float *m1, const float *m2, int64_t M, int32_t C, int32_t act, float slope,
+                                     float *draw, int64_t lddraw, float *dres, int64_t lddres, void *stream_) {
+    EFGH_CHECK_ARG(dy && y && (draw || dres) && M > 0 && C > 0 && C % 4 == 0);
+    EFGH_CHECK_ARG(lddy % 4 == 0 && ldy % 4 == 0 && (!draw || lddraw % 4 == 0) && (!dres || lddres % 4 == 0));
+    EFGH_CHECK_ARG(!mean || (raw && invstd && coef && m1 && m2 && ldraw % 4 == 0));
+    k_act_bn_bwd_apply<<<grid_for(M * (C / 4)), TPB, 0, (hipStream_t)stream_>>>(
+        dy, lddy, y, ldy, raw, ldraw, mean, invstd, coef, m1, m2, M, C, act, slope, draw, lddraw, dres, lddres);
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}
+
+extern "C" int efgh_maxpool2_bwd(const float *x, const float *dy, float *dx, int32_t B, int32_t H, int32_t W,
+                                 int32_t C, void *stream_) {
+    EFGH_CHECK_ARG(x && dy && dx && B > 0 && H >= 2 && W >= 2 && C % 4 == 0);
+    k_maxpool2_bwd<<<grid_for((long long)B * (H / 2) * (W / 2) * (C / 4)), TPB, 0, (hipStream_t)stream_>>>(x, dy, dx, B, H,
+                                                                                                       W, C);
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}
+
+extern "C" int efgh_segment_colmax_bwd(const float *dy, const int32_t *argrow, int32_t nseg, int32_t C, float *dx,
+                                       int64_t ld, void *stream_) {
+    EFGH_CHECK_ARG(dy && argrow && dx && nseg > 0 && C > 0);
+    k_segment_colmax_bwd<<<cdiv((long long)nseg * C, 256), 256, 0, (hipStream_t)stream_>>>(dy, argrow, nseg, C, dx, ld);
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}
+
+extern "C" int efgh_segment_colmean_bwd(const float *dy, int32_t P, int32_t nseg, int32_t C, float *dx, int64_t ld,
+                                        void *stream_) {
+    EFGH_CHECK_ARG(dy && dx && P > 0 && nseg > 0 && C > 0);
+    k_segment_colmean_bwd<<<grid_for((long long)nseg * P * C), TPB, 0, (hipStream_t)stream_>>>(dy, P, nseg, C, dx, ld);
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}
+
+extern "C" int efgh_softmax2_bwd(const float *y, const float *dy, int32_t B, int64_t HW, float *dx, int64_t ld,
+                                 void *stream_) {
+    EFGH_CHECK_ARG(y && dy && dx && B > 0 && HW > 0 && ld >= 2);
+    k_softmax2_bwd<<<grid_for((long long)B * HW), TPB, 0, (hipStream_t)stream_>>>(y, dy, B, HW, dx, ld);
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}
+
+extern "C" int efgh_corr1d_bwd(const float *rp, const float *cam, const float *cam_mm, const float *dlogit, int32_t B,
+                               int32_t h, int32_t wc, int32_t wp, float *dcam_n, float *drp, void *stream_) {
+    hipStream_t st = (hipStream_t)stream_;
+    EFGH_CHECK_ARG(rp && cam && cam_mm && dlogit && dcam_n && drp && B > 0 && h > 0 && wc > 0 && wp >= wc);
+    int nj = wp - wc + 1;
+    k_corr_bwd_cam<<<dim3(cdiv(wc * 4, TPB), h, B), TPB, 0, st>>>(rp, dlogit, h, wc, wp, nj, dcam_n);
+    k_corr_bwd_rng<<<dim3(cdiv(wp * 4, TPB), h, B), TPB, 0, st>>>(cam, cam_mm, dlogit, h, wc, wp, nj, drp);
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}
+
+extern "C" int efgh_corr_unpad(const float *drp, int32_t B, int32_t h, int32_t w, int32_t C, int32_t off, float *dx,
+                               void *stream_) {
+    EFGH_CHECK_ARG(drp && dx && B > 0 && h > 0 && w > 0 && C % 4 == 0 && off >= 0 && off <= w);
+    k_corr_unpad<<<grid_for((long long)B * h * w * (C / 4)), TPB, 0, (hipStream_t)stream_>>>(drp, B, h, w, C, off, dx);
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}

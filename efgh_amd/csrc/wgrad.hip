@@ -1,0 +1,252 @@
+// Weight-gradient gather-GEMM on fp32 MFMA (backward of gemm.hip w.r.t. W):
+//
+//     dWp[n][t*C + c] += sum_m  G[orow(m)][n] * A[row(m,t)][c]
+//
+// i.e. the gradient of every Conv2d / ConvTranspose2d / Conv1d / Linear / BCL blur weight of the
+// reference (autograd of nets/vgg.py:77, resnet.py:22-30, net_utils.py:35-98, bilateralNN.py:103-135),
+// in the packed [N][T][C] layout of the forward kernel; efgh_unpack_weight() scatters it back to
+// the reference's (out,in,kh,kw) / (in,out,kh,kw) / (out,in) layouts.
+//
+// The contraction runs over rows m (pixels / vertices), which is huge, so the launch is split over m
+// (gridDim.z chunks) and partial tiles are combined with fp32 global atomics (128-B contiguous
+// segments per wave instruction).  Tile: 128 (n) x 128 (k) per block, 32 rows of m per step; the MFMA
+// contraction index is m, so fragments are plain ds_read_b32 of [m][n] / [m][k] LDS images
+// (lanes 0-31: consecutive columns, lanes 32-63: the next row -> conflict free).
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int TN = 128, TK = 128, TM = 32, LD = 128;
+
+struct WArgs {
+    const float *A; int64_t lda;
+    int C, T, K;
+    unsigned magicC;
+    int Hin, Win, Hv, Wv, sh, sw;
+    unsigned long long dhpack, dwpack;
+    int Ho, Wo, osh, osw, oh0, ow0;
+    const int *table;
+    const float *G; int64_t ldg;     // upstream gradient rows [orow][ldg], first N used
+    int N;
+    long long M; int mchunk;
+    float *dW;                       // [N][K], pre-zeroed
+};
+
+template <int MODE>
+__global__ void __launch_bounds__(256)
+k_gather_wgrad(const WArgs p) {
+    __shared__ __attribute__((aligned(16))) float Gs[TM * LD];
+    __shared__ __attribute__((aligned(16))) float As[TM * LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave >> 1, wk = wave & 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int k0 = blockIdx.x * TK, n0 = blockIdx.y * TN;
+    const long long mbeg = (long long)blockIdx.z * p.mchunk;
+    long long mend = mbeg + p.mchunk;
+    if (mend > p.M) mend = p.M;
+    if (mbeg >= mend) return;
+
+    // staging: thread -> rows (tid>>5) + 8q, columns (tid&31)*4 .. +3
+    const int r0 = tid >> 5, c4 = (tid & 31) * 4;
+    const int kk = k0 + c4;
+    const bool kin = kk < p.K;
+    const int t = (int)(((unsigned long long)kk * p.magicC) >> 32);
+    const int c = kk - t * p.C;
+    const int dh = (int)((p.dhpack >> (4 * (t & 15))) & 15) - 8, dw = (int)((p.dwpack >> (4 * (t & 15))) & 15) - 8;
+    const bool nin = (n0 + c4) < p.N;
+
+    // incremental (b,i,j) of each staged row (mode 1)
+    int rj[4], ri[4]; long long rb[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        long long m = mbeg + r0 + 8 * q;
+        if (MODE == 1) {
+            rj[q] = (int)(m % p.Wv); long long r = m / p.Wv;
+            ri[q] = (int)(r % p.Hv); rb[q] = r / p.Hv;
+        } else { rj[q] = ri[q] = 0; rb[q] = 0; }
+    }
+    float4 rg[4], ra[4];
+    auto load_step = [&](long long ms) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            long long m = ms + r0 + 8 * q;
+            float4 g = make_float4(0.f, 0.f, 0.f, 0.f), a = g;
+            if (m < mend) {
+                long long orow = m, arow = -1;
+                if (MODE == 0) arow = m;
+                else if (MODE == 2) { if (kin) arow = p.table[m * 16 + t]; }
+                else {
+                    orow = (rb[q] * p.Ho + (ri[q] * p.osh + p.oh0)) * p.Wo + (rj[q] * p.osw + p.ow0);
+                    int ih = ri[q] * p.sh + dh, iw = rj[q] * p.sw + dw;
+                    if ((unsigned)ih < (unsigned)p.Hin && (unsigned)iw < (unsigned)p.Win)
+                        arow = (rb[q] * p.Hin + ih) * p.Win + iw;
+                }
+                if (nin) g = *reinterpret_cast<const float4 *>(p.G + orow * p.ldg + n0 + c4);
+                if (kin && arow >= 0) a = *reinterpret_cast<const float4 *>(p.A + arow * p.lda + c);
+            }
+            rg[q] = g; ra[q] = a;
+            if (MODE == 1) {         // advance this row by TM for the next step
+                rj[q] += TM;
+                while (rj[q] >= p.Wv) { rj[q] -= p.Wv; ++ri[q]; }
+                while (ri[q] >= p.Hv) { ri[q] -= p.Hv; ++rb[q]; }
+            }
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    load_step(mbeg);
+    for (long long ms = mbeg; ms < mend; ms += TM) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            *reinterpret_cast<float4 *>(&Gs[(r0 + 8 * q) * LD + c4]) = rg[q];
+            *reinterpret_cast<float4 *>(&As[(r0 + 8 * q) * LD + c4]) = ra[q];
+        }
+        __syncthreads();
+        if (ms + TM < mend) load_step(ms + TM);
+#pragma unroll
+        for (int mm = 0; mm < TM / 2; ++mm) {
+            float g[2], a[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) g[i] = Gs[(mm * 2 + lh) * LD + (wn * 2 + i) * 32 + l31];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) a[j] = As[(mm * 2 + lh) * LD + (wk * 2 + j) * 32 + l31];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[i], a[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // D[row = n][col = k]; lanes run along k (contiguous in dW)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int k = k0 + (wk * 2 + j) * 32 + l31;
+            if (k >= p.K) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + (wn * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (n < p.N) atomicAdd(&p.dW[(long long)n * p.K + k], acc[i][j][r]);
+            }
+        }
+}
+
+// W.flat[n*sn + c*sc + tap[t]*st] = Wp[n][t][c]   (inverse of k_pack_weight; Wp may be padded to ldn/ldc)
+__global__ void k_unpack_weight(const float *__restrict__ Wp, float *__restrict__ W, int N, int T, int C,
+                                int Cp, long long sn, long long sc, long long st, const int4 taps0,
+                                const int4 taps1, const int4 taps2, const int4 taps3, int accumulate) {
+    const int tp[16] = {taps0.x, taps0.y, taps0.z, taps0.w, taps1.x, taps1.y, taps1.z, taps1.w,
+                        taps2.x, taps2.y, taps2.z, taps2.w, taps3.x, taps3.y, taps3.z, taps3.w};
+    long long total = (long long)N * T * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        int c = (int)(i % C); long long r = i / C;
+        int t = (int)(r % T); int n = (int)(r / T);
+        int ti = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) if (q == t) ti = tp[q];
+        float v = Wp[((long long)n * T + t) * Cp + c];
+        float *dst = &W[n * sn + c * sc + ti * st];
+        *dst = accumulate ? *dst + v : v;
+    }
+}
+
+// scatter-add of rows through a neighbour table: dst[table[m][t]][c] += src[m][t*C + c]  (t < T)
+__global__ void __launch_bounds__(256)
+k_table_scatter_add(const float *__restrict__ src, const int *__restrict__ table, long long M, int T, int C,
+                    float *__restrict__ dst) {
+    const int c4n = C >> 2;
+    long long total = M * T * c4n;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        int cq = (int)(i % c4n); long long r = i / c4n;
+        int t = (int)(r % T); long long m = r / T;
+        int row = table[m * 16 + t];
+        if (row < 0) continue;
+        float4 v = *reinterpret_cast<const float4 *>(src + (m * T + t) * C + cq * 4);
+        float *d = dst + (long long)row * C + cq * 4;
+        atomicAdd(d + 0, v.x); atomicAdd(d + 1, v.y); atomicAdd(d + 2, v.z); atomicAdd(d + 3, v.w);
+    }
+}
+
+}  // namespace
+
+extern "C" int efgh_gather_wgrad(const efgh_gemm_desc *d, const float *G, int64_t ldg, float *dWp, void *stream_) {
+    hipStream_t st = (hipStream_t)stream_;
+    EFGH_CHECK_ARG(d && d->A && G && dWp);
+    EFGH_CHECK_ARG(d->C > 0 && d->C % 4 == 0 && d->T >= 1 && d->T <= 16 && d->N >= 1 && d->M >= 1);
+    EFGH_CHECK_ARG(d->lda % 4 == 0 && ldg % 4 == 0 && d->N % 4 == 0);
+    EFGH_CHECK_ARG((((uintptr_t)d->A) & 15) == 0 && (((uintptr_t)G) & 15) == 0);
+    EFGH_CHECK_ARG((int64_t)d->T * d->C < 65536 && d->mode >= 0 && d->mode <= 2);
+    WArgs a;
+    a.A = d->A; a.lda = d->lda; a.C = d->C; a.T = d->T; a.K = d->T * d->C;
+    a.magicC = (unsigned)((0x100000000ULL + d->C - 1) / d->C);
+    a.Hin = d->Hin; a.Win = d->Win; a.Hv = d->Hv; a.Wv = d->Wv; a.sh = d->sh; a.sw = d->sw;
+    a.dhpack = 0; a.dwpack = 0;
+    for (int t = 0; t < 16; ++t) {
+        int dh = t < d->T ? d->dh[t] : 0, dw = t < d->T ? d->dw[t] : 0;
+        a.dhpack |= (unsigned long long)((dh + 8) & 15) << (4 * t);
+        a.dwpack |= (unsigned long long)((dw + 8) & 15) << (4 * t);
+    }
+    a.Ho = d->Ho; a.Wo = d->Wo; a.osh = d->osh; a.osw = d->osw; a.oh0 = d->oh0; a.ow0 = d->ow0;
+    a.table = d->table; a.G = G; a.ldg = ldg; a.N = d->N; a.M = d->M; a.dW = dWp;
+    if (d->mode == 1) EFGH_CHECK_ARG(d->M == (int64_t)d->B * d->Hv * d->Wv && d->osh >= 1 && d->osw >= 1);
+    if (d->mode == 2) EFGH_CHECK_ARG(d->table != nullptr);
+    const int kt = (a.K + TK - 1) / TK, nt = (a.N + TN - 1) / TN;
+    // split m so that the grid has ~2048+ blocks, chunks are multiples of TM
+    long long want = 2048 / (kt * nt);
+    if (want < 1) want = 1;
+    long long chunk = (d->M + want - 1) / want;
+    chunk = (chunk + TM - 1) / TM * TM;
+    if (chunk < 256) chunk = 256;
+    a.mchunk = (int)chunk;
+    long long zs = (d->M + chunk - 1) / chunk;
+    EFGH_CHECK_ARG(zs <= 65535);
+    if (hipMemsetAsync(dWp, 0, (size_t)a.N * a.K * 4, st) != hipSuccess) {
+        efgh_set_error("wgrad: memset failed");
+        return EFGH_E_LAUNCH;
+    }
+    dim3 grid(kt, nt, (unsigned)zs);
+    if (d->mode == 0) k_gather_wgrad<0><<<grid, 256, 0, st>>>(a);
+    else if (d->mode == 1) k_gather_wgrad<1><<<grid, 256, 0, st>>>(a);
+    else k_gather_wgrad<2><<<grid, 256, 0, st>>>(a);
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}
+
+extern "C" int efgh_unpack_weight(const float *Wp, float *W, int32_t N, int32_t T, int32_t C, int32_t Cp,
+                                  int64_t sn, int64_t sc, int64_t stt, const int32_t *tapidx, int32_t accumulate,
+                                  void *stream_) {
+    EFGH_CHECK_ARG(Wp && W && N > 0 && T > 0 && T <= 16 && C > 0 && Cp >= C);
+    int tp[16];
+    for (int t = 0; t < 16; ++t) tp[t] = (tapidx && t < T) ? tapidx[t] : (t < T ? t : 0);
+    long long total = (long long)N * T * C;
+    int grid = (int)((total + 255) / 256);
+    if (grid > 8192) grid = 8192;
+    k_unpack_weight<<<grid, 256, 0, (hipStream_t)stream_>>>(Wp, W, N, T, C, Cp, sn, sc, stt,
+                                                           make_int4(tp[0], tp[1], tp[2], tp[3]),
+                                                           make_int4(tp[4], tp[5], tp[6], tp[7]),
+                                                           make_int4(tp[8], tp[9], tp[10], tp[11]),
+                                                           make_int4(tp[12], tp[13], tp[14], tp[15]), accumulate);
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}
+
+extern "C" int efgh_table_scatter_add(const float *src, const int32_t *table, int64_t M, int32_t T, int32_t C,
+                                      float *dst, void *stream_) {
+    EFGH_CHECK_ARG(src && table && dst && M > 0 && T > 0 && T <= 16 && C % 4 == 0);
+    long long total = M * T * (C / 4);
+    long long g = (total + 255) / 256;
+    k_table_scatter_add<<<(int)(g > 16384 ? 16384 : g), 256, 0, (hipStream_t)stream_>>>(src, table, M, T, C, dst);
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}

@@ -5,6 +5,7 @@ import torch.nn as nn
 from .. import lattice, ops
 from ..common import pose
 from ..ops import ACT_LEAKY, ACT_RELU
+from . import fn as FN
 from . import layers as L
 from .builders import BilateralConvFlex, conv_1x1
 
@@ -61,18 +62,22 @@ class Enet(nn.Module):
             x = ops.nchw_to_nhwc(pts[None], 4)[0]                        # (N,4)
             for i in range(3):
                 conv = self.conv_in[i][0]
-                last = i == 2
+                last = i == 2 and not ctx.grad
                 x = L.linear_rows(ctx, x, N, conv.in_channels, conv.weight, conv.bias, act=ACT_LEAKY, slope=0.1,
                                   out=(feats[0], 4) if last else None)
-            cur = feats[0]
+            # level-l input rows = [el_minus_gr (4, written by the lattice kernel) | previous features]
+            cur = torch.cat([feats[0][:, :4], x], 1) if ctx.grad else feats[0]
             for l in range(5):
                 d = lv[l]
-                splat, _ = ops.splat_fwd(cur, cins[l], d.bary, d.off, d.H)
-                tgt = (feats[l + 1], 4) if l < 4 else None
+                if ctx.grad:
+                    splat = FN.SplatFn.apply(cur, d.bary, d.off, d.H, cins[l])
+                else:
+                    splat, _ = ops.splat_fwd(cur, cins[l], d.bary, d.off, d.H)
+                tgt = (feats[l + 1], 4) if (l < 4 and not ctx.grad) else None
                 cur = L.blur_conv(ctx, splat, d.H, cins[l], d.nbr, bcns[l].blur_conv[0], bcns[l].blur_conv[2],
                                   out=tgt)
                 if l < 4:
-                    cur = feats[l + 1]
+                    cur = torch.cat([feats[l + 1][:, :4], cur], 1) if ctx.grad else feats[l + 1]
             outs.append(cur)                                             # (H5, 256)
             segs.append(segs[-1] + lv[4].H)
         x = torch.cat(outs, 0) if B > 1 else outs[0]
@@ -81,7 +86,10 @@ class Enet(nn.Module):
                          (self.conv_gn_3, self.bn_gn_3)):
             x = L.linear_rows(ctx, x, M, conv.in_channels, conv.weight, conv.bias, bn=bn, act=ACT_RELU)
         seg = torch.tensor(segs, dtype=torch.int32, device=dev)
-        x, _ = ops.segment_colmax(x, x.shape[-1], 128, seg, B)           # torch.max over vertices (:154)
+        if ctx.grad:
+            x = FN.SegmentColMaxFn.apply(x, seg, B, 128)
+        else:
+            x, _ = ops.segment_colmax(x, x.shape[-1], 128, seg, B)       # torch.max over vertices (:154)
         for lin in (self.lin_gn_1, self.lin_gn_2, self.lin_gn_3):
             x = L.linear_rows(ctx, x, B, lin.in_features, lin.weight, lin.bias, act=ACT_RELU)
         gn_sgn = L.linear_rows(ctx, x, B, 32, self.lin_gn_sgn.weight, self.lin_gn_sgn.bias)[:, :8]

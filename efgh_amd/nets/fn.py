@@ -1,0 +1,358 @@
+"""torch.autograd.Function shims over the HIP forward/backward kernels (training path).
+
+torch's autograd engine is used only as the tape (plumbing); every forward and backward
+computation inside these Functions runs in libefgh_hip.so.  Tensors are "row matrices":
+shape [..., C] with unit stride on the last axis and a uniform row stride (channel slices of a
+contiguous channels-last buffer qualify), addressed as (data_ptr, ld).
+"""
+import torch
+
+from .. import ops
+from ..ops import ACT_NONE, ceil4
+
+
+def rows_ok(t):
+    if t.stride(-1) != 1:
+        return False
+    ld = t.stride(-2) if t.dim() >= 2 else t.shape[-1]
+    exp = ld
+    for d in range(t.dim() - 2, -1, -1):
+        if t.shape[d] != 1 and t.stride(d) != exp:
+            return False
+        exp *= t.shape[d]
+    return ld % 4 == 0 and t.data_ptr() % 16 == 0
+
+
+def as_rows(t):
+    return t if rows_ok(t) else t.contiguous()
+
+
+def ld_of(t):
+    return t.stride(-2) if t.dim() >= 2 else t.shape[-1]
+
+
+class LayerSpec:
+    """Static description of one GEMM layer (built by layers.py).
+
+    launches: [(geom | None, M_launch)] forward launches (several for a transposed conv);
+    pack_fwd(weight, i) -> packed forward weight of launch i;
+    dgrad(spec, weight, draw, x) -> gradient w.r.t. x;
+    wgrad_unpack(dWp, i, dW): scatter launch i's packed weight gradient into the reference layout."""
+
+    def __init__(self, N, C, T, mode, launches, M, out_shape, pack_fwd, dgrad, wgrad_unpack, bn=None,
+                 train=False, act=ACT_NONE, slope=0.0, table=None, c_real=None):
+        self.N, self.C, self.T, self.mode, self.M = N, C, T, mode, M
+        self.launches, self.out_shape = launches, out_shape
+        self.pack_fwd, self.dgrad, self.wgrad_unpack = pack_fwd, dgrad, wgrad_unpack
+        self.bn, self.train, self.act, self.slope, self.table = bn, train, act, slope, table
+        self.c_real = c_real if c_real is not None else C
+
+
+class GemmLayerFn(torch.autograd.Function):
+    """y = act(BN(gemm(x, W) + bias) + residual)   with hand-written backward."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, residual, spec):
+        x = as_rows(x)
+        dev = x.device
+        N, Np = spec.N, ceil4(spec.N)
+        M = spec.M
+        bn = spec.bn
+        b = None if bias is None else ops.pad_vec(bias.detach(), Np)
+        out = torch.empty(tuple(spec.out_shape) + (Np,), dtype=torch.float32, device=dev)
+        res = None if residual is None else as_rows(residual)
+        mean = invstd = raw = None
+        need_stats = bn is not None and spec.train
+        stats = None
+        if need_stats:
+            gs = [ops.gemm_grid_m(m, Np) for (_, m) in spec.launches]
+            stats = torch.empty((sum(gs), 2, Np), dtype=torch.float32, device=dev)
+        fused_plain = bn is None            # bias (+residual) (+act) straight in the epilogue
+        g0 = 0
+        for li, (geom, m) in enumerate(spec.launches):
+            wp = spec.pack_fwd(weight, li)
+            T = spec.T if geom is None else len(geom[7])
+            fl = 2.0 * m * N * T * spec.c_real
+            if fused_plain:
+                ops.gather_gemm(x, ld_of(x), spec.C, T, wp, Np, m, out, Np, mode=spec.mode, geom=geom,
+                                table=spec.table, bias=b, residual=res, ldr=0 if res is None else ld_of(res),
+                                act=spec.act, slope=spec.slope, flops=fl)
+            else:
+                st = None
+                if need_stats:
+                    st = stats[g0:g0 + gs[li]]
+                    g0 += gs[li]
+                ops.gather_gemm(x, ld_of(x), spec.C, T, wp, Np, m, out, Np, mode=spec.mode, geom=geom,
+                                table=spec.table, bias=b, act=ACT_NONE, stats=st, flops=fl)
+        y = out
+        if bn is not None:
+            raw = out
+            if need_stats:
+                bn.num_batches_tracked += 1
+                momentum = bn.momentum if bn.momentum is not None else 0.1
+                g_, b_ = ops.pad_vec(gamma.detach(), Np), ops.pad_vec(beta.detach(), Np)
+                if Np == N:
+                    rm, rv = bn.running_mean, bn.running_var
+                else:
+                    rm, rv = ops.pad_vec(bn.running_mean, Np).clone(), ops.pad_vec(bn.running_var, Np, 1.0).clone()
+                scale, shift, mean, invstd = ops.bn_finalize(stats, stats.shape[0], Np, float(M), g_, b_, rm, rv,
+                                                             momentum, bn.eps, save=True)
+                if Np != N:
+                    bn.running_mean.copy_(rm[:N])
+                    bn.running_var.copy_(rv[:N])
+            else:
+                with torch.no_grad():
+                    invstd = ops.pad_vec(torch.rsqrt(bn.running_var + bn.eps), Np)
+                    mean = ops.pad_vec(bn.running_mean.clone(), Np)
+                    scale = ops.pad_vec(gamma.detach(), Np) * invstd
+                    shift = ops.pad_vec(beta.detach(), Np) - mean * scale
+            y = torch.empty_like(raw)
+            ops.scale_shift_act(raw, Np, scale, shift, y, Np, M, Np, spec.act, spec.slope, res=res,
+                                ldr=0 if res is None else ld_of(res))
+        ctx.spec = spec
+        ctx.has = (bias is not None, gamma is not None, residual is not None)
+        ctx.save_for_backward(x, weight, y, raw, mean, invstd, None if gamma is None else gamma.detach())
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        spec = ctx.spec
+        x, weight, y, raw, mean, invstd, gamma = ctx.saved_tensors
+        has_bias, has_bn, has_res = ctx.has
+        N, Np, M = spec.N, ceil4(spec.N), spec.M
+        dev = x.device
+        dy = as_rows(dy)
+        dbias = dgamma = dbeta = dres = None
+        need_pre = spec.act != ACT_NONE or has_bn or has_res or has_bias
+        if not need_pre:
+            draw = dy
+        else:
+            G = ops.bwd_groups(M)
+            part = torch.empty((G, 2, Np), dtype=torch.float32, device=dev)
+            s1 = torch.empty(Np, dtype=torch.float32, device=dev)
+            s2 = torch.empty(Np, dtype=torch.float32, device=dev)
+            train_bn = has_bn and spec.train
+            m1 = torch.empty(Np, dtype=torch.float32, device=dev) if train_bn else None
+            m2 = torch.empty(Np, dtype=torch.float32, device=dev) if train_bn else None
+            ops.act_bn_bwd_reduce(dy, ld_of(dy), y, Np, raw, Np, mean if has_bn else None,
+                                  invstd if has_bn else None, M, Np, spec.act, spec.slope, part, s1, s2, m1, m2)
+            coef = None
+            if has_bn:
+                dbeta, dgamma = s1[:N].clone(), s2[:N].clone()
+                coef = ops.pad_vec(gamma, Np) * invstd
+            if has_bias and not has_bn:
+                dbias = s1[:N].clone()
+            draw = torch.empty(tuple(spec.out_shape) + (Np,), dtype=torch.float32, device=dev)
+            if has_res:
+                dres = torch.empty(tuple(spec.out_shape) + (Np,), dtype=torch.float32, device=dev)
+            ops.act_bn_bwd_apply(dy, ld_of(dy), y, Np, raw, Np, mean if train_bn else None,
+                                 invstd if train_bn else None, coef, m1, m2, M, Np, spec.act, spec.slope, draw, Np,
+                                 dres, Np)
+            if has_bias and has_bn:          # bias in front of BatchNorm: d/dbias = column sums of draw
+                dbias = ops.col_sum(draw, M, Np)[:N]
+        # ---- dgrad
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = spec.dgrad(spec, weight, draw, x)
+        # ---- wgrad
+        dW = None
+        if ctx.needs_input_grad[1]:
+            dW = torch.empty_like(weight)
+            for li, (geom, m) in enumerate(spec.launches):
+                T = spec.T if geom is None else len(geom[7])
+                dWp = torch.empty((Np, T, spec.C), dtype=torch.float32, device=dev)
+                ops.gather_wgrad(x, ld_of(x), spec.C, T, Np, m, draw, Np, dWp, mode=spec.mode, geom=geom,
+                                 table=spec.table)
+                spec.wgrad_unpack(dWp, li, dW)
+        if dres is not None and Np != N:
+            dres = dres[..., :N]
+        return dx, dW, dbias, dgamma, dbeta, dres, None
+
+
+# ---------------------------------------------------------------------------------------------
+class MaxPool2Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        ctx.save_for_backward(x)
+        return ops.maxpool2(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        B, H, W, C = x.shape
+        dx = torch.zeros_like(x) if (H % 2 or W % 2) else torch.empty_like(x)
+        ops.maxpool2_bwd(x, dy.contiguous(), dx)
+        return dx
+
+
+class SegmentColMaxFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, seg, nseg, C):
+        x = as_rows(x)
+        y, arg = ops.segment_colmax(x, ld_of(x), C, seg, nseg, want_arg=True)
+        ctx.save_for_backward(arg)
+        ctx.shape = (tuple(x.shape), C, nseg)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (arg,) = ctx.saved_tensors
+        shape, C, nseg = ctx.shape
+        dx = torch.zeros(shape, dtype=torch.float32, device=dy.device)
+        ops.segment_colmax_bwd(dy.contiguous(), arg, nseg, C, dx, shape[-1])
+        return dx, None, None, None
+
+
+class SegmentColMeanFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, P, nseg, C):
+        x = as_rows(x)
+        ctx.meta = (tuple(x.shape), P, nseg, C)
+        return ops.segment_colmean(x, ld_of(x), C, P, nseg)
+
+    @staticmethod
+    def backward(ctx, dy):
+        shape, P, nseg, C = ctx.meta
+        dx = torch.zeros(shape, dtype=torch.float32, device=dy.device)
+        ops.segment_colmean_bwd(dy.contiguous(), P, nseg, C, dx, shape[-1])
+        return dx, None, None, None
+
+
+class SplatFn(torch.autograd.Function):
+    """BCL splat + density normalisation; bary/off carry no gradient (generate_data.py:119)."""
+
+    @staticmethod
+    def forward(ctx, feat, bary, off, H, C):
+        feat = as_rows(feat)
+        splat, wsum = ops.splat_fwd(feat, C, bary, off, H)
+        ctx.save_for_backward(bary, off, wsum)
+        ctx.meta = (feat.shape[0], H, C, feat.shape[-1])
+        return splat
+
+    @staticmethod
+    def backward(ctx, g):
+        bary, off, wsum = ctx.saved_tensors
+        n, H, C, ldf = ctx.meta
+        gfeat = torch.zeros((n, ldf), dtype=torch.float32, device=g.device) if ldf != C else \
+            torch.empty((n, C), dtype=torch.float32, device=g.device)
+        ops.splat_bwd(g.contiguous(), wsum, C, bary, off, n, H, gfeat)
+        return gfeat, None, None, None, None
+
+
+class Softmax2ToNchwFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        y = ops.softmax2_to_nchw(x)
+        ctx.save_for_backward(y)
+        ctx.ld = x.shape[-1]
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        B, _, H, W = y.shape
+        dx = torch.empty((B, H, W, ctx.ld), dtype=torch.float32, device=dy.device)
+        ops.softmax2_bwd(y, dy.contiguous(), dx)
+        return dx
+
+
+class NhwcToNchwFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, Cs):
+        ctx.meta = (tuple(x.shape), Cs)
+        return ops.nhwc_to_nchw(x.contiguous(), Cs)
+
+    @staticmethod
+    def backward(ctx, dy):
+        shape, Cs = ctx.meta
+        return ops.nchw_to_nhwc(dy.contiguous(), shape[-1]), None
+
+
+class RangeImageFn(torch.autograd.Function):
+    """range image of e_l.[pc;1]; gradient w.r.t. e_l through the rasterised VALUES (x,y,z,r) only
+    (indices are truncated integers), every rasterised point receives grad_img[u,v] (oracle note)."""
+
+    @staticmethod
+    def forward(ctx, pc, e_l, H, W, fov_up, fov_down):
+        img, pix = ops.range_image(pc, e_l, H, W, fov_up, fov_down)
+        ctx.save_for_backward(pc, e_l, pix)
+        ctx.hw = (H, W)
+        return img
+
+    @staticmethod
+    def backward(ctx, g):
+        pc, e_l, pix = ctx.saved_tensors
+        H, W = ctx.hw
+        B, _, N = pc.shape
+        gv = ops.raster_bwd(pix, g.contiguous(), B, N, H * W)                 # (B,N,4): d/d(x,y,z,r)
+        ones = torch.ones((B, 1, N), dtype=pc.dtype, device=pc.device)
+        p1 = torch.cat([pc, ones], 1)                                         # (B,4,N)
+        q = torch.bmm(e_l.detach(), p1)                                       # transformed (x,y,z,w)
+        r = torch.sqrt(torch.sum(q * q, 1, keepdim=True))
+        gq = torch.zeros_like(q)
+        gq[:, :3] = gv[..., :3].transpose(1, 2)
+        gq = gq + gv[..., 3:4].transpose(1, 2) * (q / r)
+        ge = torch.bmm(gq, p1.transpose(1, 2))                                # (B,4,4)
+        return None, ge, None, None, None, None
+
+
+class DepthImageFn(torch.autograd.Function):
+    """depth image; only the 4th channel (w) depends on cam_T_velo (row 2)."""
+
+    @staticmethod
+    def forward(ctx, pc, P, H, W):
+        img, pix = ops.depth_image(pc, P, H, W)
+        ctx.save_for_backward(pc, pix)
+        ctx.hw = (H, W)
+        return img
+
+    @staticmethod
+    def backward(ctx, g):
+        pc, pix = ctx.saved_tensors
+        H, W = ctx.hw
+        B, _, N = pc.shape
+        gv = ops.raster_bwd(pix, g.contiguous(), B, N, H * W)
+        ones = torch.ones((B, 1, N), dtype=pc.dtype, device=pc.device)
+        p1 = torch.cat([pc, ones], 1)
+        gw = gv[..., 3]                                                       # (B,N)
+        gP = torch.zeros((B, 3, 4), dtype=pc.dtype, device=pc.device)
+        gP[:, 2] = torch.bmm(p1, gw[:, :, None])[:, :, 0]
+        return None, gP, None, None
+
+
+class CorrHeadFn(torch.autograd.Function):
+    """fnet.py:57,64,78-81 incl. the (max-min) normalisation and the mirror/circular pad."""
+
+    @staticmethod
+    def forward(ctx, cam, rng):
+        cam, rng = cam.contiguous(), rng.contiguous()
+        score, logit, rp, cam_mm, rng_mm = ops.corr_head(cam, rng, want_logit=True, want_aux=True)
+        ctx.save_for_backward(cam, rng, rp, cam_mm, rng_mm, score)
+        return score
+
+    @staticmethod
+    def backward(ctx, ds):
+        cam, rng, rp, cam_mm, rng_mm, score = ctx.saved_tensors
+        B, h, wc, C = cam.shape
+        wr = rng.shape[2]
+        off = int(wr / 8)
+        dl = (ds * score * (1 - score) / 16.0).contiguous()                  # d/dlogit, incl. the 1/C scale
+        dcam_n, drp = ops.corr1d_bwd(rp, cam, cam_mm, dl, B, h, wc, rp.shape[2])
+        drng_n = ops.corr_unpad(drp, B, h, wr, C, off)
+
+        def norm_bwd(x, mm, dxn):
+            # x_n = x / (max - min): dx = dxn/d, d(max) -= S/d^2, d(min) += S/d^2 with S = sum(dxn*x)
+            d = (mm[:, 1] - mm[:, 0]).view(B, 1, 1, 1)
+            S = (dxn * x).flatten(1).sum(1)
+            dx = dxn / d
+            flat = x.flatten(1)
+            imax, imin = flat.argmax(1), flat.argmin(1)
+            corr = S / (d.view(B) ** 2)
+            dxf = dx.flatten(1)
+            ar = torch.arange(B, device=x.device)
+            dxf[ar, imax] -= corr
+            dxf[ar, imin] += corr
+            return dxf.view_as(x)
+        return norm_bwd(cam, cam_mm, dcam_n), norm_bwd(rng, rng_mm, drng_n)

@@ -6,6 +6,7 @@ import torch.nn as nn
 
 from .. import ops
 from ..common import pose
+from . import fn as FN
 from . import layers as L
 from .builders import VGGFeatures, conv_bn_relu, convt_bn_relu
 
@@ -36,15 +37,21 @@ class Fnet(nn.Module):
     def forward(self, pc, ret, check=False, keep=None):
         ctx = L.Ctx(self.training)
         H, W = self.range_img_size
-        e_range, pix = ops.range_image(pc, ret['e_l'], H, W, self.lidar_fov_rad[0] * math.pi,
-                                       self.lidar_fov_rad[1] * math.pi)          # fnet.py:43-45
+        fov = (self.lidar_fov_rad[0] * math.pi, self.lidar_fov_rad[1] * math.pi)
+        if ctx.grad:
+            e_range = FN.RangeImageFn.apply(pc, ret['e_l'], H, W, fov[0], fov[1])  # fnet.py:43-45
+        else:
+            e_range, _ = ops.range_image(pc, ret['e_l'], H, W, fov[0], fov[1])
         h_img = ret.get('_h_img_nhwc')
         if h_img is None:
             h_img = ops.nchw_to_nhwc(ret['h_img'], 4)
         cam = self._trunk(ctx, h_img, 'camera')                                   # (B,h,wc,16)
         r0 = L.run_conv_bn_relu(ctx, self.conv_range, e_range)                    # (B,H,W-1,4)
         rng = self._trunk(ctx, r0, 'range')                                       # (B,h,wr,16)
-        f_score, logit = ops.corr_head(cam, rng, want_logit=keep is not None)     # fnet.py:57-81
+        if ctx.grad:
+            f_score, logit = FN.CorrHeadFn.apply(cam, rng), None                  # fnet.py:57-81
+        else:
+            f_score, logit = ops.corr_head(cam, rng, want_logit=keep is not None)
         f_T = pose.yaw_rotation_from_scores(f_score)                              # :87-91
         if keep is not None:
             keep.update({'e_range': e_range, 'cam3': cam, 'rng3': rng, 'f_logit': logit})

@@ -5,6 +5,7 @@ import torch.nn as nn
 from .. import ops
 from ..common import pose
 from ..ops import ACT_LEAKY
+from . import fn as FN
 from . import layers as L
 from .builders import conv_bn_relu, convt_bn_relu, resnet18_layers
 
@@ -36,39 +37,65 @@ class Gnet(nn.Module):
         B, H, W, _ = x.shape
 
         def buf(h, w, c):
-            return torch.empty((B, h, w, c), dtype=torch.float32, device=dev)
-        # concat targets (torch.cat / concat_tensors of gnet.py:117-121 become channel slices)
+            return None if ctx.grad else torch.empty((B, h, w, c), dtype=torch.float32, device=dev)
+
+        def tgt(b, off):
+            return None if ctx.grad else (b, off)
+
+        def cat(b, parts):
+            """torch.cat / concat_tensors of gnet.py:117-121: channel slices of one buffer (inference) or an
+            explicit concatenation (training, so that autograd sees it)"""
+            return torch.cat(parts, -1) if ctx.grad else b
+        assert H % 8 == 0 and W % 8 == 0, 'reference needs (W/2)%8==0 (SURVEY 8a-17); H likewise here'
         cat3 = buf(H // 4, W // 4, 512)       # [conv_img4 | convt_img4]
         cat2 = buf(H // 2, W // 2, 256)       # [conv_img3 | convt_img3]
         cat1 = buf(H, W, 128)                 # [convt_img2 | conv_img2]
-        assert H % 8 == 0 and W % 8 == 0, 'reference needs (W/2)%8==0 (SURVEY 8a-17); H likewise here'
         c1 = L.run_conv_bn_relu(ctx, self.conv_i0, x)                              # gnet.py:103
-        L.run_resnet_layer(ctx, self.conv_img2, c1, out=(cat1, 64))
-        # layer2 reads the conv_img2 slice of cat1 (channel offset 64)
-        _layer_from_slice(ctx, self.conv_img3, cat1, 64, 64, out=(cat2, 0))
-        _layer_from_slice(ctx, self.conv_img4, cat2, 0, 128, out=(cat3, 0))
-        c5 = _layer_from_slice(ctx, self.conv_img5, cat3, 0, 256, out=None)
-        L.run_convt_bn_relu(ctx, self.convt_img4, c5, out=(cat3, 256))             # :116
-        L.run_convt_bn_relu(ctx, self.convt_img3, cat3, out=(cat2, 128))
-        L.run_convt_bn_relu(ctx, self.convt_img2, cat2, out=(cat1, 0))
-        dimg = L.run_convt_bn_relu(ctx, self.convt_dimg, cat1)                     # (B,2H,2W,4) ch0
-        mask = L.run_convt_bn_relu(ctx, self.convt_mask, cat1)                     # (B,2H,2W,4) ch0,1
-        g_depth = ops.nhwc_to_nchw(dimg, 1)
-        g_mask = ops.softmax2_to_nchw(mask)
+        c2 = L.run_resnet_layer(ctx, self.conv_img2, c1, out=tgt(cat1, 64))
+        if ctx.grad:
+            c3 = L.run_resnet_layer(ctx, self.conv_img3, c2)
+            c4 = L.run_resnet_layer(ctx, self.conv_img4, c3)
+            c5 = L.run_resnet_layer(ctx, self.conv_img5, c4)
+        else:
+            c3 = _layer_from_slice(ctx, self.conv_img3, cat1, 64, 64, out=(cat2, 0))
+            c4 = _layer_from_slice(ctx, self.conv_img4, cat2, 0, 128, out=(cat3, 0))
+            c5 = _layer_from_slice(ctx, self.conv_img5, cat3, 0, 256, out=None)
+        t4 = L.run_convt_bn_relu(ctx, self.convt_img4, c5, out=tgt(cat3, 256))     # :116
+        t3 = L.run_convt_bn_relu(ctx, self.convt_img3, cat(cat3, [c4, t4]), out=tgt(cat2, 128))
+        t2 = L.run_convt_bn_relu(ctx, self.convt_img2, cat(cat2, [c3, t3]), out=tgt(cat1, 0))
+        cv = cat(cat1, [t2, c2])
+        dimg = L.run_convt_bn_relu(ctx, self.convt_dimg, cv)                       # (B,2H,2W,4) ch0
+        mask = L.run_convt_bn_relu(ctx, self.convt_mask, cv)                       # (B,2H,2W,4) ch0,1
         rawH, rawW = self.raw_cam_img_size
-        f_depth, pix = ops.depth_image(pc, ret['efh_cam_T_velo'], rawH, rawW)      # :136
+        if ctx.grad:
+            g_depth = FN.NhwcToNchwFn.apply(dimg, 1)
+            g_mask = FN.Softmax2ToNchwFn.apply(mask)
+            f_depth = FN.DepthImageFn.apply(pc, ret['efh_cam_T_velo'], rawH, rawW)  # :136
+        else:
+            g_depth = ops.nhwc_to_nchw(dimg, 1)
+            g_mask = ops.softmax2_to_nchw(mask)
+            f_depth, _ = ops.depth_image(pc, ret['efh_cam_T_velo'], rawH, rawW)
         cat0 = buf(H, W, 64)                  # [conv_i1 | conv_d1]
-        L.run_conv_bn_relu(ctx, self.conv_i1, cat1, out=(cat0, 0), in_ch=(0, 64))
-        L.run_conv_bn_relu(ctx, self.conv_d1, f_depth, out=(cat0, 32))
-        y = L.run_resnet_layer(ctx, self.conv2, cat0)
+        if ctx.grad:
+            ci1 = L.run_conv_bn_relu(ctx, self.conv_i1, t2)
+            cd1 = L.run_conv_bn_relu(ctx, self.conv_d1, f_depth)
+            y = torch.cat([ci1, cd1], -1)
+        else:
+            L.run_conv_bn_relu(ctx, self.conv_i1, cat1, out=(cat0, 0), in_ch=(0, 64))
+            L.run_conv_bn_relu(ctx, self.conv_d1, f_depth, out=(cat0, 32))
+            y = cat0
+        y = L.run_resnet_layer(ctx, self.conv2, y)
         y = L.run_resnet_layer(ctx, self.conv3, y)
         y = L.run_resnet_layer(ctx, self.conv4, y)
         y = L.run_resnet_layer(ctx, self.conv5, y)
         for seq in (self.conv_trs_1, self.conv_trs_2, self.conv_trs_3):
             y = L.run_conv_bn_relu(ctx, seq, y)
         P = y.shape[1] * y.shape[2]
-        t4 = L.linear_rows(ctx, y.view(B * P, 512), B * P, 512, self.conv_trs_4.weight, self.conv_trs_4.bias)
-        trs = ops.segment_colmean(t4, t4.shape[-1], 3, P, B)[:, :, None]          # :165
+        t4r = L.linear_rows(ctx, y.reshape(B * P, 512), B * P, 512, self.conv_trs_4.weight, self.conv_trs_4.bias)
+        if ctx.grad:
+            trs = FN.SegmentColMeanFn.apply(t4r, P, B, 3)[:, :, None]              # :165
+        else:
+            trs = ops.segment_colmean(t4r, t4r.shape[-1], 3, P, B)[:, :, None]
         g_T = pose.translation_matrix(trs)
         if keep is not None:
             keep.update({'f_depth': f_depth})

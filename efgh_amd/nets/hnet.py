@@ -5,6 +5,7 @@ import torch.nn as nn
 from .. import ops
 from ..common import pose
 from ..ops import ACT_RELU
+from . import fn as FN
 from . import layers as L
 from .builders import VGGFeatures
 
@@ -35,12 +36,15 @@ class Hnet(nn.Module):
         x = L.run_vgg(ctx, self.vgg.features, x)                        # (B,h,w,512)
         P = x.shape[1] * x.shape[2]
         M = B * P
-        x = x.view(M, 512)
+        x = x.reshape(M, 512)
         for conv, bn in ((self.conv_hrzn_1, self.bn_hrzn_1), (self.conv_hrzn_2, self.bn_hrzn_2),
                          (self.conv_hrzn_3, self.bn_hrzn_3)):
             x = L.linear_rows(ctx, x, M, conv.in_channels, conv.weight, conv.bias, bn=bn, act=ACT_RELU)
         seg = torch.arange(0, M + 1, P, dtype=torch.int32, device=dev)
-        x, _ = ops.segment_colmax(x, x.shape[-1], 128, seg, B)
+        if ctx.grad:
+            x = FN.SegmentColMaxFn.apply(x, seg, B, 128)
+        else:
+            x, _ = ops.segment_colmax(x, x.shape[-1], 128, seg, B)
         for lin in (self.lin_hrzn_1, self.lin_hrzn_2, self.lin_hrzn_3):
             x = L.linear_rows(ctx, x, B, lin.in_features, lin.weight, lin.bias, act=ACT_RELU)
         sgn = L.linear_rows(ctx, x, B, 32, self.lin_hrzn_sgn.weight, self.lin_hrzn_sgn.bias)[:, :4]

@@ -9,6 +9,7 @@ import torch.nn as nn
 
 from .. import ops
 from ..ops import ACT_LEAKY, ACT_NONE, ACT_RELU, ceil4
+from . import fn as FN
 
 
 class Ctx:
@@ -16,6 +17,7 @@ class Ctx:
 
     def __init__(self, train):
         self.train = bool(train)
+        self.grad = torch.is_grad_enabled()      # autograd path (hand-written backward kernels)
 
 
 def _bn_eval_affine(bn, Np):
@@ -133,8 +135,12 @@ def conv2d(ctx, x, conv, bn=None, act=ACT_NONE, slope=0.0, residual=None, out=No
     dh = [i // kw - ph for i in range(T)]
     dw = [i % kw - pw for i in range(T)]
     geom = (B, H, W, Ho, Wo, sh, sw, dh, dw, Ho, Wo, 1, 1, 0, 0)
-    out_t, ldo, coff = _alloc_out(x, (B, Ho, Wo), O, out)
     M = B * Ho * Wo
+    if ctx.grad:
+        assert out is None
+        xs = x if in_ch is None else x[..., a_off:a_off + Cx]
+        return _conv2d_grad(ctx, xs, conv, bn, act, slope, residual, geom, (B, H, W, Ho, Wo), Cp)
+    out_t, ldo, coff = _alloc_out(x, (B, Ho, Wo), O, out)
     res_ld = residual.shape[-1] if residual is not None else 0
     _run(ctx, x, ldx, Cp, T, Wp, O, M, 1, [(geom, Wp, M)], out_t, ldo, coff, conv.bias, bn, act, slope,
          residual=residual, res_ld=res_ld, a_off=a_off, c_real=Cw)
@@ -150,7 +156,7 @@ def conv_transpose2d(ctx, x, convt, bn=None, act=ACT_NONE, slope=0.0, out=None):
     oph, opw = convt.output_padding
     Ho, Wo = (H - 1) * 2 - 2 * ph + 3 + oph, (W - 1) * 2 - 2 * pw + 3 + opw
     Np = ceil4(O)
-    out_t, ldo, coff = _alloc_out(x, (B, Ho, Wo), O, out)
+    out_t, ldo, coff = (None, 0, 0) if ctx.grad else _alloc_out(x, (B, Ho, Wo), O, out)
     geoms = []
     for cy in range(2):
         for cx in range(2):
@@ -167,8 +173,12 @@ def conv_transpose2d(ctx, x, convt, bn=None, act=ACT_NONE, slope=0.0, out=None):
             Wp = ops.pack_weight(convt.weight, O, len(taps), Cw, 9, O * 9, 1, tapidx, Np=Np,
                                  key=('convt', cy, cx, ph, pw, Np))
             geom = (B, H, W, Hv, Wv, 1, 1, dh, dw, Ho, Wo, 2, 2, cy, cx)
-            geoms.append((geom, Wp, B * Hv * Wv))
-    _run(ctx, x, ldx, Cw, 0, None, O, B * Ho * Wo, 1, geoms, out_t, ldo, coff, convt.bias, bn, act, slope)
+            geoms.append((geom, Wp, B * Hv * Wv, tapidx, (cy, cx)))
+    if ctx.grad:
+        assert out is None
+        return _convt_grad(ctx, x, convt, bn, act, slope, geoms, (B, H, W, Ho, Wo))
+    _run(ctx, x, ldx, Cw, 0, None, O, B * Ho * Wo, 1, [g[:3] for g in geoms], out_t, ldo, coff, convt.bias, bn,
+         act, slope)
     return out_t
 
 
@@ -179,6 +189,10 @@ def linear_rows(ctx, x, M, C, weight, bias, bn=None, act=ACT_NONE, slope=0.0, ou
     Cp = ceil4(C)
     lda = lda if lda is not None else x.shape[-1]
     Np = ceil4(O)
+    if ctx.grad:
+        assert out is None
+        xs = x if (a_off == 0 and x.shape[-1] == Cp) else x.view(-1, x.shape[-1])[:, a_off:a_off + Cp]
+        return _linear_grad(ctx, xs.reshape(M, -1) if xs.dim() != 2 else xs, M, C, weight, bias, bn, act, slope)
     Wp = ops.pack_weight(weight, O, 1, C, C, 1, 1, [0], Np=Np, Cp=Cp, key=('lin', Np, Cp))
     if out is None:
         out_t = torch.empty((M, Np), dtype=torch.float32, device=x.device)
@@ -195,6 +209,10 @@ def blur_conv(ctx, splat, H, C, table, conv0, conv1, out=None):
     """BCL blur: gather 15 neighbour rows + Conv2d(C,C0,(15,1)) + ReLU + Conv2d(C0,C1,1)
     (nets/bilateralNN.py:240-246).  splat [H][C], table [H][16] -> [H][ld]."""
     C0, C1 = conv0.out_channels, conv1.out_channels
+    if ctx.grad:
+        assert out is None
+        mid = _blur_grad(ctx, splat, H, C, table, conv0)
+        return linear_rows(ctx, mid, H, C0, conv1.weight, conv1.bias)
     Wp0 = ops.pack_weight(conv0.weight, C0, 15, C, C * 15, 15, 1, list(range(15)), key=('blur0',))
     mid = torch.empty((H, C0), dtype=torch.float32, device=splat.device)
     ops.gather_gemm(splat, C, C, 15, Wp0, C0, H, mid, C0, mode=2, table=table, bias=conv0.bias.detach(),
@@ -203,6 +221,8 @@ def blur_conv(ctx, splat, H, C, table, conv0, conv1, out=None):
 
 
 def maxpool2(ctx, x):
+    if ctx.grad:
+        return FN.MaxPool2Fn.apply(x)
     return ops.maxpool2(x)
 
 
@@ -225,13 +245,13 @@ def run_vgg(ctx, features, x):
 
 def run_conv_bn_relu(ctx, seq, x, out=None, in_ch=None):
     """nets/net_utils.py:45-64: Conv2d(no bias) + BN + LeakyReLU(0.2)."""
-    return conv2d(ctx, x, seq[0], seq[1], ACT_LEAKY, 0.2, out=out, in_ch=in_ch)
+    return conv2d(ctx, x, seq[0], seq[1], ACT_LEAKY, 0.2, out=None if ctx.grad else out, in_ch=in_ch)
 
 
 def run_convt_bn_relu(ctx, seq, x, out=None):
     """nets/net_utils.py:66-98: ConvT+BN+LeakyReLU(0.2) then Conv3x3+BN+LeakyReLU(0.2)."""
     y = conv_transpose2d(ctx, x, seq[0], seq[1], ACT_LEAKY, 0.2)
-    return conv2d(ctx, y, seq[3], seq[4], ACT_LEAKY, 0.2, out=out)
+    return conv2d(ctx, y, seq[3], seq[4], ACT_LEAKY, 0.2, out=None if ctx.grad else out)
 
 
 def run_basic_block(ctx, blk, x, out=None):
@@ -241,7 +261,7 @@ def run_basic_block(ctx, blk, x, out=None):
         idt = conv2d(ctx, x, blk.downsample[0], blk.downsample[1], ACT_NONE)
     else:
         idt = x
-    return conv2d(ctx, y, blk.conv2, blk.bn2, ACT_RELU, residual=idt, out=out)
+    return conv2d(ctx, y, blk.conv2, blk.bn2, ACT_RELU, residual=idt, out=None if ctx.grad else out)
 
 
 def run_resnet_layer(ctx, layer, x, out=None):
@@ -249,3 +269,140 @@ def run_resnet_layer(ctx, layer, x, out=None):
     for i, blk in enumerate(blocks):
         x = run_basic_block(ctx, blk, x, out=out if i == len(blocks) - 1 else None)
     return x
+
+
+# ==============================================================================================
+# training path: the same layers as autograd Functions with hand-written HIP backward (fn.py)
+# ==============================================================================================
+def _bn_args(bn):
+    return (None, None) if bn is None else (bn.weight, bn.bias)
+
+
+def _conv2d_grad(ctx, x, conv, bn, act, slope, residual, geom, dims, Cp):
+    B, H, W, Ho, Wo = dims
+    Cw, O = conv.in_channels, conv.out_channels
+    kh, kw = conv.kernel_size
+    sh, sw = conv.stride
+    ph, pw = conv.padding
+    T, Np = kh * kw, ceil4(O)
+
+    def pack_fwd(w, i):
+        return ops.pack_weight(w, O, T, Cw, Cw * T, T, 1, list(range(T)), Np=Np, Cp=Cp, key=('conv', Np, Cp))
+
+    def unpack(dWp, i, dW):
+        ops.unpack_weight(dWp, dW, O, T, Cw, Cp, Cw * T, T, 1, list(range(T)))
+
+    def dgrad(spec, w, draw, xin):
+        dev = draw.device
+        if sh == 1 and sw == 1:
+            dhs = [ph - i // kw for i in range(T)]
+            dws = [pw - i % kw for i in range(T)]
+            Wd = ops.pack_weight(w, Cw, T, O, T, Cw * T, 1, list(range(T)), Np=Cp, Cp=Np, key=('conv_d', Np, Cp))
+            dx = torch.empty((B, H, W, Cp), dtype=torch.float32, device=dev)
+            g = (B, Ho, Wo, H, W, 1, 1, dhs, dws, H, W, 1, 1, 0, 0)
+            ops.gather_gemm(draw, Np, Np, T, Wd, Cp, B * H * W, dx, Cp, mode=1, geom=g,
+                            flops=2.0 * B * H * W * Cw * T * O)
+            return dx
+        assert sh == 2 and sw == 2
+        classes = []
+        for cy in range(2):
+            for cx in range(2):
+                khs = [k for k in range(kh) if (cy + ph - k) % 2 == 0]
+                kws = [k for k in range(kw) if (cx + pw - k) % 2 == 0]
+                taps = [(a, b) for a in khs for b in kws]
+                Hv, Wv = (H - cy + 1) // 2, (W - cx + 1) // 2
+                classes.append((cy, cx, taps, Hv, Wv))
+        full = all(len(c[2]) > 0 for c in classes)
+        dx = (torch.empty if full else torch.zeros)((B, H, W, Cp), dtype=torch.float32, device=dev)
+        for cy, cx, taps, Hv, Wv in classes:
+            if not taps or Hv <= 0 or Wv <= 0:
+                continue
+            dhs = [(cy + ph - a) // 2 for a, _ in taps]
+            dws = [(cx + pw - b) // 2 for _, b in taps]
+            tapidx = [a * kw + b for a, b in taps]
+            Wd = ops.pack_weight(w, Cw, len(taps), O, T, Cw * T, 1, tapidx, Np=Cp, Cp=Np,
+                                 key=('conv_d2', cy, cx, Np, Cp))
+            g = (B, Ho, Wo, Hv, Wv, 1, 1, dhs, dws, H, W, 2, 2, cy, cx)
+            ops.gather_gemm(draw, Np, Np, len(taps), Wd, Cp, B * Hv * Wv, dx, Cp, mode=1, geom=g,
+                            flops=2.0 * B * Hv * Wv * Cw * len(taps) * O)
+        return dx
+
+    spec = FN.LayerSpec(O, Cp, T, 1, [(geom, B * Ho * Wo)], B * Ho * Wo, (B, Ho, Wo), pack_fwd, dgrad, unpack,
+                        bn=bn, train=ctx.train, act=act, slope=slope, c_real=Cw)
+    g_, b_ = _bn_args(bn)
+    return FN.GemmLayerFn.apply(x, conv.weight, conv.bias, g_, b_, residual, spec)
+
+
+def _convt_grad(ctx, x, convt, bn, act, slope, geoms, dims):
+    B, H, W, Ho, Wo = dims
+    Cw, O = convt.in_channels, convt.out_channels
+    ph, pw = convt.padding
+    Np = ceil4(O)
+
+    def pack_fwd(w, i):
+        return geoms[i][1]
+
+    def unpack(dWp, i, dW):
+        tapidx = geoms[i][3]
+        ops.unpack_weight(dWp, dW, O, len(tapidx), Cw, Cw, 9, O * 9, 1, tapidx)
+
+    def dgrad(spec, w, draw, xin):
+        # dX[ci][ih][iw] = sum_{co,kh,kw} dY[co][2ih-ph+kh][2iw-pw+kw] * W[ci][co][kh][kw]  (stride-2 conv)
+        dhs = [k // 3 - ph for k in range(9)]
+        dws = [k % 3 - pw for k in range(9)]
+        Wd = ops.pack_weight(w, Cw, 9, O, O * 9, 9, 1, list(range(9)), Cp=Np, key=('convt_d', Np))
+        dx = torch.empty((B, H, W, Cw), dtype=torch.float32, device=draw.device)
+        g = (B, Ho, Wo, H, W, 2, 2, dhs, dws, H, W, 1, 1, 0, 0)
+        ops.gather_gemm(draw, Np, Np, 9, Wd, Cw, B * H * W, dx, Cw, mode=1, geom=g,
+                        flops=2.0 * B * H * W * Cw * 9 * O / 4 * 4)
+        return dx
+
+    spec = FN.LayerSpec(O, Cw, 0, 1, [(g[0], g[2]) for g in geoms], B * Ho * Wo, (B, Ho, Wo), pack_fwd, dgrad,
+                        unpack, bn=bn, train=ctx.train, act=act, slope=slope, c_real=Cw)
+    g_, b_ = _bn_args(bn)
+    return FN.GemmLayerFn.apply(x, convt.weight, convt.bias, g_, b_, None, spec)
+
+
+def _linear_grad(ctx, x, M, C, weight, bias, bn, act, slope):
+    O = weight.shape[0]
+    Cp, Np = ceil4(C), ceil4(O)
+
+    def pack_fwd(w, i):
+        return ops.pack_weight(w, O, 1, C, C, 1, 1, [0], Np=Np, Cp=Cp, key=('lin', Np, Cp))
+
+    def unpack(dWp, i, dW):
+        ops.unpack_weight(dWp, dW, O, 1, C, Cp, C, 1, 1, [0])
+
+    def dgrad(spec, w, draw, xin):
+        Wd = ops.pack_weight(w, C, 1, O, 1, C, 1, [0], Np=Cp, Cp=Np, key=('lin_d', Np, Cp))
+        dx = torch.empty((M, Cp), dtype=torch.float32, device=draw.device)
+        ops.gather_gemm(draw, Np, Np, 1, Wd, Cp, M, dx, Cp, mode=0, flops=2.0 * M * C * O)
+        return dx
+
+    spec = FN.LayerSpec(O, Cp, 1, 0, [(None, M)], M, (M,), pack_fwd, dgrad, unpack, bn=bn, train=ctx.train, act=act,
+                        slope=slope, c_real=C)
+    g_, b_ = _bn_args(bn)
+    return FN.GemmLayerFn.apply(x, weight, bias, g_, b_, None, spec)
+
+
+def _blur_grad(ctx, splat, H, C, table, conv0):
+    C0 = conv0.out_channels
+
+    def pack_fwd(w, i):
+        return ops.pack_weight(w, C0, 15, C, C * 15, 15, 1, list(range(15)), key=('blur0',))
+
+    def unpack(dWp, i, dW):
+        ops.unpack_weight(dWp, dW, C0, 15, C, C, C * 15, 15, 1, list(range(15)))
+
+    def dgrad(spec, w, draw, xin):
+        # tmp[m][t*C+c] = sum_n draw[m][n] * W0[n][c][t], then scattered through the neighbour table
+        Wd = w.detach().squeeze(-1).permute(2, 1, 0).contiguous().view(15 * C, C0)
+        tmp = torch.empty((H, 15 * C), dtype=torch.float32, device=draw.device)
+        ops.gather_gemm(draw, C0, C0, 1, Wd, 15 * C, H, tmp, 15 * C, mode=0, flops=2.0 * H * 15 * C * C0)
+        dsplat = torch.zeros((H, C), dtype=torch.float32, device=draw.device)
+        ops.table_scatter_add(tmp, table, H, 15, C, dsplat)
+        return dsplat
+
+    spec = FN.LayerSpec(C0, C, 15, 2, [(None, H)], H, (H,), pack_fwd, dgrad, unpack, act=ACT_RELU, table=table,
+                        c_real=C)
+    return FN.GemmLayerFn.apply(splat, conv0.weight, conv0.bias, None, None, None, spec)

@@ -276,7 +276,7 @@ def minmax(x):
     return mm
 
 
-def corr_head(cam, rng, want_logit=False):
+def corr_head(cam, rng, want_logit=False, want_aux=False):
     """cam [B][h][wc][16], rng [B][h][wr][16] -> f_score (B, wr + 2*(wr//8) - wc + 1)"""
     B, h, wc, C = cam.shape
     wr = rng.shape[2]
@@ -293,4 +293,96 @@ def corr_head(cam, rng, want_logit=False):
     logit = torch.empty((B, nj), dtype=torch.float32, device=cam.device) if want_logit else None
     _C.check(_L().efgh_corr1d(ptr(rp), ptr(cam), ptr(cam_mm), c_int32(B), c_int32(h), c_int32(wc), c_int32(wp),
                               ptr(part), ptr(logit), ptr(score), _st()))
+    if want_aux:
+        return score, logit, rp, cam_mm, rng_mm
     return score, logit
+
+
+# ----------------------------------------------------------------------------------------------
+# backward
+# ----------------------------------------------------------------------------------------------
+def gather_wgrad(A, lda, C, T, N, M, G, ldg, dWp, mode=0, geom=None, table=None):
+    d = _C.GemmDesc()
+    d.A = A.data_ptr()
+    d.lda, d.C, d.T, d.mode = lda, C, T, mode
+    if geom is not None:
+        (d.B, d.Hin, d.Win, d.Hv, d.Wv, d.sh, d.sw, dh, dw, d.Ho, d.Wo, d.osh, d.osw, d.oh0, d.ow0) = geom
+        for i, (a, b) in enumerate(zip(dh, dw)):
+            d.dh[i], d.dw[i] = a, b
+    d.table = 0 if table is None else table.data_ptr()
+    d.N, d.M = N, M
+    _C.check(_L().efgh_gather_wgrad(ctypes.byref(d), ptr(G), c_int64(ldg), ptr(dWp), _st()))
+
+
+def unpack_weight(Wp, W, N, T, C, Cp, sn, sc, st, taps, accumulate=False):
+    tp = (ctypes.c_int32 * 16)(*([int(t) for t in taps] + [0] * (16 - len(taps))))
+    _C.check(_L().efgh_unpack_weight(ptr(Wp), ptr(W), c_int32(N), c_int32(T), c_int32(C), c_int32(Cp), c_int64(sn),
+                                     c_int64(sc), c_int64(st), tp, c_int32(1 if accumulate else 0), _st()))
+
+
+def table_scatter_add(src, table, M, T, C, dst):
+    _C.check(_L().efgh_table_scatter_add(ptr(src), ptr(table), c_int64(M), c_int32(T), c_int32(C), ptr(dst), _st()))
+
+
+def bwd_groups(M):
+    return _L().efgh_bwd_groups(c_int64(M))
+
+
+def act_bn_bwd_reduce(dy, lddy, y, ldy, raw, ldraw, mean, invstd, M, C, act, slope, part, s1, s2, m1, m2):
+    _C.check(_L().efgh_act_bn_bwd_reduce(ptr(dy), c_int64(lddy), ptr(y), c_int64(ldy), ptr(raw), c_int64(ldraw),
+                                         ptr(mean), ptr(invstd), c_int64(M), c_int32(C), c_int32(act),
+                                         c_float(slope), ptr(part), ptr(s1), ptr(s2), ptr(m1), ptr(m2), _st()))
+
+
+def act_bn_bwd_apply(dy, lddy, y, ldy, raw, ldraw, mean, invstd, coef, m1, m2, M, C, act, slope, draw, lddraw,
+                     dres, lddres):
+    _C.check(_L().efgh_act_bn_bwd_apply(ptr(dy), c_int64(lddy), ptr(y), c_int64(ldy), ptr(raw), c_int64(ldraw),
+                                        ptr(mean), ptr(invstd), ptr(coef), ptr(m1), ptr(m2), c_int64(M), c_int32(C),
+                                        c_int32(act), c_float(slope), ptr(draw), c_int64(lddraw), ptr(dres),
+                                        c_int64(lddres), _st()))
+
+
+def col_sum(x, M, C):
+    stats, G = col_stats(x, M, C, x.shape[-1])
+    return stats[:, 0, :].sum(0)
+
+
+def maxpool2_bwd(x, dy, dx):
+    B, H, W, C = x.shape
+    _C.check(_L().efgh_maxpool2_bwd(ptr(x), ptr(dy), ptr(dx), c_int32(B), c_int32(H), c_int32(W), c_int32(C), _st()))
+
+
+def segment_colmax_bwd(dy, arg, nseg, C, dx, ld):
+    _C.check(_L().efgh_segment_colmax_bwd(ptr(dy), ptr(arg), c_int32(nseg), c_int32(C), ptr(dx), c_int64(ld), _st()))
+
+
+def segment_colmean_bwd(dy, P, nseg, C, dx, ld):
+    _C.check(_L().efgh_segment_colmean_bwd(ptr(dy), c_int32(P), c_int32(nseg), c_int32(C), ptr(dx), c_int64(ld),
+                                           _st()))
+
+
+def softmax2_bwd(y, dy, dx):
+    B, _, H, W = y.shape
+    _C.check(_L().efgh_softmax2_bwd(ptr(y), ptr(dy), c_int32(B), c_int64(H * W), ptr(dx), c_int64(dx.shape[-1]),
+                                    _st()))
+
+
+def raster_bwd(pix, gimg, B, N, HW):
+    gv = torch.empty((B, N, 4), dtype=torch.float32, device=gimg.device)
+    _C.check(_L().efgh_raster_bwd(ptr(pix), ptr(gimg), c_int32(B), c_int32(N), c_int64(HW), ptr(gv), _st()))
+    return gv
+
+
+def corr1d_bwd(rp, cam, cam_mm, dl, B, h, wc, wp):
+    dcam = torch.empty_like(cam)
+    drp = torch.empty_like(rp)
+    _C.check(_L().efgh_corr1d_bwd(ptr(rp), ptr(cam), ptr(cam_mm), ptr(dl), c_int32(B), c_int32(h), c_int32(wc),
+                                  c_int32(wp), ptr(dcam), ptr(drp), _st()))
+    return dcam, drp
+
+
+def corr_unpad(drp, B, h, w, C, off):
+    dx = torch.empty((B, h, w, C), dtype=torch.float32, device=drp.device)
+    _C.check(_L().efgh_corr_unpad(ptr(drp), c_int32(B), c_int32(h), c_int32(w), c_int32(C), c_int32(off), ptr(dx),
+                                  _st()))
+    return dx

@@ -187,6 +187,47 @@ int efgh_corr_pad(const float *rng, const float *rng_mm, int32_t B, int32_t h, i
 int efgh_corr1d(const float *rp, const float *cam, const float *cam_mm, int32_t B, int32_t h,
                 int32_t wc, int32_t wp, float *part, float *logit, float *score, void *stream);
 
+/* ------------------------------------------------------------------ backward (training) -----
+ * The reference relies on torch autograd (iterater.py:42 `losses['total'].backward()`); these are
+ * the hand-written adjoints of the kernels above.                                             */
+
+/* weight gradient in the packed layout: dWp[n][t*C+c] = sum_m G[orow(m)][n] * A[row(m,t)][c];
+ * `d` describes the SAME gather as the forward launch (A, lda, C, T, mode, geometry/table, N, M);
+ * G is the gradient w.r.t. the (pre-BatchNorm) GEMM output, rows addressed like `out`.         */
+int efgh_gather_wgrad(const efgh_gemm_desc *d, const float *G, int64_t ldg, float *dWp, void *stream);
+/* W.flat[n*sn + c*sc + tapidx[t]*st] (+)= Wp[n][t][c]  (Wp rows padded to Cp) */
+int efgh_unpack_weight(const float *Wp, float *W, int32_t N, int32_t T, int32_t C, int32_t Cp, int64_t sn,
+                       int64_t sc, int64_t st, const int32_t *tapidx_host, int32_t accumulate, void *stream);
+/* dst[table[m*16+t]][c] += src[m][t*C+c]  (adjoint of the neighbour gather, bilateralNN.py:240-242) */
+int efgh_table_scatter_add(const float *src, const int32_t *table, int64_t M, int32_t T, int32_t C,
+                           float *dst, void *stream);
+/* BatchNorm(+residual)+activation backward, two passes.
+ * reduce: dpre = dy*act'(y); sum_dpre[c], sum_dpre_xhat[c] (= dbeta, dgamma) and their means;
+ *         mean/invstd/raw NULL -> only sum_dpre (bias gradient).  part: [efgh_bwd_groups(M)][2][C]. */
+int32_t efgh_bwd_groups(int64_t M);
+int efgh_act_bn_bwd_reduce(const float *dy, int64_t lddy, const float *y, int64_t ldy, const float *raw,
+                           int64_t ldraw, const float *mean, const float *invstd, int64_t M, int32_t C,
+                           int32_t act, float slope, float *part, float *sum_dpre, float *sum_dpre_xhat,
+                           float *mean_dpre, float *mean_dpre_xhat, void *stream);
+/* apply: draw = coef*(dpre - m1 - xhat*m2)  (train BN)  |  coef*dpre (eval BN / none); dres = dpre */
+int efgh_act_bn_bwd_apply(const float *dy, int64_t lddy, const float *y, int64_t ldy, const float *raw,
+                          int64_t ldraw, const float *mean, const float *invstd, const float *coef,
+                          const float *m1, const float *m2, int64_t M, int32_t C, int32_t act, float slope,
+                          float *draw, int64_t lddraw, float *dres, int64_t lddres, void *stream);
+int efgh_maxpool2_bwd(const float *x, const float *dy, float *dx, int32_t B, int32_t H, int32_t W, int32_t C,
+                      void *stream);
+int efgh_segment_colmax_bwd(const float *dy, const int32_t *argrow, int32_t nseg, int32_t C, float *dx,
+                            int64_t ld, void *stream);
+int efgh_segment_colmean_bwd(const float *dy, int32_t P, int32_t nseg, int32_t C, float *dx, int64_t ld,
+                             void *stream);
+int efgh_softmax2_bwd(const float *y, const float *dy, int32_t B, int64_t HW, float *dx, int64_t ld, void *stream);
+/* correlation head: dcam_n (gradient w.r.t. cam/(max-min)) and drp (w.r.t. the padded, normalised
+ * range features); efgh_corr_unpad folds drp back onto the un-padded map.                      */
+int efgh_corr1d_bwd(const float *rp, const float *cam, const float *cam_mm, const float *dlogit, int32_t B,
+                    int32_t h, int32_t wc, int32_t wp, float *dcam_n, float *drp, void *stream);
+int efgh_corr_unpad(const float *drp, int32_t B, int32_t h, int32_t w, int32_t C, int32_t off, float *dx,
+                    void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,244 @@
+"""Backward kernels (through the C-ABI + autograd shims) vs torch autograd on CPU, and the whole
+training step (forward + efghloss + backward) vs the oracle and the reference's golden gradients."""
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from efgh_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+
+def _nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def _relerr(a, b):
+    return float((a - b).norm() / (b.norm() + 1e-20))
+
+
+def _mk_bn(c):
+    bn = nn.BatchNorm2d(c)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.2)
+        bn.running_mean.normal_(0, 0.2); bn.running_var.uniform_(0.5, 1.5)
+    return bn
+
+
+@pytest.mark.parametrize('cin,cout,k,s,p,hw,res', [
+    (64, 64, 3, 1, 1, (12, 20), True), (64, 128, 3, 2, 1, (12, 20), False), (64, 128, 1, 2, 0, (12, 20), False),
+    (3, 64, 3, 1, 1, (10, 14), False), (4, 3, (1, 2), 1, 0, (6, 17), False), (128, 128, 3, 1, 1, (7, 9), True),
+    (1, 1, 3, 1, 1, (10, 12), False), (512, 512, 1, 1, 0, (4, 6), False),
+])
+@pytest.mark.parametrize('train', [True, False])
+def test_conv_bn_act_backward(cin, cout, k, s, p, hw, res, train):
+    from efgh_amd import ops
+    from efgh_amd.nets import layers as L
+    torch.manual_seed(0)
+    conv = nn.Conv2d(cin, cout, k, s, p, bias=True)
+    bn = _mk_bn(cout)
+    bn.train(train)
+    x = torch.randn(2, cin, *hw, requires_grad=True)
+    y0 = bn(conv(x))
+    r = torch.randn_like(y0) if res else None
+    if res:
+        r.requires_grad_(True)
+    y = F.relu(y0 + r) if res else F.leaky_relu(y0, 0.2)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    import copy
+    conv_g, bn_g = copy.deepcopy(conv).cuda(), copy.deepcopy(bn).cuda()
+    for m in (conv_g, bn_g):
+        for p_ in m.parameters():
+            p_.grad = None
+    bn_g.train(train)
+    cp = (cin + 3) // 4 * 4
+    xg = ops.nchw_to_nhwc(x.detach().cuda(), cp).requires_grad_(True)
+    rg = _nhwc(r.detach()).cuda().requires_grad_(True) if res else None
+    yg = L.conv2d(L.Ctx(train), xg, conv_g, bn_g, L.ACT_RELU if res else L.ACT_LEAKY, 0.2, residual=rg)
+    gyg = torch.zeros_like(yg)
+    gyg[..., :cout] = _nhwc(gy).cuda()
+    yg.backward(gyg)
+    assert _relerr(yg[..., :cout].permute(0, 3, 1, 2).detach().cpu(), y.detach()) < 1e-5
+    assert _relerr(xg.grad[..., :cin].permute(0, 3, 1, 2).cpu(), x.grad) < 2e-4
+    assert _relerr(conv_g.weight.grad.cpu(), conv.weight.grad) < 2e-4
+    assert _relerr(bn_g.weight.grad.cpu(), bn.weight.grad) < 2e-4
+    assert _relerr(bn_g.bias.grad.cpu(), bn.bias.grad) < 2e-4
+    if not train:
+        assert _relerr(conv_g.bias.grad.cpu(), conv.bias.grad) < 2e-4
+    if res:
+        assert _relerr(rg.grad.permute(0, 3, 1, 2).cpu(), r.grad) < 2e-4
+
+
+@pytest.mark.parametrize('cin,cout,pad,opad,hw', [(64, 32, 1, 0, (5, 9)), (32, 16, 0, 0, (7, 11)),
+                                                  (128, 64, 1, 1, (6, 8)), (128, 2, 1, 1, (6, 8))])
+def test_conv_transpose_backward(cin, cout, pad, opad, hw):
+    import copy
+    from efgh_amd.nets import layers as L
+    torch.manual_seed(1)
+    ct = nn.ConvTranspose2d(cin, cout, 3, 2, pad, opad, bias=False)
+    bn = _mk_bn(cout)
+    x = torch.randn(2, cin, *hw, requires_grad=True)
+    y = F.leaky_relu(bn(ct(x)), 0.2)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    ct_g, bn_g = copy.deepcopy(ct).cuda(), copy.deepcopy(bn).cuda()
+    ct_g.weight.grad = None
+    xg = _nhwc(x.detach()).cuda().requires_grad_(True)
+    yg = L.conv_transpose2d(L.Ctx(True), xg, ct_g, bn_g, L.ACT_LEAKY, 0.2)
+    gyg = torch.zeros_like(yg)
+    gyg[..., :cout] = _nhwc(gy).cuda()
+    yg.backward(gyg)
+    assert _relerr(xg.grad.permute(0, 3, 1, 2).cpu(), x.grad) < 2e-4
+    assert _relerr(ct_g.weight.grad.cpu(), ct.weight.grad) < 2e-4
+    assert _relerr(bn_g.weight.grad.cpu(), bn.weight.grad) < 2e-4
+
+
+def test_linear_pool_colmax_backward():
+    import copy
+    from efgh_amd import ops
+    from efgh_amd.nets import fn as FN, layers as L
+    torch.manual_seed(2)
+    lin, bn = nn.Linear(128, 64), nn.BatchNorm1d(64)
+    a = torch.randn(50, 128, requires_grad=True)
+    y = F.relu(bn(lin(a)))
+    seg = [0, 20, 50]
+    z = torch.stack([y[:20].max(0)[0], y[20:].max(0)[0]])
+    gz = torch.randn_like(z)
+    z.backward(gz)
+    lin_g, bn_g = copy.deepcopy(lin).cuda(), copy.deepcopy(bn).cuda()
+    lin_g.weight.grad = lin_g.bias.grad = None
+    ag = a.detach().cuda().requires_grad_(True)
+    yg = L.linear_rows(L.Ctx(True), ag, 50, 128, lin_g.weight, lin_g.bias, bn=bn_g, act=L.ACT_RELU)
+    zg = FN.SegmentColMaxFn.apply(yg, torch.tensor(seg, dtype=torch.int32).cuda(), 2, 64)
+    zg.backward(gz.cuda())
+    assert _relerr(zg.detach().cpu(), z.detach()) < 1e-5
+    assert _relerr(ag.grad.cpu(), a.grad) < 2e-4 and _relerr(lin_g.weight.grad.cpu(), lin.weight.grad) < 2e-4
+    x = torch.randn(2, 8, 10, 14, requires_grad=True)
+    p = F.max_pool2d(x, 2, 2)
+    gp = torch.randn_like(p)
+    p.backward(gp)
+    xg = _nhwc(x.detach()).cuda().requires_grad_(True)
+    pg = FN.MaxPool2Fn.apply(xg)
+    pg.backward(_nhwc(gp).cuda())
+    assert torch.equal(xg.grad.permute(0, 3, 1, 2).cpu(), x.grad)
+
+
+def test_bcl_level_backward():
+    from efgh_amd import lattice
+    from efgh_amd.nets import fn as FN, layers as L
+    from efgh_amd.nets.builders import BilateralConvFlex
+    from oracle import efgh_oracle as O, lattice as olat
+    torch.manual_seed(4)
+    pc = syn.lidar_sweep(2048, 2)
+    ref_lv = olat.generate_data(pc)[0]
+    lv = lattice.build_pyramid(torch.from_numpy(pc).cuda(), (1.0,))[0]
+    C = 36
+    feat = torch.randn(2048, C)
+    m = BilateralConvFlex(C, [32, 48])
+    with torch.no_grad():
+        for p in m.parameters():
+            p.normal_(0, 0.2)
+    P = {'b.' + k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in m.state_dict().items()}
+    fr = feat.t().contiguous().requires_grad_(True)
+    ref = O.bcl(P, 'b', fr, torch.from_numpy(ref_lv['bary']), torch.from_numpy(ref_lv['off']),
+                torch.from_numpy(ref_lv['nbr']))
+    g = torch.randn_like(ref)
+    ref.backward(g)
+    m = m.cuda()
+    fg = feat.cuda().requires_grad_(True)
+    splat = FN.SplatFn.apply(fg, lv.bary, lv.off, lv.H, C)
+    out = L.blur_conv(L.Ctx(True), splat, lv.H, C, lv.nbr, m.blur_conv[0], m.blur_conv[2])
+    out.backward(g.t().contiguous().cuda())
+    assert _relerr(fg.grad.t().cpu(), fr.grad) < 2e-4
+    assert _relerr(m.blur_conv[0].weight.grad.cpu(), P['b.blur_conv.0.weight'].grad) < 2e-4
+    assert _relerr(m.blur_conv[0].bias.grad.cpu(), P['b.blur_conv.0.bias'].grad) < 2e-4
+    assert _relerr(m.blur_conv[2].weight.grad.cpu(), P['b.blur_conv.2.weight'].grad) < 2e-4
+
+
+def test_corr_head_backward():
+    from efgh_amd.nets import fn as FN
+    from oracle import efgh_oracle as O
+    torch.manual_seed(5)
+    cam = torch.randn(1, 16, 9, 21, requires_grad=True)
+    rng = torch.randn(1, 16, 9, 85, requires_grad=True)
+    c = cam / (cam.max() - cam.min())
+    r = rng / (rng.max() - rng.min())
+    ref = torch.sigmoid(F.conv2d(O.circular_assign(r, int(85 / 8)), c).view(1, -1) / 16)
+    g = torch.randn_like(ref)
+    ref.backward(g)
+    cg, rg = _nhwc(cam.detach()).cuda().requires_grad_(True), _nhwc(rng.detach()).cuda().requires_grad_(True)
+    s = FN.CorrHeadFn.apply(cg, rg)
+    s.backward(g.cuda())
+    assert _relerr(s.detach().cpu(), ref.detach()) < 1e-5
+    assert _relerr(cg.grad.permute(0, 3, 1, 2).cpu(), cam.grad) < 2e-4
+    assert _relerr(rg.grad.permute(0, 3, 1, 2).cpu(), rng.grad) < 2e-4
+
+
+def test_training_step_vs_oracle_and_golden(golden_dir, manifest, monkeypatch):
+    """forward + efghloss + backward at the golden size; the uint8 rotate is teacher-forced to the
+    oracle's h_img (a 1-ulp angle difference would move pixels, see test_gpu_forward)."""
+    from efgh_amd import ops
+    from efgh_amd.losses import EFGHCriterion
+    from efgh_amd.nets import EFGHBackbone
+    from oracle import efgh_oracle as O
+    RAW, NPTS = (128, 256), 2048
+    G = np.load(os.path.join(golden_dir, 'e2e_small.npz'))
+    args_c, args_g = syn.default_args(RAW, 'cpu'), syn.default_args(RAW, 'cuda')
+    b = syn.make_batch(RAW, NPTS, 1)
+    T = torch.from_numpy
+    cpu = [T(b[k]) for k in ('pc', 'img', 'calib', 'A')]
+    # ---- oracle
+    P = syn.synthetic_state_dict(manifest['state_dict'], 1)
+    for k in manifest['parameters']:
+        P[k].requires_grad_(True)
+    pred_o = O.forward(P, *cpu, args_c, train=True)
+    L_o, _ = O.compute_loss(cpu[0], {k: T(v) for k, v in b['gt'].items()}, pred_o, args_c)
+    L_o['total'].backward()
+    # ---- ours (rotate teacher-forced)
+    h_img_o = pred_o['h_img'].detach().cuda()
+    monkeypatch.setattr(ops, 'rotate_nearest_u8',
+                        lambda img, rot, **kw: (h_img_o, ops.nchw_to_nhwc(h_img_o, 4)))
+    m = EFGHBackbone(args_g)
+    m.load_state_dict(syn.synthetic_state_dict(manifest['state_dict'], 1))
+    m = m.cuda().train()
+    crit = EFGHCriterion(args_g)
+    gpu = [t.cuda() for t in cpu]
+    pred = m(*gpu)
+    L, gt2 = crit.compute_loss(gpu[0], gpu[1], gpu[2], gpu[3], {k: T(v) for k, v in b['gt'].items()}, pred)
+    for k in L_o:
+        assert abs(L[k].item() - L_o[k].item()) <= 2e-4 * abs(L_o[k].item()) + 1e-6, (k, L[k].item(), L_o[k].item())
+        assert abs(L[k].item() - float(G['train.loss.' + k])) <= 2e-4 * abs(float(G['train.loss.' + k])) + 1e-6, k
+    L['total'].backward()
+    names = manifest['parameters']
+    params = dict(m.named_parameters())
+    ref_norm = G['train.grad_norm']
+    errs = {'E': [], 'H': [], 'F': [], 'G': []}
+    for i, k in enumerate(names):
+        g_o = P[k].grad
+        g = params[k].grad
+        assert g is not None, k
+        g = g.cpu()
+        if re.search(r'(features\.\d+|conv_gn_\d|conv_hrzn_\d|E\.bcn5\.blur_conv\.2)\.bias$', k):
+            continue            # bias in front of a train-mode BatchNorm: analytically zero, rounding noise
+        errs[k[0]].append((_relerr(g, g_o), k))
+        if k[0] != 'F':
+            assert abs(float(g.double().norm()) - ref_norm[i]) <= 3e-2 * ref_norm[i] + 1e-9, (k, float(g.norm()), ref_norm[i])
+    # Tolerances are set from the ORACLE'S OWN reproducibility: the same torch-CPU oracle run with 1 thread /
+    # native convs vs 8 threads / oneDNN differs by <=1.8e-5 (E, H), <=1.4e-2 (G: BatchNorm backward over 128
+    # positions behind a mean-pool head cancels catastrophically in fp32) and up to 0.39 (F: max/min
+    # normalisation + hard-negative mining are discontinuous) on this very case (measured).
+    # Every backward kernel is separately checked at 2e-4 against torch autograd in the tests above.
+    worst = {n: max(v) for n, v in errs.items()}
+    assert worst['E'][0] < 2e-3, worst['E']
+    assert worst['H'][0] < 2e-3, worst['H']
+    assert worst['G'][0] < 5e-2, worst['G']
+    med_f = sorted(e for e, _ in errs['F'])[len(errs['F']) // 2]
+    assert med_f < 5e-2, (med_f, worst['F'])
+    print('grad rel err: ' + ', '.join('%s max %.1e' % (n, worst[n][0]) for n in 'EHFG') + ', F median %.1e' % med_f)
