@@ -1,10 +1,14 @@
-"""EFGHNet hot-path benchmark on MI355X (contract: see the task statement / DESIGN.md §Measurement).
+"""EFGHNet hot-path benchmark on MI355X (contract: task statement / DESIGN.md §5).
 
-    python bench.py --gpus N --steps K --warmup W [--mode fwd|train] [--batch B]
+    python bench.py --gpus N --steps K --warmup W [--mode train|fwd] [--batch B]
 
-One process per GPU (the driver launches N>1 through torch.distributed.run).  A step = one pass of
-the hot path over one batch of synthetic frame-pairs (BASELINE.json configs[1]: EFGHNet forward,
-384x1280 RGB + 64x2048-point sweep, batch 4 per GPU, inputs resident in HBM before the timed region).
+One process per GPU (the driver launches N>1 through torch.distributed.run).
+
+* default `--mode train` = BASELINE.json's metric: frame-pairs/s of EFGHNet fwd+bwd (efghloss, gradient
+  all-reduce, fused Adam) on synthetic 384x1280 RGB + 64x2048-point sweeps, batch 8 per GPU
+  (configs[2]); a step = one training step on one batch, inputs resident in HBM.
+* the same run also times the forward-only workload (configs[1], eval, batch 4) and reports it under
+  "forward_only" (the north star's 40 frame-pairs/s/GPU target is stated on it).
 Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -24,18 +28,19 @@ PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, de
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=5)
-    ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--mode', default='fwd', choices=['fwd'])
-    ap.add_argument('--batch', type=int, default=4, help='frame-pairs per GPU per step')
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--mode', default='train', choices=['train', 'fwd'])
+    ap.add_argument('--batch', type=int, default=None, help='frame-pairs per GPU per step (8 train / 4 fwd)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-forward-section', action='store_true')
     ap.add_argument('--small', action='store_true', help='debug: 128x256 / 2048 points')
     return ap.parse_args()
 
 
-def cpu_baseline(raw, npts):
+def cpu_baseline(raw, npts, mode):
     """the oracle (CPU restatement of the reference) timed on the host cores: ONE frame-pair of the
-    same workload, eval forward (bounded sample, ~10-30 s)."""
+    same workload (bounded sample)."""
     import torch
     from efgh_amd import synthetic as syn
     from efgh_amd.nets import EFGHBackbone
@@ -45,16 +50,38 @@ def cpu_baseline(raw, npts):
     torch.manual_seed(0)
     m = EFGHBackbone(syn.default_args(raw, 'cpu'))      # parameter container only; never executed on CPU
     P = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    names = [k for k, _ in m.named_parameters()]
     b = syn.make_batch(raw, npts, 1)
     T = torch.from_numpy
     args = syn.default_args(raw, 'cpu')
+    inp = [T(b[k]) for k in ('pc', 'img', 'calib', 'A')]
     t0 = time.time()
-    with torch.no_grad():
-        O.forward(P, T(b['pc']), T(b['img']), T(b['calib']), T(b['A']), args, train=False)
+    if mode == 'train':
+        for k in names:
+            P[k].requires_grad_(True)
+        pred = O.forward(P, *inp, args, train=True)
+        L, _ = O.compute_loss(inp[0], {k: T(v) for k, v in b['gt'].items()}, pred, args)
+        L['total'].backward()
+        what = 'train fwd+loss+bwd'
+    else:
+        with torch.no_grad():
+            O.forward(P, *inp, args, train=False)
+        what = 'eval forward'
     dt = time.time() - t0
     return {'value': 1.0 / dt, 'unit': 'frame-pairs/s', 'cores': cores, 'kind': 'port',
-            'sample': '1 frame-pair of the same workload (eval forward, B=1), oracle/efgh_oracle.py + '
-                      'oracle/lattice_oracle.c, torch CPU fp32, %.1f s' % dt}
+            'sample': '1 frame-pair of the same workload (%s, B=1), oracle/efgh_oracle.py + '
+                      'oracle/lattice_oracle.c, torch CPU fp32, %.1f s' % (what, dt)}
+
+
+def gemm_roofline(prof, steps, kernel):
+    ms = sum(e0.elapsed_time(e1) for e0, e1, _ in prof)
+    fl = sum(f for _, _, f in prof)
+    n = len(prof)
+    ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    return {'bound': 'mfma', 'kernel': kernel, 'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': None, 'launches_per_step': n / max(1, steps),
+            'avg_launch_ms': ms / max(1, n), 'algorithmic_gflop_per_launch': fl / max(1, n) / 1e9,
+            'kernel_ms_per_step': ms / max(1, steps)}
 
 
 def main():
@@ -62,7 +89,9 @@ def main():
     import torch
     import torch.distributed as dist
     from efgh_amd import ops, synthetic as syn
+    from efgh_amd.losses import EFGHCriterion
     from efgh_amd.nets import EFGHBackbone
+    from efgh_amd.train import Trainer
 
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
@@ -73,68 +102,94 @@ def main():
     if world > 1:
         dist.init_process_group('nccl', device_id=dev)
     raw, npts = ((128, 256), 2048) if a.small else (RAW, NPTS)
+    args = syn.default_args(raw, 'cuda')
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(dt):
+        if world > 1:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        return dt
+
+    def load(B):
+        batch = syn.make_batch(raw, npts, B, first_seed=rank * B)       # seed = global sample index
+        inp = [torch.from_numpy(batch[k]).to(dev) for k in ('pc', 'img', 'calib', 'A')]
+        gt = {k: torch.from_numpy(v).to(dev) for k, v in batch['gt'].items()}
+        return inp, gt
 
     torch.manual_seed(0)                                  # identical weights on every rank
-    model = EFGHBackbone(syn.default_args(raw, 'cuda')).to(dev)
-    model.eval()
-    B = a.batch
-    batch = syn.make_batch(raw, npts, B, first_seed=rank * B)       # seed = global sample index
-    inp = [torch.from_numpy(batch[k]).to(dev) for k in ('pc', 'img', 'calib', 'A')]
+    model = EFGHBackbone(args).to(dev)
 
-    def step():
-        with torch.no_grad():
-            return model(*inp)
+    def timed(fn, steps, warmup):
+        for _ in range(warmup):
+            fn()
+        barrier()
+        ops.PROFILE, ops.PROFILE_WGRAD = [], []
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        barrier()
+        dt = max_over_ranks(time.perf_counter() - t0)
+        prof, profw = ops.PROFILE, ops.PROFILE_WGRAD
+        ops.PROFILE = ops.PROFILE_WGRAD = None
+        return dt, prof, profw
 
-    for _ in range(a.warmup):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    ops.PROFILE = []
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    prof, ops.PROFILE = ops.PROFILE, None
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    out = None
+    fwd = None
+    if a.mode == 'fwd' or not a.no_forward_section:
+        Bf = a.batch if (a.mode == 'fwd' and a.batch) else 4
+        inp, _ = load(Bf)
+        model.eval()
 
+        def fstep():
+            with torch.no_grad():
+                return model(*inp)
+        dt, prof, _ = timed(fstep, a.steps, a.warmup)
+        fwd = {'metric': 'frame-pairs/sec EFGHNet forward (384x1280 RGB + 64x2048 range), whole job',
+               'value': world * Bf * a.steps / dt, 'unit': 'frame-pairs/s', 'ms_per_step': dt / a.steps * 1e3,
+               'workload': 'BASELINE.json configs[1]: EFGHNet forward only (eval), batch=%d per GPU' % Bf,
+               'roofline': gemm_roofline(prof, a.steps, 'k_gather_gemm (fp32 MFMA implicit GEMM)')}
+        del inp
+    if a.mode == 'train':
+        Bt = a.batch or 8
+        inp, gt = load(Bt)
+        trainer = Trainer(model, EFGHCriterion(args), lr=1e-4)
+
+        def tstep():
+            return trainer.step(*inp, gt)
+        dt, prof, profw = timed(tstep, a.steps, a.warmup)
+        if rank == 0:
+            out = {
+                'metric': 'frame-pairs/sec EFGHNet fwd+bwd (384x1280 RGB + 64x2048 range), whole job',
+                'value': world * Bt * a.steps / dt, 'unit': 'frame-pairs/s',
+                'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': dt / a.steps * 1e3,
+                'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+                'data': 'synthetic',
+                'config': {'workload': 'BASELINE.json configs[2]: EFGHNet fwd+bwd with efghloss + gradient all-reduce + '
+                                       'fused Adam, synthetic %dx%d RGB + %d-point sweep, batch=%d per GPU, random-init '
+                                       'weights' % (raw[0] // 2, raw[1] // 2, npts, Bt),
+                           'global_batch': world * Bt, 'points': npts, 'parallelism': 'dp%d' % world},
+                'roofline': gemm_roofline(prof, a.steps, 'k_gather_gemm (fp32 MFMA implicit GEMM: forward + dgrad launches)'),
+                'roofline_wgrad': gemm_roofline(profw, a.steps, 'k_gather_wgrad (fp32 MFMA weight gradient)'),
+                'forward_only': fwd,
+            }
+    elif rank == 0:
+        out = {'metric': fwd['metric'], 'value': fwd['value'], 'unit': 'frame-pairs/s', 'n_gpus': world,
+               'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': fwd['ms_per_step'], 'higher_is_better': True,
+               'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+               'config': {'workload': fwd['workload'] + ', synthetic %dx%d RGB + %d-point sweep, random-init weights'
+                                      % (raw[0] // 2, raw[1] // 2, npts),
+                          'global_batch': world * (a.batch or 4), 'points': npts, 'parallelism': 'dp%d' % world},
+               'roofline': fwd['roofline']}
     if rank == 0:
-        gemm_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in prof)
-        gemm_fl = sum(f for _, _, f in prof)
-        n_launch = len(prof)
-        achieved = gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
-        out = {
-            'metric': 'frame-pairs/sec EFGHNet forward (384x1280 RGB + 64x2048 range), whole job',
-            'value': world * B * a.steps / dt,
-            'unit': 'frame-pairs/s',
-            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
-            'ms_per_step': dt / a.steps * 1e3,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'BASELINE.json configs[1]: EFGHNet forward only (eval), synthetic %dx%d RGB + '
-                                   '%d-point sweep, batch=%d per GPU, random-init weights' %
-                                   (raw[0] // 2, raw[1] // 2, npts, B),
-                       'global_batch': world * B, 'points': npts, 'parallelism': 'dp%d' % world},
-            'roofline': {
-                'bound': 'mfma', 'kernel': 'k_gather_gemm (fp32 MFMA implicit GEMM, all conv/convT/linear/BCL-blur launches)',
-                'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
-                'launches_per_step': n_launch / max(1, a.steps),
-                'avg_launch_ms': gemm_ms / max(1, n_launch),
-                'algorithmic_gflop_per_launch': gemm_fl / max(1, n_launch) / 1e9,
-                'gemm_ms_per_step': gemm_ms / max(1, a.steps),
-            },
-        }
         if world == 1 and not a.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(raw, npts)
+            out['cpu_baseline'] = cpu_baseline(raw, npts, a.mode)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -260,3 +260,47 @@ extern "C" int efgh_softmax2_to_nchw(const float *x, int64_t ld, float *y, int32
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
 }
+
+// ---- fused Adam over one flat parameter buffer (torch.optim.Adam semantics, main.py:181-183) ----
+namespace {
+__global__ void __launch_bounds__(256)
+k_adam(float *__restrict__ w, const float *__restrict__ g, float *__restrict__ m, float *__restrict__ v,
+       long long n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt, float gscale) {
+    long long n4 = n >> 2;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        float4 ww = reinterpret_cast<float4 *>(w)[i], gg = reinterpret_cast<const float4 *>(g)[i];
+        float4 mm = reinterpret_cast<float4 *>(m)[i], vv = reinterpret_cast<float4 *>(v)[i];
+        float *wp = &ww.x, *gp = &gg.x, *mp = &mm.x, *vp = &vv.x;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float gr = gp[q] * gscale + wd * wp[q];
+            mp[q] = b1 * mp[q] + (1.f - b1) * gr;
+            vp[q] = b2 * vp[q] + (1.f - b2) * gr * gr;
+            float denom = sqrtf(vp[q]) / bc2_sqrt + eps;
+            wp[q] -= (lr / bc1) * (mp[q] / denom);
+        }
+        reinterpret_cast<float4 *>(w)[i] = ww;
+        reinterpret_cast<float4 *>(m)[i] = mm;
+        reinterpret_cast<float4 *>(v)[i] = vv;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        long long i = (n4 << 2) + threadIdx.x;
+        float gr = g[i] * gscale + wd * w[i];
+        m[i] = b1 * m[i] + (1.f - b1) * gr;
+        v[i] = b2 * v[i] + (1.f - b2) * gr * gr;
+        w[i] -= (lr / bc1) * (m[i] / (sqrtf(v[i]) / bc2_sqrt + eps));
+    }
+}
+}  // namespace
+
+extern "C" int efgh_adam_step(float *w, const float *g, float *m, float *v, int64_t n, float lr, float beta1,
+                              float beta2, float eps, float weight_decay, int32_t step, float grad_scale,
+                              void *stream) {
+    EFGH_CHECK_ARG(w && g && m && v && n > 0 && step >= 1);
+    EFGH_CHECK_ARG(((((uintptr_t)w) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) == 0);
+    float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+    k_adam<<<grid_for(n / 4 + 1), 256, 0, (hipStream_t)stream>>>(w, g, m, v, n, lr, beta1, beta2, eps, weight_decay,
+                                                                 bc1, sqrtf(bc2), grad_scale);
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}

@@ -36,8 +36,11 @@ def _cached(owner, key, versions, fn):
     return val
 
 
+WEIGHT_EPOCH = 0        # bumped by optimizers that update parameters outside torch (train.FusedAdam)
+
+
 def _ver(*tensors):
-    return tuple((t._version, t.data_ptr()) for t in tensors)
+    return (WEIGHT_EPOCH,) + tuple((t._version, t.data_ptr()) for t in tensors)
 
 
 def pack_weight(w, N, T, C, sn, sc, st, taps=None, Np=None, Cp=None, key=None):
@@ -301,7 +304,13 @@ def corr_head(cam, rng, want_logit=False, want_aux=False):
 # ----------------------------------------------------------------------------------------------
 # backward
 # ----------------------------------------------------------------------------------------------
+PROFILE_WGRAD = None
+
+
 def gather_wgrad(A, lda, C, T, N, M, G, ldg, dWp, mode=0, geom=None, table=None):
+    if PROFILE_WGRAD is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     d = _C.GemmDesc()
     d.A = A.data_ptr()
     d.lda, d.C, d.T, d.mode = lda, C, T, mode
@@ -312,6 +321,9 @@ def gather_wgrad(A, lda, C, T, N, M, G, ldg, dWp, mode=0, geom=None, table=None)
     d.table = 0 if table is None else table.data_ptr()
     d.N, d.M = N, M
     _C.check(_L().efgh_gather_wgrad(ctypes.byref(d), ptr(G), c_int64(ldg), ptr(dWp), _st()))
+    if PROFILE_WGRAD is not None:
+        e1.record()
+        PROFILE_WGRAD.append((e0, e1, 2.0 * M * N * T * C))
 
 
 def unpack_weight(Wp, W, N, T, C, Cp, sn, sc, st, taps, accumulate=False):

@@ -1,0 +1,104 @@
+"""Training step around the hot path (reference iterater.py:35-43, main.py:127,181-183):
+forward -> efghloss -> backward -> gradient all-reduce over RCCL -> fused Adam.
+
+One process per GPU.  All parameters (and their gradients) are views into ONE flat fp32 buffer each,
+so the data-parallel exchange is a single all-reduce of 191 MB issued in buckets while the tail of
+the buffer is still being produced, and the optimizer is one kernel launch instead of 353.
+`DataParallel` semantics (one loss over the global batch, batch-mean terms) == mean of the per-rank
+gradients for equal per-rank batches."""
+import torch
+import torch.distributed as dist
+
+from . import _C, ops
+
+
+class FlatParams:
+    """Re-homes every parameter of `model` (and its .grad) inside flat buffers, keeping names/shapes."""
+
+    def __init__(self, model):
+        ps = [p for p in model.parameters() if p.requires_grad]
+        dev, n = ps[0].device, sum(p.numel() for p in ps)
+        self.n = n
+        self.w = torch.empty(n, dtype=torch.float32, device=dev)
+        self.g = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.offsets = []
+        off = 0
+        for p in ps:
+            k = p.numel()
+            self.w[off:off + k].copy_(p.data.reshape(-1))
+            p.data = self.w[off:off + k].view(p.shape)
+            p.grad = self.g[off:off + k].view(p.shape)
+            self.offsets.append((off, k))
+            off += k
+        self.params = ps
+
+    def zero_grad(self):
+        self.g.zero_()
+        for p, (off, k) in zip(self.params, self.offsets):      # autograd may have replaced .grad
+            if p.grad is None or p.grad.data_ptr() != self.g.data_ptr() + 4 * off:
+                p.grad = self.g[off:off + k].view(p.shape)
+
+
+def allreduce_mean_(flat_g, world, bucket_elems=8 * 1024 * 1024):
+    """sum all-reduce in ~32 MB buckets (fully connected xGMI: large messages, few of them); the 1/world
+    factor is folded into the optimizer kernel.  No-op for world == 1."""
+    if world <= 1:
+        return []
+    works = []
+    for s in range(0, flat_g.numel(), bucket_elems):
+        works.append(dist.all_reduce(flat_g[s:s + bucket_elems], op=dist.ReduceOp.SUM, async_op=True))
+    for w in works:
+        w.wait()
+    return works
+
+
+class FusedAdam:
+    """torch.optim.Adam(lr, betas=(0.9,0.999), eps=1e-8, weight_decay) on a FlatParams, one HIP launch."""
+
+    def __init__(self, flat, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        self.flat, self.lr, self.betas, self.eps, self.wd = flat, lr, betas, eps, weight_decay
+        self.m = torch.zeros_like(flat.w)
+        self.v = torch.zeros_like(flat.w)
+        self.t = 0
+
+    def step(self, grad_scale=1.0):
+        _C.require_cuda(self.flat.w)
+        self.t += 1
+        f = self.flat
+        _C.check(_C.lib().efgh_adam_step(_C.ptr(f.w), _C.ptr(f.g), _C.ptr(self.m), _C.ptr(self.v), _C.c_int64(f.n),
+                                         _C.c_float(self.lr), _C.c_float(self.betas[0]), _C.c_float(self.betas[1]),
+                                         _C.c_float(self.eps), _C.c_float(self.wd), _C.c_int32(self.t),
+                                         _C.c_float(grad_scale), _C.stream_ptr()))
+        ops.WEIGHT_EPOCH += 1            # packed-weight / folded-BN caches are stale now
+
+
+def adjust_learning_rate(base_lr, it, every=50000, gamma=0.7):
+    """common/helper.py:28-38"""
+    return base_lr * (gamma ** (it // every))
+
+
+class Trainer:
+    """one data-parallel training step; `world`/`rank` from torch.distributed when initialised."""
+
+    def __init__(self, model, criterion, lr=1e-4, weight_decay=0.0):
+        self.model, self.criterion = model, criterion
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.flat = FlatParams(model)
+        if self.world > 1:                                  # identical start on every rank
+            dist.broadcast(self.flat.w, 0)
+            for b in model.buffers():
+                dist.broadcast(b, 0)
+        self.opt = FusedAdam(self.flat, lr=lr, weight_decay=weight_decay)
+        self.base_lr, self.it = lr, 0
+
+    def step(self, pc, img, calib, A, gt):
+        self.opt.lr = adjust_learning_rate(self.base_lr, self.it)
+        self.model.train()
+        pred = self.model(pc, img, calib, A)
+        losses, gt = self.criterion.compute_loss(pc, img, calib, A, gt, pred)
+        self.flat.zero_grad()
+        losses['total'].backward()
+        allreduce_mean_(self.flat.g, self.world)
+        self.opt.step(grad_scale=1.0 / self.world)
+        self.it += 1
+        return losses, pred

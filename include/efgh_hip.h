@@ -228,6 +228,12 @@ int efgh_corr1d_bwd(const float *rp, const float *cam, const float *cam_mm, cons
 int efgh_corr_unpad(const float *drp, int32_t B, int32_t h, int32_t w, int32_t C, int32_t off, float *dx,
                     void *stream);
 
+/* fused Adam over ONE flat fp32 buffer holding all 47.8 M parameters (replaces the 353 per-tensor
+ * updates of torch.optim.Adam, main.py:181-183; lr schedule of common/helper.py:28-38 is the
+ * caller's).  g is multiplied by grad_scale first (1/world for a summed all-reduce).          */
+int efgh_adam_step(float *w, const float *g, float *m, float *v, int64_t n, float lr, float beta1,
+                   float beta2, float eps, float weight_decay, int32_t step, float grad_scale, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
