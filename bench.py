@@ -73,9 +73,24 @@ def cpu_baseline(raw, npts, mode):
                       'oracle/lattice_oracle.c, torch CPU fp32, %.1f s' % (what, dt)}
 
 
+def dump_shapes(prof, path):
+    """per-shape launch table (debug aid: EFGH_BENCH_SHAPES=file)"""
+    agg = {}
+    for e0, e1, f, key in prof:
+        a = agg.setdefault(key, [0, 0.0, 0.0])
+        a[0] += 1; a[1] += e0.elapsed_time(e1); a[2] += f
+    rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
+    with open(path, 'a') as fh:
+        fh.write('mode M N T C | calls ms TFLOP/s\n')
+        for key, (n, ms, f) in rows[:40]:
+            fh.write('%s | %d %.2f %.1f\n' % (' '.join(map(str, key)), n, ms, f / (ms * 1e-3) / 1e12 if ms > 0 else 0))
+
+
 def gemm_roofline(prof, steps, kernel):
-    ms = sum(e0.elapsed_time(e1) for e0, e1, _ in prof)
-    fl = sum(f for _, _, f in prof)
+    if os.environ.get('EFGH_BENCH_SHAPES'):
+        dump_shapes(prof, os.environ['EFGH_BENCH_SHAPES'])
+    ms = sum(p[0].elapsed_time(p[1]) for p in prof)
+    fl = sum(p[2] for p in prof)
     n = len(prof)
     ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     return {'bound': 'mfma', 'kernel': kernel, 'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',

@@ -13,34 +13,60 @@ __device__ __forceinline__ float dact(float y, int act, float slope) {
 }
 
 // per-column partial sums of  dpre = dy*act'(y)  and  dpre*xhat,  xhat = (raw-mean)*invstd
-// (mean == NULL: xhat := 0, only sum dpre is meaningful -> bias gradient)
+// (mean == NULL: xhat := 0, only sum dpre is meaningful -> bias gradient).
+// block = (CL float4 channel lanes) x (256/CL row lanes), 512 rows per block.
 __global__ void __launch_bounds__(TPB)
 k_act_bn_bwd_reduce(const float *__restrict__ dy, long long lddy, const float *__restrict__ y, long long ldy,
                     const float *__restrict__ raw, long long ldraw, const float *__restrict__ mean,
                     const float *__restrict__ invstd, long long M, int C, int act, float slope, int rows_per_block,
-                    float *__restrict__ part) {
-    int c = blockIdx.x * TPB + threadIdx.x;
-    if (c >= C) return;
+                    int CL, float *__restrict__ part) {
+    __shared__ float4 s1s[TPB], s2s[TPB];
+    const int cl = threadIdx.x % CL, rl = threadIdx.x / CL, RL = TPB / CL;
+    const int c = (blockIdx.x * CL + cl) * 4;
     long long r0 = (long long)blockIdx.y * rows_per_block, r1 = r0 + rows_per_block;
     if (r1 > M) r1 = M;
-    float mu = mean ? mean[c] : 0.f, is = mean ? invstd[c] : 0.f;
-    float s1 = 0.f, s2 = 0.f;
-    for (long long r = r0; r < r1; ++r) {
-        float g = dy[r * lddy + c] * dact(y[r * ldy + c], act, slope);
-        s1 += g;
-        if (mean) s2 += g * ((raw[r * ldraw + c] - mu) * is);
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+    if (c < C) {
+        float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), is = mu;
+        if (mean) { mu = *reinterpret_cast<const float4 *>(mean + c); is = *reinterpret_cast<const float4 *>(invstd + c); }
+        for (long long r = r0 + rl; r < r1; r += RL) {
+            float4 g = *reinterpret_cast<const float4 *>(dy + r * lddy + c);
+            float4 yy = *reinterpret_cast<const float4 *>(y + r * ldy + c);
+            g.x *= dact(yy.x, act, slope); g.y *= dact(yy.y, act, slope);
+            g.z *= dact(yy.z, act, slope); g.w *= dact(yy.w, act, slope);
+            s1.x += g.x; s1.y += g.y; s1.z += g.z; s1.w += g.w;
+            if (mean) {
+                float4 rw = *reinterpret_cast<const float4 *>(raw + r * ldraw + c);
+                s2.x += g.x * ((rw.x - mu.x) * is.x); s2.y += g.y * ((rw.y - mu.y) * is.y);
+                s2.z += g.z * ((rw.z - mu.z) * is.z); s2.w += g.w * ((rw.w - mu.w) * is.w);
+            }
+        }
     }
-    part[((long long)blockIdx.y * 2) * C + c] = s1;
-    part[((long long)blockIdx.y * 2 + 1) * C + c] = s2;
+    s1s[threadIdx.x] = s1; s2s[threadIdx.x] = s2;
+    __syncthreads();
+    if (rl != 0 || c >= C) return;
+    for (int i = 1; i < RL; ++i) {
+        float4 a = s1s[i * CL + cl], b = s2s[i * CL + cl];
+        s1.x += a.x; s1.y += a.y; s1.z += a.z; s1.w += a.w; s2.x += b.x; s2.y += b.y; s2.z += b.z; s2.w += b.w;
+    }
+    *reinterpret_cast<float4 *>(&part[((long long)blockIdx.y * 2) * C + c]) = s1;
+    *reinterpret_cast<float4 *>(&part[((long long)blockIdx.y * 2 + 1) * C + c]) = s2;
 }
 
-__global__ void k_bwd_finalize(const float *__restrict__ part, int G, int C, double count,
-                               float *__restrict__ sum_dpre, float *__restrict__ sum_dpre_xhat,
-                               float *__restrict__ mean_dpre, float *__restrict__ mean_dpre_xhat) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+__global__ void __launch_bounds__(1024)
+k_bwd_finalize(const float *__restrict__ part, int G, int C, double count,
+               float *__restrict__ sum_dpre, float *__restrict__ sum_dpre_xhat,
+               float *__restrict__ mean_dpre, float *__restrict__ mean_dpre_xhat) {
+    __shared__ double sa[32][33], sb[32][33];
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int c = blockIdx.x * 32 + tx;
     double a = 0.0, b = 0.0;
-    for (int g = 0; g < G; ++g) { a += part[((long long)g * 2) * C + c]; b += part[((long long)g * 2 + 1) * C + c]; }
+    if (c < C)
+        for (int g = ty; g < G; g += 32) { a += part[((long long)g * 2) * C + c]; b += part[((long long)g * 2 + 1) * C + c]; }
+    sa[ty][tx] = a; sb[ty][tx] = b;
+    __syncthreads();
+    if (ty != 0 || c >= C) return;
+    for (int i = 1; i < 32; ++i) { a += sa[i][tx]; b += sb[i][tx]; }
     sum_dpre[c] = (float)a; sum_dpre_xhat[c] = (float)b;
     if (mean_dpre) { mean_dpre[c] = (float)(a / count); mean_dpre_xhat[c] = (float)(b / count); }
 }
@@ -220,13 +246,16 @@ extern "C" int efgh_act_bn_bwd_reduce(const float *dy, int64_t lddy, const float
                                       int32_t act, float slope, float *part, float *sum_dpre, float *sum_dpre_xhat,
                                       float *mean_dpre, float *mean_dpre_xhat, void *stream_) {
     hipStream_t st = (hipStream_t)stream_;
-    EFGH_CHECK_ARG(dy && y && part && sum_dpre && sum_dpre_xhat && M > 0 && C > 0);
+    EFGH_CHECK_ARG(dy && y && part && sum_dpre && sum_dpre_xhat && M > 0 && C > 0 && C % 4 == 0);
     EFGH_CHECK_ARG(!mean || (raw && invstd));
+    EFGH_CHECK_ARG(lddy % 4 == 0 && ldy % 4 == 0 && (!mean || ldraw % 4 == 0));
     int G = efgh_bwd_groups(M);
-    k_act_bn_bwd_reduce<<<dim3(cdiv(C, TPB), G), TPB, 0, st>>>(dy, lddy, y, ldy, raw, ldraw, mean, invstd, M, C, act,
-                                                              slope, 512, part);
-    k_bwd_finalize<<<cdiv(C, 64), 64, 0, st>>>(part, G, C, (double)M, sum_dpre, sum_dpre_xhat, mean_dpre,
-                                               mean_dpre_xhat);
+    int CL = 1;
+    while (CL < 64 && CL * 4 < C) CL <<= 1;
+    k_act_bn_bwd_reduce<<<dim3(cdiv(C / 4, CL), G), TPB, 0, st>>>(dy, lddy, y, ldy, raw, ldraw, mean, invstd, M, C,
+                                                                 act, slope, 512, CL, part);
+    k_bwd_finalize<<<cdiv(C, 32), dim3(32, 32), 0, st>>>(part, G, C, (double)M, sum_dpre, sum_dpre_xhat, mean_dpre,
+                                                         mean_dpre_xhat);
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
 }

@@ -15,15 +15,23 @@ __device__ __forceinline__ float act_f(float v, int act, float slope) {
 
 // stats: [G][2][C] per-block partial (sum, sumsq) from the GEMM epilogue.
 // -> scale/shift for y = x*scale + shift, running stats update (nn.BatchNorm, momentum form).
-__global__ void k_bn_finalize(const float *__restrict__ stats, int G, int C, double count,
-                              const float *__restrict__ gamma, const float *__restrict__ beta,
-                              float *__restrict__ rmean, float *__restrict__ rvar, float momentum, float eps,
-                              float *__restrict__ scale, float *__restrict__ shift,
-                              float *__restrict__ save_mean, float *__restrict__ save_invstd) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// block = (32 channels, 32 partial-lanes): lanes stride over the G partial rows, LDS tree over lanes.
+__global__ void __launch_bounds__(1024)
+k_bn_finalize(const float *__restrict__ stats, int G, int C, double count,
+              const float *__restrict__ gamma, const float *__restrict__ beta,
+              float *__restrict__ rmean, float *__restrict__ rvar, float momentum, float eps,
+              float *__restrict__ scale, float *__restrict__ shift,
+              float *__restrict__ save_mean, float *__restrict__ save_invstd) {
+    __shared__ double ss[32][33], sq[32][33];
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int c = blockIdx.x * 32 + tx;
     double s = 0.0, q = 0.0;
-    for (int g = 0; g < G; ++g) { s += stats[((long long)g * 2) * C + c]; q += stats[((long long)g * 2 + 1) * C + c]; }
+    if (c < C)
+        for (int g = ty; g < G; g += 32) { s += stats[((long long)g * 2) * C + c]; q += stats[((long long)g * 2 + 1) * C + c]; }
+    ss[ty][tx] = s; sq[ty][tx] = q;
+    __syncthreads();
+    if (ty != 0 || c >= C) return;
+    for (int i = 1; i < 32; ++i) { s += ss[i][tx]; q += sq[i][tx]; }
     double mean = s / count;
     double var = q / count - mean * mean;
     if (var < 0) var = 0;
@@ -39,19 +47,32 @@ __global__ void k_bn_finalize(const float *__restrict__ stats, int G, int C, dou
     }
 }
 
-// per-column (sum, sumsq) partials of a [M][ld] matrix (used when the producer is not the GEMM)
+// per-column (sum, sumsq) partials of a [M][ld] matrix (used when the producer is not the GEMM).
+// block = (CL float4 channel lanes) x (256/CL row lanes); rows_per_block rows per block.
 __global__ void __launch_bounds__(TPB)
-k_col_stats(const float *__restrict__ x, long long M, int C, long long ld, int rows_per_block,
+k_col_stats(const float *__restrict__ x, long long M, int C, long long ld, int rows_per_block, int CL,
             float *__restrict__ stats) {
-    // blockDim = (C rounded to 32 lanes?) simple version: each thread owns one column, loops rows
-    int c = blockIdx.x * TPB + threadIdx.x;
+    __shared__ float4 s1s[TPB], s2s[TPB];
+    const int cl = threadIdx.x % CL, rl = threadIdx.x / CL, RL = TPB / CL;
+    const int c = (blockIdx.x * CL + cl) * 4;
     long long r0 = (long long)blockIdx.y * rows_per_block, r1 = r0 + rows_per_block;
     if (r1 > M) r1 = M;
-    if (c >= C) return;
-    float s = 0.f, q = 0.f;
-    for (long long r = r0; r < r1; ++r) { float v = x[r * ld + c]; s += v; q += v * v; }
-    stats[((long long)blockIdx.y * 2) * C + c] = s;
-    stats[((long long)blockIdx.y * 2 + 1) * C + c] = q;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = s;
+    if (c < C)
+        for (long long r = r0 + rl; r < r1; r += RL) {
+            float4 v = *reinterpret_cast<const float4 *>(x + r * ld + c);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            q.x += v.x * v.x; q.y += v.y * v.y; q.z += v.z * v.z; q.w += v.w * v.w;
+        }
+    s1s[threadIdx.x] = s; s2s[threadIdx.x] = q;
+    __syncthreads();
+    if (rl != 0 || c >= C) return;
+    for (int i = 1; i < RL; ++i) {
+        float4 a = s1s[i * CL + cl], b = s2s[i * CL + cl];
+        s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w; q.x += b.x; q.y += b.y; q.z += b.z; q.w += b.w;
+    }
+    *reinterpret_cast<float4 *>(&stats[((long long)blockIdx.y * 2) * C + c]) = s;
+    *reinterpret_cast<float4 *>(&stats[((long long)blockIdx.y * 2 + 1) * C + c]) = q;
 }
 
 // y[r][c] = act(x[r][c]*scale[c] + shift[c] + res[r][c]); vector of 4 channels per thread
@@ -182,9 +203,9 @@ extern "C" int efgh_bn_finalize(const float *stats, int32_t G, int32_t C, double
                                 float *scale, float *shift, float *save_mean, float *save_invstd,
                                 void *stream) {
     EFGH_CHECK_ARG(stats && gamma && beta && scale && shift && C > 0 && G > 0 && count > 0);
-    k_bn_finalize<<<cdiv(C, 64), 64, 0, (hipStream_t)stream>>>(stats, G, C, count, gamma, beta, rmean, rvar,
-                                                               momentum, eps, scale, shift, save_mean,
-                                                               save_invstd);
+    k_bn_finalize<<<cdiv(C, 32), dim3(32, 32), 0, (hipStream_t)stream>>>(stats, G, C, count, gamma, beta, rmean,
+                                                                         rvar, momentum, eps, scale, shift,
+                                                                         save_mean, save_invstd);
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
 }
@@ -192,9 +213,11 @@ extern "C" int efgh_bn_finalize(const float *stats, int32_t G, int32_t C, double
 extern "C" int32_t efgh_col_stats_groups(int64_t M) { return (int32_t)((M + 511) / 512); }
 
 extern "C" int efgh_col_stats(const float *x, int64_t M, int32_t C, int64_t ld, float *stats, void *stream) {
-    EFGH_CHECK_ARG(x && stats && M > 0 && C > 0);
-    dim3 grid(cdiv(C, TPB), efgh_col_stats_groups(M));
-    k_col_stats<<<grid, TPB, 0, (hipStream_t)stream>>>(x, M, C, ld, 512, stats);
+    EFGH_CHECK_ARG(x && stats && M > 0 && C > 0 && C % 4 == 0 && ld % 4 == 0);
+    int CL = 1;
+    while (CL < 64 && CL * 4 < C) CL <<= 1;
+    dim3 grid(cdiv(C / 4, CL), efgh_col_stats_groups(M));
+    k_col_stats<<<grid, TPB, 0, (hipStream_t)stream>>>(x, M, C, ld, 512, CL, stats);
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
 }

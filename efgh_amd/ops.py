@@ -114,7 +114,7 @@ def gather_gemm(A, lda, C, T, Wp, N, M, out, ldo, mode=0, geom=None, table=None,
     _C.check(_L().efgh_gather_gemm(ctypes.byref(d), _st()))
     if PROFILE is not None:
         e1.record()
-        PROFILE.append((e0, e1, float(flops) if flops is not None else 2.0 * M * N * T * C))
+        PROFILE.append((e0, e1, float(flops) if flops is not None else 2.0 * M * N * T * C, (mode, M, N, T, C)))
 
 
 # ----------------------------------------------------------------------------------------------
@@ -323,7 +323,7 @@ def gather_wgrad(A, lda, C, T, N, M, G, ldg, dWp, mode=0, geom=None, table=None)
     _C.check(_L().efgh_gather_wgrad(ctypes.byref(d), ptr(G), c_int64(ldg), ptr(dWp), _st()))
     if PROFILE_WGRAD is not None:
         e1.record()
-        PROFILE_WGRAD.append((e0, e1, 2.0 * M * N * T * C))
+        PROFILE_WGRAD.append((e0, e1, 2.0 * M * N * T * C, (mode, M, N, T, C)))
 
 
 def unpack_weight(Wp, W, N, T, C, Cp, sn, sc, st, taps, accumulate=False):

@@ -88,6 +88,7 @@ def test_conv_transpose(L, cin, cout, pad, opad, hw, train):
 def test_conv_1x2_and_residual_and_concat(L):
     torch.manual_seed(2)
     from efgh_amd import ops
+    torch.set_grad_enabled(False)          # inference path: fused epilogues, channel-slice outputs
     conv = nn.Conv2d(4, 3, (1, 2), 1, 0, bias=False)
     x = torch.randn(1, 4, 8, 33)
     ref = conv(x)
@@ -103,6 +104,7 @@ def test_conv_1x2_and_residual_and_concat(L):
              out=(buf, 64), in_ch=(64, 64))
     assert _rel(buf[..., 64:128].permute(0, 3, 1, 2).cpu(), ref) < 1e-5
     assert float((buf[..., :64] - 7).abs().max()) == 0 and float((buf[..., 128:] - 7).abs().max()) == 0
+    torch.set_grad_enabled(True)
 
 
 def test_maxpool_linear_colmax(L):
