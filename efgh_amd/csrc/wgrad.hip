@@ -17,7 +17,7 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int TN = 128, TK = 128, TM = 32, LD = 128;
+constexpr int TK = 128, TM = 32, LD = 128;
 
 struct WArgs {
     const float *A; int64_t lda;
@@ -33,13 +33,16 @@ struct WArgs {
     float *dW;                       // [N][K], pre-zeroed
 };
 
-template <int MODE>
+// TN = 128: waves 2(n) x 2(k), each 64x64;  TN = 64 (layers with <= 64 outputs): waves 1 x 4, each 64(n) x 32(k)
+template <int MODE, int TN>
 __global__ void __launch_bounds__(256)
 k_gather_wgrad(const WArgs p) {
-    __shared__ __attribute__((aligned(16))) float Gs[TM * LD];
+    constexpr int TJ = TN == 128 ? 2 : 1;        // k tiles per wave
+    constexpr int NGQ = TN == 128 ? 4 : 2;       // G float4 slots per thread
+    __shared__ __attribute__((aligned(16))) float Gs[TM * TN];
     __shared__ __attribute__((aligned(16))) float As[TM * LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wn = wave >> 1, wk = wave & 1;
+    const int wn = TN == 128 ? (wave >> 1) : 0, wk = TN == 128 ? (wave & 1) : wave;
     const int l31 = lane & 31, lh = lane >> 5;
     const int k0 = blockIdx.x * TK, n0 = blockIdx.y * TN;
     const long long mbeg = (long long)blockIdx.z * p.mchunk;
@@ -54,7 +57,10 @@ k_gather_wgrad(const WArgs p) {
     const int t = (int)(((unsigned long long)kk * p.magicC) >> 32);
     const int c = kk - t * p.C;
     const int dh = (int)((p.dhpack >> (4 * (t & 15))) & 15) - 8, dw = (int)((p.dwpack >> (4 * (t & 15))) & 15) - 8;
-    const bool nin = (n0 + c4) < p.N;
+    // G staging: TN/4 float4 columns per row
+    const int gc4 = (tid % (TN / 4)) * 4, gr0 = tid / (TN / 4);
+    constexpr int GRS = 256 / (TN / 4);          // rows covered per G slot pass (8 or 16)
+    const bool nin = (n0 + gc4) < p.N;
 
     // incremental (b,i,j) of each staged row (mode 1)
     int rj[4], ri[4]; long long rb[4];
@@ -66,8 +72,25 @@ k_gather_wgrad(const WArgs p) {
             ri[q] = (int)(r % p.Hv); rb[q] = r / p.Hv;
         } else { rj[q] = ri[q] = 0; rb[q] = 0; }
     }
-    float4 rg[4], ra[4];
+    float4 rg[NGQ], ra[4];
     auto load_step = [&](long long ms) {
+        if (TN != 128) {                         // G rows are staged on their own (row, column) grid
+#pragma unroll
+            for (int q = 0; q < NGQ; ++q) {
+                long long m = ms + gr0 + GRS * q;
+                float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (m < mend && nin) {
+                    long long orow = m;
+                    if (MODE == 1) {
+                        int j = (int)(m % p.Wv); long long r = m / p.Wv;
+                        int i = (int)(r % p.Hv); long long b = r / p.Hv;
+                        orow = (b * p.Ho + (i * p.osh + p.oh0)) * p.Wo + (j * p.osw + p.ow0);
+                    }
+                    g = *reinterpret_cast<const float4 *>(p.G + orow * p.ldg + n0 + gc4);
+                }
+                rg[q] = g;
+            }
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             long long m = ms + r0 + 8 * q;
@@ -82,10 +105,11 @@ k_gather_wgrad(const WArgs p) {
                     if ((unsigned)ih < (unsigned)p.Hin && (unsigned)iw < (unsigned)p.Win)
                         arow = (rb[q] * p.Hin + ih) * p.Win + iw;
                 }
-                if (nin) g = *reinterpret_cast<const float4 *>(p.G + orow * p.ldg + n0 + c4);
+                if (TN == 128 && nin) g = *reinterpret_cast<const float4 *>(p.G + orow * p.ldg + n0 + c4);
                 if (kin && arow >= 0) a = *reinterpret_cast<const float4 *>(p.A + arow * p.lda + c);
             }
-            rg[q] = g; ra[q] = a;
+            if (TN == 128) rg[q] = g;
+            ra[q] = a;
             if (MODE == 1) {         // advance this row by TM for the next step
                 rj[q] += TM;
                 while (rj[q] >= p.Wv) { rj[q] -= p.Wv; ++ri[q]; }
@@ -94,34 +118,35 @@ k_gather_wgrad(const WArgs p) {
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][TJ];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     load_step(mbeg);
     for (long long ms = mbeg; ms < mend; ms += TM) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            *reinterpret_cast<float4 *>(&Gs[(r0 + 8 * q) * LD + c4]) = rg[q];
+        for (int q = 0; q < 4; ++q)
             *reinterpret_cast<float4 *>(&As[(r0 + 8 * q) * LD + c4]) = ra[q];
-        }
+#pragma unroll
+        for (int q = 0; q < NGQ; ++q)
+            *reinterpret_cast<float4 *>(&Gs[(gr0 + GRS * q) * TN + gc4]) = rg[q];
         __syncthreads();
         if (ms + TM < mend) load_step(ms + TM);
 #pragma unroll
         for (int mm = 0; mm < TM / 2; ++mm) {
-            float g[2], a[2];
+            float g[2], a[TJ];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) g[i] = Gs[(mm * 2 + lh) * LD + (wn * 2 + i) * 32 + l31];
+            for (int i = 0; i < 2; ++i) g[i] = Gs[(mm * 2 + lh) * TN + (wn * 2 + i) * 32 + l31];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) a[j] = As[(mm * 2 + lh) * LD + (wk * 2 + j) * 32 + l31];
+            for (int j = 0; j < TJ; ++j) a[j] = As[(mm * 2 + lh) * LD + (wk * TJ + j) * 32 + l31];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < TJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[i], a[j], acc[i][j], 0, 0, 0);
         }
         __syncthreads();
@@ -130,8 +155,8 @@ k_gather_wgrad(const WArgs p) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int k = k0 + (wk * 2 + j) * 32 + l31;
+        for (int j = 0; j < TJ; ++j) {
+            const int k = k0 + (wk * TJ + j) * 32 + l31;
             if (k >= p.K) continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -201,6 +226,7 @@ extern "C" int efgh_gather_wgrad(const efgh_gemm_desc *d, const float *G, int64_
     a.table = d->table; a.G = G; a.ldg = ldg; a.N = d->N; a.M = d->M; a.dW = dWp;
     if (d->mode == 1) EFGH_CHECK_ARG(d->M == (int64_t)d->B * d->Hv * d->Wv && d->osh >= 1 && d->osw >= 1);
     if (d->mode == 2) EFGH_CHECK_ARG(d->table != nullptr);
+    const int TN = a.N <= 64 ? 64 : 128;
     const int kt = (a.K + TK - 1) / TK, nt = (a.N + TN - 1) / TN;
     // split m so that the grid has ~2048+ blocks, chunks are multiples of TM
     long long want = 2048 / (kt * nt);
@@ -216,9 +242,15 @@ extern "C" int efgh_gather_wgrad(const efgh_gemm_desc *d, const float *G, int64_
         return EFGH_E_LAUNCH;
     }
     dim3 grid(kt, nt, (unsigned)zs);
-    if (d->mode == 0) k_gather_wgrad<0><<<grid, 256, 0, st>>>(a);
-    else if (d->mode == 1) k_gather_wgrad<1><<<grid, 256, 0, st>>>(a);
-    else k_gather_wgrad<2><<<grid, 256, 0, st>>>(a);
+    if (TN == 128) {
+        if (d->mode == 0) k_gather_wgrad<0, 128><<<grid, 256, 0, st>>>(a);
+        else if (d->mode == 1) k_gather_wgrad<1, 128><<<grid, 256, 0, st>>>(a);
+        else k_gather_wgrad<2, 128><<<grid, 256, 0, st>>>(a);
+    } else {
+        if (d->mode == 0) k_gather_wgrad<0, 64><<<grid, 256, 0, st>>>(a);
+        else if (d->mode == 1) k_gather_wgrad<1, 64><<<grid, 256, 0, st>>>(a);
+        else k_gather_wgrad<2, 64><<<grid, 256, 0, st>>>(a);
+    }
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
 }

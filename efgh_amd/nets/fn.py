@@ -64,7 +64,9 @@ class GemmLayerFn(torch.autograd.Function):
         mean = invstd = raw = None
         need_stats = bn is not None and spec.train
         stats = None
-        if need_stats:
+        thin = all(ops.thin_eligible(spec.mode, spec.C, Np, spec.T if g is None else len(g[7]))
+                   for g, _ in spec.launches)
+        if need_stats and not thin:
             gs = [ops.gemm_grid_m(m, Np) for (_, m) in spec.launches]
             stats = torch.empty((sum(gs), 2, Np), dtype=torch.float32, device=dev)
         fused_plain = bn is None            # bias (+residual) (+act) straight in the epilogue
@@ -79,7 +81,7 @@ class GemmLayerFn(torch.autograd.Function):
                                 act=spec.act, slope=spec.slope, flops=fl)
             else:
                 st = None
-                if need_stats:
+                if need_stats and not thin:
                     st = stats[g0:g0 + gs[li]]
                     g0 += gs[li]
                 ops.gather_gemm(x, ld_of(x), spec.C, T, wp, Np, m, out, Np, mode=spec.mode, geom=geom,
@@ -87,6 +89,8 @@ class GemmLayerFn(torch.autograd.Function):
         y = out
         if bn is not None:
             raw = out
+            if need_stats and thin:
+                stats, _ = ops.col_stats(out, M, Np, Np)
             if need_stats:
                 bn.num_batches_tracked += 1
                 momentum = bn.momentum if bn.momentum is not None else 0.1

@@ -102,14 +102,22 @@ def _run(ctx, x, lda, C, T, Wp, N, M, mode, geoms, out_t, ldo, coff, bias, bn, a
                             act=act, slope=slope, a_off=a_off, out_off=coff, res_off=res_off, flops=fl(geom, m))
         return
     # train-mode BatchNorm: raw conv output + per-block column statistics, then normalise in place
-    gs = [ops.gemm_grid_m(m, Np) for _, _, m in geoms]
-    stats = torch.empty((sum(gs), 2, Np), dtype=torch.float32, device=x.device)
-    g0 = 0
-    for (geom, wp, m), g in zip(geoms, gs):
-        ops.gather_gemm(x, lda, C, T if geom is None else len(geom[7]), wp, Np, m, out_t, ldo, mode=mode, geom=geom,
-                        table=table, bias=b, act=ACT_NONE, stats=stats[g0:g0 + g], a_off=a_off, out_off=coff,
-                        flops=fl(geom, m))
-        g0 += g
+    thin = all(ops.thin_eligible(mode, C, Np, T if geom is None else len(geom[7])) for geom, _, _ in geoms)
+    if thin:       # VALU kernels carry no statistics epilogue: one extra streaming pass over the (small) output
+        for geom, wp, m in geoms:
+            ops.gather_gemm(x, lda, C, len(geom[7]), wp, Np, m, out_t, ldo, mode=mode, geom=geom, bias=b,
+                            act=ACT_NONE, a_off=a_off, out_off=coff, flops=fl(geom, m))
+        stats, _ = ops.col_stats(out_t, M, Np, ldo, x_off=coff)
+        gs = [stats.shape[0]]
+    else:
+        gs = [ops.gemm_grid_m(m, Np) for _, _, m in geoms]
+        stats = torch.empty((sum(gs), 2, Np), dtype=torch.float32, device=x.device)
+        g0 = 0
+        for (geom, wp, m), g in zip(geoms, gs):
+            ops.gather_gemm(x, lda, C, T if geom is None else len(geom[7]), wp, Np, m, out_t, ldo, mode=mode,
+                            geom=geom, table=table, bias=b, act=ACT_NONE, stats=stats[g0:g0 + g], a_off=a_off,
+                            out_off=coff, flops=fl(geom, m))
+            g0 += g
     cnt = count if count is not None else M
     scale, shift = _bn_train(ctx, bn, stats, sum(gs), Np, float(cnt))
     ops.scale_shift_act(out_t, ldo, scale, shift, out_t, ldo, M, Np, act, slope, res=residual, ldr=res_ld,

@@ -82,6 +82,18 @@ def gemm_grid_m(M, N):
     return _L().efgh_gather_gemm_grid_m(c_int64(M), c_int32(N))
 
 
+USE_THIN = True
+
+
+def thin_eligible(mode, C, N, T):
+    """shapes served by the VALU "thin" kernels (thin.hip) instead of the MFMA tile"""
+    if not USE_THIN or mode != 1 or N % 4 or C % 4:
+        return False
+    if C == 4 and N <= 256 and T * N * 16 <= 60 * 1024:
+        return True
+    return N == 4 and T * C * 16 <= 60 * 1024
+
+
 PROFILE = None          # bench.py sets this to a list: (start_event, end_event, algorithmic_flops) per launch
 
 
@@ -111,8 +123,16 @@ def gather_gemm(A, lda, C, T, Wp, N, M, out, ldo, mode=0, geom=None, table=None,
     d.out = out.data_ptr() + out_off * es
     d.ldo = ldo
     d.stats = 0 if stats is None else stats.data_ptr()
-    _C.check(_L().efgh_gather_gemm(ctypes.byref(d), _st()))
-    if PROFILE is not None:
+    thin = stats is None and M_dev is None and thin_eligible(mode, C, N, T)
+    if thin:
+        _C.check(_L().efgh_thin_gemm(ctypes.byref(d), _st()))
+    else:
+        _C.check(_L().efgh_gather_gemm(ctypes.byref(d), _st()))
+    if PROFILE is not None and thin:
+        e1.record()
+        if PROFILE_THIN is not None:
+            PROFILE_THIN.append((e0, e1, float(flops) if flops is not None else 2.0 * M * N * T * C, (mode, M, N, T, C)))
+    elif PROFILE is not None:
         e1.record()
         PROFILE.append((e0, e1, float(flops) if flops is not None else 2.0 * M * N * T * C, (mode, M, N, T, C)))
 
@@ -305,6 +325,7 @@ def corr_head(cam, rng, want_logit=False, want_aux=False):
 # backward
 # ----------------------------------------------------------------------------------------------
 PROFILE_WGRAD = None
+PROFILE_THIN = None
 
 
 def gather_wgrad(A, lda, C, T, N, M, G, ldg, dWp, mode=0, geom=None, table=None):
@@ -320,8 +341,16 @@ def gather_wgrad(A, lda, C, T, N, M, G, ldg, dWp, mode=0, geom=None, table=None)
             d.dh[i], d.dw[i] = a, b
     d.table = 0 if table is None else table.data_ptr()
     d.N, d.M = N, M
-    _C.check(_L().efgh_gather_wgrad(ctypes.byref(d), ptr(G), c_int64(ldg), ptr(dWp), _st()))
-    if PROFILE_WGRAD is not None:
+    thin = thin_eligible(mode, C, N, T) and (N == 4 or T in (1, 2, 4, 9))
+    if thin:
+        _C.check(_L().efgh_thin_wgrad(ctypes.byref(d), ptr(G), c_int64(ldg), ptr(dWp), _st()))
+    else:
+        _C.check(_L().efgh_gather_wgrad(ctypes.byref(d), ptr(G), c_int64(ldg), ptr(dWp), _st()))
+    if PROFILE_WGRAD is not None and thin:
+        e1.record()
+        if PROFILE_THIN is not None:
+            PROFILE_THIN.append((e0, e1, 2.0 * M * N * T * C, (mode, M, N, T, C)))
+    elif PROFILE_WGRAD is not None:
         e1.record()
         PROFILE_WGRAD.append((e0, e1, 2.0 * M * N * T * C, (mode, M, N, T, C)))
 

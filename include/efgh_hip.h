@@ -234,6 +234,13 @@ int efgh_corr_unpad(const float *drp, int32_t B, int32_t h, int32_t w, int32_t C
 int efgh_adam_step(float *w, const float *g, float *m, float *v, int64_t n, float lr, float beta1,
                    float beta2, float eps, float weight_decay, int32_t step, float grad_scale, void *stream);
 
+/* "thin" layers (<= 4 channels on one side: RGB/range/depth input convs, the 1-/2-channel heads and
+ * their dgrad/wgrad): HBM-bound VALU kernels with the descriptor, gather modes and epilogue of
+ * efgh_gather_gemm (mode 1 only, no `stats`).  efgh_thin_supported: 0 = no, 1 = C==4 form, 2 = N==4. */
+int efgh_thin_supported(const efgh_gemm_desc *d);
+int efgh_thin_gemm(const efgh_gemm_desc *d, void *stream);
+int efgh_thin_wgrad(const efgh_gemm_desc *d, const float *G, int64_t ldg, float *dWp, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
