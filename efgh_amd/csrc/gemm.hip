@@ -43,7 +43,7 @@ struct KArgs {
 };
 
 template <int MODE, int BM, int BN, int WM, int WN>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 3)
 k_gather_gemm(const KArgs p) {
     constexpr int MI = BM / WM / 32, NI = BN / WN / 32;
     constexpr int NA = BM / 32, NB = BN / 32;

@@ -57,34 +57,64 @@ __device__ __forceinline__ void epilogue_store(const TArgs &p, long long orow, i
     *reinterpret_cast<float4 *>(p.out + orow * p.ldo + n) = make_float4(o[0], o[1], o[2], o[3]);
 }
 
-// ---- C == 4: thread = (row, n-quad); weights in LDS as [t][n][4] ---------------------------------
+// ---- C == 4: one thread = one output row, ALL n (in passes of 64 channels); the <=9 input taps live
+// in registers, weights are wave-uniform LDS broadcasts ([t][n][4]); the 64-channel result is
+// transposed through a padded LDS stage so that global stores are full 256-B row segments.
+template <int T>
 __global__ void __launch_bounds__(TPB)
 k_thin_c4(const TArgs p) {
-    extern __shared__ __attribute__((aligned(16))) float wl[];          // T*N*4 floats
-    for (int i = threadIdx.x; i < p.T * p.N; i += TPB) {                // (t, n) -> float4 of W[n][t][0..3]
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *wl = smem;                                    // T*N*4 floats
+    float *stage = smem + (size_t)T * p.N * 4;           // 4 waves x 64 rows x 68 floats
+    for (int i = threadIdx.x; i < T * p.N; i += TPB) {
         int t = i / p.N, n = i - t * p.N;
-        reinterpret_cast<float4 *>(wl)[i] = *reinterpret_cast<const float4 *>(p.W + ((long long)n * p.T + t) * 4);
+        reinterpret_cast<float4 *>(wl)[i] = *reinterpret_cast<const float4 *>(p.W + ((long long)n * T + t) * 4);
     }
     __syncthreads();
-    const int nq = p.N >> 2;
-    const long long total = p.M * nq;
-    for (long long g = (long long)blockIdx.x * TPB + threadIdx.x; g < total; g += (long long)gridDim.x * TPB) {
-        long long m = g / nq; int q = (int)(g - m * nq), n = q * 4;
-        int i, j; long long b;
-        decode(p, m, i, j, b);
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int t = 0; t < p.T; ++t) {
-            long long r = in_row(p, i, j, b, t);
-            if (r < 0) continue;
-            float4 a = *reinterpret_cast<const float4 *>(p.A + r * p.lda);
-            const float4 *w = reinterpret_cast<const float4 *>(wl) + t * p.N + n;
-            float4 w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
-            acc.x += a.x * w0.x + a.y * w0.y + a.z * w0.z + a.w * w0.w;
-            acc.y += a.x * w1.x + a.y * w1.y + a.z * w1.z + a.w * w1.w;
-            acc.z += a.x * w2.x + a.y * w2.y + a.z * w2.z + a.w * w2.w;
-            acc.w += a.x * w3.x + a.y * w3.y + a.z * w3.z + a.w * w3.w;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float *st = stage + wave * 64 * 68;
+    const long long nwaves = (long long)gridDim.x * (TPB / 64);
+    for (long long w0 = ((long long)blockIdx.x * (TPB / 64) + wave) * 64; w0 < p.M; w0 += nwaves * 64) {
+        const long long m = w0 + lane;
+        const bool ok = m < p.M;
+        int i = 0, j = 0; long long b = 0;
+        if (ok) decode(p, m, i, j, b);
+        float4 a[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            long long r = ok ? in_row(p, i, j, b, t) : -1;
+            a[t] = r >= 0 ? *reinterpret_cast<const float4 *>(p.A + r * p.lda) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        epilogue_store(p, out_row(p, i, j, b), n, acc);
+        const long long orow = ok ? out_row(p, i, j, b) : 0;
+        for (int nb = 0; nb < p.N; nb += 64) {
+            const int nq = (p.N - nb) < 64 ? (p.N - nb) >> 2 : 16;     // n-quads in this pass
+            for (int q = 0; q < nq; ++q) {
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    const float4 *w = reinterpret_cast<const float4 *>(wl) + t * p.N + nb + q * 4;
+                    float4 w0_ = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
+                    acc.x += a[t].x * w0_.x + a[t].y * w0_.y + a[t].z * w0_.z + a[t].w * w0_.w;
+                    acc.y += a[t].x * w1.x + a[t].y * w1.y + a[t].z * w1.z + a[t].w * w1.w;
+                    acc.z += a[t].x * w2.x + a[t].y * w2.y + a[t].z * w2.z + a[t].w * w2.w;
+                    acc.w += a[t].x * w3.x + a[t].y * w3.y + a[t].z * w3.z + a[t].w * w3.w;
+                }
+                if (nq == 1) { if (ok) epilogue_store(p, orow, nb, acc); }
+                else *reinterpret_cast<float4 *>(&st[lane * 68 + q * 4]) = acc;
+            }
+            if (nq > 1) {
+                // cooperative, coalesced store: slot s -> (row = s / nq, quad = s % nq)
+                const int slots = 64 * nq;
+                for (int s = lane; s < slots; s += 64) {
+                    int rr = s / nq, qq = s - rr * nq;
+                    long long mm = w0 + rr;
+                    long long orr = __shfl(orow, rr);          // all 64 lanes active here
+                    if (mm >= p.M) continue;
+                    float4 v = *reinterpret_cast<const float4 *>(&st[rr * 68 + qq * 4]);
+                    epilogue_store(p, orr, nb + qq * 4, v);
+                }
+            }
+        }
     }
 }
 
@@ -240,7 +270,8 @@ int grid_for(long long total, int per) {
 
 extern "C" int efgh_thin_supported(const efgh_gemm_desc *d) {
     if (!d || d->mode != 1 || d->N % 4 != 0 || d->C % 4 != 0 || d->stats) return 0;
-    if (d->C == 4 && d->N <= 256 && (int64_t)d->T * d->N * 16 <= 60 * 1024) return 1;
+    if (d->C == 4 && d->N <= 256 && (d->T == 1 || d->T == 2 || d->T == 4 || d->T == 9) &&
+        (int64_t)d->T * d->N * 16 + 4 * 64 * 68 * 4 <= 64 * 1024) return 1;
     if (d->N == 4 && (int64_t)d->T * d->C * 16 <= 60 * 1024) return 2;
     return 0;
 }
@@ -252,9 +283,17 @@ extern "C" int efgh_thin_gemm(const efgh_gemm_desc *d, void *stream_) {
     EFGH_CHECK_ARG(d->A && d->W && d->out && d->M == (int64_t)d->B * d->Hv * d->Wv && d->lda % 4 == 0 && d->ldo % 4 == 0);
     TArgs a;
     fill(a, d);
-    if (kind == 1)
-        k_thin_c4<<<grid_for(a.M * (a.N / 4), TPB), TPB, (size_t)a.T * a.N * 16, st>>>(a);
-    else
+    if (kind == 1) {
+        size_t lds = (size_t)a.T * a.N * 16 + 4 * 64 * 68 * 4;
+        int grid = grid_for(a.M, TPB);
+        switch (a.T) {
+        case 1: k_thin_c4<1><<<grid, TPB, lds, st>>>(a); break;
+        case 2: k_thin_c4<2><<<grid, TPB, lds, st>>>(a); break;
+        case 4: k_thin_c4<4><<<grid, TPB, lds, st>>>(a); break;
+        case 9: k_thin_c4<9><<<grid, TPB, lds, st>>>(a); break;
+        default: efgh_set_error("thin c4: unsupported tap count %d", a.T); return EFGH_E_INVALID;
+        }
+    } else
         k_thin_n4<<<grid_for(a.M, TPB / 8), TPB, (size_t)a.K * 16, st>>>(a);
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;

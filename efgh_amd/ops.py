@@ -89,7 +89,7 @@ def thin_eligible(mode, C, N, T):
     """shapes served by the VALU "thin" kernels (thin.hip) instead of the MFMA tile"""
     if not USE_THIN or mode != 1 or N % 4 or C % 4:
         return False
-    if C == 4 and N <= 256 and T * N * 16 <= 60 * 1024:
+    if C == 4 and N <= 256 and T in (1, 2, 4, 9) and T * N * 16 + 4 * 64 * 68 * 4 <= 64 * 1024:
         return True
     return N == 4 and T * C * 16 <= 60 * 1024
 
