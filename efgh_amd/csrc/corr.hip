@@ -55,12 +55,16 @@ k_norm_pad(const float *__restrict__ x, const float *__restrict__ mm, int B, int
 }
 
 // ---- correlation partials: part[b][y][j] = sum_{x,c} rp[b][y][j+x][c] * cam[b][y][x][c]/(max-min) ----
-// one block = one (b, y, tile of 256 j); the normalised camera row lives in LDS.
+// one block = one (b, y, tile of 256*JT shifts); the normalised camera row lives in LDS; every thread
+// owns JT consecutive shifts and slides a register window over the range row, so each 64-B range
+// pixel fetched feeds JT*16 FMAs.
+constexpr int JT = 4;
 __global__ void __launch_bounds__(TPB)
 k_corr_rows(const float *__restrict__ rp, const float *__restrict__ cam, const float *__restrict__ cam_mm,
             int h, int wc, int wp, int nj, float *__restrict__ part) {
     extern __shared__ __attribute__((aligned(16))) float srow[];      // wc*16 floats
-    const int b = blockIdx.z, y = blockIdx.y, j = blockIdx.x * TPB + threadIdx.x;
+    const int b = blockIdx.z, y = blockIdx.y;
+    const int j0 = (blockIdx.x * TPB + threadIdx.x) * JT;
     const float d = cam_mm[b * 2 + 1] - cam_mm[b * 2];
     const float4 *crow = reinterpret_cast<const float4 *>(cam + (((long long)b * h + y) * wc) * 16);
     for (int i = threadIdx.x; i < wc * 4; i += TPB) {
@@ -69,19 +73,40 @@ k_corr_rows(const float *__restrict__ rp, const float *__restrict__ cam, const f
         reinterpret_cast<float4 *>(srow)[i] = v;
     }
     __syncthreads();
-    if (j >= nj) return;
-    const float4 *r = reinterpret_cast<const float4 *>(rp + (((long long)b * h + y) * wp + j) * 16);
+    if (j0 >= nj) return;
+    const float4 *r = reinterpret_cast<const float4 *>(rp + (((long long)b * h + y) * wp) * 16);
     const float4 *s = reinterpret_cast<const float4 *>(srow);
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    for (int x = 0; x < wc * 4; x += 4) {
-        float4 r0 = r[x], r1 = r[x + 1], r2 = r[x + 2], r3 = r[x + 3];
-        float4 s0 = s[x], s1 = s[x + 1], s2 = s[x + 2], s3 = s[x + 3];
-        a0 += r0.x * s0.x + r0.y * s0.y + r0.z * s0.z + r0.w * s0.w;
-        a1 += r1.x * s1.x + r1.y * s1.y + r1.z * s1.z + r1.w * s1.w;
-        a2 += r2.x * s2.x + r2.y * s2.y + r2.z * s2.z + r2.w * s2.w;
-        a3 += r3.x * s3.x + r3.y * s3.y + r3.z * s3.z + r3.w * s3.w;
+    float acc[JT];
+    float4 win[JT][4];                     // range pixels j0+x .. j0+x+JT-1 (4 float4 = 16 channels each)
+#pragma unroll
+    for (int q = 0; q < JT; ++q) {
+        acc[q] = 0.f;
+        int px = j0 + q; if (px > wp - 1) px = wp - 1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) win[q][k] = r[(long long)px * 4 + k];
     }
-    part[((long long)b * h + y) * nj + j] = (a0 + a1) + (a2 + a3);
+    for (int x = 0; x < wc; ++x) {
+        float4 s0 = s[x * 4], s1 = s[x * 4 + 1], s2 = s[x * 4 + 2], s3 = s[x * 4 + 3];
+#pragma unroll
+        for (int q = 0; q < JT; ++q) {
+            float4 a0 = win[q][0], a1 = win[q][1], a2 = win[q][2], a3 = win[q][3];
+            acc[q] += (a0.x * s0.x + a0.y * s0.y + a0.z * s0.z + a0.w * s0.w) +
+                      (a1.x * s1.x + a1.y * s1.y + a1.z * s1.z + a1.w * s1.w) +
+                      (a2.x * s2.x + a2.y * s2.y + a2.z * s2.z + a2.w * s2.w) +
+                      (a3.x * s3.x + a3.y * s3.y + a3.z * s3.z + a3.w * s3.w);
+        }
+        // slide: drop pixel j0+x, fetch pixel j0+x+JT
+#pragma unroll
+        for (int q = 0; q < JT - 1; ++q)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) win[q][k] = win[q + 1][k];
+        int px = j0 + x + JT; if (px > wp - 1) px = wp - 1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) win[JT - 1][k] = r[(long long)px * 4 + k];
+    }
+#pragma unroll
+    for (int q = 0; q < JT; ++q)
+        if (j0 + q < nj) part[((long long)b * h + y) * nj + j0 + q] = acc[q];
 }
 
 // ---- reduce over rows, scale by 1/C, sigmoid -------------------------------------------------------
@@ -135,7 +160,7 @@ extern "C" int efgh_corr1d(const float *rp, const float *cam, const float *cam_m
     EFGH_CHECK_ARG(rp && cam && cam_mm && part && score && B > 0 && h > 0 && wc > 0 && wp >= wc);
     EFGH_CHECK_ARG(wc * 16 * 4 <= 64 * 1024);
     int nj = wp - wc + 1;
-    dim3 grid(cdiv(nj, TPB), h, B);
+    dim3 grid(cdiv(nj, TPB * JT), h, B);
     k_corr_rows<<<grid, TPB, (size_t)wc * 16 * 4, st>>>(rp, cam, cam_mm, h, wc, wp, nj, part);
     k_corr_finish<<<grid_for((long long)B * nj), TPB, 0, st>>>(part, B, h, nj, 1.0f / 16.0f, logit, score);
     EFGH_CHECK_LAUNCH();

@@ -168,13 +168,19 @@ k_segment_colmax(const float *__restrict__ x, long long ld, int C, const int *__
     if (argrow) argrow[(long long)s * C + c] = am;
 }
 
-// per-segment column mean
+// per-segment column mean: block = (32 columns) x (8 row lanes), tree over the row lanes
 __global__ void __launch_bounds__(TPB)
 k_segment_colmean(const float *__restrict__ x, long long ld, int C, int rows_per_seg, float *__restrict__ y) {
-    int s = blockIdx.y, c = blockIdx.x * TPB + threadIdx.x;
-    if (c >= C) return;
+    __shared__ double sm[8][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int s = blockIdx.y, c = blockIdx.x * 32 + tx;
     double a = 0.0;
-    for (int r = 0; r < rows_per_seg; ++r) a += x[((long long)s * rows_per_seg + r) * ld + c];
+    if (c < C)
+        for (int r = ty; r < rows_per_seg; r += 8) a += x[((long long)s * rows_per_seg + r) * ld + c];
+    sm[ty][tx] = a;
+    __syncthreads();
+    if (ty != 0 || c >= C) return;
+    for (int i = 1; i < 8; ++i) a += sm[i][tx];
     y[(long long)s * C + c] = (float)(a / rows_per_seg);
 }
 
@@ -271,7 +277,7 @@ extern "C" int efgh_segment_colmax(const float *x, int64_t ld, int32_t C, const 
 extern "C" int efgh_segment_colmean(const float *x, int64_t ld, int32_t C, int32_t rows_per_seg, int32_t nseg,
                                     float *y, void *stream) {
     EFGH_CHECK_ARG(x && y && C > 0 && nseg > 0 && rows_per_seg > 0);
-    dim3 grid(cdiv(C, TPB), nseg);
+    dim3 grid(cdiv(C, 32), nseg);
     k_segment_colmean<<<grid, TPB, 0, (hipStream_t)stream>>>(x, ld, C, rows_per_seg, y);
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;

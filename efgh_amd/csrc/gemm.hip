@@ -61,24 +61,31 @@ k_gather_gemm(const KArgs p) {
     if (m0 >= M) return;
 
     // ---- per-thread row state for the staging loads --------------------------------------
+    // mode 0: abase = row offset (floats) | mode 1: abase = centre pixel index, amask bit t = tap t in bounds
+    // mode 2: abase = m*16 (neighbour-table row)
     const int arow = tid >> 3, kv = (tid & 7) * 4;
-    long long abase[NA];     // mode 0: row offset (floats) | mode 1: pixel base of image b | mode 2: m*16
-    int aih[NA], aiw[NA];
-    bool aval[NA];
+    long long abase[NA];
+    unsigned amask[NA];
 #pragma unroll
     for (int q = 0; q < NA; ++q) {
         long long m = m0 + q * 32 + arow;
-        aval[q] = m < M;
-        aih[q] = aiw[q] = 0;
+        const bool ok = m < M;
         abase[q] = 0;
-        if (aval[q]) {
-            if (MODE == 0) abase[q] = m * p.lda;
-            else if (MODE == 2) abase[q] = m * 16;
+        amask[q] = 0;
+        if (ok) {
+            if (MODE == 0) { abase[q] = m * p.lda; amask[q] = 1; }
+            else if (MODE == 2) { abase[q] = m * 16; amask[q] = 0xFFFFu; }
             else {
                 int j = (int)(m % p.Wv); long long r = m / p.Wv;
                 int i = (int)(r % p.Hv); long long b = r / p.Hv;
-                aih[q] = i * p.sh; aiw[q] = j * p.sw;
-                abase[q] = b * p.Hin * p.Win;
+                const int ih0 = i * p.sh, iw0 = j * p.sw;
+                abase[q] = (b * p.Hin + ih0) * p.Win + iw0;
+                unsigned mk = 0;
+                for (int t = 0; t < p.T; ++t) {
+                    int ih = ih0 + (int)((p.dhpack >> (4 * t)) & 15) - 8, iw = iw0 + (int)((p.dwpack >> (4 * t)) & 15) - 8;
+                    if ((unsigned)ih < (unsigned)p.Hin && (unsigned)iw < (unsigned)p.Win) mk |= 1u << t;
+                }
+                amask[q] = mk;
             }
         }
     }
@@ -107,30 +114,37 @@ k_gather_gemm(const KArgs p) {
         const bool kin = kk < p.K;
         int t = (int)(((unsigned long long)kk * p.magicC) >> 32);
         int c = kk - t * p.C;
-        int dh = (int)((p.dhpack >> (4 * t)) & 15) - 8, dw = (int)((p.dwpack >> (4 * t)) & 15) - 8;
+        if (MODE == 1) {
+            // branch-free: out-of-image taps read a valid dummy address (row 0) and are zeroed by select
+            const int dh = (int)((p.dhpack >> (4 * (t & 15))) & 15) - 8, dw = (int)((p.dwpack >> (4 * (t & 15))) & 15) - 8;
+            const long long delta = (long long)dh * p.Win + dw;
 #pragma unroll
-        for (int q = 0; q < NA; ++q) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (aval[q] && kin) {
-                if (MODE == 0) {
-                    v = *reinterpret_cast<const float4 *>(p.A + abase[q] + kk);
-                } else if (MODE == 1) {
-                    int ih = aih[q] + dh, iw = aiw[q] + dw;
-                    if ((unsigned)ih < (unsigned)p.Hin && (unsigned)iw < (unsigned)p.Win)
-                        v = *reinterpret_cast<const float4 *>(
-                            p.A + (abase[q] + (long long)ih * p.Win + iw) * p.lda + c);
-                } else {
-                    int r = p.table[abase[q] + t];
-                    if (r >= 0) v = *reinterpret_cast<const float4 *>(p.A + (long long)r * p.lda + c);
-                }
+            for (int q = 0; q < NA; ++q) {
+                const bool ok = kin && ((amask[q] >> t) & 1u);
+                const long long off = ok ? (abase[q] + delta) * p.lda + c : 0;
+                float4 v = *reinterpret_cast<const float4 *>(p.A + off);
+                ra[q] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
             }
-            ra[q] = v;
+        } else {
+#pragma unroll
+            for (int q = 0; q < NA; ++q) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (amask[q] && kin) {
+                    if (MODE == 0) {
+                        v = *reinterpret_cast<const float4 *>(p.A + abase[q] + kk);
+                    } else {
+                        int r = p.table[abase[q] + t];
+                        if (r >= 0) v = *reinterpret_cast<const float4 *>(p.A + (long long)r * p.lda + c);
+                    }
+                }
+                ra[q] = v;
+            }
         }
 #pragma unroll
         for (int q = 0; q < NB; ++q) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (bval[q] && kin) v = *reinterpret_cast<const float4 *>(p.W + bbase[q] + kk);
-            rb[q] = v;
+            const bool ok = bval[q] && kin;
+            float4 v = *reinterpret_cast<const float4 *>(p.W + (ok ? bbase[q] + kk : 0));
+            rb[q] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
 
@@ -249,11 +263,11 @@ void launch(const KArgs &a, hipStream_t st) {
 template <int MODE>
 void dispatch(const KArgs &a, hipStream_t st) {
     if (a.N > 64) launch<MODE, 128, 128, 2, 2>(a, st);
-    else if (a.N > 32) launch<MODE, 256, 64, 4, 1>(a, st);
+    else if (a.N > 32) launch<MODE, 128, 64, 2, 2>(a, st);
     else launch<MODE, 256, 32, 4, 1>(a, st);
 }
 
-int tile_m(int N) { return N > 64 ? 128 : 256; }
+int tile_m(int N) { return N > 32 ? 128 : 256; }
 
 }  // namespace
 
