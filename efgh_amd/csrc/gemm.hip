@@ -22,9 +22,36 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BK = 32;
-constexpr int LDS_LD = BK + 4;
+constexpr int LDS_LD = BK + 4;       // fp32 path: floats per LDS row
+constexpr int LDH = BK + 8;          // split-bf16 path: bf16 per LDS row (80 B: conflict-free b128 reads)
+
+// x = hi + mid + lo (+ O(2^-25 |x|)): three bf16 terms carry the full fp32 significand
+__device__ __forceinline__ void split4x3(const float4 v, bf16x4 &hi, bf16x4 &mid, bf16x4 &lo) {
+    const float f[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        __bf16 h = (__bf16)f[q];
+        float r = f[q] - (float)h;
+        __bf16 m = (__bf16)r;
+        hi[q] = h; mid[q] = m;
+        lo[q] = (__bf16)(r - (float)m);
+    }
+}
+
+// x = hi + lo (+ O(2^-17 |x|)) with hi, lo in bf16
+__device__ __forceinline__ void split4(const float4 v, bf16x4 &hi, bf16x4 &lo) {
+    const float f[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        __bf16 h = (__bf16)f[q];
+        hi[q] = h;
+        lo[q] = (__bf16)(f[q] - (float)h);
+    }
+}
 
 struct KArgs {
     const float *A; int64_t lda;
@@ -35,6 +62,7 @@ struct KArgs {
     int Ho, Wo, osh, osw, oh0, ow0;
     const int *table;
     const float *W; int N;
+    const __bf16 *Wh, *Wm, *Wl;     // split-bf16 paths: packed weights as bf16 hi / (mid) / lo, [N][K]
     long long M; const int *M_dev;
     const float *bias, *scale, *shift, *residual; int64_t ldr;
     int act; float slope;
@@ -42,13 +70,21 @@ struct KArgs {
     float *stats;
 };
 
-template <int MODE, int BM, int BN, int WM, int WN>
-__global__ void __launch_bounds__(256, 3)
+// MATH 0: exact fp32 MFMA (v_mfma_f32_32x32x2_f32).
+// MATH 1: split-bf16: every fp32 operand is hi+lo in bf16 and a*b ~= ah*bh + ah*bl + al*bh on
+//         v_mfma_f32_32x32x16_bf16 with fp32 accumulation (per-product relative error ~2^-17).
+template <int MODE, int BM, int BN, int WM, int WN, int MATH>
+__global__ void __launch_bounds__(256, MATH == 2 ? 2 : 3)
 k_gather_gemm(const KArgs p) {
     constexpr int MI = BM / WM / 32, NI = BN / WN / 32;
     constexpr int NA = BM / 32, NB = BN / 32;
-    __shared__ __attribute__((aligned(16))) float As[BM * LDS_LD];
-    __shared__ __attribute__((aligned(16))) float Bs[BN * LDS_LD];
+    // LDS in floats: fp32 rows of 36 | 2 (MATH 1) or 3 (MATH 2) bf16 arrays with rows of 40
+    constexpr int A_ELEMS = MATH == 0 ? BM * LDS_LD : (MATH == 1 ? BM * LDH : BM * LDH * 3 / 2);
+    constexpr int B_ELEMS = MATH == 0 ? BN * LDS_LD : (MATH == 1 ? BN * LDH : BN * LDH * 3 / 2);
+    __shared__ __attribute__((aligned(16))) float As[A_ELEMS];
+    __shared__ __attribute__((aligned(16))) float Bs[B_ELEMS];
+    __bf16 *Ah = reinterpret_cast<__bf16 *>(As), *Al = Ah + BM * LDH, *Am = Al + BM * LDH;
+    __bf16 *Bh = reinterpret_cast<__bf16 *>(Bs), *Bl = Bh + BN * LDH, *Bm = Bl + BN * LDH;
     __shared__ long long rowout[BM];          // output row (pixel) index per tile row, -1 = masked
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -109,6 +145,7 @@ k_gather_gemm(const KArgs p) {
     }
 
     float4 ra[NA], rb[NB];
+    float2 rbm[NB];            // MATH 2: mid term of the weights
     auto load_chunk = [&](int k0) {
         const int kk = k0 + kv;
         const bool kin = kk < p.K;
@@ -143,8 +180,18 @@ k_gather_gemm(const KArgs p) {
 #pragma unroll
         for (int q = 0; q < NB; ++q) {
             const bool ok = bval[q] && kin;
-            float4 v = *reinterpret_cast<const float4 *>(p.W + (ok ? bbase[q] + kk : 0));
-            rb[q] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (MATH == 0) {
+                float4 v = *reinterpret_cast<const float4 *>(p.W + (ok ? bbase[q] + kk : 0));
+                rb[q] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {                      // rb[q] = {hi(4 x bf16), lo(4 x bf16)} as raw bits
+                const long long o = ok ? bbase[q] + kk : 0;
+                float2 h = *reinterpret_cast<const float2 *>(p.Wh + o), l = *reinterpret_cast<const float2 *>(p.Wl + o);
+                rb[q] = ok ? make_float4(h.x, h.y, l.x, l.y) : make_float4(0.f, 0.f, 0.f, 0.f);
+                if (MATH == 2) {
+                    float2 m = *reinterpret_cast<const float2 *>(p.Wm + o);
+                    rbm[q] = ok ? m : make_float2(0.f, 0.f);
+                }
+            }
         }
     };
 
@@ -159,34 +206,92 @@ k_gather_gemm(const KArgs p) {
     const int nchunks = (p.K + BK - 1) / BK;
     load_chunk(0);
     for (int ch = 0; ch < nchunks; ++ch) {
+        if (MATH == 0) {
 #pragma unroll
-        for (int q = 0; q < NA; ++q)
-            *reinterpret_cast<float4 *>(&As[(q * 32 + arow) * LDS_LD + kv]) = ra[q];
+            for (int q = 0; q < NA; ++q)
+                *reinterpret_cast<float4 *>(&As[(q * 32 + arow) * LDS_LD + kv]) = ra[q];
 #pragma unroll
-        for (int q = 0; q < NB; ++q)
-            *reinterpret_cast<float4 *>(&Bs[(q * 32 + arow) * LDS_LD + kv]) = rb[q];
+            for (int q = 0; q < NB; ++q)
+                *reinterpret_cast<float4 *>(&Bs[(q * 32 + arow) * LDS_LD + kv]) = rb[q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < NA; ++q) {
+                bf16x4 hi, mid, lo;
+                if (MATH == 1) split4(ra[q], hi, lo);
+                else {
+                    split4x3(ra[q], hi, mid, lo);
+                    *reinterpret_cast<bf16x4 *>(&Am[(q * 32 + arow) * LDH + kv]) = mid;
+                }
+                *reinterpret_cast<bf16x4 *>(&Ah[(q * 32 + arow) * LDH + kv]) = hi;
+                *reinterpret_cast<bf16x4 *>(&Al[(q * 32 + arow) * LDH + kv]) = lo;
+            }
+#pragma unroll
+            for (int q = 0; q < NB; ++q) {
+                *reinterpret_cast<float2 *>(&Bh[(q * 32 + arow) * LDH + kv]) = make_float2(rb[q].x, rb[q].y);
+                *reinterpret_cast<float2 *>(&Bl[(q * 32 + arow) * LDH + kv]) = make_float2(rb[q].z, rb[q].w);
+                if (MATH == 2) *reinterpret_cast<float2 *>(&Bm[(q * 32 + arow) * LDH + kv]) = rbm[q];
+            }
+        }
         __syncthreads();
         if (ch + 1 < nchunks) load_chunk((ch + 1) * BK);
+        if (MATH == 0) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            float4 a[MI], b[NI];
+            for (int g = 0; g < 4; ++g) {
+                float4 a[MI], b[NI];
 #pragma unroll
-            for (int i = 0; i < MI; ++i)
-                a[i] = *reinterpret_cast<const float4 *>(
-                    &As[((wm * MI + i) * 32 + l31) * LDS_LD + g * 8 + lh * 4]);
+                for (int i = 0; i < MI; ++i)
+                    a[i] = *reinterpret_cast<const float4 *>(
+                        &As[((wm * MI + i) * 32 + l31) * LDS_LD + g * 8 + lh * 4]);
 #pragma unroll
-            for (int j = 0; j < NI; ++j)
-                b[j] = *reinterpret_cast<const float4 *>(
-                    &Bs[((wn * NI + j) * 32 + l31) * LDS_LD + g * 8 + lh * 4]);
+                for (int j = 0; j < NI; ++j)
+                    b[j] = *reinterpret_cast<const float4 *>(
+                        &Bs[((wn * NI + j) * 32 + l31) * LDS_LD + g * 8 + lh * 4]);
 #pragma unroll
-            for (int i = 0; i < MI; ++i)
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+                    }
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {       // two k-steps of 16; lane holds k = 8*lh + j of the step
+                bf16x8 ah[MI], am[MI], al[MI], bh[NI], bm[NI], bl[NI];
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    const int o = ((wm * MI + i) * 32 + l31) * LDH + ks * 16 + lh * 8;
+                    ah[i] = *reinterpret_cast<const bf16x8 *>(&Ah[o]);
+                    al[i] = *reinterpret_cast<const bf16x8 *>(&Al[o]);
+                    if (MATH == 2) am[i] = *reinterpret_cast<const bf16x8 *>(&Am[o]);
+                }
 #pragma unroll
                 for (int j = 0; j < NI; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+                    const int o = ((wn * NI + j) * 32 + l31) * LDH + ks * 16 + lh * 8;
+                    bh[j] = *reinterpret_cast<const bf16x8 *>(&Bh[o]);
+                    bl[j] = *reinterpret_cast<const bf16x8 *>(&Bl[o]);
+                    if (MATH == 2) bm[j] = *reinterpret_cast<const bf16x8 *>(&Bm[o]);
                 }
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) {
+                        if (MATH == 1) {     // smallest terms first
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                        } else {             // h/m/l x h/m/l, every term >= 2^-16 of the product kept
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bm[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bh[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bm[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                        }
+                    }
+            }
         }
         __syncthreads();
     }
@@ -254,17 +359,30 @@ __global__ void k_pack_weight(const float *__restrict__ W, float *__restrict__ W
     }
 }
 
-template <int MODE, int BM, int BN, int WM, int WN>
+template <int MODE, int BM, int BN, int WM, int WN, int MATH>
 void launch(const KArgs &a, hipStream_t st) {
     dim3 grid((a.N + BN - 1) / BN, (unsigned)((a.M + BM - 1) / BM));
-    k_gather_gemm<MODE, BM, BN, WM, WN><<<grid, 256, 0, st>>>(a);
+    k_gather_gemm<MODE, BM, BN, WM, WN, MATH><<<grid, 256, 0, st>>>(a);
 }
 
-template <int MODE>
+template <int MODE, int MATH>
 void dispatch(const KArgs &a, hipStream_t st) {
-    if (a.N > 64) launch<MODE, 128, 128, 2, 2>(a, st);
-    else if (a.N > 32) launch<MODE, 128, 64, 2, 2>(a, st);
-    else launch<MODE, 256, 32, 4, 1>(a, st);
+    if (a.N > 64) launch<MODE, 128, 128, 2, 2, MATH>(a, st);
+    else if (a.N > 32) launch<MODE, 128, 64, 2, 2, MATH>(a, st);
+    else launch<MODE, 256, 32, 4, 1, MATH>(a, st);
+}
+
+// hi/lo bf16 split of a packed fp32 weight matrix
+__global__ void k_split_bf16(const float *__restrict__ w, __bf16 *__restrict__ hi, __bf16 *__restrict__ mid,
+                             __bf16 *__restrict__ lo, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float v = w[i];
+        __bf16 h = (__bf16)v;
+        hi[i] = h;
+        float r = v - (float)h;
+        if (mid) { __bf16 m = (__bf16)r; mid[i] = m; r -= (float)m; }
+        lo[i] = (__bf16)r;
+    }
 }
 
 int tile_m(int N) { return N > 32 ? 128 : 256; }
@@ -276,15 +394,13 @@ extern "C" int32_t efgh_gather_gemm_grid_m(int64_t M, int32_t N) {
     return (int32_t)((M + bm - 1) / bm);
 }
 
-extern "C" int efgh_gather_gemm(const efgh_gemm_desc *d, void *stream_) {
-    hipStream_t st = (hipStream_t)stream_;
+static int fill_args(const efgh_gemm_desc *d, KArgs &a) {
     EFGH_CHECK_ARG(d && d->A && d->W && d->out);
     EFGH_CHECK_ARG(d->C > 0 && d->C % 4 == 0 && d->T >= 1 && d->T <= 16);
     EFGH_CHECK_ARG(d->N >= 1 && d->M >= 1 && d->lda % 4 == 0);
     EFGH_CHECK_ARG((((uintptr_t)d->A) & 15) == 0 && (((uintptr_t)d->W) & 15) == 0);
     EFGH_CHECK_ARG(d->mode >= 0 && d->mode <= 2);
     EFGH_CHECK_ARG((int64_t)d->T * d->C < 65536);
-    KArgs a;
     a.A = d->A; a.lda = d->lda; a.C = d->C; a.T = d->T; a.K = d->T * d->C;
     a.magicC = (unsigned)((0x100000000ULL + d->C - 1) / d->C);
     a.Hin = d->Hin; a.Win = d->Win; a.Hv = d->Hv; a.Wv = d->Wv; a.sh = d->sh; a.sw = d->sw;
@@ -299,6 +415,7 @@ extern "C" int efgh_gather_gemm(const efgh_gemm_desc *d, void *stream_) {
     a.table = d->table; a.W = d->W; a.N = d->N; a.M = d->M; a.M_dev = d->M_dev;
     a.bias = d->bias; a.scale = d->scale; a.shift = d->shift; a.residual = d->residual; a.ldr = d->ldr;
     a.act = d->act; a.slope = d->slope; a.out = d->out; a.ldo = d->ldo; a.stats = d->stats;
+    a.Wh = a.Wm = a.Wl = nullptr;
     if (d->mode == 1) {
         EFGH_CHECK_ARG(d->B > 0 && d->Hin > 0 && d->Win > 0 && d->Hv > 0 && d->Wv > 0);
         EFGH_CHECK_ARG(d->M == (int64_t)d->B * d->Hv * d->Wv);
@@ -306,9 +423,56 @@ extern "C" int efgh_gather_gemm(const efgh_gemm_desc *d, void *stream_) {
     }
     if (d->mode == 2) EFGH_CHECK_ARG(d->table != nullptr);
     if (d->mode == 0) EFGH_CHECK_ARG(d->T == 1);
-    if (d->mode == 0) dispatch<0>(a, st);
-    else if (d->mode == 1) dispatch<1>(a, st);
-    else dispatch<2>(a, st);
+    return EFGH_OK;
+}
+
+extern "C" int efgh_gather_gemm(const efgh_gemm_desc *d, void *stream_) {
+    hipStream_t st = (hipStream_t)stream_;
+    KArgs a;
+    int rc = fill_args(d, a);
+    if (rc != EFGH_OK) return rc;
+    if (d->mode == 0) dispatch<0, 0>(a, st);
+    else if (d->mode == 1) dispatch<1, 0>(a, st);
+    else dispatch<2, 0>(a, st);
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}
+
+extern "C" int efgh_gather_gemm_bf16x3(const efgh_gemm_desc *d, const void *W_hi, const void *W_lo, void *stream_) {
+    hipStream_t st = (hipStream_t)stream_;
+    KArgs a;
+    int rc = fill_args(d, a);
+    if (rc != EFGH_OK) return rc;
+    EFGH_CHECK_ARG(W_hi && W_lo && (((uintptr_t)W_hi) & 7) == 0 && (((uintptr_t)W_lo) & 7) == 0);
+    a.Wh = (const __bf16 *)W_hi; a.Wl = (const __bf16 *)W_lo;
+    if (d->mode == 0) dispatch<0, 1>(a, st);
+    else if (d->mode == 1) dispatch<1, 1>(a, st);
+    else dispatch<2, 1>(a, st);
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}
+
+extern "C" int efgh_gather_gemm_bf16x6(const efgh_gemm_desc *d, const void *W_hi, const void *W_mid, const void *W_lo,
+                                       void *stream_) {
+    hipStream_t st = (hipStream_t)stream_;
+    KArgs a;
+    int rc = fill_args(d, a);
+    if (rc != EFGH_OK) return rc;
+    EFGH_CHECK_ARG(W_hi && W_mid && W_lo);
+    EFGH_CHECK_ARG(((((uintptr_t)W_hi) | ((uintptr_t)W_mid) | ((uintptr_t)W_lo)) & 7) == 0);
+    a.Wh = (const __bf16 *)W_hi; a.Wm = (const __bf16 *)W_mid; a.Wl = (const __bf16 *)W_lo;
+    if (d->mode == 0) dispatch<0, 2>(a, st);
+    else if (d->mode == 1) dispatch<1, 2>(a, st);
+    else dispatch<2, 2>(a, st);
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}
+
+extern "C" int efgh_split_bf16(const float *w, void *hi, void *mid, void *lo, int64_t n, void *stream_) {
+    EFGH_CHECK_ARG(w && hi && lo && n > 0);
+    long long g = (n + 255) / 256;
+    k_split_bf16<<<(int)(g > 8192 ? 8192 : g), 256, 0, (hipStream_t)stream_>>>(w, (__bf16 *)hi, (__bf16 *)mid,
+                                                                             (__bf16 *)lo, n);
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
 }

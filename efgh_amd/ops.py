@@ -83,6 +83,21 @@ def gemm_grid_m(M, N):
 
 
 USE_THIN = True
+import os as _os
+MATH = _os.environ.get('EFGH_MATH', 'f32')   # 'f32': exact fp32 MFMA | 'bf16x3': split-bf16 MFMA (3 products, fp32 accumulate)
+
+
+def split_weight(Wp, terms=2):
+    """(hi, [mid,] lo) bf16 split of a packed fp32 weight, cached on the packed tensor"""
+    def make():
+        n = Wp.numel()
+        hi = torch.empty(n, dtype=torch.bfloat16, device=Wp.device)
+        lo = torch.empty(n, dtype=torch.bfloat16, device=Wp.device)
+        mid = torch.empty(n, dtype=torch.bfloat16, device=Wp.device) if terms == 3 else None
+        _C.check(_L().efgh_split_bf16(ptr(Wp), ptr(hi), ptr(mid), ptr(lo), c_int64(n), _st()))
+        return hi, mid, lo
+    return _cached(Wp, ('split', terms), _ver(Wp), make)
+
 
 
 def thin_eligible(mode, C, N, T):
@@ -126,6 +141,12 @@ def gather_gemm(A, lda, C, T, Wp, N, M, out, ldo, mode=0, geom=None, table=None,
     thin = stats is None and M_dev is None and thin_eligible(mode, C, N, T)
     if thin:
         _C.check(_L().efgh_thin_gemm(ctypes.byref(d), _st()))
+    elif MATH == 'bf16x3':
+        hi, _, lo = split_weight(Wp, 2)
+        _C.check(_L().efgh_gather_gemm_bf16x3(ctypes.byref(d), ptr(hi), ptr(lo), _st()))
+    elif MATH == 'bf16x6':
+        hi, mid, lo = split_weight(Wp, 3)
+        _C.check(_L().efgh_gather_gemm_bf16x6(ctypes.byref(d), ptr(hi), ptr(mid), ptr(lo), _st()))
     else:
         _C.check(_L().efgh_gather_gemm(ctypes.byref(d), _st()))
     if PROFILE is not None and thin:

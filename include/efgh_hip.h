@@ -241,6 +241,18 @@ int efgh_thin_supported(const efgh_gemm_desc *d);
 int efgh_thin_gemm(const efgh_gemm_desc *d, void *stream);
 int efgh_thin_wgrad(const efgh_gemm_desc *d, const float *G, int64_t ldg, float *dWp, void *stream);
 
+/* split-bf16 variant of efgh_gather_gemm: every fp32 operand x is used as hi+lo (two bf16 numbers,
+ * |x-hi-lo| <= 2^-17|x|) and each product as ah*bh + ah*bl + al*bh on v_mfma_f32_32x32x16_bf16 with fp32
+ * accumulation: 3 bf16 MFMAs of K=16 replace 8 fp32 MFMAs of K=2.  Activations are split on the fly
+ * in the staging pass; W_hi / W_lo are the packed weights [N][K] as bf16 (efgh_split_bf16).     */
+int efgh_gather_gemm_bf16x3(const efgh_gemm_desc *d, const void *W_hi, const void *W_lo, void *stream);
+/* three-term split x = hi+mid+lo (all 24 significand bits) and the six products >= 2^-16 of a*b:
+ * fp32-equivalent accuracy (dropped terms <= 2^-24) on bf16 MFMAs: 6 x K=16 instead of 8 x K=2.  */
+int efgh_gather_gemm_bf16x6(const efgh_gemm_desc *d, const void *W_hi, const void *W_mid, const void *W_lo,
+                            void *stream);
+/* w[i] -> hi[i] (+ mid[i], optional: NULL for the two-term split) + lo[i], each bf16 */
+int efgh_split_bf16(const float *w, void *hi, void *mid, void *lo, int64_t n, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -118,3 +118,35 @@ def test_cpu_tensors_are_refused(manifest):
     _, inp = _inputs()
     with pytest.raises(_C.EfghError):
         m(*[t.cpu() for t in inp])
+
+
+def test_split_bf16x3_forward_logits_within_1e4(golden_dir, manifest):
+    """the opt-in fast math (EFGH_MATH=bf16x3) keeps the north-star tolerance on the pose logits
+    (stage-wise teacher-forced, eval mode)"""
+    from efgh_amd import ops
+    from oracle import efgh_oracle as O
+    old = ops.MATH
+    ops.MATH = 'bf16x3'
+    try:
+        m = _model(manifest, False)
+        b, inp = _inputs()
+        P = syn.synthetic_state_dict(manifest['state_dict'], 1)
+        args = syn.default_args(RAW, 'cpu')
+        cpu = [t.cpu() for t in inp]
+        with torch.no_grad():
+            rete, reth = O.enet(P, cpu[0], False), O.hnet(P, cpu[1], False)
+            r = dict(rete); r.update(reth); r['network'] = 'EH'
+            r['eh_cam_T_velo'] = O.compute_cam_T_velo(r['intrinsic_sensor2'], r['sensor2_T_sensor1'], cpu[2], cpu[3])
+            rf = O.fnet(P, cpu[0], r, args, False)
+            rf['efh_cam_T_velo'] = O.compute_cam_T_velo(rf['intrinsic_sensor2'], rf['sensor2_T_sensor1'], cpu[2], cpu[3])
+            rg = O.gnet(P, cpu[0], cpu[1], rf, args, False)
+            dev = lambda d: {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in d.items()}
+            e, h = m.E(inp[0]), m.H(inp[1])
+            f = m.F(inp[0], dev(r))
+            g = m.G(inp[0], inp[1], dev(rf))
+        for got, ref, keys in ((e, rete, ('e_gn_sgn', 'e_gn_abs')), (h, reth, ('h_hrzn_sgn', 'h_hrzn_abs')),
+                               (f, rf, ('f_score',)), (g, rg, ('g_trs',))):
+            for k in keys:
+                assert _rel(got[k].cpu().numpy(), ref[k].numpy()) < 1e-4, k
+    finally:
+        ops.MATH = old

@@ -188,3 +188,26 @@ def test_corr_head():
         ref = F.conv2d(O.circular_assign(r, int(245 / 8)), c).view(-1) / 16
         assert _rel(logit[b].cpu(), ref) < 2e-5
         assert _rel(score[b].cpu(), torch.sigmoid(ref)) < 2e-5
+
+
+@pytest.mark.parametrize('math,tol', [('bf16x3', 3e-5), ('bf16x6', 6e-6)])
+def test_split_bf16_math_modes(L, math, tol):
+    """opt-in split-bf16 MFMA paths (x = hi+lo or hi+mid+lo in bf16, fp32 accumulation) vs the exact
+    fp32-MFMA path and vs torch fp32: 2^-17 per product (x3) / fp32-equivalent (x6)."""
+    from efgh_amd import ops
+    torch.manual_seed(7)
+    old = ops.MATH
+    try:
+        with torch.no_grad():
+            for (ci, co, k, s_, hw) in [(64, 64, 3, 1, (24, 40)), (128, 256, 3, 2, (17, 23)), (512, 96, 1, 1, (6, 10))]:
+                conv = nn.Conv2d(ci, co, k, s_, k // 2, bias=True).cuda()
+                x = torch.randn(2, *hw, ci, device='cuda')
+                ops.MATH = 'f32'
+                ref = L.conv2d(L.Ctx(False), x, conv, None, L.ACT_LEAKY, 0.2)
+                ops.MATH = math
+                got = L.conv2d(L.Ctx(False), x, conv, None, L.ACT_LEAKY, 0.2)
+                cpu = F.leaky_relu(conv.cpu()(x.cpu().permute(0, 3, 1, 2)), 0.2)
+                assert _rel(got, ref) < tol, (ci, co, _rel(got, ref))
+                assert _rel(got.permute(0, 3, 1, 2).cpu(), cpu) < tol
+    finally:
+        ops.MATH = old
