@@ -91,6 +91,16 @@ def dump_shapes(prof, path):
             fh.write('%s | %d %.2f %.1f\n' % (' '.join(map(str, key)), n, ms, f / (ms * 1e-3) / 1e12 if ms > 0 else 0))
 
 
+def committed_traffic():
+    """HBM bytes per k_gather_gemm launch from the committed rocprofv3 PMC passes (FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE); collected offline on the forward workload,
+    see profiles/README.md.  PMC collection cannot run inside the timed region."""
+    try:
+        return json.load(open(os.path.join(ROOT, 'profiles', 'r01_gemm_hbm_traffic.json')))['per_launch']['traffic_bytes']
+    except Exception:
+        return None
+
+
 def gemm_roofline(prof, steps, kernel):
     if os.environ.get('EFGH_BENCH_SHAPES'):
         dump_shapes(prof, os.environ['EFGH_BENCH_SHAPES'])
@@ -99,7 +109,9 @@ def gemm_roofline(prof, steps, kernel):
     n = len(prof)
     ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     return {'bound': 'mfma', 'kernel': kernel, 'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-            'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': None, 'launches_per_step': n / max(1, steps),
+            'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': committed_traffic() if 'wgrad' not in kernel else None,
+            'traffic_unit': 'bytes per launch (committed PMC pass on the forward workload)',
+            'launches_per_step': n / max(1, steps),
             'avg_launch_ms': ms / max(1, n), 'algorithmic_gflop_per_launch': fl / max(1, n) / 1e9,
             'kernel_ms_per_step': ms / max(1, steps)}
 

@@ -68,6 +68,7 @@ struct KArgs {
     int act; float slope;
     float *out; int64_t ldo;
     float *stats;
+    unsigned nbx;              // n-tiles per m-tile (set by the launcher)
 };
 
 // MATH 0: exact fp32 MFMA (v_mfma_f32_32x32x2_f32).
@@ -92,8 +93,16 @@ k_gather_gemm(const KArgs p) {
     const int l31 = lane & 31, lh = lane >> 5;
     long long M = p.M;
     if (p.M_dev) { long long md = *p.M_dev; M = md < M ? md : M; }
-    const long long m0 = (long long)blockIdx.y * BM;
-    const int n0 = blockIdx.x * BN;
+    // XCD-aware tile order: the dispatcher deals consecutive workgroups round-robin over the 8 XCDs, so
+    // workgroup b and b+8 share an L2.  Give every XCD one contiguous band of output tiles (n fastest,
+    // then m), so that vertically adjacent image tiles - which re-read each other's halo rows - hit the
+    // same L2 instead of each fetching them from the fabric.  Pure speed: any placement is correct.
+    const unsigned nbx = p.nbx, nblk = gridDim.x;
+    const unsigned q8 = nblk >> 3, r8 = nblk & 7, xcd = blockIdx.x & 7, within = blockIdx.x >> 3;
+    const unsigned lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + within;
+    const unsigned tile_m = lin / nbx, tile_n = lin - tile_m * nbx;
+    const long long m0 = (long long)tile_m * BM;
+    const int n0 = tile_n * BN;
     if (m0 >= M) return;
 
     // ---- per-thread row state for the staging loads --------------------------------------
@@ -335,8 +344,8 @@ k_gather_gemm(const KArgs p) {
                 float a = 0.f, b = 0.f;
 #pragma unroll
                 for (int w = 0; w < WM; ++w) { a += ssum[w * BN + c]; b += ssq[w * BN + c]; }
-                p.stats[((long long)blockIdx.y * 2 + 0) * p.N + n0 + c] = a;
-                p.stats[((long long)blockIdx.y * 2 + 1) * p.N + n0 + c] = b;
+                p.stats[((long long)tile_m * 2 + 0) * p.N + n0 + c] = a;
+                p.stats[((long long)tile_m * 2 + 1) * p.N + n0 + c] = b;
             }
         }
     }
@@ -360,9 +369,11 @@ __global__ void k_pack_weight(const float *__restrict__ W, float *__restrict__ W
 }
 
 template <int MODE, int BM, int BN, int WM, int WN, int MATH>
-void launch(const KArgs &a, hipStream_t st) {
-    dim3 grid((a.N + BN - 1) / BN, (unsigned)((a.M + BM - 1) / BM));
-    k_gather_gemm<MODE, BM, BN, WM, WN, MATH><<<grid, 256, 0, st>>>(a);
+void launch(const KArgs &a0, hipStream_t st) {
+    KArgs a = a0;
+    a.nbx = (unsigned)((a.N + BN - 1) / BN);
+    const long long nby = (a.M + BM - 1) / BM;
+    k_gather_gemm<MODE, BM, BN, WM, WN, MATH><<<(unsigned)(a.nbx * nby), 256, 0, st>>>(a);
 }
 
 template <int MODE, int MATH>
