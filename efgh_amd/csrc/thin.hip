@@ -58,21 +58,21 @@ __device__ __forceinline__ void epilogue_store(const TArgs &p, long long orow, i
 }
 
 // ---- C == 4: one thread = one output row, ALL n (in passes of 64 channels); the <=9 input taps live
-// in registers, weights are wave-uniform LDS broadcasts ([t][n][4]); the 64-channel result is
-// transposed through a padded LDS stage so that global stores are full 256-B row segments.
+// in registers, weights are wave-uniform LDS broadcasts ([t][n][4]); each 32-channel slab of the result is
+// transposed through a padded LDS stage so that global stores are full 128-B row segments.
 template <int T>
 __global__ void __launch_bounds__(TPB)
 k_thin_c4(const TArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *wl = smem;                                    // T*N*4 floats
-    float *stage = smem + (size_t)T * p.N * 4;           // 4 waves x 64 rows x 68 floats
+    float *stage = smem + (size_t)T * p.N * 4;           // 4 waves x 64 rows x 36 floats
     for (int i = threadIdx.x; i < T * p.N; i += TPB) {
         int t = i / p.N, n = i - t * p.N;
         reinterpret_cast<float4 *>(wl)[i] = *reinterpret_cast<const float4 *>(p.W + ((long long)n * T + t) * 4);
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float *st = stage + wave * 64 * 68;
+    float *st = stage + wave * 64 * 36;
     const long long nwaves = (long long)gridDim.x * (TPB / 64);
     for (long long w0 = ((long long)blockIdx.x * (TPB / 64) + wave) * 64; w0 < p.M; w0 += nwaves * 64) {
         const long long m = w0 + lane;
@@ -86,8 +86,8 @@ k_thin_c4(const TArgs p) {
             a[t] = r >= 0 ? *reinterpret_cast<const float4 *>(p.A + r * p.lda) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         const long long orow = ok ? out_row(p, i, j, b) : 0;
-        for (int nb = 0; nb < p.N; nb += 64) {
-            const int nq = (p.N - nb) < 64 ? (p.N - nb) >> 2 : 16;     // n-quads in this pass
+        for (int nb = 0; nb < p.N; nb += 32) {
+            const int nq = (p.N - nb) < 32 ? (p.N - nb) >> 2 : 8;      // n-quads in this pass
             for (int q = 0; q < nq; ++q) {
                 float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -100,7 +100,7 @@ k_thin_c4(const TArgs p) {
                     acc.w += a[t].x * w3.x + a[t].y * w3.y + a[t].z * w3.z + a[t].w * w3.w;
                 }
                 if (nq == 1) { if (ok) epilogue_store(p, orow, nb, acc); }
-                else *reinterpret_cast<float4 *>(&st[lane * 68 + q * 4]) = acc;
+                else *reinterpret_cast<float4 *>(&st[lane * 36 + q * 4]) = acc;
             }
             if (nq > 1) {
                 // cooperative, coalesced store: slot s -> (row = s / nq, quad = s % nq)
@@ -110,7 +110,7 @@ k_thin_c4(const TArgs p) {
                     long long mm = w0 + rr;
                     long long orr = __shfl(orow, rr);          // all 64 lanes active here
                     if (mm >= p.M) continue;
-                    float4 v = *reinterpret_cast<const float4 *>(&st[rr * 68 + qq * 4]);
+                    float4 v = *reinterpret_cast<const float4 *>(&st[rr * 36 + qq * 4]);
                     epilogue_store(p, orr, nb + qq * 4, v);
                 }
             }
@@ -271,7 +271,7 @@ int grid_for(long long total, int per) {
 extern "C" int efgh_thin_supported(const efgh_gemm_desc *d) {
     if (!d || d->mode != 1 || d->N % 4 != 0 || d->C % 4 != 0 || d->stats) return 0;
     if (d->C == 4 && d->N <= 256 && (d->T == 1 || d->T == 2 || d->T == 4 || d->T == 9) &&
-        (int64_t)d->T * d->N * 16 + 4 * 64 * 68 * 4 <= 64 * 1024) return 1;
+        (int64_t)d->T * d->N * 16 + 4 * 64 * 36 * 4 <= 64 * 1024) return 1;
     if (d->N == 4 && (int64_t)d->T * d->C * 16 <= 60 * 1024) return 2;
     return 0;
 }
@@ -284,7 +284,7 @@ extern "C" int efgh_thin_gemm(const efgh_gemm_desc *d, void *stream_) {
     TArgs a;
     fill(a, d);
     if (kind == 1) {
-        size_t lds = (size_t)a.T * a.N * 16 + 4 * 64 * 68 * 4;
+        size_t lds = (size_t)a.T * a.N * 16 + 4 * 64 * 36 * 4;
         int grid = grid_for(a.M, TPB);
         switch (a.T) {
         case 1: k_thin_c4<1><<<grid, TPB, lds, st>>>(a); break;
@@ -327,6 +327,91 @@ extern "C" int efgh_thin_wgrad(const efgh_gemm_desc *d, const float *G, int64_t 
         efgh_set_error("thin wgrad: unsupported shape C=%d N=%d T=%d", d->C, d->N, d->T);
         return EFGH_E_INVALID;
     }
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}
+
+// ---- stride-2 transposed conv with <= 2 output channels as GEMM + col2im ------------------------------
+// (gnet.py:56-68 heads).  Y[pix_in][(kh*3+kw)*O + o] = x[pix_in][:] . W[:, o, kh, kw] comes from ONE
+// gather-GEMM launch that reads the 128-channel input once; these kernels fold / unfold the 3x3 taps.
+namespace {
+// out[b][oh][ow][o] = act(scale*(sum_{taps} Y[b][ih][iw][tap*O+o]) + shift), oh = 2*ih - pad + kh
+__global__ void __launch_bounds__(256)
+k_convt_col2im(const float *__restrict__ Y, long long ldy, int B, int Hin, int Win, int Ho, int Wo, int O, int pad,
+               const float *__restrict__ scale, const float *__restrict__ shift, int act, float slope,
+               float *__restrict__ out, long long ldo) {
+    long long total = (long long)B * Ho * Wo;
+    for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < total; g += (long long)gridDim.x * 256) {
+        int ow = (int)(g % Wo); long long r = g / Wo;
+        int oh = (int)(r % Ho); long long b = r / Ho;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            int th = oh + pad - kh;
+            if (th < 0 || (th & 1)) continue;
+            int ih = th >> 1;
+            if (ih >= Hin) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                int tw = ow + pad - kw;
+                if (tw < 0 || (tw & 1)) continue;
+                int iw = tw >> 1;
+                if (iw >= Win) continue;
+                const float *y = Y + ((b * Hin + ih) * Win + iw) * ldy + (kh * 3 + kw) * O;
+                for (int o = 0; o < O; ++o) acc[o] += y[o];
+            }
+        }
+        float4 v;
+        float *vp = &v.x;
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            float x = acc[o];
+            if (o < O) {
+                x = x * (scale ? scale[o] : 1.f) + (shift ? shift[o] : 0.f);
+                x = act_f(x, act, slope);
+            } else x = 0.f;
+            vp[o] = x;
+        }
+        *reinterpret_cast<float4 *>(out + g * ldo) = v;
+    }
+}
+
+// dYcol[b][ih][iw][tap*O+o] = G[b][2ih-pad+kh][2iw-pad+kw][o]  (0 outside), columns >= 9*O zero
+__global__ void __launch_bounds__(256)
+k_convt_im2col(const float *__restrict__ G, long long ldg, int B, int Hin, int Win, int Ho, int Wo, int O, int pad,
+               float *__restrict__ Ycol, long long ldy) {
+    long long total = (long long)B * Hin * Win;
+    for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < total; g += (long long)gridDim.x * 256) {
+        int iw = (int)(g % Win); long long r = g / Win;
+        int ih = (int)(r % Hin); long long b = r / Hin;
+        float *y = Ycol + g * ldy;
+        for (int t = 0; t < 9; ++t) {
+            int oh = 2 * ih - pad + t / 3, ow = 2 * iw - pad + t % 3;
+            bool ok = oh >= 0 && oh < Ho && ow >= 0 && ow < Wo;
+            const float *src = G + ((b * Ho + (ok ? oh : 0)) * Wo + (ok ? ow : 0)) * ldg;
+            for (int o = 0; o < O; ++o) y[t * O + o] = ok ? src[o] : 0.f;
+        }
+        for (int c = 9 * O; c < ldy; ++c) y[c] = 0.f;
+    }
+}
+}  // namespace
+
+extern "C" int efgh_convt_col2im(const float *Y, int64_t ldy, int32_t B, int32_t Hin, int32_t Win, int32_t Ho,
+                                 int32_t Wo, int32_t O, int32_t pad, const float *scale, const float *shift,
+                                 int32_t act, float slope, float *out, int64_t ldo, void *stream_) {
+    EFGH_CHECK_ARG(Y && out && B > 0 && Hin > 0 && Win > 0 && Ho > 0 && Wo > 0 && O >= 1 && O <= 4);
+    EFGH_CHECK_ARG(ldy >= 9 * O && ldo >= 4 && ldo % 4 == 0);
+    k_convt_col2im<<<grid_for((long long)B * Ho * Wo, 256), 256, 0, (hipStream_t)stream_>>>(
+        Y, ldy, B, Hin, Win, Ho, Wo, O, pad, scale, shift, act, slope, out, ldo);
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}
+
+extern "C" int efgh_convt_im2col(const float *G, int64_t ldg, int32_t B, int32_t Hin, int32_t Win, int32_t Ho,
+                                 int32_t Wo, int32_t O, int32_t pad, float *Ycol, int64_t ldy, void *stream_) {
+    EFGH_CHECK_ARG(G && Ycol && B > 0 && Hin > 0 && Win > 0 && Ho > 0 && Wo > 0 && O >= 1 && O <= 4 && ldy >= 9 * O);
+    k_convt_im2col<<<grid_for((long long)B * Hin * Win, 256), 256, 0, (hipStream_t)stream_>>>(G, ldg, B, Hin, Win, Ho,
+                                                                                             Wo, O, pad, Ycol, ldy);
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
 }

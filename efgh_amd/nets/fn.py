@@ -40,12 +40,15 @@ class LayerSpec:
     wgrad_unpack(dWp, i, dW): scatter launch i's packed weight gradient into the reference layout."""
 
     def __init__(self, N, C, T, mode, launches, M, out_shape, pack_fwd, dgrad, wgrad_unpack, bn=None,
-                 train=False, act=ACT_NONE, slope=0.0, table=None, c_real=None):
+                 train=False, act=ACT_NONE, slope=0.0, table=None, c_real=None, custom_forward=None,
+                 custom_wgrad=None):
         self.N, self.C, self.T, self.mode, self.M = N, C, T, mode, M
         self.launches, self.out_shape = launches, out_shape
         self.pack_fwd, self.dgrad, self.wgrad_unpack = pack_fwd, dgrad, wgrad_unpack
         self.bn, self.train, self.act, self.slope, self.table = bn, train, act, slope, table
         self.c_real = c_real if c_real is not None else C
+        # optional replacements of the launch loop / weight gradient (e.g. transposed conv as GEMM + col2im)
+        self.custom_forward, self.custom_wgrad = custom_forward, custom_wgrad
 
 
 class GemmLayerFn(torch.autograd.Function):
@@ -64,14 +67,17 @@ class GemmLayerFn(torch.autograd.Function):
         mean = invstd = raw = None
         need_stats = bn is not None and spec.train
         stats = None
-        thin = all(ops.thin_eligible(spec.mode, spec.C, Np, spec.T if g is None else len(g[7]))
-                   for g, _ in spec.launches)
+        thin = spec.custom_forward is not None or all(
+            ops.thin_eligible(spec.mode, spec.C, Np, spec.T if g is None else len(g[7])) for g, _ in spec.launches)
         if need_stats and not thin:
             gs = [ops.gemm_grid_m(m, Np) for (_, m) in spec.launches]
             stats = torch.empty((sum(gs), 2, Np), dtype=torch.float32, device=dev)
         fused_plain = bn is None            # bias (+residual) (+act) straight in the epilogue
         g0 = 0
-        for li, (geom, m) in enumerate(spec.launches):
+        if spec.custom_forward is not None:
+            assert bn is not None and bias is None
+            spec.custom_forward(x, weight, out)
+        for li, (geom, m) in enumerate(spec.launches if spec.custom_forward is None else []):
             wp = spec.pack_fwd(weight, li)
             T = spec.T if geom is None else len(geom[7])
             fl = 2.0 * m * N * T * spec.c_real
@@ -160,7 +166,9 @@ class GemmLayerFn(torch.autograd.Function):
             dx = spec.dgrad(spec, weight, draw, x)
         # ---- wgrad
         dW = None
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and spec.custom_wgrad is not None:
+            dW = spec.custom_wgrad(x, weight, draw)
+        elif ctx.needs_input_grad[1]:
             dW = torch.empty_like(weight)
             for li, (geom, m) in enumerate(spec.launches):
                 T = spec.T if geom is None else len(geom[7])

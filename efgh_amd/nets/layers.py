@@ -155,8 +155,34 @@ def conv2d(ctx, x, conv, bn=None, act=ACT_NONE, slope=0.0, residual=None, out=No
     return out_t
 
 
+def _convt_wcol(convt):
+    """[ceil4(9*O)][C] weight of the GEMM+col2im form: row (kh*3+kw)*O+o = W[:, o, kh, kw]"""
+    Cw, O = convt.in_channels, convt.out_channels
+    w = convt.weight
+
+    def make():
+        wd = w.detach().reshape(Cw, O, 9).permute(2, 1, 0).reshape(9 * O, Cw)
+        full = torch.zeros((ceil4(9 * O), Cw), dtype=torch.float32, device=wd.device)
+        full[:9 * O] = wd
+        return full
+    return ops._cached(w, ('wcol',), ops._ver(w), make)
+
+
+def _convt_small_forward(x, convt, out_raw, scale=None, shift=None, act=ACT_NONE, slope=0.0):
+    """x [B][H][W][C] -> out_raw [B][Ho][Wo][4]: one GEMM over the input pixels + col2im fold"""
+    B, H, W, Cw = x.shape
+    O = convt.out_channels
+    Ho, Wo = out_raw.shape[1], out_raw.shape[2]
+    wcol = _convt_wcol(convt)
+    Y = torch.empty((B * H * W, wcol.shape[0]), dtype=torch.float32, device=x.device)
+    ops.gather_gemm(x, FN.ld_of(x), Cw, 1, wcol, wcol.shape[0], B * H * W, Y, wcol.shape[0], mode=0,
+                    flops=2.0 * B * H * W * 9 * O * Cw)
+    ops.convt_col2im(Y, B, H, W, Ho, Wo, O, convt.padding[0], scale, shift, act, slope, out_raw)
+
+
 def conv_transpose2d(ctx, x, convt, bn=None, act=ACT_NONE, slope=0.0, out=None):
-    """nn.ConvTranspose2d(k=3, s=2) as four stride-1 sub-convolutions, one per output parity class."""
+    """nn.ConvTranspose2d(k=3, s=2) as four stride-1 sub-convolutions, one per output parity class
+    (or, for <= 2 output channels, as ONE GEMM over the input pixels + a col2im fold)."""
     B, H, W, ldx = x.shape
     Cw, O = convt.in_channels, convt.out_channels
     assert convt.kernel_size == (3, 3) and convt.stride == (2, 2) and ldx == Cw and Cw % 4 == 0
@@ -164,6 +190,17 @@ def conv_transpose2d(ctx, x, convt, bn=None, act=ACT_NONE, slope=0.0, out=None):
     oph, opw = convt.output_padding
     Ho, Wo = (H - 1) * 2 - 2 * ph + 3 + oph, (W - 1) * 2 - 2 * pw + 3 + opw
     Np = ceil4(O)
+    if O <= 2 and ph == pw and convt.bias is None and bn is not None and out is None and not ctx.grad:
+        out_t = torch.empty((B, Ho, Wo, 4), dtype=torch.float32, device=x.device)
+        if not ctx.train:
+            sc, sh = _bn_eval_affine(bn, 4)
+            _convt_small_forward(x, convt, out_t, sc, sh, act, slope)
+        else:
+            _convt_small_forward(x, convt, out_t)
+            stats, G = ops.col_stats(out_t, B * Ho * Wo, 4, 4)
+            scale, shift = _bn_train(ctx, bn, stats, G, 4, float(B * Ho * Wo))
+            ops.scale_shift_act(out_t, 4, scale, shift, out_t, 4, B * Ho * Wo, 4, act, slope)
+        return out_t
     out_t, ldo, coff = (None, 0, 0) if ctx.grad else _alloc_out(x, (B, Ho, Wo), O, out)
     geoms = []
     for cy in range(2):
@@ -365,8 +402,23 @@ def _convt_grad(ctx, x, convt, bn, act, slope, geoms, dims):
                         flops=2.0 * B * H * W * Cw * 9 * O / 4 * 4)
         return dx
 
+    custom_fwd = custom_wgrad = None
+    if O <= 2 and ph == pw and convt.bias is None and bn is not None:
+        def custom_fwd(xin, w, out_raw):
+            _convt_small_forward(xin, convt, out_raw)
+
+        def custom_wgrad(xin, w, draw):
+            # dWcol[(tap,o)][c] = sum_pix im2col(draw)[pix][(tap,o)] * x[pix][c]
+            n9 = ceil4(9 * O)
+            ycol = torch.empty((B * H * W, n9), dtype=torch.float32, device=draw.device)
+            ops.convt_im2col(draw, B, H, W, Ho, Wo, O, ph, ycol)
+            dwcol = torch.empty((n9, 1, Cw), dtype=torch.float32, device=draw.device)
+            ops.gather_wgrad(xin, FN.ld_of(xin), Cw, 1, n9, B * H * W, ycol, n9, dwcol, mode=0)
+            return dwcol[:9 * O, 0].reshape(9, O, Cw).permute(2, 1, 0).reshape(Cw, O, 3, 3).contiguous()
+
     spec = FN.LayerSpec(O, Cw, 0, 1, [(g[0], g[2]) for g in geoms], B * Ho * Wo, (B, Ho, Wo), pack_fwd, dgrad,
-                        unpack, bn=bn, train=ctx.train, act=act, slope=slope, c_real=Cw)
+                        unpack, bn=bn, train=ctx.train, act=act, slope=slope, c_real=Cw,
+                        custom_forward=custom_fwd, custom_wgrad=custom_wgrad)
     g_, b_ = _bn_args(bn)
     return FN.GemmLayerFn.apply(x, convt.weight, convt.bias, g_, b_, None, spec)
 

@@ -104,7 +104,7 @@ def thin_eligible(mode, C, N, T):
     """shapes served by the VALU "thin" kernels (thin.hip) instead of the MFMA tile"""
     if not USE_THIN or mode != 1 or N % 4 or C % 4:
         return False
-    if C == 4 and N <= 256 and T in (1, 2, 4, 9) and T * N * 16 + 4 * 64 * 68 * 4 <= 64 * 1024:
+    if C == 4 and N <= 256 and T in (1, 2, 4, 9) and T * N * 16 + 4 * 64 * 36 * 4 <= 64 * 1024:
         return True
     return N == 4 and T * C * 16 <= 60 * 1024
 
@@ -448,3 +448,14 @@ def corr_unpad(drp, B, h, w, C, off):
     _C.check(_L().efgh_corr_unpad(ptr(drp), c_int32(B), c_int32(h), c_int32(w), c_int32(C), c_int32(off), ptr(dx),
                                   _st()))
     return dx
+
+
+def convt_col2im(Y, B, Hin, Win, Ho, Wo, O, pad, scale, shift, act, slope, out):
+    _C.check(_L().efgh_convt_col2im(ptr(Y), c_int64(Y.shape[-1]), c_int32(B), c_int32(Hin), c_int32(Win), c_int32(Ho),
+                                    c_int32(Wo), c_int32(O), c_int32(pad), ptr(scale), ptr(shift), c_int32(act),
+                                    c_float(slope), ptr(out), c_int64(out.shape[-1]), _st()))
+
+
+def convt_im2col(G, B, Hin, Win, Ho, Wo, O, pad, Ycol):
+    _C.check(_L().efgh_convt_im2col(ptr(G), c_int64(G.shape[-1]), c_int32(B), c_int32(Hin), c_int32(Win), c_int32(Ho),
+                                    c_int32(Wo), c_int32(O), c_int32(pad), ptr(Ycol), c_int64(Ycol.shape[-1]), _st()))

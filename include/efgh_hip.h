@@ -253,6 +253,16 @@ int efgh_gather_gemm_bf16x6(const efgh_gemm_desc *d, const void *W_hi, const voi
 /* w[i] -> hi[i] (+ mid[i], optional: NULL for the two-term split) + lo[i], each bf16 */
 int efgh_split_bf16(const float *w, void *hi, void *mid, void *lo, int64_t n, void *stream);
 
+/* stride-2 3x3 transposed conv with <= 4 output channels (G's depth / mask heads, gnet.py:56-68) as
+ * ONE gather-GEMM over the input pixels (Y [B*Hin*Win][ldy], column (kh*3+kw)*O+o) + this fold:
+ * out[b][oh][ow][o] = act(scale[o]*sum_{oh=2ih-pad+kh, ow=2iw-pad+kw} Y[b][ih][iw][..] + shift[o]).
+ * efgh_convt_im2col is the adjoint unfold of the output gradient (feeds the weight-gradient GEMM). */
+int efgh_convt_col2im(const float *Y, int64_t ldy, int32_t B, int32_t Hin, int32_t Win, int32_t Ho, int32_t Wo,
+                      int32_t O, int32_t pad, const float *scale, const float *shift, int32_t act, float slope,
+                      float *out, int64_t ldo, void *stream);
+int efgh_convt_im2col(const float *G, int64_t ldg, int32_t B, int32_t Hin, int32_t Win, int32_t Ho, int32_t Wo,
+                      int32_t O, int32_t pad, float *Ycol, int64_t ldy, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
