@@ -129,10 +129,16 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
     assert world == a.gpus, (world, a.gpus)
+    local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     if world > 1:
-        dist.init_process_group('nccl', device_id=dev)
+        # RCCL over xGMI ('nccl' is RCCL on ROCm); EFGH_DIST_BACKEND=gloo only for single-GPU plumbing tests
+        backend = os.environ.get('EFGH_DIST_BACKEND', 'nccl')
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
     raw, npts = ((128, 256), 2048) if a.small else (RAW, NPTS)
     args = syn.default_args(raw, 'cuda')
 

@@ -87,3 +87,28 @@ def test_product_does_not_import_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M), f
                 assert '/root/reference' not in src, f
+
+
+def test_criterion_api_matches_reference():
+    """losses.EFGHCriterion: constructor, loss_name order (efghloss.py:13-17), name lookup (main.py:129)"""
+    import efgh_amd.losses as losses
+    from efgh_amd import synthetic as syn
+    c = losses.__dict__['EFGH' + 'Criterion'](syn.default_args((128, 256)))
+    assert c.loss_name == ['total', 'e_gn', 'e_gn_sgn', 'e_gn_abs', 'h_hrzn', 'h_hrzn_abs', 'h_hrzn_sgn', 'fov',
+                           'g_trs', 'g_depth', 'g_mask']
+    assert callable(c.compute_loss)
+
+
+def test_lr_schedule_and_flat_params_cpu():
+    from efgh_amd.train import FlatParams, adjust_learning_rate
+    assert adjust_learning_rate(1e-4, 0) == 1e-4
+    assert abs(adjust_learning_rate(1e-4, 50000) - 0.7e-4) < 1e-12          # common/helper.py:28-38
+    assert abs(adjust_learning_rate(1e-4, 149999) - 0.49e-4) < 1e-12
+    m = torch.nn.Sequential(torch.nn.Linear(5, 3), torch.nn.Linear(3, 2))
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    f = FlatParams(m)
+    assert f.n == 5 * 3 + 3 + 3 * 2 + 2
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, before[k])
+    m(torch.randn(4, 5)).sum().backward()
+    assert float(f.g.abs().sum()) > 0 and all(p.grad.data_ptr() >= f.g.data_ptr() for p in f.params)
