@@ -195,25 +195,35 @@ k_corr_bwd_cam(const float *__restrict__ rp, const float *__restrict__ dl, int h
     reinterpret_cast<float4 *>(dcam + (((long long)b * h + y) * wc) * 16)[i] = a;
 }
 
-// drp[b][y][xp][c] = sum_{x: 0<=xp-x<nj... } dl[b][xp-x] * cam_n[b][y][x][c]
+// drp[b][y][xp][c] = sum_x dl[b][xp-x] * cam_n[b][y][x][c]   (0 <= xp-x < nj)
+// block = one (b, y): the normalised camera row and dl live in LDS; thread = one (xp, channel quad)
 __global__ void __launch_bounds__(TPB)
 k_corr_bwd_rng(const float *__restrict__ cam, const float *__restrict__ cam_mm, const float *__restrict__ dl,
                int h, int wc, int wp, int nj, float *__restrict__ drp) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];        // wc*16 floats + nj floats
+    float4 *srow = reinterpret_cast<float4 *>(sm);
+    float *sdl = sm + (size_t)wc * 16;
     const int b = blockIdx.z, y = blockIdx.y;
-    int i = blockIdx.x * TPB + threadIdx.x;           // over wp*4
-    if (i >= wp * 4) return;
-    int xp = i >> 2, cq = i & 3;
     const float d = cam_mm[b * 2 + 1] - cam_mm[b * 2];
     const float4 *cr = reinterpret_cast<const float4 *>(cam + (((long long)b * h + y) * wc) * 16);
-    const float *g = dl + (long long)b * nj;
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-    int x0 = xp - (nj - 1); if (x0 < 0) x0 = 0;
-    int x1 = xp < wc - 1 ? xp : wc - 1;
-    for (int x = x0; x <= x1; ++x) {
-        float w = g[xp - x]; float4 v = cr[x * 4 + cq];
-        a.x += w * (v.x / d); a.y += w * (v.y / d); a.z += w * (v.z / d); a.w += w * (v.w / d);
+    for (int i = threadIdx.x; i < wc * 4; i += TPB) {
+        float4 v = cr[i];
+        v.x /= d; v.y /= d; v.z /= d; v.w /= d;
+        srow[i] = v;
     }
-    reinterpret_cast<float4 *>(drp + (((long long)b * h + y) * wp) * 16)[i] = a;
+    for (int i = threadIdx.x; i < nj; i += TPB) sdl[i] = dl[(long long)b * nj + i];
+    __syncthreads();
+    for (int i = blockIdx.x * TPB + threadIdx.x; i < wp * 4; i += gridDim.x * TPB) {
+        int xp = i >> 2, cq = i & 3;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        int x0 = xp - (nj - 1); if (x0 < 0) x0 = 0;
+        int x1 = xp < wc - 1 ? xp : wc - 1;
+        for (int x = x0; x <= x1; ++x) {
+            float w = sdl[xp - x]; float4 v = srow[x * 4 + cq];
+            a.x += w * v.x; a.y += w * v.y; a.z += w * v.z; a.w += w * v.w;
+        }
+        reinterpret_cast<float4 *>(drp + (((long long)b * h + y) * wp) * 16)[i] = a;
+    }
 }
 
 // fold the padded gradient back: drng_n[b][y][xs][c] = drp[xs+off] (+ drp[w-1-xs] if w-1-xs < off) (+ drp[xs+off+w] if xs < off)
@@ -312,7 +322,9 @@ extern "C" int efgh_corr1d_bwd(const float *rp, const float *cam, const float *c
     EFGH_CHECK_ARG(rp && cam && cam_mm && dlogit && dcam_n && drp && B > 0 && h > 0 && wc > 0 && wp >= wc);
     int nj = wp - wc + 1;
     k_corr_bwd_cam<<<dim3(cdiv(wc * 4, TPB), h, B), TPB, 0, st>>>(rp, dlogit, h, wc, wp, nj, dcam_n);
-    k_corr_bwd_rng<<<dim3(cdiv(wp * 4, TPB), h, B), TPB, 0, st>>>(cam, cam_mm, dlogit, h, wc, wp, nj, drp);
+    EFGH_CHECK_ARG((size_t)wc * 64 + (size_t)nj * 4 <= 64 * 1024);
+    k_corr_bwd_rng<<<dim3(cdiv(wp * 4, TPB * 4), h, B), TPB, (size_t)wc * 64 + (size_t)nj * 4, st>>>(cam, cam_mm, dlogit, h, wc, wp, nj,
+                                                                                              drp);
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
 }
