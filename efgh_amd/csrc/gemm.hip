@@ -24,6 +24,9 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+constexpr float F16_LO_SCALE = 2048.0f;      // lo terms are stored x 2^11 so that they stay normal fp16 numbers
 
 constexpr int BK = 32;
 constexpr int LDS_LD = BK + 4;       // fp32 path: floats per LDS row
@@ -39,6 +42,18 @@ __device__ __forceinline__ void split4x3(const float4 v, bf16x4 &hi, bf16x4 &mid
         __bf16 m = (__bf16)r;
         hi[q] = h; mid[q] = m;
         lo[q] = (__bf16)(r - (float)m);
+    }
+}
+
+// x = hi + lo/2^11 (+ O(2^-22 |x|)) with hi, lo in fp16; |x| must stay below 65504 (saturates otherwise)
+__device__ __forceinline__ void split4_f16(const float4 v, f16x4 &hi, f16x4 &lo) {
+    const float f[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float x = fminf(fmaxf(f[q], -65504.f), 65504.f);
+        _Float16 h = (_Float16)x;
+        hi[q] = h;
+        lo[q] = (_Float16)((x - (float)h) * F16_LO_SCALE);
     }
 }
 
@@ -74,14 +89,17 @@ struct KArgs {
 // MATH 0: exact fp32 MFMA (v_mfma_f32_32x32x2_f32).
 // MATH 1: split-bf16: every fp32 operand is hi+lo in bf16 and a*b ~= ah*bh + ah*bl + al*bh on
 //         v_mfma_f32_32x32x16_bf16 with fp32 accumulation (per-product relative error ~2^-17).
+// MATH 2: three-term bf16 split, six products (fp32-equivalent).
+// MATH 3: split-fp16: x = hi + lo/2^11 in fp16 (22 significand bits), ah*bh in one accumulator and
+//         ah*bl' + al'*bh in a second one that is folded in with 2^-11 at the end (error ~2^-22/product).
 template <int MODE, int BM, int BN, int WM, int WN, int MATH>
-__global__ void __launch_bounds__(256, MATH == 2 ? 2 : 3)
+__global__ void __launch_bounds__(256, (MATH == 2 || MATH == 3) ? 2 : 3)
 k_gather_gemm(const KArgs p) {
     constexpr int MI = BM / WM / 32, NI = BN / WN / 32;
     constexpr int NA = BM / 32, NB = BN / 32;
     // LDS in floats: fp32 rows of 36 | 2 (MATH 1) or 3 (MATH 2) bf16 arrays with rows of 40
-    constexpr int A_ELEMS = MATH == 0 ? BM * LDS_LD : (MATH == 1 ? BM * LDH : BM * LDH * 3 / 2);
-    constexpr int B_ELEMS = MATH == 0 ? BN * LDS_LD : (MATH == 1 ? BN * LDH : BN * LDH * 3 / 2);
+    constexpr int A_ELEMS = MATH == 0 ? BM * LDS_LD : (MATH == 2 ? BM * LDH * 3 / 2 : BM * LDH);
+    constexpr int B_ELEMS = MATH == 0 ? BN * LDS_LD : (MATH == 2 ? BN * LDH * 3 / 2 : BN * LDH);
     __shared__ __attribute__((aligned(16))) float As[A_ELEMS];
     __shared__ __attribute__((aligned(16))) float Bs[B_ELEMS];
     __bf16 *Ah = reinterpret_cast<__bf16 *>(As), *Al = Ah + BM * LDH, *Am = Al + BM * LDH;
@@ -205,12 +223,16 @@ k_gather_gemm(const KArgs p) {
     };
 
     f32x16 acc[MI][NI];
+    f32x16 acs[MATH == 3 ? MI : 1][MATH == 3 ? NI : 1];      // MATH 3: the 2^-11-scaled cross terms
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < 16; ++r) {
+                acc[i][j][r] = 0.f;
+                if (MATH == 3) acs[i][j][r] = 0.f;
+            }
 
     const int nchunks = (p.K + BK - 1) / BK;
     load_chunk(0);
@@ -225,6 +247,13 @@ k_gather_gemm(const KArgs p) {
         } else {
 #pragma unroll
             for (int q = 0; q < NA; ++q) {
+                if (MATH == 3) {
+                    f16x4 h16, l16;
+                    split4_f16(ra[q], h16, l16);
+                    *reinterpret_cast<f16x4 *>(&Ah[(q * 32 + arow) * LDH + kv]) = h16;
+                    *reinterpret_cast<f16x4 *>(&Al[(q * 32 + arow) * LDH + kv]) = l16;
+                    continue;
+                }
                 bf16x4 hi, mid, lo;
                 if (MATH == 1) split4(ra[q], hi, lo);
                 else {
@@ -265,6 +294,31 @@ k_gather_gemm(const KArgs p) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
                     }
             }
+        } else if (MATH == 3) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                f16x8 ah[MI], al[MI], bh[NI], bl[NI];
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    const int o = ((wm * MI + i) * 32 + l31) * LDH + ks * 16 + lh * 8;
+                    ah[i] = *reinterpret_cast<const f16x8 *>(&Ah[o]);
+                    al[i] = *reinterpret_cast<const f16x8 *>(&Al[o]);
+                }
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    const int o = ((wn * NI + j) * 32 + l31) * LDH + ks * 16 + lh * 8;
+                    bh[j] = *reinterpret_cast<const f16x8 *>(&Bh[o]);
+                    bl[j] = *reinterpret_cast<const f16x8 *>(&Bl[o]);
+                }
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) {
+                        acs[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acs[i][j], 0, 0, 0);
+                        acs[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acs[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    }
+            }
         } else {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {       // two k-steps of 16; lane holds k = 8*lh + j of the step
@@ -303,6 +357,15 @@ k_gather_gemm(const KArgs p) {
             }
         }
         __syncthreads();
+    }
+
+    if (MATH == 3) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] += acs[i][j][r] * (1.0f / F16_LO_SCALE);
     }
 
     // ---- epilogue -----------------------------------------------------------------------
@@ -365,6 +428,15 @@ __global__ void k_pack_weight(const float *__restrict__ W, float *__restrict__ W
 #pragma unroll
         for (int q = 0; q < 16; ++q) if (q == t) ti = tp[q];
         Wp[i] = W[n * sn + c * sc + ti * st];
+    }
+}
+
+__global__ void k_split_f16(const float *__restrict__ w, _Float16 *__restrict__ hi, _Float16 *__restrict__ lo, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float v = fminf(fmaxf(w[i], -65504.f), 65504.f);
+        _Float16 h = (_Float16)v;
+        hi[i] = h;
+        lo[i] = (_Float16)((v - (float)h) * F16_LO_SCALE);
     }
 }
 
@@ -475,6 +547,28 @@ extern "C" int efgh_gather_gemm_bf16x6(const efgh_gemm_desc *d, const void *W_hi
     if (d->mode == 0) dispatch<0, 2>(a, st);
     else if (d->mode == 1) dispatch<1, 2>(a, st);
     else dispatch<2, 2>(a, st);
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}
+
+extern "C" int efgh_gather_gemm_f16x3(const efgh_gemm_desc *d, const void *W_hi, const void *W_lo, void *stream_) {
+    hipStream_t st = (hipStream_t)stream_;
+    KArgs a;
+    int rc = fill_args(d, a);
+    if (rc != EFGH_OK) return rc;
+    EFGH_CHECK_ARG(W_hi && W_lo && (((uintptr_t)W_hi) & 7) == 0 && (((uintptr_t)W_lo) & 7) == 0);
+    a.Wh = (const __bf16 *)W_hi; a.Wl = (const __bf16 *)W_lo;       // raw 16-bit storage, fp16 in this mode
+    if (d->mode == 0) dispatch<0, 3>(a, st);
+    else if (d->mode == 1) dispatch<1, 3>(a, st);
+    else dispatch<2, 3>(a, st);
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}
+
+extern "C" int efgh_split_f16(const float *w, void *hi, void *lo, int64_t n, void *stream_) {
+    EFGH_CHECK_ARG(w && hi && lo && n > 0);
+    long long g = (n + 255) / 256;
+    k_split_f16<<<(int)(g > 8192 ? 8192 : g), 256, 0, (hipStream_t)stream_>>>(w, (_Float16 *)hi, (_Float16 *)lo, n);
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
 }

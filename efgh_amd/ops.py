@@ -99,6 +99,16 @@ def split_weight(Wp, terms=2):
     return _cached(Wp, ('split', terms), _ver(Wp), make)
 
 
+def split_weight_f16(Wp):
+    def make():
+        n = Wp.numel()
+        hi = torch.empty(n, dtype=torch.float16, device=Wp.device)
+        lo = torch.empty(n, dtype=torch.float16, device=Wp.device)
+        _C.check(_L().efgh_split_f16(ptr(Wp), ptr(hi), ptr(lo), c_int64(n), _st()))
+        return hi, lo
+    return _cached(Wp, ('split_f16',), _ver(Wp), make)
+
+
 
 def thin_eligible(mode, C, N, T):
     """shapes served by the VALU "thin" kernels (thin.hip) instead of the MFMA tile"""
@@ -144,6 +154,9 @@ def gather_gemm(A, lda, C, T, Wp, N, M, out, ldo, mode=0, geom=None, table=None,
     elif MATH == 'bf16x3':
         hi, _, lo = split_weight(Wp, 2)
         _C.check(_L().efgh_gather_gemm_bf16x3(ctypes.byref(d), ptr(hi), ptr(lo), _st()))
+    elif MATH == 'f16x3':
+        hi, lo = split_weight_f16(Wp)
+        _C.check(_L().efgh_gather_gemm_f16x3(ctypes.byref(d), ptr(hi), ptr(lo), _st()))
     elif MATH == 'bf16x6':
         hi, mid, lo = split_weight(Wp, 3)
         _C.check(_L().efgh_gather_gemm_bf16x6(ctypes.byref(d), ptr(hi), ptr(mid), ptr(lo), _st()))

@@ -250,6 +250,11 @@ int efgh_gather_gemm_bf16x3(const efgh_gemm_desc *d, const void *W_hi, const voi
  * fp32-equivalent accuracy (dropped terms <= 2^-24) on bf16 MFMAs: 6 x K=16 instead of 8 x K=2.  */
 int efgh_gather_gemm_bf16x6(const efgh_gemm_desc *d, const void *W_hi, const void *W_mid, const void *W_lo,
                             void *stream);
+/* split-fp16: x = hi + lo*2^-11 with hi, lo in fp16 (22 significand bits, |x| < 65504); the cross terms
+ * ah*bl + al*bh are summed in a second accumulator and folded in with 2^-11: ~2^-22 per product at the
+ * cost of three fp16 MFMAs (intended for inference; gradients would need loss scaling).             */
+int efgh_gather_gemm_f16x3(const efgh_gemm_desc *d, const void *W_hi, const void *W_lo, void *stream);
+int efgh_split_f16(const float *w, void *hi, void *lo, int64_t n, void *stream);
 /* w[i] -> hi[i] (+ mid[i], optional: NULL for the two-term split) + lo[i], each bf16 */
 int efgh_split_bf16(const float *w, void *hi, void *mid, void *lo, int64_t n, void *stream);
 

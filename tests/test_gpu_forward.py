@@ -120,13 +120,14 @@ def test_cpu_tensors_are_refused(manifest):
         m(*[t.cpu() for t in inp])
 
 
-def test_split_bf16x3_forward_logits_within_1e4(golden_dir, manifest):
-    """the opt-in fast math (EFGH_MATH=bf16x3) keeps the north-star tolerance on the pose logits
-    (stage-wise teacher-forced, eval mode)"""
+@pytest.mark.parametrize('math', ['bf16x3', 'f16x3'])
+def test_split_math_forward_logits_within_1e4(golden_dir, manifest, math):
+    """the opt-in fast math modes (EFGH_MATH=bf16x3 | f16x3) keep the north-star tolerance on the pose
+    logits (stage-wise teacher-forced, eval mode)"""
     from efgh_amd import ops
     from oracle import efgh_oracle as O
     old = ops.MATH
-    ops.MATH = 'bf16x3'
+    ops.MATH = math
     try:
         m = _model(manifest, False)
         b, inp = _inputs()

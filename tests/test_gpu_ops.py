@@ -190,10 +190,10 @@ def test_corr_head():
         assert _rel(score[b].cpu(), torch.sigmoid(ref)) < 2e-5
 
 
-@pytest.mark.parametrize('math,tol', [('bf16x3', 3e-5), ('bf16x6', 6e-6)])
+@pytest.mark.parametrize('math,tol', [('bf16x3', 3e-5), ('bf16x6', 6e-6), ('f16x3', 6e-6)])
 def test_split_bf16_math_modes(L, math, tol):
-    """opt-in split-bf16 MFMA paths (x = hi+lo or hi+mid+lo in bf16, fp32 accumulation) vs the exact
-    fp32-MFMA path and vs torch fp32: 2^-17 per product (x3) / fp32-equivalent (x6)."""
+    """opt-in split MFMA paths (x = hi+lo / hi+mid+lo in bf16, or hi + lo*2^-11 in fp16; fp32 accumulation)
+    vs the exact fp32-MFMA path and vs torch fp32: 2^-17 per product (bf16x3) / fp32-equivalent (bf16x6, f16x3)."""
     from efgh_amd import ops
     torch.manual_seed(7)
     old = ops.MATH
