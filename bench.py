@@ -39,23 +39,21 @@ def parse():
 
 
 def cpu_baseline(raw, npts, mode):
-    """the oracle (CPU restatement of the reference) timed on the host cores, on a BOUNDED sample: one
-    frame-pair at a quarter of the pixels / points of the workload (conv FLOPs scale with the area), same
-    network, same mode.  `value` is the full-size equivalent (measured rate x 1/4)."""
+    """the oracle (CPU restatement of the reference) timed on the host cores on a BOUNDED sample: ONE
+    frame-pair of the same workload (same sizes, same mode), ~10-30 s."""
     import torch
     from efgh_amd import synthetic as syn
     from efgh_amd.nets import EFGHBackbone
     from oracle import efgh_oracle as O
-    cores = min(os.cpu_count() or 1, 32)        # torch CPU ops stop scaling (and regress) far below 256 threads
+    cores = min(os.cpu_count() or 1, 32)        # torch CPU ops stop scaling (and regress badly) far below 256 threads
     torch.set_num_threads(cores)
-    raw_s, npts_s = (raw[0] // 2, raw[1] // 2), npts // 4
     torch.manual_seed(0)
-    m = EFGHBackbone(syn.default_args(raw_s, 'cpu'))    # parameter container only; never executed on CPU
+    m = EFGHBackbone(syn.default_args(raw, 'cpu'))      # parameter container only; never executed on CPU
     P = {k: v.detach().clone() for k, v in m.state_dict().items()}
     names = [k for k, _ in m.named_parameters()]
-    b = syn.make_batch(raw_s, npts_s, 1)
+    b = syn.make_batch(raw, npts, 1)
     T = torch.from_numpy
-    args = syn.default_args(raw_s, 'cpu')
+    args = syn.default_args(raw, 'cpu')
     inp = [T(b[k]) for k in ('pc', 'img', 'calib', 'A')]
     t0 = time.time()
     if mode == 'train':
@@ -70,12 +68,10 @@ def cpu_baseline(raw, npts, mode):
             O.forward(P, *inp, args, train=False)
         what = 'eval forward'
     dt = time.time() - t0
-    return {'value': 0.25 / dt, 'unit': 'frame-pairs/s', 'cores': cores, 'kind': 'port',
-            'measured_sample_rate': 1.0 / dt,
-            'sample': '1 frame-pair at 1/4 size (%dx%d RGB, %d points; %s, B=1) through oracle/efgh_oracle.py + '
-                      'oracle/lattice_oracle.c, torch CPU fp32, %d threads, %.1f s; value = measured rate / 4 '
-                      '(full-size equivalent, conv FLOPs scale with area)' %
-                      (raw_s[0] // 2, raw_s[1] // 2, npts_s, what, cores, dt)}
+    return {'value': 1.0 / dt, 'unit': 'frame-pairs/s', 'cores': cores, 'kind': 'port',
+            'sample': '1 frame-pair of the same workload (%dx%d RGB, %d points; %s, B=1) through '
+                      'oracle/efgh_oracle.py + oracle/lattice_oracle.c, torch CPU fp32, %d threads, %.1f s' %
+                      (raw[0] // 2, raw[1] // 2, npts, what, cores, dt)}
 
 
 def dump_shapes(prof, path):
