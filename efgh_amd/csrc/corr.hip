@@ -37,19 +37,23 @@ __global__ void k_minmax_final(const float *__restrict__ part, int G, float *__r
 }
 
 // ---- normalise + pad: rng [B][h][w][C] -> rp [B][h][w+2*off][C] -----------------------------------
+// rows of y have `wpitch` >= w + 2*off pixels; the pixels past the padded width are zero
 __global__ void __launch_bounds__(TPB)
-k_norm_pad(const float *__restrict__ x, const float *__restrict__ mm, int B, int h, int w, int C, int off,
+k_norm_pad(const float *__restrict__ x, const float *__restrict__ mm, int B, int h, int w, int C, int off, int wpitch,
            float *__restrict__ y) {
     const int wp = w + 2 * off, c4n = C >> 2;
-    long long total = (long long)B * h * wp * c4n;
+    long long total = (long long)B * h * wpitch * c4n;
     for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
         int cq = (int)(i % c4n); long long r = i / c4n;
-        int xp = (int)(r % wp); r /= wp;
+        int xp = (int)(r % wpitch); r /= wpitch;
         int yy = (int)(r % h); int b = (int)(r / h);
-        int xs = xp < off ? (w - 1 - xp) : (xp < off + w ? xp - off : xp - off - w);
-        float d = mm[b * 2 + 1] - mm[b * 2];
-        float4 v = *reinterpret_cast<const float4 *>(x + (((long long)b * h + yy) * w + xs) * C + cq * 4);
-        v.x /= d; v.y /= d; v.z /= d; v.w /= d;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (xp < wp) {
+            int xs = xp < off ? (w - 1 - xp) : (xp < off + w ? xp - off : xp - off - w);
+            float d = mm[b * 2 + 1] - mm[b * 2];
+            v = *reinterpret_cast<const float4 *>(x + (((long long)b * h + yy) * w + xs) * C + cq * 4);
+            v.x /= d; v.y /= d; v.z /= d; v.w /= d;
+        }
         reinterpret_cast<float4 *>(y)[i] = v;
     }
 }
@@ -124,6 +128,50 @@ k_corr_finish(const float *__restrict__ part, int B, int h, int nj, float invC, 
     }
 }
 
+// ---- MFMA formulation of the correlation (fnet.py:79): the camera row is cut into N segments of `segw`
+// pixels; P[m][s] = sum_{y, x<segw, c} rp[y][m+x][c] * cam_n[y][s*segw+x][c] is ONE gather-GEMM (mode 3:
+// tap = image row, C = segw*16 contiguous floats), and score[j] = sigmoid((1/16) sum_s P[j + s*segw][s]).
+// Wc[b][ks][s][yy][x*16+c] = cam[b][ks*T+yy][s*segw+x][c] / (max-min)   (0 beyond the camera width);
+// the image rows are cut into nsplit groups of T = h/nsplit (split-K: one GEMM problem per group)
+__global__ void __launch_bounds__(TPB)
+k_corr_pack_cam(const float *__restrict__ cam, const float *__restrict__ cam_mm, int B, int h, int wc, int segw,
+                int nseg, int nsplit, float *__restrict__ Wc) {
+    const int cseg = segw * 4;                        // float4 per (segment, row)
+    const int T = h / nsplit;
+    long long total = (long long)B * nseg * h * cseg;
+    for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
+        int q = (int)(i % cseg); long long r = i / cseg;
+        int yy = (int)(r % T); r /= T;
+        int s = (int)(r % nseg); r /= nseg;
+        int ks = (int)(r % nsplit); int b = (int)(r / nsplit);
+        int y = ks * T + yy;
+        int x = s * segw + (q >> 2);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (x < wc) {
+            const float d = cam_mm[b * 2 + 1] - cam_mm[b * 2];
+            v = reinterpret_cast<const float4 *>(cam + (((long long)b * h + y) * wc + x) * 16)[q & 3];
+            v.x /= d; v.y /= d; v.z /= d; v.w /= d;
+        }
+        reinterpret_cast<float4 *>(Wc)[i] = v;
+    }
+}
+
+__global__ void __launch_bounds__(TPB)
+k_corr_fold(const float *__restrict__ P, int B, int nsplit, long long Mv, int ldp, int nseg, int segw, int nj,
+            float invC, float *__restrict__ logit, float *__restrict__ score) {
+    long long total = (long long)B * nj;
+    for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
+        int b = (int)(i / nj), j = (int)(i - (long long)b * nj);
+        float a = 0.f;
+        for (int ks = 0; ks < nsplit; ++ks)
+            for (int s = 0; s < nseg; ++s)
+                a += P[(((long long)b * nsplit + ks) * Mv + j + (long long)s * segw) * ldp + s];
+        a *= invC;
+        if (logit) logit[i] = a;
+        score[i] = 1.0f / (1.0f + expf(-a));
+    }
+}
+
 int grid_for(long long total) {
     long long g = (total + TPB - 1) / TPB;
     return (int)(g > 16384 ? 16384 : (g < 1 ? 1 : g));
@@ -146,10 +194,11 @@ extern "C" int efgh_minmax(const float *x, int32_t B, int64_t n, float *part, fl
 }
 
 extern "C" int efgh_corr_pad(const float *rng, const float *rng_mm, int32_t B, int32_t h, int32_t w, int32_t C,
-                             int32_t off, float *rp, void *stream_) {
+                             int32_t off, int32_t wpitch, float *rp, void *stream_) {
     EFGH_CHECK_ARG(rng && rng_mm && rp && B > 0 && h > 0 && w > 0 && C % 4 == 0 && off >= 0 && off <= w);
-    k_norm_pad<<<grid_for((long long)B * h * (w + 2 * off) * (C / 4)), TPB, 0, (hipStream_t)stream_>>>(
-        rng, rng_mm, B, h, w, C, off, rp);
+    EFGH_CHECK_ARG(wpitch >= w + 2 * off);
+    k_norm_pad<<<grid_for((long long)B * h * wpitch * (C / 4)), TPB, 0, (hipStream_t)stream_>>>(
+        rng, rng_mm, B, h, w, C, off, wpitch, rp);
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
 }
@@ -163,6 +212,27 @@ extern "C" int efgh_corr1d(const float *rp, const float *cam, const float *cam_m
     dim3 grid(cdiv(nj, TPB * JT), h, B);
     k_corr_rows<<<grid, TPB, (size_t)wc * 16 * 4, st>>>(rp, cam, cam_mm, h, wc, wp, nj, part);
     k_corr_finish<<<grid_for((long long)B * nj), TPB, 0, st>>>(part, B, h, nj, 1.0f / 16.0f, logit, score);
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}
+
+
+extern "C" int efgh_corr_pack_cam(const float *cam, const float *cam_mm, int32_t B, int32_t h, int32_t wc, int32_t segw,
+                                  int32_t nseg, int32_t nsplit, float *Wc, void *stream_) {
+    EFGH_CHECK_ARG(cam && cam_mm && Wc && B > 0 && h > 0 && wc > 0 && segw > 0 && nseg * segw >= wc);
+    EFGH_CHECK_ARG(nsplit >= 1 && h % nsplit == 0);
+    k_corr_pack_cam<<<grid_for((long long)B * nseg * h * segw * 4), TPB, 0, (hipStream_t)stream_>>>(cam, cam_mm, B, h, wc,
+                                                                                                  segw, nseg, nsplit, Wc);
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}
+
+extern "C" int efgh_corr_fold(const float *P, int32_t B, int32_t nsplit, int64_t Mv, int32_t ldp, int32_t nseg,
+                              int32_t segw, int32_t nj, float *logit, float *score, void *stream_) {
+    EFGH_CHECK_ARG(P && score && B > 0 && nsplit >= 1 && Mv > 0 && nseg > 0 && nseg <= ldp && nj > 0);
+    EFGH_CHECK_ARG((int64_t)(nj - 1) + (int64_t)(nseg - 1) * segw < Mv);
+    k_corr_fold<<<grid_for((long long)B * nj), TPB, 0, (hipStream_t)stream_>>>(P, B, nsplit, Mv, ldp, nseg, segw, nj,
+                                                                             1.0f / 16.0f, logit, score);
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
 }

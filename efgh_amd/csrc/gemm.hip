@@ -84,6 +84,8 @@ struct KArgs {
     float *out; int64_t ldo;
     float *stats;
     unsigned nbx;              // n-tiles per m-tile (set by the launcher)
+    unsigned nbatch;
+    long long bsA, bsW, bsO;   // batched launch: per-problem element strides (blockIdx.y = problem)
 };
 
 // MATH 0: exact fp32 MFMA (v_mfma_f32_32x32x2_f32).
@@ -94,7 +96,7 @@ struct KArgs {
 //         ah*bl' + al'*bh in a second one that is folded in with 2^-11 at the end (error ~2^-22/product).
 template <int MODE, int BM, int BN, int WM, int WN, int MATH>
 __global__ void __launch_bounds__(256, (MATH == 2 || MATH == 3) ? 2 : 3)
-k_gather_gemm(const KArgs p) {
+k_gather_gemm(const KArgs p_in) {
     constexpr int MI = BM / WM / 32, NI = BN / WN / 32;
     constexpr int NA = BM / 32, NB = BN / 32;
     // LDS in floats: fp32 rows of 36 | 2 (MATH 1) or 3 (MATH 2) bf16 arrays with rows of 40
@@ -106,6 +108,11 @@ k_gather_gemm(const KArgs p) {
     __bf16 *Bh = reinterpret_cast<__bf16 *>(Bs), *Bl = Bh + BN * LDH, *Bm = Bl + BN * LDH;
     __shared__ long long rowout[BM];          // output row (pixel) index per tile row, -1 = masked
 
+    KArgs p = p_in;
+    if (blockIdx.y) {              // batched launch: shift the operand pointers to problem blockIdx.y
+        p.A += blockIdx.y * p.bsA; p.W += blockIdx.y * p.bsW; p.out += blockIdx.y * p.bsO;
+        if (MATH != 0) { p.Wh += blockIdx.y * p.bsW; p.Wl += blockIdx.y * p.bsW; if (MATH == 2) p.Wm += blockIdx.y * p.bsW; }
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int l31 = lane & 31, lh = lane >> 5;
@@ -138,7 +145,10 @@ k_gather_gemm(const KArgs p) {
         if (ok) {
             if (MODE == 0) { abase[q] = m * p.lda; amask[q] = 1; }
             else if (MODE == 2) { abase[q] = m * 16; amask[q] = 0xFFFFu; }
-            else {
+            else if (MODE == 3) {            // row stack: tap t = image row t, window of C floats starting at pixel j
+                long long b = m / p.Wv; int j = (int)(m - b * p.Wv);
+                abase[q] = b * p.Hin * p.Win + j; amask[q] = 1;
+            } else {
                 int j = (int)(m % p.Wv); long long r = m / p.Wv;
                 int i = (int)(r % p.Hv); long long b = r / p.Hv;
                 const int ih0 = i * p.sh, iw0 = j * p.sw;
@@ -187,6 +197,14 @@ k_gather_gemm(const KArgs p) {
                 const bool ok = kin && ((amask[q] >> t) & 1u);
                 const long long off = ok ? (abase[q] + delta) * p.lda + c : 0;
                 float4 v = *reinterpret_cast<const float4 *>(p.A + off);
+                ra[q] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        } else if (MODE == 3) {
+            const long long delta = (long long)t * p.Win;
+#pragma unroll
+            for (int q = 0; q < NA; ++q) {
+                const bool ok = kin && amask[q];
+                float4 v = *reinterpret_cast<const float4 *>(p.A + (ok ? (abase[q] + delta) * p.lda + c : 0));
                 ra[q] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         } else {
@@ -445,7 +463,7 @@ void launch(const KArgs &a0, hipStream_t st) {
     KArgs a = a0;
     a.nbx = (unsigned)((a.N + BN - 1) / BN);
     const long long nby = (a.M + BM - 1) / BM;
-    k_gather_gemm<MODE, BM, BN, WM, WN, MATH><<<(unsigned)(a.nbx * nby), 256, 0, st>>>(a);
+    k_gather_gemm<MODE, BM, BN, WM, WN, MATH><<<dim3((unsigned)(a.nbx * nby), a.nbatch), 256, 0, st>>>(a);
 }
 
 template <int MODE, int MATH>
@@ -479,10 +497,10 @@ extern "C" int32_t efgh_gather_gemm_grid_m(int64_t M, int32_t N) {
 
 static int fill_args(const efgh_gemm_desc *d, KArgs &a) {
     EFGH_CHECK_ARG(d && d->A && d->W && d->out);
-    EFGH_CHECK_ARG(d->C > 0 && d->C % 4 == 0 && d->T >= 1 && d->T <= 16);
+    EFGH_CHECK_ARG(d->C > 0 && d->C % 4 == 0 && d->T >= 1 && (d->T <= 16 || d->mode == 3));
     EFGH_CHECK_ARG(d->N >= 1 && d->M >= 1 && d->lda % 4 == 0);
     EFGH_CHECK_ARG((((uintptr_t)d->A) & 15) == 0 && (((uintptr_t)d->W) & 15) == 0);
-    EFGH_CHECK_ARG(d->mode >= 0 && d->mode <= 2);
+    EFGH_CHECK_ARG(d->mode >= 0 && d->mode <= 3);
     EFGH_CHECK_ARG((int64_t)d->T * d->C < 65536);
     a.A = d->A; a.lda = d->lda; a.C = d->C; a.T = d->T; a.K = d->T * d->C;
     a.magicC = (unsigned)((0x100000000ULL + d->C - 1) / d->C);
@@ -499,6 +517,9 @@ static int fill_args(const efgh_gemm_desc *d, KArgs &a) {
     a.bias = d->bias; a.scale = d->scale; a.shift = d->shift; a.residual = d->residual; a.ldr = d->ldr;
     a.act = d->act; a.slope = d->slope; a.out = d->out; a.ldo = d->ldo; a.stats = d->stats;
     a.Wh = a.Wm = a.Wl = nullptr;
+    a.nbatch = d->nbatch > 1 ? (unsigned)d->nbatch : 1u;
+    a.bsA = d->batch_stride_a; a.bsW = d->batch_stride_w; a.bsO = d->batch_stride_out;
+    if (a.nbatch > 1) EFGH_CHECK_ARG(!d->stats && !d->residual && a.nbatch <= 65535 && a.bsA % 4 == 0 && a.bsW % 4 == 0);
     if (d->mode == 1) {
         EFGH_CHECK_ARG(d->B > 0 && d->Hin > 0 && d->Win > 0 && d->Hv > 0 && d->Wv > 0);
         EFGH_CHECK_ARG(d->M == (int64_t)d->B * d->Hv * d->Wv);
@@ -506,6 +527,7 @@ static int fill_args(const efgh_gemm_desc *d, KArgs &a) {
     }
     if (d->mode == 2) EFGH_CHECK_ARG(d->table != nullptr);
     if (d->mode == 0) EFGH_CHECK_ARG(d->T == 1);
+    if (d->mode == 3) EFGH_CHECK_ARG(d->B > 0 && d->Hin == d->T && d->Win > 0 && d->Wv > 0 && d->M == (int64_t)d->B * d->Wv);
     return EFGH_OK;
 }
 
@@ -516,7 +538,8 @@ extern "C" int efgh_gather_gemm(const efgh_gemm_desc *d, void *stream_) {
     if (rc != EFGH_OK) return rc;
     if (d->mode == 0) dispatch<0, 0>(a, st);
     else if (d->mode == 1) dispatch<1, 0>(a, st);
-    else dispatch<2, 0>(a, st);
+    else if (d->mode == 2) dispatch<2, 0>(a, st);
+    else dispatch<3, 0>(a, st);
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
 }
@@ -530,7 +553,8 @@ extern "C" int efgh_gather_gemm_bf16x3(const efgh_gemm_desc *d, const void *W_hi
     a.Wh = (const __bf16 *)W_hi; a.Wl = (const __bf16 *)W_lo;
     if (d->mode == 0) dispatch<0, 1>(a, st);
     else if (d->mode == 1) dispatch<1, 1>(a, st);
-    else dispatch<2, 1>(a, st);
+    else if (d->mode == 2) dispatch<2, 1>(a, st);
+    else dispatch<3, 1>(a, st);
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
 }
@@ -546,7 +570,8 @@ extern "C" int efgh_gather_gemm_bf16x6(const efgh_gemm_desc *d, const void *W_hi
     a.Wh = (const __bf16 *)W_hi; a.Wm = (const __bf16 *)W_mid; a.Wl = (const __bf16 *)W_lo;
     if (d->mode == 0) dispatch<0, 2>(a, st);
     else if (d->mode == 1) dispatch<1, 2>(a, st);
-    else dispatch<2, 2>(a, st);
+    else if (d->mode == 2) dispatch<2, 2>(a, st);
+    else dispatch<3, 2>(a, st);
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
 }
@@ -560,7 +585,8 @@ extern "C" int efgh_gather_gemm_f16x3(const efgh_gemm_desc *d, const void *W_hi,
     a.Wh = (const __bf16 *)W_hi; a.Wl = (const __bf16 *)W_lo;       // raw 16-bit storage, fp16 in this mode
     if (d->mode == 0) dispatch<0, 3>(a, st);
     else if (d->mode == 1) dispatch<1, 3>(a, st);
-    else dispatch<2, 3>(a, st);
+    else if (d->mode == 2) dispatch<2, 3>(a, st);
+    else dispatch<3, 3>(a, st);
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
 }

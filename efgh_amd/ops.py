@@ -124,7 +124,7 @@ PROFILE = None          # bench.py sets this to a list: (start_event, end_event,
 
 def gather_gemm(A, lda, C, T, Wp, N, M, out, ldo, mode=0, geom=None, table=None, bias=None, scale=None,
                 shift=None, residual=None, ldr=0, act=ACT_NONE, slope=0.0, stats=None, a_off=0, out_off=0,
-                res_off=0, M_dev=None, flops=None):
+                res_off=0, M_dev=None, flops=None, batch=None):
     """See efgh_gemm_desc.  A/out/residual may be addressed with an element offset (channel slices)."""
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -148,6 +148,8 @@ def gather_gemm(A, lda, C, T, Wp, N, M, out, ldo, mode=0, geom=None, table=None,
     d.out = out.data_ptr() + out_off * es
     d.ldo = ldo
     d.stats = 0 if stats is None else stats.data_ptr()
+    if batch is not None:
+        d.nbatch, d.batch_stride_a, d.batch_stride_w, d.batch_stride_out = batch
     thin = stats is None and M_dev is None and thin_eligible(mode, C, N, T)
     if thin:
         _C.check(_L().efgh_thin_gemm(ctypes.byref(d), _st()))
@@ -333,6 +335,9 @@ def minmax(x):
     return mm
 
 
+USE_MFMA_CORR = True
+
+
 def corr_head(cam, rng, want_logit=False, want_aux=False):
     """cam [B][h][wc][16], rng [B][h][wr][16] -> f_score (B, wr + 2*(wr//8) - wc + 1)"""
     B, h, wc, C = cam.shape
@@ -340,14 +345,34 @@ def corr_head(cam, rng, want_logit=False, want_aux=False):
     assert C == 16 and rng.shape[1] == h
     off = int(wr / 8)
     wp = wr + 2 * off
-    cam_mm, rng_mm = minmax(cam), minmax(rng)
-    rp = torch.empty((B, h, wp, C), dtype=torch.float32, device=cam.device)
-    _C.check(_L().efgh_corr_pad(ptr(rng), ptr(rng_mm), c_int32(B), c_int32(h), c_int32(wr), c_int32(C),
-                                c_int32(off), ptr(rp), _st()))
     nj = wp - wc + 1
-    part = torch.empty((B, h, nj), dtype=torch.float32, device=cam.device)
-    score = torch.empty((B, nj), dtype=torch.float32, device=cam.device)
-    logit = torch.empty((B, nj), dtype=torch.float32, device=cam.device) if want_logit else None
+    dev = cam.device
+    cam_mm, rng_mm = minmax(cam), minmax(rng)
+    score = torch.empty((B, nj), dtype=torch.float32, device=dev)
+    logit = torch.empty((B, nj), dtype=torch.float32, device=dev) if want_logit else None
+    segw = (wc + 31) // 32
+    nseg = ceil4((wc + segw - 1) // segw)
+    mfma = USE_MFMA_CORR and not want_aux and h * segw * 16 < 65536 and nseg <= 32
+    wpitch = wp + segw if mfma else wp
+    rp = torch.empty((B, h, wpitch, C), dtype=torch.float32, device=dev)
+    _C.check(_L().efgh_corr_pad(ptr(rng), ptr(rng_mm), c_int32(B), c_int32(h), c_int32(wr), c_int32(C),
+                                c_int32(off), c_int32(wpitch), ptr(rp), _st()))
+    if mfma:
+        # MFMA formulation: camera-row segments become the N dimension, groups of image rows the batch (split-K)
+        nsplit = max(d for d in range(1, 17) if h % d == 0)
+        T = h // nsplit
+        nseg_real = (wc + segw - 1) // segw
+        Wc = torch.empty((B, nsplit, nseg, T, segw * 16), dtype=torch.float32, device=dev)
+        _C.check(_L().efgh_corr_pack_cam(ptr(cam), ptr(cam_mm), c_int32(B), c_int32(h), c_int32(wc), c_int32(segw),
+                                         c_int32(nseg), c_int32(nsplit), ptr(Wc), _st()))
+        P = torch.empty((B, nsplit, wp, nseg), dtype=torch.float32, device=dev)
+        geom = (1, T, wpitch, 1, wp, 1, 1, [], [], 1, wp, 1, 1, 0, 0)
+        gather_gemm(rp, 16, segw * 16, T, Wc, nseg, wp, P, nseg, mode=3, geom=geom, flops=2.0 * B * nj * h * wc * 16,
+                    batch=(B * nsplit, T * wpitch * 16, nseg * T * segw * 16, wp * nseg))
+        _C.check(_L().efgh_corr_fold(ptr(P), c_int32(B), c_int32(nsplit), c_int64(wp), c_int32(nseg),
+                                     c_int32(nseg_real), c_int32(segw), c_int32(nj), ptr(logit), ptr(score), _st()))
+        return score, logit
+    part = torch.empty((B, h, nj), dtype=torch.float32, device=dev)
     _C.check(_L().efgh_corr1d(ptr(rp), ptr(cam), ptr(cam_mm), c_int32(B), c_int32(h), c_int32(wc), c_int32(wp),
                               ptr(part), ptr(logit), ptr(score), _st()))
     if want_aux:

@@ -94,7 +94,9 @@ typedef struct {
     int64_t lda;
     int32_t C;             /* channels per tap, multiple of 4 */
     int32_t T;             /* taps (<= 16) */
-    int32_t mode;          /* 0 = direct rows (row = m), 1 = conv geometry, 2 = neighbour table */
+    int32_t mode;          /* 0 = direct rows (row = m), 1 = conv geometry, 2 = neighbour table,
+                              3 = row stack: m = b*Wv + j, tap t = image row t (T = Hin, may exceed 16), the C
+                              floats of a tap start at pixel j (sliding window; F correlation) */
     /* mode 1: m = (b*Hv + i)*Wv + j ;  input pixel (i*sh + dh[t], j*sw + dw[t]) of image b */
     int32_t B, Hin, Win, Hv, Wv, sh, sw;
     int8_t dh[16], dw[16];
@@ -115,6 +117,10 @@ typedef struct {
     float *out; int64_t ldo;
     float *stats;          /* optional [gridM][2][N] per-block column sum / sum of squares of the
                               pre-activation value (train-mode BatchNorm statistics) */
+    /* optional batching: nbatch > 1 runs nbatch independent problems of identical shape in ONE launch;
+     * problem z uses A + z*batch_stride_a, W + z*batch_stride_w, out + z*batch_stride_out (elements) */
+    int32_t nbatch;
+    int64_t batch_stride_a, batch_stride_w, batch_stride_out;
 } efgh_gemm_desc;
 
 int efgh_gather_gemm(const efgh_gemm_desc *d, void *stream);
@@ -179,9 +185,10 @@ int efgh_rotate_nearest_u8(const float *img, const float *rot_deg, int32_t B, in
 int32_t efgh_minmax_groups(int64_t n);
 /* per-sample global (min,max): x [B][n] -> mm [B][2]; part [B][groups][2] scratch */
 int efgh_minmax(const float *x, int32_t B, int64_t n, float *part, float *mm, void *stream);
-/* rp [B][h][w+2*off][C] = pad(rng / (max-min)) : mirror on the left, circular on the right */
+/* rp [B][h][wpitch][C] = pad(rng / (max-min)) : mirror on the left, circular on the right; row pitch
+ * wpitch >= w+2*off, pixels past the padded width are zero */
 int efgh_corr_pad(const float *rng, const float *rng_mm, int32_t B, int32_t h, int32_t w, int32_t C,
-                  int32_t off, float *rp, void *stream);
+                  int32_t off, int32_t wpitch, float *rp, void *stream);
 /* score [B][wp-wc+1] = sigmoid(corr / 16); cam [B][h][wc][16] is divided by (max-min) on the fly;
  * part [B][h][wp-wc+1] scratch; logit optional (pre-sigmoid, for tests / backward)           */
 int efgh_corr1d(const float *rp, const float *cam, const float *cam_mm, int32_t B, int32_t h,
@@ -267,6 +274,16 @@ int efgh_convt_col2im(const float *Y, int64_t ldy, int32_t B, int32_t Hin, int32
                       float *out, int64_t ldo, void *stream);
 int efgh_convt_im2col(const float *G, int64_t ldg, int32_t B, int32_t Hin, int32_t Win, int32_t Ho, int32_t Wo,
                       int32_t O, int32_t pad, float *Ycol, int64_t ldy, void *stream);
+
+/* MFMA formulation of the F correlation: the camera row is cut into nseg segments of segw pixels;
+ * the image rows into nsplit groups of T = h/nsplit (split-K).  efgh_corr_pack_cam builds
+ * Wc [B][nsplit][nseg][T][segw*16] (normalised, zero past the camera width); ONE batched
+ * efgh_gather_gemm (mode 3, nbatch = B*nsplit) gives P[b][ks][m][s] = sum_{y in group,x<segw,c}
+ * rp[b][y][m+x][c]*Wc[..], and efgh_corr_fold sums score[b][j] = sigmoid((1/16) sum_{ks,s} P[b][ks][j+s*segw][s]). */
+int efgh_corr_pack_cam(const float *cam, const float *cam_mm, int32_t B, int32_t h, int32_t wc, int32_t segw,
+                       int32_t nseg, int32_t nsplit, float *Wc, void *stream);
+int efgh_corr_fold(const float *P, int32_t B, int32_t nsplit, int64_t Mv, int32_t ldp, int32_t nseg, int32_t segw,
+                   int32_t nj, float *logit, float *score, void *stream);
 
 #ifdef __cplusplus
 }
