@@ -18,7 +18,8 @@ __device__ __forceinline__ float dact(float y, int act, float slope) {
 __global__ void __launch_bounds__(TPB)
 k_act_bn_bwd_reduce(const float *__restrict__ dy, long long lddy, const float *__restrict__ y, long long ldy,
                     const float *__restrict__ raw, long long ldraw, const float *__restrict__ mean,
-                    const float *__restrict__ invstd, long long M, int C, int act, float slope, int rows_per_block,
+                    const float *__restrict__ invstd, const float *__restrict__ pscale,
+                    const float *__restrict__ pshift, long long M, int C, int act, float slope, int rows_per_block,
                     int CL, float *__restrict__ part) {
     __shared__ float4 s1s[TPB], s2s[TPB];
     const int cl = threadIdx.x % CL, rl = threadIdx.x / CL, RL = TPB / CL;
@@ -27,16 +28,20 @@ k_act_bn_bwd_reduce(const float *__restrict__ dy, long long lddy, const float *_
     if (r1 > M) r1 = M;
     float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
     if (c < C) {
-        float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), is = mu;
+        float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), is = mu, psc = mu, psh = mu;
         if (mean) { mu = *reinterpret_cast<const float4 *>(mean + c); is = *reinterpret_cast<const float4 *>(invstd + c); }
+        if (!y) { psc = *reinterpret_cast<const float4 *>(pscale + c); psh = *reinterpret_cast<const float4 *>(pshift + c); }
         for (long long r = r0 + rl; r < r1; r += RL) {
             float4 g = *reinterpret_cast<const float4 *>(dy + r * lddy + c);
-            float4 yy = *reinterpret_cast<const float4 *>(y + r * ldy + c);
+            float4 rw = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (mean || !y) rw = *reinterpret_cast<const float4 *>(raw + r * ldraw + c);
+            float4 yy;
+            if (y) yy = *reinterpret_cast<const float4 *>(y + r * ldy + c);
+            else yy = make_float4(rw.x * psc.x + psh.x, rw.y * psc.y + psh.y, rw.z * psc.z + psh.z, rw.w * psc.w + psh.w);
             g.x *= dact(yy.x, act, slope); g.y *= dact(yy.y, act, slope);
             g.z *= dact(yy.z, act, slope); g.w *= dact(yy.w, act, slope);
             s1.x += g.x; s1.y += g.y; s1.z += g.z; s1.w += g.w;
             if (mean) {
-                float4 rw = *reinterpret_cast<const float4 *>(raw + r * ldraw + c);
                 s2.x += g.x * ((rw.x - mu.x) * is.x); s2.y += g.y * ((rw.y - mu.y) * is.y);
                 s2.z += g.z * ((rw.z - mu.z) * is.z); s2.w += g.w * ((rw.w - mu.w) * is.w);
             }
@@ -78,7 +83,8 @@ __global__ void __launch_bounds__(TPB)
 k_act_bn_bwd_apply(const float *__restrict__ dy, long long lddy, const float *__restrict__ y, long long ldy,
                    const float *__restrict__ raw, long long ldraw, const float *__restrict__ mean,
                    const float *__restrict__ invstd, const float *__restrict__ coef,
-                   const float *__restrict__ m1, const float *__restrict__ m2, long long M, int C, int act,
+                   const float *__restrict__ m1, const float *__restrict__ m2, const float *__restrict__ pscale,
+                   const float *__restrict__ pshift, long long M, int C, int act,
                    float slope, float *__restrict__ draw, long long lddraw, float *__restrict__ dres,
                    long long lddres) {
     const int c4n = C >> 2;
@@ -86,13 +92,17 @@ k_act_bn_bwd_apply(const float *__restrict__ dy, long long lddy, const float *__
     for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
         long long r = i / c4n; int c = (int)(i - r * c4n) * 4;
         float4 g = *reinterpret_cast<const float4 *>(dy + r * lddy + c);
-        float4 yy = *reinterpret_cast<const float4 *>(y + r * ldy + c);
+        float4 rw = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (mean || !y) rw = *reinterpret_cast<const float4 *>(raw + r * ldraw + c);
+        float4 yy;
+        if (y) yy = *reinterpret_cast<const float4 *>(y + r * ldy + c);
+        else yy = make_float4(rw.x * pscale[c] + pshift[c], rw.y * pscale[c + 1] + pshift[c + 1],
+                              rw.z * pscale[c + 2] + pshift[c + 2], rw.w * pscale[c + 3] + pshift[c + 3]);
         float gv[4] = {g.x * dact(yy.x, act, slope), g.y * dact(yy.y, act, slope), g.z * dact(yy.z, act, slope),
                        g.w * dact(yy.w, act, slope)};
         if (dres) *reinterpret_cast<float4 *>(dres + r * lddres + c) = make_float4(gv[0], gv[1], gv[2], gv[3]);
         float o[4];
         if (mean) {
-            float4 rw = *reinterpret_cast<const float4 *>(raw + r * ldraw + c);
             float rv[4] = {rw.x, rw.y, rw.z, rw.w};
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -252,18 +262,20 @@ int grid_for(long long total) {
 extern "C" int32_t efgh_bwd_groups(int64_t M) { return (int32_t)((M + 511) / 512); }
 
 extern "C" int efgh_act_bn_bwd_reduce(const float *dy, int64_t lddy, const float *y, int64_t ldy, const float *raw,
-                                      int64_t ldraw, const float *mean, const float *invstd, int64_t M, int32_t C,
+                                      int64_t ldraw, const float *mean, const float *invstd, const float *pscale,
+                                      const float *pshift, int64_t M, int32_t C,
                                       int32_t act, float slope, float *part, float *sum_dpre, float *sum_dpre_xhat,
                                       float *mean_dpre, float *mean_dpre_xhat, void *stream_) {
     hipStream_t st = (hipStream_t)stream_;
-    EFGH_CHECK_ARG(dy && y && part && sum_dpre && sum_dpre_xhat && M > 0 && C > 0 && C % 4 == 0);
+    EFGH_CHECK_ARG(dy && part && sum_dpre && sum_dpre_xhat && M > 0 && C > 0 && C % 4 == 0);
+    EFGH_CHECK_ARG(y || (raw && pscale && pshift));
     EFGH_CHECK_ARG(!mean || (raw && invstd));
     EFGH_CHECK_ARG(lddy % 4 == 0 && ldy % 4 == 0 && (!mean || ldraw % 4 == 0));
     int G = efgh_bwd_groups(M);
     int CL = 1;
     while (CL < 64 && CL * 4 < C) CL <<= 1;
-    k_act_bn_bwd_reduce<<<dim3(cdiv(C / 4, CL), G), TPB, 0, st>>>(dy, lddy, y, ldy, raw, ldraw, mean, invstd, M, C,
-                                                                 act, slope, 512, CL, part);
+    k_act_bn_bwd_reduce<<<dim3(cdiv(C / 4, CL), G), TPB, 0, st>>>(dy, lddy, y, ldy, raw, ldraw, mean, invstd, pscale,
+                                                                 pshift, M, C, act, slope, 512, CL, part);
     k_bwd_finalize<<<cdiv(C, 32), dim3(32, 32), 0, st>>>(part, G, C, (double)M, sum_dpre, sum_dpre_xhat, mean_dpre,
                                                          mean_dpre_xhat);
     EFGH_CHECK_LAUNCH();
@@ -272,13 +284,16 @@ extern "C" int efgh_act_bn_bwd_reduce(const float *dy, int64_t lddy, const float
 
 extern "C" int efgh_act_bn_bwd_apply(const float *dy, int64_t lddy, const float *y, int64_t ldy, const float *raw,
                                      int64_t ldraw, const float *mean, const float *invstd, const float *coef,
-                                     const float *m1, const float *m2, int64_t M, int32_t C, int32_t act, float slope,
+                                     const float *m1, const float *m2, const float *pscale, const float *pshift,
+                                     int64_t M, int32_t C, int32_t act, float slope,
                                      float *draw, int64_t lddraw, float *dres, int64_t lddres, void *stream_) {
-    EFGH_CHECK_ARG(dy && y && (draw || dres) && M > 0 && C > 0 && C % 4 == 0);
+    EFGH_CHECK_ARG(dy && (draw || dres) && M > 0 && C > 0 && C % 4 == 0);
+    EFGH_CHECK_ARG(y || (raw && pscale && pshift && ldraw % 4 == 0));
     EFGH_CHECK_ARG(lddy % 4 == 0 && ldy % 4 == 0 && (!draw || lddraw % 4 == 0) && (!dres || lddres % 4 == 0));
     EFGH_CHECK_ARG(!mean || (raw && invstd && coef && m1 && m2 && ldraw % 4 == 0));
     k_act_bn_bwd_apply<<<grid_for(M * (C / 4)), TPB, 0, (hipStream_t)stream_>>>(
-        dy, lddy, y, ldy, raw, ldraw, mean, invstd, coef, m1, m2, M, C, act, slope, draw, lddraw, dres, lddres);
+        dy, lddy, y, ldy, raw, ldraw, mean, invstd, coef, m1, m2, pscale, pshift, M, C, act, slope, draw, lddraw, dres,
+        lddres);
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
 }

@@ -15,6 +15,24 @@ __device__ __forceinline__ float act_f(float v, int act, float slope) {
 
 // stats: [G][2][C] per-block partial (sum, sumsq) from the GEMM epilogue.
 // -> scale/shift for y = x*scale + shift, running stats update (nn.BatchNorm, momentum form).
+// stage 1 for many partial rows: slice s sums rows g = s, s+S, s+2S, ... into row s (in place: row s is
+// read only by the block that owns slice s, before it writes)
+__global__ void __launch_bounds__(1024)
+k_stats_fold(float *__restrict__ stats, int G, int C, int S) {
+    __shared__ double ss[32][33], sq[32][33];
+    const int tx = threadIdx.x, ty = threadIdx.y, sl = blockIdx.y;
+    const int c = blockIdx.x * 32 + tx;
+    double s = 0.0, q = 0.0;
+    if (c < C)
+        for (int g = sl + S * ty; g < G; g += S * 32) { s += stats[((long long)g * 2) * C + c]; q += stats[((long long)g * 2 + 1) * C + c]; }
+    ss[ty][tx] = s; sq[ty][tx] = q;
+    __syncthreads();
+    if (ty != 0 || c >= C) return;
+    for (int i = 1; i < 32; ++i) { s += ss[i][tx]; q += sq[i][tx]; }
+    stats[((long long)sl * 2) * C + c] = (float)s;
+    stats[((long long)sl * 2 + 1) * C + c] = (float)q;
+}
+
 // block = (32 channels, 32 partial-lanes): lanes stride over the G partial rows, LDS tree over lanes.
 __global__ void __launch_bounds__(1024)
 k_bn_finalize(const float *__restrict__ stats, int G, int C, double count,
@@ -209,6 +227,11 @@ extern "C" int efgh_bn_finalize(const float *stats, int32_t G, int32_t C, double
                                 float *scale, float *shift, float *save_mean, float *save_invstd,
                                 void *stream) {
     EFGH_CHECK_ARG(stats && gamma && beta && scale && shift && C > 0 && G > 0 && count > 0);
+    if (G > 256) {       // two-stage reduction of the per-block partials (`stats` is scratch and is overwritten)
+        const int S = 16;
+        k_stats_fold<<<dim3(cdiv(C, 32), S), dim3(32, 32), 0, (hipStream_t)stream>>>(const_cast<float *>(stats), G, C, S);
+        G = S;
+    }
     k_bn_finalize<<<cdiv(C, 32), dim3(32, 32), 0, (hipStream_t)stream>>>(stats, G, C, count, gamma, beta, rmean,
                                                                          rvar, momentum, eps, scale, shift,
                                                                          save_mean, save_invstd);

@@ -121,13 +121,16 @@ class GemmLayerFn(torch.autograd.Function):
                                 ldr=0 if res is None else ld_of(res))
         ctx.spec = spec
         ctx.has = (bias is not None, gamma is not None, residual is not None)
-        ctx.save_for_backward(x, weight, y, raw, mean, invstd, None if gamma is None else gamma.detach())
+        # layers without a residual re-derive the activation mask from raw*scale+shift in backward
+        psc, psh = (scale, shift) if (bn is not None and residual is None) else (None, None)
+        ctx.save_for_backward(x, weight, y, raw, mean, invstd, None if gamma is None else gamma.detach(), psc, psh)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         spec = ctx.spec
-        x, weight, y, raw, mean, invstd, gamma = ctx.saved_tensors
+        x, weight, y, raw, mean, invstd, gamma, psc, psh = ctx.saved_tensors
+        ymask = None if psc is not None else y
         has_bias, has_bn, has_res = ctx.has
         N, Np, M = spec.N, ceil4(spec.N), spec.M
         dev = x.device
@@ -144,8 +147,9 @@ class GemmLayerFn(torch.autograd.Function):
             train_bn = has_bn and spec.train
             m1 = torch.empty(Np, dtype=torch.float32, device=dev) if train_bn else None
             m2 = torch.empty(Np, dtype=torch.float32, device=dev) if train_bn else None
-            ops.act_bn_bwd_reduce(dy, ld_of(dy), y, Np, raw, Np, mean if has_bn else None,
-                                  invstd if has_bn else None, M, Np, spec.act, spec.slope, part, s1, s2, m1, m2)
+            ops.act_bn_bwd_reduce(dy, ld_of(dy), ymask, Np, raw, Np, mean if has_bn else None,
+                                  invstd if has_bn else None, M, Np, spec.act, spec.slope, part, s1, s2, m1, m2,
+                                  pscale=psc, pshift=psh)
             coef = None
             if has_bn:
                 dbeta, dgamma = s1[:N].clone(), s2[:N].clone()
@@ -155,9 +159,9 @@ class GemmLayerFn(torch.autograd.Function):
             draw = torch.empty(tuple(spec.out_shape) + (Np,), dtype=torch.float32, device=dev)
             if has_res:
                 dres = torch.empty(tuple(spec.out_shape) + (Np,), dtype=torch.float32, device=dev)
-            ops.act_bn_bwd_apply(dy, ld_of(dy), y, Np, raw, Np, mean if train_bn else None,
+            ops.act_bn_bwd_apply(dy, ld_of(dy), ymask, Np, raw, Np, mean if train_bn else None,
                                  invstd if train_bn else None, coef, m1, m2, M, Np, spec.act, spec.slope, draw, Np,
-                                 dres, Np)
+                                 dres, Np, pscale=psc, pshift=psh)
             if has_bias and has_bn:          # bias in front of BatchNorm: d/dbias = column sums of draw
                 dbias = ops.col_sum(draw, M, Np)[:N]
         # ---- dgrad

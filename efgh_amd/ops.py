@@ -428,16 +428,19 @@ def bwd_groups(M):
     return _L().efgh_bwd_groups(c_int64(M))
 
 
-def act_bn_bwd_reduce(dy, lddy, y, ldy, raw, ldraw, mean, invstd, M, C, act, slope, part, s1, s2, m1, m2):
+def act_bn_bwd_reduce(dy, lddy, y, ldy, raw, ldraw, mean, invstd, M, C, act, slope, part, s1, s2, m1, m2,
+                      pscale=None, pshift=None):
     _C.check(_L().efgh_act_bn_bwd_reduce(ptr(dy), c_int64(lddy), ptr(y), c_int64(ldy), ptr(raw), c_int64(ldraw),
-                                         ptr(mean), ptr(invstd), c_int64(M), c_int32(C), c_int32(act),
+                                         ptr(mean), ptr(invstd), ptr(pscale), ptr(pshift), c_int64(M), c_int32(C),
+                                         c_int32(act),
                                          c_float(slope), ptr(part), ptr(s1), ptr(s2), ptr(m1), ptr(m2), _st()))
 
 
 def act_bn_bwd_apply(dy, lddy, y, ldy, raw, ldraw, mean, invstd, coef, m1, m2, M, C, act, slope, draw, lddraw,
-                     dres, lddres):
+                     dres, lddres, pscale=None, pshift=None):
     _C.check(_L().efgh_act_bn_bwd_apply(ptr(dy), c_int64(lddy), ptr(y), c_int64(ldy), ptr(raw), c_int64(ldraw),
-                                        ptr(mean), ptr(invstd), ptr(coef), ptr(m1), ptr(m2), c_int64(M), c_int32(C),
+                                        ptr(mean), ptr(invstd), ptr(coef), ptr(m1), ptr(m2), ptr(pscale), ptr(pshift),
+                                        c_int64(M), c_int32(C),
                                         c_int32(act), c_float(slope), ptr(draw), c_int64(lddraw), ptr(dres),
                                         c_int64(lddres), _st()))
 
