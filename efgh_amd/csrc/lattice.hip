@@ -47,16 +47,17 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x) {
     return x;
 }
 
-__global__ void k_init_minmax(int *mm) {
-    int t = threadIdx.x;
-    if (t < 4) mm[t] = INT32_MAX; else if (t < 8) mm[t] = INT32_MIN;
+__global__ void k_init_minmax(int *mm, int nsamples, int *seg_first) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nsamples * 8) mm[i] = (i & 7) < 4 ? INT32_MAX : INT32_MIN;
+    if (seg_first && i < nsamples) seg_first[i] = INT32_MAX;
 }
 
 // ---- K1: one thread per point ------------------------------------------------------------
 __global__ void __launch_bounds__(TPB)
 k_point_keys(const float *__restrict__ pts, int64_t cstride, int n, float scale32, float std32,
              float *__restrict__ bary, float *__restrict__ emg_out, int64_t emg_ps, int64_t emg_rs,
-             int4 *__restrict__ keys, int *__restrict__ mm) {
+             int4 *__restrict__ keys, int *__restrict__ mm, const int *__restrict__ sid) {
     int p = blockIdx.x * TPB + threadIdx.x;
     int kmin[4] = {INT32_MAX, INT32_MAX, INT32_MAX, INT32_MAX};
     int kmax[4] = {INT32_MIN, INT32_MIN, INT32_MIN, INT32_MIN};
@@ -134,6 +135,23 @@ k_point_keys(const float *__restrict__ pts, int64_t cstride, int n, float scale3
             keys[(int64_t)p * 4 + rem] = make_int4(k[0], k[1], k[2], k[3]);
         }
     }
+    if (sid) {      // several samples in one launch: per-sample extrema
+        const int b = p < n ? sid[p] : -1;
+        const int b0 = __shfl(b, 0);
+        if (__all(b == b0 || b < 0)) {           // the usual case: the whole wave belongs to one sample
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                int a = kmin[c], z = kmax[c];
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) { a = min(a, __shfl_xor(a, o)); z = max(z, __shfl_xor(z, o)); }
+                if ((threadIdx.x & 63) == 0 && b0 >= 0) { atomicMin(&mm[8 * b0 + c], a); atomicMax(&mm[8 * b0 + 4 + c], z); }
+            }
+        } else if (b >= 0) {                     // a wave straddling two samples: per-lane atomics
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { atomicMin(&mm[8 * b + c], kmin[c]); atomicMax(&mm[8 * b + 4 + c], kmax[c]); }
+        }
+        return;
+    }
     // block reduce min / max, one atomic per block and coordinate
     __shared__ int smin[4][TPB / 64], smax[4][TPB / 64];
     int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -157,12 +175,14 @@ k_point_keys(const float *__restrict__ pts, int64_t cstride, int n, float scale3
 __global__ void __launch_bounds__(TPB)
 k_insert(const int4 *__restrict__ keys, int n4, const int *__restrict__ mm,
          unsigned long long *__restrict__ hkeys, int *__restrict__ minpos, int64_t hmask,
-         int *__restrict__ slot) {
+         int *__restrict__ slot, const int *__restrict__ sid, int nsamples) {
     int f = blockIdx.x * TPB + threadIdx.x;
     if (f >= n4) return;
     int4 kk = keys[f];
     int k[4] = {kk.x, kk.y, kk.z, kk.w};
-    unsigned long long ki = (unsigned long long)key2int(k, mm);
+    const int b = sid ? sid[f >> 2] : 0;
+    // the map key is (key integer of the sample, sample): vertices of different samples never merge
+    unsigned long long ki = (unsigned long long)(key2int(k, mm + 8 * b) * nsamples + b);
     uint64_t h = mix64(ki) & (uint64_t)hmask;
     const unsigned long long EMPTY = ~0ULL;
     while (true) {
@@ -224,7 +244,8 @@ k_scan_sums(int *__restrict__ bsum, int nb, int *__restrict__ H_out) {
 __global__ void __launch_bounds__(TPB)
 k_assign(const int4 *__restrict__ keys, const int *__restrict__ slot, const int *__restrict__ minpos,
          int n4, const int *__restrict__ bsum, int *__restrict__ hvals, int4 *__restrict__ vkeys,
-         float *__restrict__ pts_next, int64_t cap, float div32) {
+         float *__restrict__ pts_next, int64_t cap, float div32, const int *__restrict__ sid,
+         int *__restrict__ vsid, int *__restrict__ seg_first) {
     int base = blockIdx.x * (TPB * 4) + threadIdx.x * 4, c = 0;
     bool fl[4];
     int sl[4];
@@ -243,6 +264,13 @@ k_assign(const int4 *__restrict__ keys, const int *__restrict__ slot, const int 
         int4 kk = keys[base + j];
         hvals[sl[j]] = idx;
         vkeys[idx] = kk;
+        if (sid) {
+            const int f = base + j, pp = f >> 2, b = sid[pp];
+            vsid[idx] = b;
+            // vertices are numbered sample-major, and the very first key of a sample is always new:
+            // its index is the sample's first vertex index
+            if ((f & 3) == 0 && (pp == 0 || sid[pp - 1] != b)) seg_first[b] = idx;
+        }
         // generate_data.py:176-178: key (as fp32) / float32(std*scale), then E^T . (4-term fma chain)
         float kf[4] = {__fdiv_rn((float)kk.x, div32), __fdiv_rn((float)kk.y, div32),
                        __fdiv_rn((float)kk.z, div32), __fdiv_rn((float)kk.w, div32)};
@@ -274,7 +302,7 @@ k_offsets(const int *__restrict__ slot, const int *__restrict__ hvals, int n, in
 __global__ void __launch_bounds__(TPB)
 k_neighbors(const int4 *__restrict__ vkeys, const int *__restrict__ mm,
             const unsigned long long *__restrict__ hkeys, const int *__restrict__ hvals, int64_t hmask,
-            const int *__restrict__ H_dev, int *__restrict__ nbr) {
+            const int *__restrict__ H_dev, int *__restrict__ nbr, const int *__restrict__ vsid, int nsamples) {
     int H = *H_dev;
     for (int64_t g = (int64_t)blockIdx.x * TPB + threadIdx.x; g < (int64_t)H * 16;
          g += (int64_t)gridDim.x * TPB) {
@@ -283,8 +311,10 @@ k_neighbors(const int4 *__restrict__ vkeys, const int *__restrict__ mm,
         if (t < 15) {
             int4 kk = vkeys[h];
             int k[4] = {kk.x + c_nbr[t][0], kk.y + c_nbr[t][1], kk.z + c_nbr[t][2], kk.w + c_nbr[t][3]};
-            int64_t ki = key2int(k, mm);
+            const int b = vsid ? vsid[h] : 0;
+            int64_t ki = key2int(k, mm + 8 * b);
             if (ki >= 0) {   // every inserted key integer is >= 0
+                ki = ki * nsamples + b;
                 uint64_t s = mix64((uint64_t)ki) & (uint64_t)hmask;
                 while (true) {
                     unsigned long long cur = hkeys[s];
@@ -315,13 +345,16 @@ extern "C" int64_t efgh_lattice_workspace_bytes(int32_t n_in) {
     return ws_off_minpos(n_in) + efgh_lattice_hash_capacity(n_in) * 4 + 256;
 }
 
-extern "C" int efgh_lattice_build(const float *pts, int64_t pts_cstride, int32_t n, float scale32,
-                                  float div32, float *bary, float *emg, int64_t emg_ps, int64_t emg_rs,
-                                  int32_t *off, int32_t *vkeys, float *pts_next, int32_t *minmax,
-                                  int64_t *hash_keys, int32_t *hash_vals, int64_t hcap, int32_t *H_out,
-                                  void *workspace, void *stream_) {
+static int lattice_build_impl(const float *pts, int64_t pts_cstride, int32_t n, float scale32,
+                              float div32, float *bary, float *emg, int64_t emg_ps, int64_t emg_rs,
+                              int32_t *off, int32_t *vkeys, float *pts_next, int32_t *minmax,
+                              int64_t *hash_keys, int32_t *hash_vals, int64_t hcap, int32_t *H_out,
+                              void *workspace, const int32_t *sid, int32_t nsamples, int32_t *vsid,
+                              int32_t *seg_first, void *stream_) {
     hipStream_t st = (hipStream_t)stream_;
     EFGH_CHECK_ARG(n > 0 && n < (1 << 28));
+    EFGH_CHECK_ARG(nsamples >= 1 && (nsamples == 1 || (sid && vsid && seg_first)));
+    if (nsamples == 1) sid = nullptr;
     EFGH_CHECK_ARG(hcap >= (int64_t)n * 8 && (hcap & (hcap - 1)) == 0);
     EFGH_CHECK_ARG(pts && bary && emg && off && vkeys && pts_next && minmax && hash_keys && hash_vals && H_out && workspace);
     char *ws = (char *)workspace;
@@ -340,16 +373,52 @@ extern "C" int efgh_lattice_build(const float *pts, int64_t pts_cstride, int32_t
                        hipGetErrorString(e2), n, (long long)hcap);
         return EFGH_E_LAUNCH;
     }
-    k_init_minmax<<<1, 64, 0, st>>>(minmax);
+    k_init_minmax<<<cdiv(nsamples * 8, 64), 64, 0, st>>>(minmax, nsamples, sid ? seg_first : nullptr);
     k_point_keys<<<cdiv(n, TPB), TPB, 0, st>>>(pts, pts_cstride, n, scale32, std32, bary, emg, emg_ps,
-                                              emg_rs, keys, minmax);
+                                              emg_rs, keys, minmax, sid);
     k_insert<<<cdiv(n4, TPB), TPB, 0, st>>>(keys, n4, minmax, (unsigned long long *)hash_keys, minpos,
-                                           hcap - 1, slot);
+                                           hcap - 1, slot, sid, nsamples);
     k_flag_count<<<nb, TPB, 0, st>>>(slot, minpos, n4, bsum);
     k_scan_sums<<<1, TPB, 0, st>>>(bsum, nb, H_out);
     k_assign<<<nb, TPB, 0, st>>>(keys, slot, minpos, n4, bsum, hash_vals, (int4 *)vkeys, pts_next,
-                                 (int64_t)n * 4, div32);
+                                 (int64_t)n * 4, div32, sid, vsid, seg_first);
     k_offsets<<<cdiv(n, TPB), TPB, 0, st>>>(slot, hash_vals, n, off);
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}
+
+extern "C" int efgh_lattice_build(const float *pts, int64_t pts_cstride, int32_t n, float scale32,
+                                  float div32, float *bary, float *emg, int64_t emg_ps, int64_t emg_rs,
+                                  int32_t *off, int32_t *vkeys, float *pts_next, int32_t *minmax,
+                                  int64_t *hash_keys, int32_t *hash_vals, int64_t hcap, int32_t *H_out,
+                                  void *workspace, void *stream_) {
+    return lattice_build_impl(pts, pts_cstride, n, scale32, div32, bary, emg, emg_ps, emg_rs, off, vkeys, pts_next,
+                              minmax, hash_keys, hash_vals, hcap, H_out, workspace, nullptr, 1, nullptr, nullptr,
+                              stream_);
+}
+
+extern "C" int efgh_lattice_build_batched(const float *pts, int64_t pts_cstride, int32_t n, float scale32,
+                                          float div32, float *bary, float *emg, int64_t emg_ps, int64_t emg_rs,
+                                          int32_t *off, int32_t *vkeys, float *pts_next, int32_t *minmax,
+                                          int64_t *hash_keys, int32_t *hash_vals, int64_t hcap, int32_t *H_out,
+                                          void *workspace, const int32_t *sid, int32_t nsamples, int32_t *vsid,
+                                          int32_t *seg_first, void *stream_) {
+    return lattice_build_impl(pts, pts_cstride, n, scale32, div32, bary, emg, emg_ps, emg_rs, off, vkeys, pts_next,
+                              minmax, hash_keys, hash_vals, hcap, H_out, workspace, sid, nsamples, vsid, seg_first,
+                              stream_);
+}
+
+extern "C" int efgh_lattice_neighbors_batched(const int32_t *vkeys, const int32_t *minmax, const int64_t *hash_keys,
+                                              const int32_t *hash_vals, int64_t hcap, const int32_t *H_dev,
+                                              int32_t h_bound, int32_t *nbr, const int32_t *vsid, int32_t nsamples,
+                                              void *stream_) {
+    hipStream_t st = (hipStream_t)stream_;
+    EFGH_CHECK_ARG(vkeys && minmax && hash_keys && hash_vals && H_dev && nbr && h_bound > 0 && nsamples >= 1);
+    EFGH_CHECK_ARG(nsamples == 1 || vsid);
+    int grid = cdiv((int64_t)h_bound * 16, TPB);
+    if (grid > 4096) grid = 4096;
+    k_neighbors<<<grid, TPB, 0, st>>>((const int4 *)vkeys, minmax, (const unsigned long long *)hash_keys,
+                                      hash_vals, hcap - 1, H_dev, nbr, nsamples > 1 ? vsid : nullptr, nsamples);
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
 }
@@ -362,7 +431,7 @@ extern "C" int efgh_lattice_neighbors(const int32_t *vkeys, const int32_t *minma
     int grid = cdiv((int64_t)h_bound * 16, TPB);
     if (grid > 4096) grid = 4096;
     k_neighbors<<<grid, TPB, 0, st>>>((const int4 *)vkeys, minmax, (const unsigned long long *)hash_keys,
-                                      hash_vals, hcap - 1, H_dev, nbr);
+                                      hash_vals, hcap - 1, H_dev, nbr, nullptr, 1);
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
 }

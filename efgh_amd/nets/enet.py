@@ -44,43 +44,40 @@ class Enet(nn.Module):
         dev = pc.device
         bcns = [self.bcn1, self.bcn2, self.bcn3, self.bcn4, self.bcn5]
         scales = [s for s, _ in self.scale_map]
-        outs, segs = [], [0]
-        for b in range(B):
-            pts = pc[b].contiguous()
-            cins = [m.num_input for m in bcns]
-            feats = [None] * 5
+        cins = [m.num_input for m in bcns]
+        feats = [None] * 5
 
-            def mk(l):
-                def alloc(n):
-                    feats[l] = torch.empty((n, cins[l]), dtype=torch.float32, device=dev)
-                    return feats[l]
-                return alloc
-            lv = lattice.build_pyramid(pts, scales, feat_bufs=[mk(l) for l in range(5)])
-            if keep is not None:
-                keep.setdefault('lattice', []).append(lv)
-            # conv_in on [N][4] (x,y,z,0) -> channels 4..35 of the level-0 feature rows
-            x = ops.nchw_to_nhwc(pts[None], 4)[0]                        # (N,4)
-            for i in range(3):
-                conv = self.conv_in[i][0]
-                last = i == 2 and not ctx.grad
-                x = L.linear_rows(ctx, x, N, conv.in_channels, conv.weight, conv.bias, act=ACT_LEAKY, slope=0.1,
-                                  out=(feats[0], 4) if last else None)
-            # level-l input rows = [el_minus_gr (4, written by the lattice kernel) | previous features]
-            cur = torch.cat([feats[0][:, :4], x], 1) if ctx.grad else feats[0]
-            for l in range(5):
-                d = lv[l]
-                if ctx.grad:
-                    splat = FN.SplatFn.apply(cur, d.bary, d.off, d.H, cins[l])
-                else:
-                    splat, _ = ops.splat_fwd(cur, cins[l], d.bary, d.off, d.H)
-                tgt = (feats[l + 1], 4) if (l < 4 and not ctx.grad) else None
-                cur = L.blur_conv(ctx, splat, d.H, cins[l], d.nbr, bcns[l].blur_conv[0], bcns[l].blur_conv[2],
-                                  out=tgt)
-                if l < 4:
-                    cur = torch.cat([feats[l + 1][:, :4], cur], 1) if ctx.grad else feats[l + 1]
-            outs.append(cur)                                             # (H5, 256)
-            segs.append(segs[-1] + lv[4].H)
-        x = torch.cat(outs, 0) if B > 1 else outs[0]
+        def mk(l):
+            def alloc(n):
+                feats[l] = torch.empty((n, cins[l]), dtype=torch.float32, device=dev)
+                return feats[l]
+            return alloc
+        # all samples in one launch sequence per level (every sample keeps its own lattice)
+        lv = lattice.build_pyramid_batched(pc, scales, feat_bufs=[mk(l) for l in range(5)])
+        if keep is not None:
+            keep['lattice'] = lv
+        # conv_in on [B*N][4] (x,y,z,0) -> channels 4..35 of the level-0 feature rows
+        x = ops.nchw_to_nhwc(pc, 4).view(B * N, 4)
+        for i in range(3):
+            conv = self.conv_in[i][0]
+            last = i == 2 and not ctx.grad
+            x = L.linear_rows(ctx, x, B * N, conv.in_channels, conv.weight, conv.bias, act=ACT_LEAKY, slope=0.1,
+                              out=(feats[0], 4) if last else None)
+        # level-l input rows = [el_minus_gr (4, written by the lattice kernel) | previous features]
+        cur = torch.cat([feats[0][:, :4], x], 1) if ctx.grad else feats[0]
+        for l in range(5):
+            d = lv[l]
+            if ctx.grad:
+                splat = FN.SplatFn.apply(cur, d.bary, d.off, d.H, cins[l])
+            else:
+                splat, _ = ops.splat_fwd(cur, cins[l], d.bary, d.off, d.H)
+            tgt = (feats[l + 1], 4) if (l < 4 and not ctx.grad) else None
+            cur = L.blur_conv(ctx, splat, d.H, cins[l], d.nbr, bcns[l].blur_conv[0], bcns[l].blur_conv[2],
+                              out=tgt)
+            if l < 4:
+                cur = torch.cat([feats[l + 1][:, :4], cur], 1) if ctx.grad else feats[l + 1]
+        x = cur                                                          # (sum_b H5_b, 256)
+        segs = lv[4].seg
         M = x.shape[0]
         for conv, bn in ((self.conv_gn_1, self.bn_gn_1), (self.conv_gn_2, self.bn_gn_2),
                          (self.conv_gn_3, self.bn_gn_3)):

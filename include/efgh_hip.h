@@ -67,6 +67,22 @@ int efgh_lattice_neighbors(const int32_t *vkeys, const int32_t *minmax, const in
                            const int32_t *hash_vals, int64_t hcap, const int32_t *H_dev,
                            int32_t h_bound, int32_t *nbr, void *stream);
 
+/* Batched forms: the points of `nsamples` frame-pairs are concatenated (sample-major); sid[p] is the
+ * sample of point p.  Every sample keeps its own key_mins/maxs (minmax [nsamples][8]) and its own hash
+ * keys, vertices are numbered sample-major, so vertex index - seg_first[sample] and the neighbour
+ * indices are exactly the per-sample results of the reference; vsid[h] = sample of vertex h (the next
+ * level's sid).  One launch sequence per level for the whole batch.                            */
+int efgh_lattice_build_batched(const float *pts, int64_t pts_cstride, int32_t n_in, float scale32,
+                               float div32, float *bary, float *emg, int64_t emg_pstride,
+                               int64_t emg_rstride, int32_t *off, int32_t *vkeys, float *pts_next,
+                               int32_t *minmax, int64_t *hash_keys, int32_t *hash_vals, int64_t hcap,
+                               int32_t *H_out, void *workspace, const int32_t *sid, int32_t nsamples,
+                               int32_t *vsid, int32_t *seg_first, void *stream);
+int efgh_lattice_neighbors_batched(const int32_t *vkeys, const int32_t *minmax, const int64_t *hash_keys,
+                                   const int32_t *hash_vals, int64_t hcap, const int32_t *H_dev,
+                                   int32_t h_bound, int32_t *nbr, const int32_t *vsid, int32_t nsamples,
+                                   void *stream);
+
 /* ------------------------------------------------------------------ BCL splat (K3) ---------
  * replaces SparseSum + density normalisation, nets/bilateralNN.py:6-40, 179-211.
  * feat [n_in][ldf] (first C columns used), bary [4][n_in], off [4][n_in]  ->

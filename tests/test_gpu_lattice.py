@@ -74,3 +74,24 @@ def test_degenerate_inputs():
         out = _gpu(pc)
         for d, r in zip(out, ref):
             assert d['H'] == r['H'] and np.array_equal(d['off'], r['off']) and np.array_equal(d['nbr'], r['nbr'])
+
+
+def test_batched_build_equals_per_sample():
+    """the batched lattice (one launch sequence for all samples) reproduces every sample's own lattice:
+    local offsets / neighbours / barycentric weights bit-exact vs the oracle"""
+    from efgh_amd import lattice
+    from oracle import lattice as olat
+    pcs = [syn.lidar_sweep(4096, 0), syn.lidar_sweep(4096, 7),
+           (np.random.RandomState(3).randn(3, 4096) * np.array([[15.], [15.], [1.5]])).astype(np.float32)]
+    pc = torch.from_numpy(np.stack(pcs)).cuda()
+    lv = lattice.build_pyramid_batched(pc, SCALES)
+    for b, p in enumerate(pcs):
+        ref = olat.generate_data(p)
+        for l, r in enumerate(ref):
+            d = lv[l].sample(b)
+            assert d.H == r['H'], (b, l)
+            assert np.array_equal(d.off.cpu().numpy().astype(np.int64), r['off']), (b, l)
+            assert np.array_equal(d.nbr.cpu().numpy()[:, :15].T.astype(np.int64), r['nbr']), (b, l)
+            assert np.array_equal(d.bary.cpu().numpy().view(np.uint32), r['bary'].view(np.uint32)), (b, l)
+            assert np.array_equal(d.emg.cpu().numpy().view(np.uint32), r['emg'].view(np.uint32)), (b, l)
+            assert np.array_equal(d.pts_next.cpu().numpy().view(np.uint32), r['pts_next'].view(np.uint32)), (b, l)
