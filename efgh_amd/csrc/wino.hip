@@ -1,0 +1,273 @@
+// Winograd F(4,3) along the image row for the 3x3 / stride 1 / pad 1 convolutions on fp32 MFMA (gfx950).
+//
+// Every VGG layer and most ResNet-18 layers of the H/F/G nets (nets/vgg.py:77, nets/resnet.py:22-30) and
+// their data gradients are "same" 3x3 convolutions: ~85 % of the contraction FLOPs of the hot path.
+// For 4 consecutive output pixels of a row and one kernel row kh
+//     y[0..3] = A^T ( (G w[kh][0..2]) .* (B^T d[0..5]) )            (Lavin & Gray, F(4,3))
+// needs 6 products instead of 12; with the kernel row folded into the contraction axis the layer becomes
+// six GEMMs  M_a[tile][n] = sum_{kh,c} V_a[tile][kh][c] * U_a[n][kh][c]  (a = 0..5) of depth 3C: half the
+// MFMA work of the direct form, all in fp32 (products and accumulation; no reduced-precision operand).
+// Rounding: the transforms add ~2-3x the error of a k-ordered fp32 dot product (measured 3e-6 relative at
+// C = 512), far inside the 1e-4 parity budget.
+//
+// One workgroup (256 threads = 2 x 2 waves) owns 64 tiles (= 256 output pixels, tiles are consecutive in
+// (b, y, x/4) order) x 64 output channels; every wave holds ALL six M_a accumulators of its 32 x 32 block
+// (96 VGPRs), so the inverse transform A^T runs on registers in the epilogue.  Per 16-channel chunk:
+// global -> registers (6 input pixels x float4 per thread, 6 x float4 of U), B^T on the VALU, ds_write_b128
+// into V[a][tile][16+4] / U[a][n][16+4] (rows of 20 floats: conflict-free ds_read_b128 fragments), then
+// 48 v_mfma_f32_32x32x2_f32 per wave.  Epilogue = that of k_gather_gemm (bias, BN scale/shift, residual,
+// activation, per-tile column statistics).
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int TM = 64, TN = 64, KC = 16, LD = KC + 4;
+
+struct WinoArgs {
+    const float *A; long long lda; int C;
+    int B, H, W, TW;                 // TW = ceil(W / 4) tiles per image row
+    const float *U; int N;           // U [3C/16][6][N][16]
+    long long Mt;                    // B * H * TW
+    const float *bias, *scale, *shift, *residual; long long ldr;
+    int act; float slope;
+    float *out; long long ldo;
+    float *stats;
+    unsigned nbx;
+};
+
+__global__ void __launch_bounds__(256, 2) k_wino43(const WinoArgs p) {
+    __shared__ __attribute__((aligned(16))) float Vs[6 * TM * LD];
+    __shared__ __attribute__((aligned(16))) float Us[6 * TN * LD];
+    __shared__ long long tpix[TM];       // first output pixel of the tile, -1 = no such tile
+    __shared__ int tcnt[TM];             // valid pixels in the tile (ragged right edge)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, lh = lane >> 5;
+    // XCD-aware tile order (see k_gather_gemm): one contiguous band of tiles per XCD
+    const unsigned nbx = p.nbx, nblk = gridDim.x;
+    const unsigned q8 = nblk >> 3, r8 = nblk & 7, xcd = blockIdx.x & 7, within = blockIdx.x >> 3;
+    const unsigned lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + within;
+    const unsigned tile_m = lin / nbx, tile_n = lin - tile_m * nbx;
+    const long long m0 = (long long)tile_m * TM;
+    const int n0 = tile_n * TN;
+    if (m0 >= p.Mt) return;
+
+    // ---- staging state: thread = (tile st, channel quad cq) ---------------------------------
+    const int st = tid >> 2, cq = (tid & 3) * 4;
+    long long pix0 = 0;
+    unsigned cmask = 0, rmask = 0;
+    {
+        const long long t = m0 + st;
+        if (t < p.Mt) {
+            const int xt = (int)(t % p.TW); const long long r = t / p.TW;
+            const int y = (int)(r % p.H); const long long b = r / p.H;
+            const int x0 = 4 * xt - 1;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) if ((unsigned)(x0 + q) < (unsigned)p.W) cmask |= 1u << q;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) if ((unsigned)(y + kh - 1) < (unsigned)p.H) rmask |= 1u << kh;
+            pix0 = (b * p.H + y) * p.W + x0;
+        }
+    }
+    if (tid < TM) {
+        const long long t = m0 + tid;
+        long long o = -1; int cnt = 0;
+        if (t < p.Mt) {
+            const int xt = (int)(t % p.TW); const long long r = t / p.TW;
+            o = r * p.W + 4 * xt;                       // r = b*H + y
+            cnt = p.W - 4 * xt; cnt = cnt > 4 ? 4 : cnt;
+        }
+        tpix[tid] = o; tcnt[tid] = cnt;
+    }
+    const long long ustride = (long long)p.N * KC;      // one alpha slab of a chunk
+    const float *ubase = p.U + (long long)(n0 + st) * KC + cq;
+
+    // (named registers, not arrays: keeps the prefetched chunk out of scratch memory)
+    float4 ra0, ra1, ra2, ra3, ra4, ra5, ru0, ru1, ru2, ru3, ru4, ru5;
+#define EFGH_LDA(q, dst)                                                                              \
+    {                                                                                                \
+        const bool ok = rok && ((cmask >> q) & 1u);                                                  \
+        const float4 v = *reinterpret_cast<const float4 *>(p.A + (ok ? (rowpix + q) * p.lda + c0 : 0)); \
+        dst.x = ok ? v.x : 0.f; dst.y = ok ? v.y : 0.f; dst.z = ok ? v.z : 0.f; dst.w = ok ? v.w : 0.f;  \
+    }
+#define EFGH_LOAD_CHUNK(chv)                                                                          \
+    {                                                                                                \
+        const int ch_ = (chv);                                                                       \
+        const int cc = ch_ / 3, kh = ch_ - cc * 3;                                                   \
+        const bool rok = (rmask >> kh) & 1u;                                                         \
+        const long long rowpix = pix0 + (long long)(kh - 1) * p.W;                                   \
+        const int c0 = cc * KC + cq;                                                                 \
+        EFGH_LDA(0, ra0) EFGH_LDA(1, ra1) EFGH_LDA(2, ra2) EFGH_LDA(3, ra3) EFGH_LDA(4, ra4) EFGH_LDA(5, ra5) \
+        const float *u = ubase + (long long)ch_ * 6 * ustride;                                       \
+        ru0 = *reinterpret_cast<const float4 *>(u);                                                  \
+        ru1 = *reinterpret_cast<const float4 *>(u + ustride);                                        \
+        ru2 = *reinterpret_cast<const float4 *>(u + 2 * ustride);                                    \
+        ru3 = *reinterpret_cast<const float4 *>(u + 3 * ustride);                                    \
+        ru4 = *reinterpret_cast<const float4 *>(u + 4 * ustride);                                    \
+        ru5 = *reinterpret_cast<const float4 *>(u + 5 * ustride);                                    \
+    }
+
+    f32x16 acc[6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+
+    const int nchunks = 3 * (p.C / KC);
+    EFGH_LOAD_CHUNK(0)
+    for (int ch = 0; ch < nchunks; ++ch) {
+        {   // B^T d on the four channels of this thread, then one ds_write_b128 per alpha
+            float4 v0, v1, v2, v3, v4, v5;
+#define EFGH_BT(e)                                                                                   \
+            {                                                                                        \
+                const float d0 = ra0.e, d1 = ra1.e, d2 = ra2.e, d3 = ra3.e, d4 = ra4.e, d5 = ra5.e;    \
+                const float p42 = d4 - 4.f * d2, p31 = d3 - 4.f * d1;                                \
+                const float q42 = d4 - d2, q31 = 2.f * (d3 - d1);                                    \
+                v0.e = 4.f * d0 - 5.f * d2 + d4;                                                     \
+                v1.e = p42 + p31;                                                                    \
+                v2.e = p42 - p31;                                                                    \
+                v3.e = q42 + q31;                                                                    \
+                v4.e = q42 - q31;                                                                    \
+                v5.e = 4.f * d1 - 5.f * d3 + d5;                                                     \
+            }
+            EFGH_BT(x) EFGH_BT(y) EFGH_BT(z) EFGH_BT(w)
+#undef EFGH_BT
+#define EFGH_ST(a, vv, uu)                                                                            \
+            *reinterpret_cast<float4 *>(&Vs[(a * TM + st) * LD + cq]) = vv;                          \
+            *reinterpret_cast<float4 *>(&Us[(a * TN + st) * LD + cq]) = uu;
+            EFGH_ST(0, v0, ru0) EFGH_ST(1, v1, ru1) EFGH_ST(2, v2, ru2) EFGH_ST(3, v3, ru3) EFGH_ST(4, v4, ru4) EFGH_ST(5, v5, ru5)
+#undef EFGH_ST
+        }
+        __syncthreads();
+        if (ch + 1 < nchunks) EFGH_LOAD_CHUNK(ch + 1)
+        {   // fragments of alpha a+1 are fetched while the eight MFMAs of alpha a run (two register sets)
+            const float *va = &Vs[(wm * 32 + l31) * LD + lh * 8];
+            const float *ub = &Us[(wn * 32 + l31) * LD + lh * 8];
+            float4 fa[2][2], fb[2][2];
+            fa[0][0] = *reinterpret_cast<const float4 *>(va); fa[0][1] = *reinterpret_cast<const float4 *>(va + 4);
+            fb[0][0] = *reinterpret_cast<const float4 *>(ub); fb[0][1] = *reinterpret_cast<const float4 *>(ub + 4);
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                const int cur = a & 1, nxt = cur ^ 1;
+                if (a < 5) {
+                    fa[nxt][0] = *reinterpret_cast<const float4 *>(va + (a + 1) * TM * LD);
+                    fa[nxt][1] = *reinterpret_cast<const float4 *>(va + (a + 1) * TM * LD + 4);
+                    fb[nxt][0] = *reinterpret_cast<const float4 *>(ub + (a + 1) * TN * LD);
+                    fb[nxt][1] = *reinterpret_cast<const float4 *>(ub + (a + 1) * TN * LD + 4);
+                }
+                __builtin_amdgcn_sched_barrier(0);      // keep the prefetch ahead of the MFMAs (the scheduler would sink it)
+                acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][0].x, fb[cur][0].x, acc[a], 0, 0, 0);
+                acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][0].y, fb[cur][0].y, acc[a], 0, 0, 0);
+                acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][0].z, fb[cur][0].z, acc[a], 0, 0, 0);
+                acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][0].w, fb[cur][0].w, acc[a], 0, 0, 0);
+                acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][1].x, fb[cur][1].x, acc[a], 0, 0, 0);
+                acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][1].y, fb[cur][1].y, acc[a], 0, 0, 0);
+                acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][1].z, fb[cur][1].z, acc[a], 0, 0, 0);
+                acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][1].w, fb[cur][1].w, acc[a], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: A^T on registers, then the k_gather_gemm epilogue --------------------------
+    float *ssum = Vs, *ssq = Vs + 2 * TN;
+    const int coll = wn * 32 + l31, col = n0 + coll;
+    const float bi = p.bias ? p.bias[col] : 0.f;
+    const float sc = p.scale ? p.scale[col] : 1.f;
+    const float sf = p.shift ? p.shift[col] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int rl = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const long long opix = tpix[rl];
+        const int cnt = tcnt[rl];
+        if (opix < 0) continue;
+        const float m0_ = acc[0][r], m1 = acc[1][r], m2 = acc[2][r], m3 = acc[3][r], m4 = acc[4][r], m5 = acc[5][r];
+        const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+        const float y0 = m0_ + s12 + s34, y1 = d12 + 2.f * d34, y2 = s12 + 4.f * s34, y3 = d12 + 8.f * d34 + m5;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i >= cnt) continue;
+            float v = (i == 0 ? y0 : i == 1 ? y1 : i == 2 ? y2 : y3) + bi;
+            s1 += v; s2 += v * v;
+            v = v * sc + sf;
+            if (p.residual) v += p.residual[(opix + i) * p.ldr + col];
+            if (p.act == 1) v = v > 0.f ? v : 0.f;
+            else if (p.act == 2) v = v > 0.f ? v : v * p.slope;
+            p.out[(opix + i) * p.ldo + col] = v;
+        }
+    }
+    if (p.stats) {
+        s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+        if (lh == 0) { ssum[wm * TN + coll] = s1; ssq[wm * TN + coll] = s2; }
+        __syncthreads();
+        if (tid < TN) {
+            p.stats[((long long)tile_m * 2 + 0) * p.N + n0 + tid] = ssum[tid] + ssum[TN + tid];
+            p.stats[((long long)tile_m * 2 + 1) * p.N + n0 + tid] = ssq[tid] + ssq[TN + tid];
+        }
+    }
+}
+
+// U[(cc*3 + kh)*6 + a][n][ci] = sum_kw G[a][kw] * Wp[n][kh*3 + kw][cc*16 + ci]      (Wp: packed [N][9][C])
+__global__ void k_wino_pack(const float *__restrict__ Wp, float *__restrict__ U, int N, int C) {
+    const double G[6][3] = {{0.25, 0., 0.}, {-1. / 6, -1. / 6, -1. / 6}, {-1. / 6, 1. / 6, -1. / 6},
+                            {1. / 24, 1. / 12, 1. / 6}, {1. / 24, -1. / 12, 1. / 6}, {0., 0., 1.}};
+    const long long total = 3LL * C * N;        // (ch, n, ci) triples, six outputs each
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % KC); long long r = i / KC;
+        const int n = (int)(r % N); const int ch = (int)(r / N);
+        const int cc = ch / 3, kh = ch - cc * 3, c = cc * KC + ci;
+        const float *w = Wp + ((long long)n * 9 + kh * 3) * C + c;
+        const double w0 = w[0], w1 = w[C], w2 = w[2 * (long long)C];
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+            U[(((long long)ch * 6 + a) * N + n) * KC + ci] = (float)(G[a][0] * w0 + G[a][1] * w1 + G[a][2] * w2);
+    }
+}
+
+bool supported(const efgh_gemm_desc *d) {
+    if (!d || d->mode != 1 || d->T != 9 || d->C % KC || d->N % TN || d->M_dev || d->nbatch > 1) return false;
+    if (d->sh != 1 || d->sw != 1 || d->osh != 1 || d->osw != 1 || d->oh0 || d->ow0) return false;
+    if (d->Hv != d->Hin || d->Wv != d->Win || d->Ho != d->Hin || d->Wo != d->Win) return false;
+    for (int t = 0; t < 9; ++t) if (d->dh[t] != t / 3 - 1 || d->dw[t] != t % 3 - 1) return false;
+    return d->lda % 4 == 0;
+}
+
+}  // namespace
+
+extern "C" int efgh_wino_supported(const efgh_gemm_desc *d) { return supported(d) ? 1 : 0; }
+
+extern "C" int32_t efgh_wino_grid_m(int32_t B, int32_t H, int32_t W) {
+    const long long mt = (long long)B * H * ((W + 3) / 4);
+    return (int32_t)((mt + TM - 1) / TM);
+}
+
+extern "C" int efgh_wino_pack(const float *Wp, float *U, int32_t N, int32_t C, void *stream_) {
+    EFGH_CHECK_ARG(Wp && U && N > 0 && C > 0 && C % KC == 0);
+    const long long total = 3LL * C * N;
+    long long g = (total + 255) / 256;
+    k_wino_pack<<<(int)(g > 8192 ? 8192 : g), 256, 0, (hipStream_t)stream_>>>(Wp, U, N, C);
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}
+
+extern "C" int efgh_wino_conv3x3(const efgh_gemm_desc *d, const float *U, void *stream_) {
+    EFGH_CHECK_ARG(supported(d) && U && d->A && d->out);
+    EFGH_CHECK_ARG((((uintptr_t)d->A) & 15) == 0 && (((uintptr_t)U) & 15) == 0);
+    EFGH_CHECK_ARG(d->B > 0 && d->M == (int64_t)d->B * d->Hin * d->Win);
+    WinoArgs a;
+    a.A = d->A; a.lda = d->lda; a.C = d->C;
+    a.B = d->B; a.H = d->Hin; a.W = d->Win; a.TW = (d->Win + 3) / 4;
+    a.U = U; a.N = d->N; a.Mt = (long long)d->B * d->Hin * a.TW;
+    a.bias = d->bias; a.scale = d->scale; a.shift = d->shift; a.residual = d->residual; a.ldr = d->ldr;
+    a.act = d->act; a.slope = d->slope; a.out = d->out; a.ldo = d->ldo; a.stats = d->stats;
+    a.nbx = (unsigned)(d->N / TN);
+    const long long nby = (a.Mt + TM - 1) / TM;
+    EFGH_CHECK_ARG(a.nbx * nby < 0x7fffffffLL);
+    k_wino43<<<(unsigned)(a.nbx * nby), 256, 0, (hipStream_t)stream_>>>(a);
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}

@@ -70,7 +70,7 @@ class GemmLayerFn(torch.autograd.Function):
         thin = spec.custom_forward is not None or all(
             ops.thin_eligible(spec.mode, spec.C, Np, spec.T if g is None else len(g[7])) for g, _ in spec.launches)
         if need_stats and not thin:
-            gs = [ops.gemm_grid_m(m, Np) for (_, m) in spec.launches]
+            gs = [ops.stats_rows(spec.mode, spec.C, Np, g, m) for (g, m) in spec.launches]
             stats = torch.empty((sum(gs), 2, Np), dtype=torch.float32, device=dev)
         fused_plain = bn is None            # bias (+residual) (+act) straight in the epilogue
         g0 = 0

@@ -110,7 +110,7 @@ def _run(ctx, x, lda, C, T, Wp, N, M, mode, geoms, out_t, ldo, coff, bias, bn, a
         stats, _ = ops.col_stats(out_t, M, Np, ldo, x_off=coff)
         gs = [stats.shape[0]]
     else:
-        gs = [ops.gemm_grid_m(m, Np) for _, _, m in geoms]
+        gs = [ops.stats_rows(mode, C, Np, geom, m) for geom, _, m in geoms]
         stats = torch.empty((sum(gs), 2, Np), dtype=torch.float32, device=x.device)
         g0 = 0
         for (geom, wp, m), g in zip(geoms, gs):

@@ -1,6 +1,7 @@
 """Tensor-level wrappers over the C-ABI (include/efgh_hip.h).  torch is used for device memory and
 the stream only; every arithmetic op below runs in libefgh_hip.so.  No CPU fallback."""
 import ctypes
+import os as _os
 
 import torch
 
@@ -82,8 +83,35 @@ def gemm_grid_m(M, N):
     return _L().efgh_gather_gemm_grid_m(c_int64(M), c_int32(N))
 
 
+USE_WINO = _os.environ.get('EFGH_WINO', '1') != '0'   # Winograd F(4,3) kernel for the "same" 3x3 convolutions
+
+
+def wino_eligible(mode, C, N, geom, T=None):
+    """the layers efgh_wino_conv3x3 serves (mirror of efgh_wino_supported): 3x3, stride 1, pad 1, C%16 == N%64 == 0"""
+    if not USE_WINO or MATH != 'f32' or mode != 1 or geom is None or C % 16 or N % 64:
+        return False
+    (B, Hin, Win, Hv, Wv, sh, sw, dh, dw, Ho, Wo, osh, osw, oh0, ow0) = geom
+    return (len(dh) == 9 and (sh, sw, osh, osw, oh0, ow0) == (1, 1, 1, 1, 0, 0) and Hv == Hin == Ho and Wv == Win == Wo
+            and list(dh) == [t // 3 - 1 for t in range(9)] and list(dw) == [t % 3 - 1 for t in range(9)])
+
+
+def stats_rows(mode, C, N, geom, M):
+    """rows of the per-tile BatchNorm statistics buffer the GEMM launch for this layer writes"""
+    if wino_eligible(mode, C, N, geom):
+        return _L().efgh_wino_grid_m(c_int32(geom[0]), c_int32(geom[1]), c_int32(geom[2]))
+    return gemm_grid_m(M, N)
+
+
+def wino_weight(Wp, N, C):
+    """U = G w of a packed [N][9][C] weight (efgh_wino_pack), cached on the packed tensor"""
+    def make():
+        U = torch.empty((3 * C // 16, 6, N, 16), dtype=torch.float32, device=Wp.device)
+        _C.check(_L().efgh_wino_pack(ptr(Wp), ptr(U), c_int32(N), c_int32(C), _st()))
+        return U
+    return _cached(Wp, ('wino',), _ver(Wp), make)
+
+
 USE_THIN = True
-import os as _os
 MATH = _os.environ.get('EFGH_MATH', 'f32')   # 'f32': exact fp32 MFMA | 'bf16x3': split-bf16 MFMA (3 products, fp32 accumulate)
 
 
@@ -119,6 +147,7 @@ def thin_eligible(mode, C, N, T):
     return N == 4 and T * C * 16 <= 60 * 1024
 
 
+PROFILE_WINO = None     # launches served by the Winograd kernel (else they are listed in PROFILE)
 PROFILE = None          # bench.py sets this to a list: (start_event, end_event, algorithmic_flops) per launch
 
 
@@ -151,8 +180,12 @@ def gather_gemm(A, lda, C, T, Wp, N, M, out, ldo, mode=0, geom=None, table=None,
     if batch is not None:
         d.nbatch, d.batch_stride_a, d.batch_stride_w, d.batch_stride_out = batch
     thin = stats is None and M_dev is None and thin_eligible(mode, C, N, T)
+    wino = False
     if thin:
         _C.check(_L().efgh_thin_gemm(ctypes.byref(d), _st()))
+    elif M_dev is None and batch is None and wino_eligible(mode, C, N, geom):
+        wino = True
+        _C.check(_L().efgh_wino_conv3x3(ctypes.byref(d), ptr(wino_weight(Wp, N, C)), _st()))
     elif MATH == 'bf16x3':
         hi, _, lo = split_weight(Wp, 2)
         _C.check(_L().efgh_gather_gemm_bf16x3(ctypes.byref(d), ptr(hi), ptr(lo), _st()))
@@ -170,7 +203,8 @@ def gather_gemm(A, lda, C, T, Wp, N, M, out, ldo, mode=0, geom=None, table=None,
             PROFILE_THIN.append((e0, e1, float(flops) if flops is not None else 2.0 * M * N * T * C, (mode, M, N, T, C)))
     elif PROFILE is not None:
         e1.record()
-        PROFILE.append((e0, e1, float(flops) if flops is not None else 2.0 * M * N * T * C, (mode, M, N, T, C)))
+        rec = (e0, e1, float(flops) if flops is not None else 2.0 * M * N * T * C, (mode, M, N, T, C))
+        (PROFILE_WINO if (wino and PROFILE_WINO is not None) else PROFILE).append(rec)
 
 
 # ----------------------------------------------------------------------------------------------

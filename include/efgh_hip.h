@@ -305,6 +305,17 @@ int efgh_corr_pack_cam(const float *cam, const float *cam_mm, int32_t B, int32_t
 int efgh_corr_fold(const float *P, int32_t B, int32_t nsplit, int64_t Mv, int32_t ldp, int32_t nseg, int32_t segw,
                    int32_t nj, float *logit, float *score, void *stream);
 
+/* Winograd F(4,3) (along the image row) form of the "same" 3x3 / stride-1 convolutions of nets/vgg.py:77 and
+ * nets/resnet.py:22-30 (and of their data gradients): six GEMMs of depth 3C over 4-pixel tiles, half the MFMA
+ * work of efgh_gather_gemm on the same layer, all operands and accumulation in fp32.  `d` is the mode-1
+ * descriptor of the layer (T = 9, taps (t/3-1, t%3-1), stride 1, C % 16 == 0, N % 64 == 0); d->W is ignored and
+ * U = efgh_wino_pack(packed weight [N][9][C]) is used instead.  Same epilogue as efgh_gather_gemm; `stats` has
+ * efgh_wino_grid_m(B, H, W) rows.  efgh_wino_supported: 1 if `d` qualifies.                               */
+int efgh_wino_supported(const efgh_gemm_desc *d);
+int32_t efgh_wino_grid_m(int32_t B, int32_t H, int32_t W);
+int efgh_wino_pack(const float *Wp, float *U, int32_t N, int32_t C, void *stream);
+int efgh_wino_conv3x3(const efgh_gemm_desc *d, const float *U, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -211,3 +211,45 @@ def test_split_bf16_math_modes(L, math, tol):
                 assert _rel(got.permute(0, 3, 1, 2).cpu(), cpu) < tol
     finally:
         ops.MATH = old
+
+
+@pytest.mark.parametrize('cin,cout,hw,B', [(64, 64, (24, 40), 2), (128, 256, (9, 13), 2), (256, 128, (5, 3), 1),
+                                           (64, 192, (17, 262), 1), (512, 512, (6, 10), 3)])
+def test_winograd_conv3x3_vs_direct_and_fp64(L, cin, cout, hw, B):
+    """efgh_wino_conv3x3 (F(4,3) on fp32 MFMA) against the direct gather-GEMM and a float64 reference: ragged
+    widths (W % 4 != 0, W < 4), residual + ReLU epilogue, train-mode BatchNorm statistics"""
+    from efgh_amd import ops
+    torch.manual_seed(1)
+    conv = nn.Conv2d(cin, cout, 3, 1, 1, bias=True)
+    x = torch.randn(B, cin, *hw).clamp_min(-0.5)
+    res = torch.randn(B, cout, *hw)
+    ref = F.relu(F.conv2d(x.double(), conv.weight.double(), conv.bias.double(), padding=1) + res.double())
+    cg = nn.Conv2d(cin, cout, 3, 1, 1, bias=True).cuda()
+    cg.load_state_dict(conv.state_dict())
+    xg, rg = ops.nchw_to_nhwc(x.cuda(), cin), ops.nchw_to_nhwc(res.cuda(), cout)
+    out = {}
+    for wino in (True, False):
+        ops.USE_WINO = wino
+        try:
+            assert ops.wino_eligible(1, cin, cout, (B, hw[0], hw[1], hw[0], hw[1], 1, 1, [t // 3 - 1 for t in range(9)],
+                                                    [t % 3 - 1 for t in range(9)], hw[0], hw[1], 1, 1, 0, 0)) == wino
+            with torch.no_grad():
+                y = L.conv2d(L.Ctx(False), xg, cg, None, L.ACT_RELU, 0.0, residual=rg)
+            out[wino] = y.permute(0, 3, 1, 2).double().cpu()
+        finally:
+            ops.USE_WINO = True
+    e_w, e_d = _rel(out[True], ref), _rel(out[False], ref)
+    assert e_w < 1e-5 and e_d < 1e-5, (e_w, e_d)
+    assert e_w < 8 * e_d + 1e-6, (e_w, e_d)          # the transforms cost a small constant factor of rounding
+    # train-mode BatchNorm on top (per-tile statistics epilogue of the Winograd kernel)
+    bn = nn.BatchNorm2d(cout)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.2)
+    bng = nn.BatchNorm2d(cout).cuda()
+    bng.load_state_dict(bn.state_dict())
+    bn.train(); bng.train()
+    refb = F.relu(bn(conv(x)))
+    with torch.no_grad():
+        yb = L.conv2d(L.Ctx(True), xg, cg, bng, L.ACT_RELU, 0.0)
+    assert _rel(yb.permute(0, 3, 1, 2).cpu(), refb) < 2e-5
+    assert _rel(bng.running_var.cpu(), bn.running_var) < 1e-5 and _rel(bng.running_mean.cpu(), bn.running_mean) < 1e-4
