@@ -14,7 +14,7 @@
 // (b, y, x/4) order) x 64 output channels; every wave holds ALL six M_a accumulators of its 32 x 32 block
 // (96 VGPRs), so the inverse transform A^T runs on registers in the epilogue.  Per 16-channel chunk:
 // global -> registers (6 input pixels x float4 per thread, 6 x float4 of U), B^T on the VALU, ds_write_b128
-// into V[a][tile][16+4] / U[a][n][16+4] (rows of 20 floats: conflict-free ds_read_b128 fragments), then
+// into V[a][tile][16] / U[a][n][16] (64-B rows with XOR-swizzled quads: conflict-free b128 writes AND reads), then
 // 48 v_mfma_f32_32x32x2_f32 per wave.  Epilogue = that of k_gather_gemm (bias, BN scale/shift, residual,
 // activation, per-tile column statistics).
 #include "common.h"
@@ -23,7 +23,7 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int TM = 64, TN = 64, KC = 16, LD = KC + 4;
+constexpr int TM = 64, TN = 64, KC = 16, LD = KC;     // 64-B LDS rows, 16-B quads XOR-swizzled by (row >> 2) & 3
 
 struct WinoArgs {
     const float *A; long long lda; int C;
@@ -56,6 +56,10 @@ __global__ void __launch_bounds__(256, 2) k_wino43(const WinoArgs p) {
 
     // ---- staging state: thread = (tile st, channel quad cq) ---------------------------------
     const int st = tid >> 2, cq = (tid & 3) * 4;
+    // LDS image: row = tile (or channel n), four 16-B quads per row stored at quad ^ ((row >> 2) & 3): the eight
+    // lanes of a ds_write_b128 group (2 rows x 4 quads) and the sixteen rows of a ds_read_b128 group (one quad
+    // each) then fall on distinct bank slots without padding
+    const int cqs = ((tid & 3) ^ ((st >> 2) & 3)) * 4;
     long long pix0 = 0;
     unsigned cmask = 0, rmask = 0;
     {
@@ -135,27 +139,28 @@ __global__ void __launch_bounds__(256, 2) k_wino43(const WinoArgs p) {
             EFGH_BT(x) EFGH_BT(y) EFGH_BT(z) EFGH_BT(w)
 #undef EFGH_BT
 #define EFGH_ST(a, vv, uu)                                                                            \
-            *reinterpret_cast<float4 *>(&Vs[(a * TM + st) * LD + cq]) = vv;                          \
-            *reinterpret_cast<float4 *>(&Us[(a * TN + st) * LD + cq]) = uu;
+            *reinterpret_cast<float4 *>(&Vs[(a * TM + st) * LD + cqs]) = vv;                         \
+            *reinterpret_cast<float4 *>(&Us[(a * TN + st) * LD + cqs]) = uu;
             EFGH_ST(0, v0, ru0) EFGH_ST(1, v1, ru1) EFGH_ST(2, v2, ru2) EFGH_ST(3, v3, ru3) EFGH_ST(4, v4, ru4) EFGH_ST(5, v5, ru5)
 #undef EFGH_ST
         }
         __syncthreads();
         if (ch + 1 < nchunks) EFGH_LOAD_CHUNK(ch + 1)
         {   // fragments of alpha a+1 are fetched while the eight MFMAs of alpha a run (two register sets)
-            const float *va = &Vs[(wm * 32 + l31) * LD + lh * 8];
-            const float *ub = &Us[(wn * 32 + l31) * LD + lh * 8];
+            const int sw = (l31 >> 2) & 3, q0 = ((2 * lh) ^ sw) * 4, q1 = ((2 * lh + 1) ^ sw) * 4;
+            const float *va = &Vs[(wm * 32 + l31) * LD];
+            const float *ub = &Us[(wn * 32 + l31) * LD];
             float4 fa[2][2], fb[2][2];
-            fa[0][0] = *reinterpret_cast<const float4 *>(va); fa[0][1] = *reinterpret_cast<const float4 *>(va + 4);
-            fb[0][0] = *reinterpret_cast<const float4 *>(ub); fb[0][1] = *reinterpret_cast<const float4 *>(ub + 4);
+            fa[0][0] = *reinterpret_cast<const float4 *>(va + q0); fa[0][1] = *reinterpret_cast<const float4 *>(va + q1);
+            fb[0][0] = *reinterpret_cast<const float4 *>(ub + q0); fb[0][1] = *reinterpret_cast<const float4 *>(ub + q1);
 #pragma unroll
             for (int a = 0; a < 6; ++a) {
                 const int cur = a & 1, nxt = cur ^ 1;
                 if (a < 5) {
-                    fa[nxt][0] = *reinterpret_cast<const float4 *>(va + (a + 1) * TM * LD);
-                    fa[nxt][1] = *reinterpret_cast<const float4 *>(va + (a + 1) * TM * LD + 4);
-                    fb[nxt][0] = *reinterpret_cast<const float4 *>(ub + (a + 1) * TN * LD);
-                    fb[nxt][1] = *reinterpret_cast<const float4 *>(ub + (a + 1) * TN * LD + 4);
+                    fa[nxt][0] = *reinterpret_cast<const float4 *>(va + (a + 1) * TM * LD + q0);
+                    fa[nxt][1] = *reinterpret_cast<const float4 *>(va + (a + 1) * TM * LD + q1);
+                    fb[nxt][0] = *reinterpret_cast<const float4 *>(ub + (a + 1) * TN * LD + q0);
+                    fb[nxt][1] = *reinterpret_cast<const float4 *>(ub + (a + 1) * TN * LD + q1);
                 }
                 __builtin_amdgcn_sched_barrier(0);      // keep the prefetch ahead of the MFMAs (the scheduler would sink it)
                 acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][0].x, fb[cur][0].x, acc[a], 0, 0, 0);

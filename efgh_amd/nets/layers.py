@@ -340,9 +340,11 @@ def _conv2d_grad(ctx, x, conv, bn, act, slope, residual, geom, dims, Cp):
     def dgrad(spec, w, draw, xin):
         dev = draw.device
         if sh == 1 and sw == 1:
-            dhs = [ph - i // kw for i in range(T)]
-            dws = [pw - i % kw for i in range(T)]
-            Wd = ops.pack_weight(w, Cw, T, O, T, Cw * T, 1, list(range(T)), Np=Cp, Cp=Np, key=('conv_d', Np, Cp))
+            # taps in ascending (dh, dw) order = the canonical 3x3 order the Winograd kernel recognises
+            order = sorted(range(T), key=lambda i: (ph - i // kw, pw - i % kw))
+            dhs = [ph - i // kw for i in order]
+            dws = [pw - i % kw for i in order]
+            Wd = ops.pack_weight(w, Cw, T, O, T, Cw * T, 1, order, Np=Cp, Cp=Np, key=('conv_d', Np, Cp))
             dx = torch.empty((B, H, W, Cp), dtype=torch.float32, device=dev)
             g = (B, Ho, Wo, H, W, 1, 1, dhs, dws, H, W, 1, 1, 0, 0)
             ops.gather_gemm(draw, Np, Np, T, Wd, Cp, B * H * W, dx, Cp, mode=1, geom=g,
