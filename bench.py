@@ -116,6 +116,7 @@ KERNELS = {
     'gemm': 'k_gather_gemm (fp32 MFMA implicit GEMM: every contraction that is not a "same" 3x3 convolution)',
     'wino': 'k_wino43 (Winograd F(4,3) on fp32 MFMA: the 3x3 / stride-1 convolutions and their data gradients)',
     'wgrad': 'k_gather_wgrad (fp32 MFMA weight gradient)',
+    'wino_wgrad': 'k_wino_wgrad (Winograd F(3,4) weight gradient of the 3x3 / stride-1 convolutions, fp32 MFMA)',
 }
 
 
@@ -129,7 +130,7 @@ def rooflines(prof, steps):
             r = gemm_roofline(lst, steps, KERNELS[name])
             if name != 'gemm':
                 r['traffic'] = None
-            if name == 'wino':
+            if name.startswith('wino'):
                 r['mfma_executed_tflops'] = r['achieved'] / 2
                 r['mfma_executed_frac'] = r['frac'] / 2
             rl[name] = r
@@ -195,14 +196,15 @@ def main():
         for _ in range(warmup):
             fn()
         barrier()
-        ops.PROFILE, ops.PROFILE_WGRAD, ops.PROFILE_WINO = [], [], []
+        ops.PROFILE, ops.PROFILE_WGRAD, ops.PROFILE_WINO, ops.PROFILE_WINO_WGRAD = [], [], [], []
         t0 = time.perf_counter()
         for _ in range(steps):
             fn()
         barrier()
         dt = max_over_ranks(time.perf_counter() - t0)
-        prof = {'gemm': ops.PROFILE, 'wgrad': ops.PROFILE_WGRAD, 'wino': ops.PROFILE_WINO}
-        ops.PROFILE = ops.PROFILE_WGRAD = ops.PROFILE_WINO = None
+        prof = {'gemm': ops.PROFILE, 'wgrad': ops.PROFILE_WGRAD, 'wino': ops.PROFILE_WINO,
+                'wino_wgrad': ops.PROFILE_WINO_WGRAD}
+        ops.PROFILE = ops.PROFILE_WGRAD = ops.PROFILE_WINO = ops.PROFILE_WINO_WGRAD = None
         return dt, prof
 
     out = None

@@ -233,6 +233,163 @@ __global__ void k_wino_pack(const float *__restrict__ Wp, float *__restrict__ U,
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Weight gradient of the same layers in Winograd form (F(3,4): three taps out of a 4-pixel gradient tile):
+//     dW[n][kh][kw][c] = sum_alpha A3^T[kw][alpha] * S_alpha[n][kh][c],
+//     S_alpha[n][kh][c] = sum_tiles (G4 dy)_alpha[tile][n] * (B^T x)_alpha[tile][kh][c]
+// six GEMMs contracted over the tiles (18 instead of 36 products per tile, tap row and channel pair).  One
+// workgroup = 64 n x 64 (kh, c) columns x all six alpha; the tiles are split over gridDim.z and the partial
+// S blocks combined with fp32 atomics; k_wino_wgrad_finish applies A3^T and writes the packed [N][9][C] layout.
+constexpr int TT = 16;            // tiles per contraction step
+
+struct WinoWArgs {
+    const float *A; long long lda; int C;
+    const float *G; long long ldg; int N;
+    int B, H, W, TW;
+    long long Mt; long long tchunk;
+    float *S;                      // [6][N][3C], pre-zeroed
+};
+
+__global__ void __launch_bounds__(256, 2) k_wino_wgrad(const WinoWArgs p) {
+    __shared__ __attribute__((aligned(16))) float Gs[6 * TT * 64];
+    __shared__ __attribute__((aligned(16))) float Vs[6 * TT * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave >> 1, wc = wave & 1, l31 = lane & 31, lh = lane >> 5;
+    const int k0 = blockIdx.x * 64;                   // column block inside [3][C]
+    const int kh = k0 / p.C, c0 = k0 - kh * p.C;
+    const int n0 = blockIdx.y * 64;
+    const long long tbeg = (long long)blockIdx.z * p.tchunk;
+    long long tend = tbeg + p.tchunk;
+    if (tend > p.Mt) tend = p.Mt;
+    if (tbeg >= tend) return;
+
+    // staging: thread = (tile ts of the step, channel quad q)
+    const int ts = tid >> 4, q4 = (tid & 15) * 4;
+    int xt, y; long long b;
+    {
+        const long long t = tbeg + ts;
+        xt = (int)(t % p.TW); const long long r = t / p.TW;
+        y = (int)(r % p.H); b = r / p.H;
+    }
+    float4 rx0, rx1, rx2, rx3, rx4, rx5, rg0, rg1, rg2, rg3;
+#define EFGH_LDX(q, dst)                                                                              \
+    {                                                                                                \
+        const bool ok = rok && (unsigned)(x0 + q) < (unsigned)p.W;                                   \
+        const float4 v = *reinterpret_cast<const float4 *>(p.A + (ok ? (xpix + q) * p.lda + c0 + q4 : 0)); \
+        dst.x = ok ? v.x : 0.f; dst.y = ok ? v.y : 0.f; dst.z = ok ? v.z : 0.f; dst.w = ok ? v.w : 0.f;  \
+    }
+#define EFGH_LDG(i, dst)                                                                              \
+    {                                                                                                \
+        const bool ok = tv && (4 * xt + i) < p.W;                                                    \
+        const float4 v = *reinterpret_cast<const float4 *>(p.G + (ok ? (opix + i) * p.ldg + n0 + q4 : 0)); \
+        dst.x = ok ? v.x : 0.f; dst.y = ok ? v.y : 0.f; dst.z = ok ? v.z : 0.f; dst.w = ok ? v.w : 0.f;  \
+    }
+#define EFGH_LOAD_STEP(t0)                                                                            \
+    {                                                                                                \
+        const bool tv = (t0) + ts < tend;                                                            \
+        const long long rowb = b * p.H + y;                                                          \
+        const long long opix = rowb * p.W + 4 * xt;                                                  \
+        const int x0 = 4 * xt - 1;                                                                   \
+        const bool rok = tv && (unsigned)(y + kh - 1) < (unsigned)p.H;                               \
+        const long long xpix = (rowb + (kh - 1)) * p.W + x0;                                         \
+        EFGH_LDX(0, rx0) EFGH_LDX(1, rx1) EFGH_LDX(2, rx2) EFGH_LDX(3, rx3) EFGH_LDX(4, rx4) EFGH_LDX(5, rx5) \
+        EFGH_LDG(0, rg0) EFGH_LDG(1, rg1) EFGH_LDG(2, rg2) EFGH_LDG(3, rg3)                          \
+        xt += TT;                                                                                    \
+        while (xt >= p.TW) { xt -= p.TW; ++y; }                                                      \
+        while (y >= p.H) { y -= p.H; ++b; }                                                          \
+    }
+
+    f32x16 acc[6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+
+    EFGH_LOAD_STEP(tbeg)
+    for (long long t0 = tbeg; t0 < tend; t0 += TT) {
+        {
+            float4 v0, v1, v2, v3, v4, v5, u0, u1, u2, u3, u4, u5;
+#define EFGH_TR(e)                                                                                    \
+            {                                                                                        \
+                const float d0 = rx0.e, d1 = rx1.e, d2 = rx2.e, d3 = rx3.e, d4 = rx4.e, d5 = rx5.e;    \
+                const float p42 = d4 - 4.f * d2, p31 = d3 - 4.f * d1;                                \
+                const float q42 = d4 - d2, q31 = 2.f * (d3 - d1);                                    \
+                v0.e = 4.f * d0 - 5.f * d2 + d4;                                                     \
+                v1.e = p42 + p31; v2.e = p42 - p31; v3.e = q42 + q31; v4.e = q42 - q31;              \
+                v5.e = 4.f * d1 - 5.f * d3 + d5;                                                     \
+                const float g0 = rg0.e, g1 = rg1.e, g2 = rg2.e, g3 = rg3.e;                          \
+                const float ev = g0 + g2, od = g1 + g3, e2 = g0 + 4.f * g2, o2 = 2.f * g1 + 8.f * g3; \
+                u0.e = 0.25f * g0;                                                                   \
+                u1.e = (ev + od) * (-1.f / 6.f); u2.e = (ev - od) * (-1.f / 6.f);                    \
+                u3.e = (e2 + o2) * (1.f / 24.f); u4.e = (e2 - o2) * (1.f / 24.f);                    \
+                u5.e = g3;                                                                           \
+            }
+            EFGH_TR(x) EFGH_TR(y) EFGH_TR(z) EFGH_TR(w)
+#undef EFGH_TR
+#define EFGH_STW(a, vv, uu)                                                                           \
+            *reinterpret_cast<float4 *>(&Vs[(a * TT + ts) * 64 + q4]) = vv;                          \
+            *reinterpret_cast<float4 *>(&Gs[(a * TT + ts) * 64 + q4]) = uu;
+            EFGH_STW(0, v0, u0) EFGH_STW(1, v1, u1) EFGH_STW(2, v2, u2) EFGH_STW(3, v3, u3) EFGH_STW(4, v4, u4) EFGH_STW(5, v5, u5)
+#undef EFGH_STW
+        }
+        __syncthreads();
+        if (t0 + TT < tend) EFGH_LOAD_STEP(t0 + TT)
+        {   // contraction index = tile: lane half lh takes tile 2s + lh; operands are single dwords of the images
+            const float *gp = &Gs[lh * 64 + wn * 32 + l31];
+            const float *vp = &Vs[lh * 64 + wc * 32 + l31];
+            float fg[2][8], fv[2][8];
+#pragma unroll
+            for (int s8 = 0; s8 < 8; ++s8) { fg[0][s8] = gp[s8 * 128]; fv[0][s8] = vp[s8 * 128]; }
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                const int cur = a & 1, nxt = cur ^ 1;
+                if (a < 5) {
+#pragma unroll
+                    for (int s8 = 0; s8 < 8; ++s8) {
+                        fg[nxt][s8] = gp[(a + 1) * TT * 64 + s8 * 128];
+                        fv[nxt][s8] = vp[(a + 1) * TT * 64 + s8 * 128];
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s8 = 0; s8 < 8; ++s8)
+                    acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(fg[cur][s8], fv[cur][s8], acc[a], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();
+    }
+#undef EFGH_LOAD_STEP
+#undef EFGH_LDX
+#undef EFGH_LDG
+    // D[row = n][col = c]: lanes run along c (contiguous in S)
+    const long long K3 = 3LL * p.C;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+        float *sa = p.S + ((long long)a * p.N + n0 + wn * 32) * K3 + k0 + wc * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int nl = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            atomicAdd(sa + nl * K3, acc[a][r]);
+        }
+    }
+}
+
+// dWp[n][kh*3 + kw][c] = sum_alpha A3^T[kw][alpha] * S[alpha][n][kh*C + c]
+__global__ void k_wino_wgrad_finish(const float *__restrict__ S, float *__restrict__ dWp, int N, int C) {
+    const long long K3 = 3LL * C, total = (long long)N * K3, plane = total;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int kc = (int)(i % K3); const long long n = i / K3;
+        const int kh = kc / C, c = kc - kh * C;
+        const float s0 = S[i], s1 = S[plane + i], s2 = S[2 * plane + i], s3 = S[3 * plane + i], s4 = S[4 * plane + i],
+                    s5 = S[5 * plane + i];
+        float *o = dWp + (n * 9 + kh * 3) * C + c;
+        o[0] = s0 + s1 + s2 + s3 + s4;
+        o[C] = (s1 - s2) + 2.f * (s3 - s4);
+        o[2 * (long long)C] = (s1 + s2) + 4.f * (s3 + s4) + s5;
+    }
+}
+
 bool supported(const efgh_gemm_desc *d) {
     if (!d || d->mode != 1 || d->T != 9 || d->C % KC || d->N % TN || d->M_dev || d->nbatch > 1) return false;
     if (d->sh != 1 || d->sw != 1 || d->osh != 1 || d->osw != 1 || d->oh0 || d->ow0) return false;
@@ -273,6 +430,44 @@ extern "C" int efgh_wino_conv3x3(const efgh_gemm_desc *d, const float *U, void *
     const long long nby = (a.Mt + TM - 1) / TM;
     EFGH_CHECK_ARG(a.nbx * nby < 0x7fffffffLL);
     k_wino43<<<(unsigned)(a.nbx * nby), 256, 0, (hipStream_t)stream_>>>(a);
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}
+
+extern "C" int efgh_wino_wgrad_supported(const efgh_gemm_desc *d) {
+    return (supported(d) && d->C % 64 == 0) ? 1 : 0;
+}
+
+extern "C" int efgh_wino_wgrad(const efgh_gemm_desc *d, const float *G, int64_t ldg, float *S, float *dWp,
+                               void *stream_) {
+    hipStream_t st = (hipStream_t)stream_;
+    EFGH_CHECK_ARG(supported(d) && d->C % 64 == 0 && d->A && G && S && dWp && ldg % 4 == 0);
+    EFGH_CHECK_ARG((((uintptr_t)d->A) & 15) == 0 && (((uintptr_t)G) & 15) == 0);
+    EFGH_CHECK_ARG(d->B > 0 && d->M == (int64_t)d->B * d->Hin * d->Win);
+    WinoWArgs a;
+    a.A = d->A; a.lda = d->lda; a.C = d->C; a.G = G; a.ldg = ldg; a.N = d->N;
+    a.B = d->B; a.H = d->Hin; a.W = d->Win; a.TW = (d->Win + 3) / 4;
+    a.Mt = (long long)d->B * d->Hin * a.TW;
+    a.S = S;
+    const int kt = 3 * d->C / 64, nt = d->N / 64;
+    long long want = 1536 / (kt * nt);                 // ~3 workgroups per CU-slot pair
+    if (want < 1) want = 1;
+    long long chunk = (a.Mt + want - 1) / want;
+    chunk = (chunk + TT - 1) / TT * TT;
+    if (chunk < 8 * TT) chunk = 8 * TT;
+    a.tchunk = chunk;
+    const long long zs = (a.Mt + chunk - 1) / chunk;
+    EFGH_CHECK_ARG(zs <= 65535);
+    const size_t sbytes = (size_t)6 * d->N * 3 * d->C * 4;
+    if (hipMemsetAsync(S, 0, sbytes, st) != hipSuccess) {
+        efgh_set_error("wino wgrad: memset failed");
+        return EFGH_E_LAUNCH;
+    }
+    k_wino_wgrad<<<dim3(kt, nt, (unsigned)zs), 256, 0, st>>>(a);
+    EFGH_CHECK_LAUNCH();
+    const long long total = (long long)d->N * 3 * d->C;
+    long long g = (total + 255) / 256;
+    k_wino_wgrad_finish<<<(int)(g > 4096 ? 4096 : g), 256, 0, st>>>(S, dWp, d->N, d->C);
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
 }

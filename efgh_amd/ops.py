@@ -418,7 +418,9 @@ def corr_head(cam, rng, want_logit=False, want_aux=False):
 # backward
 # ----------------------------------------------------------------------------------------------
 PROFILE_WGRAD = None
+PROFILE_WINO_WGRAD = None
 PROFILE_THIN = None
+USE_WINO_WGRAD = _os.environ.get('EFGH_WINO_WGRAD', '1') != '0'
 
 
 def gather_wgrad(A, lda, C, T, N, M, G, ldg, dWp, mode=0, geom=None, table=None):
@@ -435,8 +437,13 @@ def gather_wgrad(A, lda, C, T, N, M, G, ldg, dWp, mode=0, geom=None, table=None)
     d.table = 0 if table is None else table.data_ptr()
     d.N, d.M = N, M
     thin = thin_eligible(mode, C, N, T) and (N == 4 or T in (1, 2, 4, 9))
+    wino = False
     if thin:
         _C.check(_L().efgh_thin_wgrad(ctypes.byref(d), ptr(G), c_int64(ldg), ptr(dWp), _st()))
+    elif USE_WINO_WGRAD and C % 64 == 0 and wino_eligible(mode, C, N, geom):
+        wino = True
+        S = torch.empty((6, N, 3 * C), dtype=torch.float32, device=dWp.device)       # zeroed by the C-ABI call
+        _C.check(_L().efgh_wino_wgrad(ctypes.byref(d), ptr(G), c_int64(ldg), ptr(S), ptr(dWp), _st()))
     else:
         _C.check(_L().efgh_gather_wgrad(ctypes.byref(d), ptr(G), c_int64(ldg), ptr(dWp), _st()))
     if PROFILE_WGRAD is not None and thin:
@@ -445,7 +452,8 @@ def gather_wgrad(A, lda, C, T, N, M, G, ldg, dWp, mode=0, geom=None, table=None)
             PROFILE_THIN.append((e0, e1, 2.0 * M * N * T * C, (mode, M, N, T, C)))
     elif PROFILE_WGRAD is not None:
         e1.record()
-        PROFILE_WGRAD.append((e0, e1, 2.0 * M * N * T * C, (mode, M, N, T, C)))
+        rec = (e0, e1, 2.0 * M * N * T * C, (mode, M, N, T, C))
+        (PROFILE_WINO_WGRAD if (wino and PROFILE_WINO_WGRAD is not None) else PROFILE_WGRAD).append(rec)
 
 
 def unpack_weight(Wp, W, N, T, C, Cp, sn, sc, st, taps, accumulate=False):

@@ -315,6 +315,11 @@ int efgh_wino_supported(const efgh_gemm_desc *d);
 int32_t efgh_wino_grid_m(int32_t B, int32_t H, int32_t W);
 int efgh_wino_pack(const float *Wp, float *U, int32_t N, int32_t C, void *stream);
 int efgh_wino_conv3x3(const efgh_gemm_desc *d, const float *U, void *stream);
+/* weight gradient of the same layers (replaces efgh_gather_wgrad for them; additionally C % 64 == 0): Winograd
+ * F(3,4) over 4-pixel gradient tiles, six tile-contracted GEMMs accumulated into the scratch S [6][N][3C]
+ * (zeroed here) with fp32 atomics, then folded into the packed dWp [N][9][C].                              */
+int efgh_wino_wgrad_supported(const efgh_gemm_desc *d);
+int efgh_wino_wgrad(const efgh_gemm_desc *d, const float *G, int64_t ldg, float *S, float *dWp, void *stream);
 
 #ifdef __cplusplus
 }

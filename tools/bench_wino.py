@@ -34,3 +34,28 @@ for (B, H, W, ci, co) in shapes:
     print('B%d %dx%d %d->%d : direct %.3f ms %.1f TF | wino %.3f ms %.1f TF (algorithmic)  x%.2f  rel diff %.1e' % (
         B, H, W, ci, co, res[False][0], fl / res[False][0] / 1e9, res[True][0], fl / res[True][0] / 1e9,
         res[False][0] / res[True][0], err))
+
+print('--- weight gradient')
+for (B, H, W, ci, co) in shapes:
+    x = torch.randn(B, H, W, ci, device='cuda').clamp_min(0)
+    g = torch.randn(B, H, W, co, device='cuda')
+    geom = (B, H, W, H, W, 1, 1, [t // 3 - 1 for t in range(9)], [t % 3 - 1 for t in range(9)], H, W, 1, 1, 0, 0)
+    res = {}
+    for wino in (False, True):
+        ops.USE_WINO_WGRAD = wino
+        dWp = torch.empty((co, 9, ci), device='cuda')
+        for _ in range(2):
+            ops.gather_wgrad(x, ci, ci, 9, co, B * H * W, g, co, dWp, mode=1, geom=geom)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        n = 5
+        for _ in range(n):
+            ops.gather_wgrad(x, ci, ci, 9, co, B * H * W, g, co, dWp, mode=1, geom=geom)
+        e1.record(); torch.cuda.synchronize()
+        res[wino] = (e0.elapsed_time(e1) / n, dWp)
+    fl = 2.0 * B * H * W * co * ci * 9
+    err = (res[True][1] - res[False][1]).norm().item() / res[False][1].norm().item()
+    print('B%d %dx%d %d->%d : direct %.3f ms %.1f TF | wino %.3f ms %.1f TF (algorithmic)  x%.2f  rel diff %.1e' % (
+        B, H, W, ci, co, res[False][0], fl / res[False][0] / 1e9, res[True][0], fl / res[True][0] / 1e9,
+        res[False][0] / res[True][0], err))
