@@ -23,6 +23,9 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// out-of-image taps read this zero page (address select) instead of being zeroed after the load
+__device__ __attribute__((aligned(16))) float g_zero_page[16];
+
 constexpr int TM = 64, TN = 64, KC = 16, LD = KC;     // 64-B LDS rows, 16-B quads XOR-swizzled by (row >> 2) & 3
 
 struct WinoArgs {
@@ -90,21 +93,23 @@ __global__ void __launch_bounds__(256, 2) k_wino43(const WinoArgs p) {
 
     // (named registers, not arrays: keeps the prefetched chunk out of scratch memory)
     float4 ra0, ra1, ra2, ra3, ra4, ra5, ru0, ru1, ru2, ru3, ru4, ru5;
+    // per-thread part of the address once; per chunk only workgroup-uniform offsets (kernel row, channel block)
+    const float *abase = p.A + (pix0 * p.lda + cq);
+    const float *zpage = g_zero_page;
 #define EFGH_LDA(q, dst)                                                                              \
     {                                                                                                \
-        const bool ok = rok && ((cmask >> q) & 1u);                                                  \
-        const float4 v = *reinterpret_cast<const float4 *>(p.A + (ok ? (rowpix + q) * p.lda + c0 : 0)); \
-        dst.x = ok ? v.x : 0.f; dst.y = ok ? v.y : 0.f; dst.z = ok ? v.z : 0.f; dst.w = ok ? v.w : 0.f;  \
+        const float *src = (rok && ((cmask >> q) & 1u)) ? arow + (long long)q * p.lda : zpage;        \
+        dst = *reinterpret_cast<const float4 *>(src);                                                \
     }
 #define EFGH_LOAD_CHUNK(chv)                                                                          \
     {                                                                                                \
         const int ch_ = (chv);                                                                       \
-        const int cc = ch_ / 3, kh = ch_ - cc * 3;                                                   \
+        /* channel block fastest: consecutive chunks use the two 64-B halves of the same 128-B lines */ \
+        const int kh = ch_ / ccn, cc = ch_ - kh * ccn;                                               \
         const bool rok = (rmask >> kh) & 1u;                                                         \
-        const long long rowpix = pix0 + (long long)(kh - 1) * p.W;                                   \
-        const int c0 = cc * KC + cq;                                                                 \
+        const float *arow = abase + ((long long)(kh - 1) * p.W * p.lda + cc * KC);                   \
         EFGH_LDA(0, ra0) EFGH_LDA(1, ra1) EFGH_LDA(2, ra2) EFGH_LDA(3, ra3) EFGH_LDA(4, ra4) EFGH_LDA(5, ra5) \
-        const float *u = ubase + (long long)ch_ * 6 * ustride;                                       \
+        const float *u = ubase + (long long)(cc * 3 + kh) * 6 * ustride;                             \
         ru0 = *reinterpret_cast<const float4 *>(u);                                                  \
         ru1 = *reinterpret_cast<const float4 *>(u + ustride);                                        \
         ru2 = *reinterpret_cast<const float4 *>(u + 2 * ustride);                                    \
@@ -119,7 +124,7 @@ __global__ void __launch_bounds__(256, 2) k_wino43(const WinoArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
 
-    const int nchunks = 3 * (p.C / KC);
+    const int ccn = p.C / KC, nchunks = 3 * ccn;
     EFGH_LOAD_CHUNK(0)
     for (int ch = 0; ch < nchunks; ++ch) {
         {   // B^T d on the four channels of this thread, then one ds_write_b128 per alpha
