@@ -142,7 +142,9 @@ def thin_eligible(mode, C, N, T):
     """shapes served by the VALU "thin" kernels (thin.hip) instead of the MFMA tile"""
     if not USE_THIN or mode != 1 or N % 4 or C % 4:
         return False
-    if C == 4 and N <= 256 and T in (1, 2, 4, 9) and T * N * 16 + 4 * 64 * 36 * 4 <= 64 * 1024:
+    # C == 4 with many outputs (the 3->64 input convs) is faster on the MFMA tile (fwd 1.2x, wgrad 2x, fused BN
+    # statistics: tools/bench_thin.py); the VALU form is kept for the narrow ones (4->3 range conv)
+    if C == 4 and N <= 16 and T in (1, 2, 4, 9) and T * N * 16 + 4 * 64 * 36 * 4 <= 64 * 1024:
         return True
     return N == 4 and T * C * 16 <= 60 * 1024
 
