@@ -101,21 +101,23 @@ __global__ void __launch_bounds__(256, 2) k_wino43(const WinoArgs p) {
         const float *src = (rok && ((cmask >> q) & 1u)) ? arow + (long long)q * p.lda : zpage;        \
         dst = *reinterpret_cast<const float4 *>(src);                                                \
     }
-#define EFGH_LOAD_CHUNK(chv)                                                                          \
+    // the 12 loads of the next chunk are issued two at a time between the MFMA groups of the current one (a burst of
+    // 12 right after the barrier backs up the address path and delays the first MFMAs of every wave)
+    const float *arow = abase, *urow = ubase;
+    bool rok = false;
+#define EFGH_CHUNK_ADDR(chv)                                                                          \
     {                                                                                                \
         const int ch_ = (chv);                                                                       \
         /* channel block fastest: consecutive chunks use the two 64-B halves of the same 128-B lines */ \
         const int kh = ch_ / ccn, cc = ch_ - kh * ccn;                                               \
-        const bool rok = (rmask >> kh) & 1u;                                                         \
-        const float *arow = abase + ((long long)(kh - 1) * p.W * p.lda + cc * KC);                   \
-        EFGH_LDA(0, ra0) EFGH_LDA(1, ra1) EFGH_LDA(2, ra2) EFGH_LDA(3, ra3) EFGH_LDA(4, ra4) EFGH_LDA(5, ra5) \
-        const float *u = ubase + (long long)(cc * 3 + kh) * 6 * ustride;                             \
-        ru0 = *reinterpret_cast<const float4 *>(u);                                                  \
-        ru1 = *reinterpret_cast<const float4 *>(u + ustride);                                        \
-        ru2 = *reinterpret_cast<const float4 *>(u + 2 * ustride);                                    \
-        ru3 = *reinterpret_cast<const float4 *>(u + 3 * ustride);                                    \
-        ru4 = *reinterpret_cast<const float4 *>(u + 4 * ustride);                                    \
-        ru5 = *reinterpret_cast<const float4 *>(u + 5 * ustride);                                    \
+        rok = (rmask >> kh) & 1u;                                                                    \
+        arow = abase + ((long long)(kh - 1) * p.W * p.lda + cc * KC);                                \
+        urow = ubase + (long long)(cc * 3 + kh) * 6 * ustride;                                       \
+    }
+#define EFGH_LOAD_PAIR(q, da, du)                                                                     \
+    {                                                                                                \
+        EFGH_LDA(q, da)                                                                              \
+        du = *reinterpret_cast<const float4 *>(urow + q * ustride);                                  \
     }
 
     f32x16 acc[6];
@@ -125,7 +127,9 @@ __global__ void __launch_bounds__(256, 2) k_wino43(const WinoArgs p) {
         for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
 
     const int ccn = p.C / KC, nchunks = 3 * ccn;
-    EFGH_LOAD_CHUNK(0)
+    EFGH_CHUNK_ADDR(0)
+    EFGH_LOAD_PAIR(0, ra0, ru0) EFGH_LOAD_PAIR(1, ra1, ru1) EFGH_LOAD_PAIR(2, ra2, ru2)
+    EFGH_LOAD_PAIR(3, ra3, ru3) EFGH_LOAD_PAIR(4, ra4, ru4) EFGH_LOAD_PAIR(5, ra5, ru5)
     for (int ch = 0; ch < nchunks; ++ch) {
         {   // B^T d on the four channels of this thread, then one ds_write_b128 per alpha
             float4 v0, v1, v2, v3, v4, v5;
@@ -150,7 +154,8 @@ __global__ void __launch_bounds__(256, 2) k_wino43(const WinoArgs p) {
 #undef EFGH_ST
         }
         __syncthreads();
-        if (ch + 1 < nchunks) EFGH_LOAD_CHUNK(ch + 1)
+        const bool more = ch + 1 < nchunks;
+        if (more) EFGH_CHUNK_ADDR(ch + 1)
         {   // fragments of alpha a+1 are fetched while the eight MFMAs of alpha a run (two register sets)
             const int sw = (l31 >> 2) & 3, q0 = ((2 * lh) ^ sw) * 4, q1 = ((2 * lh + 1) ^ sw) * 4;
             const float *va = &Vs[(wm * 32 + l31) * LD];
@@ -166,6 +171,14 @@ __global__ void __launch_bounds__(256, 2) k_wino43(const WinoArgs p) {
                     fa[nxt][1] = *reinterpret_cast<const float4 *>(va + (a + 1) * TM * LD + q1);
                     fb[nxt][0] = *reinterpret_cast<const float4 *>(ub + (a + 1) * TN * LD + q0);
                     fb[nxt][1] = *reinterpret_cast<const float4 *>(ub + (a + 1) * TN * LD + q1);
+                }
+                if (more) {
+                    if (a == 0) EFGH_LOAD_PAIR(0, ra0, ru0)
+                    if (a == 1) EFGH_LOAD_PAIR(1, ra1, ru1)
+                    if (a == 2) EFGH_LOAD_PAIR(2, ra2, ru2)
+                    if (a == 3) EFGH_LOAD_PAIR(3, ra3, ru3)
+                    if (a == 4) EFGH_LOAD_PAIR(4, ra4, ru4)
+                    if (a == 5) EFGH_LOAD_PAIR(5, ra5, ru5)
                 }
                 __builtin_amdgcn_sched_barrier(0);      // keep the prefetch ahead of the MFMAs (the scheduler would sink it)
                 acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][0].x, fb[cur][0].x, acc[a], 0, 0, 0);
@@ -277,32 +290,27 @@ __global__ void __launch_bounds__(256, 2) k_wino_wgrad(const WinoWArgs p) {
         y = (int)(r % p.H); b = r / p.H;
     }
     float4 rx0, rx1, rx2, rx3, rx4, rx5, rg0, rg1, rg2, rg3;
-#define EFGH_LDX(q, dst)                                                                              \
+    // addresses of the next step once per step; the ten loads are then issued between the MFMA groups (see k_wino43)
+    const float *zpage = g_zero_page;
+    const float *xrow = p.A, *grow = p.G;
+    bool rok = false, tv = false;
+    int x0 = 0, xg = 0;
+#define EFGH_STEP_ADDR(t0)                                                                            \
     {                                                                                                \
-        const bool ok = rok && (unsigned)(x0 + q) < (unsigned)p.W;                                   \
-        const float4 v = *reinterpret_cast<const float4 *>(p.A + (ok ? (xpix + q) * p.lda + c0 + q4 : 0)); \
-        dst.x = ok ? v.x : 0.f; dst.y = ok ? v.y : 0.f; dst.z = ok ? v.z : 0.f; dst.w = ok ? v.w : 0.f;  \
-    }
-#define EFGH_LDG(i, dst)                                                                              \
-    {                                                                                                \
-        const bool ok = tv && (4 * xt + i) < p.W;                                                    \
-        const float4 v = *reinterpret_cast<const float4 *>(p.G + (ok ? (opix + i) * p.ldg + n0 + q4 : 0)); \
-        dst.x = ok ? v.x : 0.f; dst.y = ok ? v.y : 0.f; dst.z = ok ? v.z : 0.f; dst.w = ok ? v.w : 0.f;  \
-    }
-#define EFGH_LOAD_STEP(t0)                                                                            \
-    {                                                                                                \
-        const bool tv = (t0) + ts < tend;                                                            \
+        tv = (t0) + ts < tend;                                                                       \
         const long long rowb = b * p.H + y;                                                          \
-        const long long opix = rowb * p.W + 4 * xt;                                                  \
-        const int x0 = 4 * xt - 1;                                                                   \
-        const bool rok = tv && (unsigned)(y + kh - 1) < (unsigned)p.H;                               \
-        const long long xpix = (rowb + (kh - 1)) * p.W + x0;                                         \
-        EFGH_LDX(0, rx0) EFGH_LDX(1, rx1) EFGH_LDX(2, rx2) EFGH_LDX(3, rx3) EFGH_LDX(4, rx4) EFGH_LDX(5, rx5) \
-        EFGH_LDG(0, rg0) EFGH_LDG(1, rg1) EFGH_LDG(2, rg2) EFGH_LDG(3, rg3)                          \
+        x0 = 4 * xt - 1; xg = 4 * xt;                                                                \
+        rok = tv && (unsigned)(y + kh - 1) < (unsigned)p.H;                                          \
+        xrow = p.A + (((rowb + (kh - 1)) * p.W + x0) * p.lda + c0 + q4);                             \
+        grow = p.G + ((rowb * p.W + xg) * p.ldg + n0 + q4);                                          \
         xt += TT;                                                                                    \
         while (xt >= p.TW) { xt -= p.TW; ++y; }                                                      \
         while (y >= p.H) { y -= p.H; ++b; }                                                          \
     }
+#define EFGH_LDX(q, dst)                                                                              \
+    dst = *reinterpret_cast<const float4 *>((rok && (unsigned)(x0 + q) < (unsigned)p.W) ? xrow + (long long)q * p.lda : zpage);
+#define EFGH_LDG(i, dst)                                                                              \
+    dst = *reinterpret_cast<const float4 *>((tv && (xg + i) < p.W) ? grow + (long long)i * p.ldg : zpage);
 
     f32x16 acc[6];
 #pragma unroll
@@ -310,7 +318,9 @@ __global__ void __launch_bounds__(256, 2) k_wino_wgrad(const WinoWArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
 
-    EFGH_LOAD_STEP(tbeg)
+    EFGH_STEP_ADDR(tbeg)
+    EFGH_LDX(0, rx0) EFGH_LDX(1, rx1) EFGH_LDX(2, rx2) EFGH_LDX(3, rx3) EFGH_LDX(4, rx4) EFGH_LDX(5, rx5)
+    EFGH_LDG(0, rg0) EFGH_LDG(1, rg1) EFGH_LDG(2, rg2) EFGH_LDG(3, rg3)
     for (long long t0 = tbeg; t0 < tend; t0 += TT) {
         {
             float4 v0, v1, v2, v3, v4, v5, u0, u1, u2, u3, u4, u5;
@@ -338,7 +348,8 @@ __global__ void __launch_bounds__(256, 2) k_wino_wgrad(const WinoWArgs p) {
 #undef EFGH_STW
         }
         __syncthreads();
-        if (t0 + TT < tend) EFGH_LOAD_STEP(t0 + TT)
+        const bool more = t0 + TT < tend;
+        if (more) EFGH_STEP_ADDR(t0 + TT)
         {   // contraction index = tile: lane half lh takes tile 2s + lh; operands are single dwords of the images
             const float *gp = &Gs[lh * 64 + wn * 32 + l31];
             const float *vp = &Vs[lh * 64 + wc * 32 + l31];
@@ -355,6 +366,14 @@ __global__ void __launch_bounds__(256, 2) k_wino_wgrad(const WinoWArgs p) {
                         fv[nxt][s8] = vp[(a + 1) * TT * 64 + s8 * 128];
                     }
                 }
+                if (more) {
+                    if (a == 0) { EFGH_LDX(0, rx0) EFGH_LDG(0, rg0) }
+                    if (a == 1) { EFGH_LDX(1, rx1) EFGH_LDG(1, rg1) }
+                    if (a == 2) { EFGH_LDX(2, rx2) EFGH_LDG(2, rg2) }
+                    if (a == 3) { EFGH_LDX(3, rx3) EFGH_LDG(3, rg3) }
+                    if (a == 4) { EFGH_LDX(4, rx4) }
+                    if (a == 5) { EFGH_LDX(5, rx5) }
+                }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int s8 = 0; s8 < 8; ++s8)
@@ -364,7 +383,7 @@ __global__ void __launch_bounds__(256, 2) k_wino_wgrad(const WinoWArgs p) {
         }
         __syncthreads();
     }
-#undef EFGH_LOAD_STEP
+#undef EFGH_STEP_ADDR
 #undef EFGH_LDX
 #undef EFGH_LDG
     // D[row = n][col = c]: lanes run along c (contiguous in S)
