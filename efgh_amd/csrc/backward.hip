@@ -259,7 +259,17 @@ int grid_for(long long total) {
 }
 }  // namespace
 
-extern "C" int32_t efgh_bwd_groups(int64_t M) { return (int32_t)((M + 511) / 512); }
+// rows per partial-sum block: 512, grown for huge tensors so that the finalize pass folds at most 4096 partial rows
+static long long bwd_rows_per_block(long long M) {
+    long long rows = (M + 4095) / 4096;
+    rows = (rows + 63) / 64 * 64;
+    return rows < 512 ? 512 : rows;
+}
+
+extern "C" int32_t efgh_bwd_groups(int64_t M) {
+    const long long rows = bwd_rows_per_block(M);
+    return (int32_t)((M + rows - 1) / rows);
+}
 
 extern "C" int efgh_act_bn_bwd_reduce(const float *dy, int64_t lddy, const float *y, int64_t ldy, const float *raw,
                                       int64_t ldraw, const float *mean, const float *invstd, const float *pscale,
@@ -275,7 +285,7 @@ extern "C" int efgh_act_bn_bwd_reduce(const float *dy, int64_t lddy, const float
     int CL = 1;
     while (CL < 64 && CL * 4 < C) CL <<= 1;
     k_act_bn_bwd_reduce<<<dim3(cdiv(C / 4, CL), G), TPB, 0, st>>>(dy, lddy, y, ldy, raw, ldraw, mean, invstd, pscale,
-                                                                 pshift, M, C, act, slope, 512, CL, part);
+                                                                 pshift, M, C, act, slope, (int)bwd_rows_per_block(M), CL, part);
     k_bwd_finalize<<<cdiv(C, 32), dim3(32, 32), 0, st>>>(part, G, C, (double)M, sum_dpre, sum_dpre_xhat, mean_dpre,
                                                          mean_dpre_xhat);
     EFGH_CHECK_LAUNCH();
