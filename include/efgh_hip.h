@@ -321,6 +321,39 @@ int efgh_wino_conv3x3(const efgh_gemm_desc *d, const float *U, void *stream);
 int efgh_wino_wgrad_supported(const efgh_gemm_desc *d);
 int efgh_wino_wgrad(const efgh_gemm_desc *d, const float *G, int64_t ldg, float *S, float *dWp, void *stream);
 
+/* ------------------------------------------------------------------ sample preparation --
+ * GPU form of the reference's per-sample CPU transforms, data_loader/loader_utils.py:104-202 (called from
+ * kitti_odom_loader.py:251-273 / rellis3d_loader.py:306-339).  Images are (H,W,3) uint8, device resident.  The O(1)
+ * geometry is host work (efgh_amd/data/prepare.py restates Pillow's Image.rotate / Resample.c coefficient code).   */
+/* Image.rotate(angle, expand) NEAREST (common/numpy_utils.py:426-445): xin = (c[2]+c[0]*x+c[1]*y)>>16,
+ * yin = (c[5]+c[3]*x+c[4]*y)>>16 (Pillow's 16.16 affine_fixed), zero fill; out is (nh,nw,3).                       */
+int efgh_prep_affine_nearest_u8(const uint8_t *in, int32_t h, int32_t w, const int64_t *coef6_host, uint8_t *out,
+                                int32_t nh, int32_t nw, void *stream);
+/* crop_image / zero_pad_image (numpy_utils.py:447-503): out[y][x] = in[y+oy][x+ox] or 0                            */
+int efgh_prep_crop_pad_u8(const uint8_t *in, int32_t h, int32_t w, int32_t oy, int32_t ox, uint8_t *out, int32_t th,
+                          int32_t tw, void *stream);
+/* one pass of Image.resize's 8-bit resampler (numpy_utils.py:474-486; Pillow Resample.c): along axis (1 = x, 0 = y),
+ * out = clip8((2^21 + sum_k in[bounds[2o]+k]*coeffs[o][k]) >> 22), k < bounds[2o+1]; tables are device int32        */
+int efgh_prep_resample_u8(const uint8_t *in, int32_t h, int32_t w, int32_t axis, int32_t out_size, const int32_t *bounds,
+                          const int32_t *coeffs, int32_t ksize, uint8_t *out, void *stream);
+/* (H,W,3) -> (3,H,W) uint8 and/or image_valid_mask (1,H,W) (numpy_utils.py:505-517)                                */
+int efgh_prep_hwc_to_chw_u8(const uint8_t *in, int32_t h, int32_t w, uint8_t *chw, uint8_t *mask, void *stream);
+/* network input: zero pad to (th,tw) at (oy,ox), uint8 -> float32, (3,th,tw) (loader_utils.py:110-114)              */
+int efgh_prep_u8_to_f32_chw_pad(const uint8_t *in, int32_t h, int32_t w, int32_t oy, int32_t ox, float *out, int32_t th,
+                                int32_t tw, void *stream);
+/* preproc_pcd (loader_utils.py:160-202): stable compaction of the points with -r <= x,y < r (pcd [n][4] fp32,
+ * optionally pre-gathered by pre_idx (lidar-line reduction) and with x,y negated (RELLIS axis flip));
+ * keep_idx [n] receives the surviving source rows in order, *count their number;
+ * block_scratch has efgh_prep_filter_blocks(n) ints.                                                               */
+int32_t efgh_prep_filter_blocks(int32_t n);
+int efgh_prep_radius_filter(const float *pcd, const int32_t *pre_idx, int32_t n, int32_t flip_xy, float radius,
+                            int32_t *block_scratch, int32_t *keep_idx, int32_t *count, void *stream);
+/* out[r][j] = rand_init_l[r] . (x,y,z,1) in float64 for point keep_idx[sel[j]] (sel NULL: j), j < n_sel; the remaining
+ * columns are the transform of (0,0,0,1).  T34 = 12 doubles (device).  out32 (3,num_points) fp32 and/or out64.      */
+int efgh_prep_gather_transform(const float *pcd, const int32_t *keep_idx, const int32_t *sel, int32_t n_sel,
+                               int32_t flip_xy, const double *T34, int32_t num_points, float *out32, double *out64,
+                               void *stream);
+
 #ifdef __cplusplus
 }
 #endif
