@@ -354,6 +354,13 @@ int efgh_prep_gather_transform(const float *pcd, const int32_t *keep_idx, const 
                                int32_t flip_xy, const double *T34, int32_t num_points, float *out32, double *out64,
                                void *stream);
 
+/* ------------------------------------------------------------------ evaluation metrics --
+ * Err.calc_error_odom_np (mode 0: arccos((tr(pred_R^T gt_R)-1)/2) in degrees, |pred_t - gt_t|_2; common/helper.py:198-207)
+ * and Err.calc_error_raw_np (mode 1: quaternion distance 2*atan2(|v|,|w|) of gt*pred^-1 in degrees, mean |dt|;
+ * helper.py:165-196) for B pairs of row-major 4x4 poses on the device.                                           */
+int efgh_pose_errors(const float *gt, const float *pred, int32_t B, int32_t mode, float *rot_err, float *trs_err,
+                     void *stream);
+
 #ifdef __cplusplus
 }
 #endif
