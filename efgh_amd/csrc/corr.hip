@@ -176,6 +176,63 @@ int grid_for(long long total) {
     long long g = (total + TPB - 1) / TPB;
     return (int)(g > 16384 ? 16384 : (g < 1 ? 1 : g));
 }
+
+// ---- MFMA formulation of the correlation's backward -----------------------------------------------------
+// dcam_n[b][y][x][c] = sum_j dl[b][j] rp[b][y][j+x][c]  and  drp[b][y][m][c] = sum_x dl[b][m-x] cam_n[b][y][x][c]
+// are products with the Toeplitz matrix of dl once the operands are laid out as planes [(y,c)][position]:
+//   dcamT[(y,c)][x] = sum_m rpT[(y,c)][m] * T[x][m],   T[x][m]  = dl[m - x]
+//   drpT [(y,c)][m] = sum_x camT[(y,c)][x] * TT[m][x],  TT[m][x] = dl[m - x]
+// i.e. two batched efgh_gather_gemm launches (mode 0, M = 16h, depth wp resp. wc) instead of 2*nj FMAs per output element on
+// the VALU.  The kernels below only re-lay out the operands (HBM-bound, a few hundred MB per step).
+__global__ void k_corr_planes(const float *__restrict__ x, const float *__restrict__ mm, int h, int w, int w_in_pitch,
+                              int wP, float *__restrict__ out) {
+    // block = 64 positions x 16 channels of one (b, y); LDS transpose so that both sides are coalesced
+    __shared__ float tile[64][17];
+    const int b = blockIdx.z, y = blockIdx.y, m0 = blockIdx.x * 64;
+    const float inv = mm ? 1.0f / (mm[b * 2 + 1] - mm[b * 2]) : 1.0f;
+    const float *src = x + (((long long)b * h + y) * w_in_pitch) * 16;
+    for (int i = threadIdx.x; i < 64 * 16; i += TPB) {
+        const int m = i >> 4, c = i & 15;
+        tile[m][c] = (m0 + m < w) ? src[(long long)(m0 + m) * 16 + c] : 0.f;
+    }
+    __syncthreads();
+    float *dst = out + (((long long)b * h + y) * 16) * wP;
+    for (int i = threadIdx.x; i < 64 * 16; i += TPB) {
+        const int c = i >> 6, m = i & 63;
+        if (m0 + m < wP) dst[(long long)c * wP + m0 + m] = mm ? tile[m][c] * inv : tile[m][c];
+    }
+}
+
+__global__ void k_corr_unplanes(const float *__restrict__ in, int h, int w, int wP, float *__restrict__ out) {
+    __shared__ float tile[16][65];
+    const int b = blockIdx.z, y = blockIdx.y, m0 = blockIdx.x * 64;
+    const float *src = in + (((long long)b * h + y) * 16) * wP;
+    for (int i = threadIdx.x; i < 64 * 16; i += TPB) {
+        const int c = i >> 6, m = i & 63;
+        tile[c][m] = (m0 + m < w) ? src[(long long)c * wP + m0 + m] : 0.f;
+    }
+    __syncthreads();
+    float *dst = out + (((long long)b * h + y) * w) * 16;
+    for (int i = threadIdx.x; i < 64 * 16; i += TPB) {
+        const int m = i >> 4, c = i & 15;
+        if (m0 + m < w) dst[(long long)(m0 + m) * 16 + c] = tile[c][m];
+    }
+}
+
+// T[b][r][c] = dl[b][c - r] (transpose == 0) or dl[b][r - c] (transpose == 1); zero outside [0, nj) and in the row padding
+__global__ void k_corr_toeplitz(const float *__restrict__ dl, int nj, int rows, int cols, int colsP, int transpose,
+                                float *__restrict__ T) {
+    const int b = blockIdx.y;
+    const long long total = (long long)rows * colsP;
+    const float *g = dl + (long long)b * nj;
+    float *dst = T + (long long)b * total;
+    for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
+        const int c = (int)(i % colsP), r = (int)(i / colsP);
+        const int j = transpose ? r - c : c - r;
+        dst[i] = (c < cols && j >= 0 && j < nj) ? g[j] : 0.f;
+    }
+}
+
 }  // namespace
 
 extern "C" int32_t efgh_minmax_groups(int64_t n) {
@@ -233,6 +290,32 @@ extern "C" int efgh_corr_fold(const float *P, int32_t B, int32_t nsplit, int64_t
     EFGH_CHECK_ARG((int64_t)(nj - 1) + (int64_t)(nseg - 1) * segw < Mv);
     k_corr_fold<<<grid_for((long long)B * nj), TPB, 0, (hipStream_t)stream_>>>(P, B, nsplit, Mv, ldp, nseg, segw, nj,
                                                                              1.0f / 16.0f, logit, score);
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}
+
+extern "C" int efgh_corr_planes(const float *x, const float *mm, int32_t B, int32_t h, int32_t w, int32_t w_in_pitch,
+                                int32_t wP, float *out, void *stream_) {
+    EFGH_CHECK_ARG(x && out && B > 0 && h > 0 && w > 0 && w_in_pitch >= w && wP >= w && wP % 4 == 0);
+    k_corr_planes<<<dim3(cdiv(wP, 64), h, B), TPB, 0, (hipStream_t)stream_>>>(x, mm, h, w, w_in_pitch, wP, out);
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}
+
+extern "C" int efgh_corr_unplanes(const float *in, int32_t B, int32_t h, int32_t w, int32_t wP, float *out, void *stream_) {
+    EFGH_CHECK_ARG(in && out && B > 0 && h > 0 && w > 0 && wP >= w);
+    k_corr_unplanes<<<dim3(cdiv(w, 64), h, B), TPB, 0, (hipStream_t)stream_>>>(in, h, w, wP, out);
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}
+
+extern "C" int efgh_corr_toeplitz(const float *dl, int32_t B, int32_t nj, int32_t rows, int32_t cols, int32_t colsP,
+                                  int32_t transpose, float *T, void *stream_) {
+    EFGH_CHECK_ARG(dl && T && B > 0 && nj > 0 && rows > 0 && cols > 0 && colsP >= cols && colsP % 4 == 0);
+    const long long total = (long long)rows * colsP;
+    long long g = (total + TPB - 1) / TPB;
+    k_corr_toeplitz<<<dim3((unsigned)(g > 4096 ? 4096 : g), B), TPB, 0, (hipStream_t)stream_>>>(dl, nj, rows, cols, colsP,
+                                                                                               transpose, T);
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
 }

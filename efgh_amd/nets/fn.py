@@ -355,7 +355,7 @@ class CorrHeadFn(torch.autograd.Function):
         wr = rng.shape[2]
         off = int(wr / 8)
         dl = (ds * score * (1 - score) / 16.0).contiguous()                  # d/dlogit, incl. the 1/C scale
-        dcam_n, drp = ops.corr1d_bwd(rp, cam, cam_mm, dl, B, h, wc, rp.shape[2])
+        dcam_n, drp = ops.corr1d_bwd(rp, cam, cam_mm, dl, B, h, wc, wr + 2 * off)
         drng_n = ops.corr_unpad(drp, B, h, wr, C, off)
 
         def norm_bwd(x, mm, dxn):

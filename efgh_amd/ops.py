@@ -388,7 +388,8 @@ def corr_head(cam, rng, want_logit=False, want_aux=False):
     logit = torch.empty((B, nj), dtype=torch.float32, device=dev) if want_logit else None
     segw = (wc + 31) // 32
     nseg = ceil4((wc + segw - 1) // segw)
-    mfma = USE_MFMA_CORR and not want_aux and h * segw * 16 < 65536 and nseg <= 32
+    # training (want_aux) takes the MFMA path whenever its backward does (corr1d_bwd): rp then has pitch wpitch, not wp
+    mfma = USE_MFMA_CORR and (not want_aux or h * 16 >= 128) and h * segw * 16 < 65536 and nseg <= 32
     wpitch = wp + segw if mfma else wp
     rp = torch.empty((B, h, wpitch, C), dtype=torch.float32, device=dev)
     _C.check(_L().efgh_corr_pad(ptr(rng), ptr(rng_mm), c_int32(B), c_int32(h), c_int32(wr), c_int32(C),
@@ -407,6 +408,8 @@ def corr_head(cam, rng, want_logit=False, want_aux=False):
                     batch=(B * nsplit, T * wpitch * 16, nseg * T * segw * 16, wp * nseg))
         _C.check(_L().efgh_corr_fold(ptr(P), c_int32(B), c_int32(nsplit), c_int64(wp), c_int32(nseg),
                                      c_int32(nseg_real), c_int32(segw), c_int32(nj), ptr(logit), ptr(score), _st()))
+        if want_aux:
+            return score, logit, rp, cam_mm, rng_mm
         return score, logit
     part = torch.empty((B, h, nj), dtype=torch.float32, device=dev)
     _C.check(_L().efgh_corr1d(ptr(rp), ptr(cam), ptr(cam_mm), c_int32(B), c_int32(h), c_int32(wc), c_int32(wp),
@@ -520,7 +523,40 @@ def raster_bwd(pix, gimg, B, N, HW):
     return gv
 
 
+def corr1d_bwd_mfma(rp, cam, cam_mm, dl, B, h, wc, wp, rp_pitch=None):
+    """the two correlation gradients as Toeplitz GEMMs on the MFMA kernel (see efgh_corr_planes); rp [B][h][rp_pitch][16]"""
+    dev = cam.device
+    nj = wp - wc + 1
+    rp_pitch = rp_pitch or wp
+    wpP, wcP = ceil4(wp), ceil4(wc)
+    f = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+    rpT, camT = f(B, h * 16, wpP), f(B, h * 16, wcP)
+    _C.check(_L().efgh_corr_planes(ptr(rp), None, c_int32(B), c_int32(h), c_int32(wp), c_int32(rp_pitch), c_int32(wpP),
+                                   ptr(rpT), _st()))
+    _C.check(_L().efgh_corr_planes(ptr(cam), ptr(cam_mm), c_int32(B), c_int32(h), c_int32(wc), c_int32(wc), c_int32(wcP),
+                                   ptr(camT), _st()))
+    T, TT = f(B, wc, wpP), f(B, wp, wcP)
+    _C.check(_L().efgh_corr_toeplitz(ptr(dl), c_int32(B), c_int32(nj), c_int32(wc), c_int32(wp), c_int32(wpP), c_int32(0),
+                                     ptr(T), _st()))
+    _C.check(_L().efgh_corr_toeplitz(ptr(dl), c_int32(B), c_int32(nj), c_int32(wp), c_int32(wc), c_int32(wcP), c_int32(1),
+                                     ptr(TT), _st()))
+    dcamT, drpT = f(B, h * 16, wc), f(B, h * 16, wp)
+    M = h * 16
+    gather_gemm(rpT, wpP, wpP, 1, T, wc, M, dcamT, wc, mode=0, flops=2.0 * B * h * wc * 16 * nj,
+                batch=(B, M * wpP, wc * wpP, M * wc))
+    gather_gemm(camT, wcP, wcP, 1, TT, wp, M, drpT, wp, mode=0, flops=2.0 * B * h * wc * 16 * nj,
+                batch=(B, M * wcP, wp * wcP, M * wp))
+    dcam, drp = f(B, h, wc, 16), f(B, h, wp, 16)
+    _C.check(_L().efgh_corr_unplanes(ptr(dcamT), c_int32(B), c_int32(h), c_int32(wc), c_int32(wc), ptr(dcam), _st()))
+    _C.check(_L().efgh_corr_unplanes(ptr(drpT), c_int32(B), c_int32(h), c_int32(wp), c_int32(wp), ptr(drp), _st()))
+    return dcam, drp
+
+
 def corr1d_bwd(rp, cam, cam_mm, dl, B, h, wc, wp):
+    """rp [B][h][pitch >= wp][16] (the MFMA forward pads the rows); returns (dcam_n [B][h][wc][16], drp [B][h][wp][16])"""
+    pitch = rp.shape[2]
+    if (USE_MFMA_CORR and h * 16 >= 128) or pitch != wp:
+        return corr1d_bwd_mfma(rp, cam, cam_mm, dl, B, h, wc, wp, rp_pitch=pitch)
     dcam = torch.empty_like(cam)
     drp = torch.empty_like(rp)
     _C.check(_L().efgh_corr1d_bwd(ptr(rp), ptr(cam), ptr(cam_mm), ptr(dl), c_int32(B), c_int32(h), c_int32(wc),

@@ -304,6 +304,15 @@ int efgh_corr_pack_cam(const float *cam, const float *cam_mm, int32_t B, int32_t
                        int32_t nseg, int32_t nsplit, float *Wc, void *stream);
 int efgh_corr_fold(const float *P, int32_t B, int32_t nsplit, int64_t Mv, int32_t ldp, int32_t nseg, int32_t segw,
                    int32_t nj, float *logit, float *score, void *stream);
+/* MFMA formulation of the correlation's backward (adjoint of fnet.py:78-81 w.r.t. both feature maps): with the operands as
+ * planes [(y,c)][position] (efgh_corr_planes; `mm` != NULL also applies the 1/(max-min) normalisation) and the Toeplitz matrix
+ * of d(logit) (efgh_corr_toeplitz: T[r][c] = dl[c-r], or dl[r-c] when transpose), both gradients are batched mode-0
+ * efgh_gather_gemm products; efgh_corr_unplanes restores the [y][position][c] layout.                                          */
+int efgh_corr_planes(const float *x, const float *mm, int32_t B, int32_t h, int32_t w, int32_t w_in_pitch, int32_t wP,
+                     float *out, void *stream);
+int efgh_corr_unplanes(const float *in, int32_t B, int32_t h, int32_t w, int32_t wP, float *out, void *stream);
+int efgh_corr_toeplitz(const float *dl, int32_t B, int32_t nj, int32_t rows, int32_t cols, int32_t colsP, int32_t transpose,
+                       float *T, void *stream);
 
 /* Winograd F(4,3) (along the image row) form of the "same" 3x3 / stride-1 convolutions of nets/vgg.py:77 and
  * nets/resnet.py:22-30 (and of their data gradients): six GEMMs of depth 3C over 4-pixel tiles, half the MFMA

@@ -167,20 +167,32 @@ def test_bcl_level_backward():
     assert _relerr(m.blur_conv[2].weight.grad.cpu(), P['b.blur_conv.2.weight'].grad) < 2e-4
 
 
-def test_corr_head_backward():
+@pytest.mark.parametrize('mfma', [True, False])
+@pytest.mark.parametrize('h,wc,wr', [(9, 21, 85), (8, 37, 150), (3, 5, 24)])
+def test_corr_head_backward(mfma, h, wc, wr):
+    """forward + both gradients of the F correlation head: VALU kernels and the Toeplitz-GEMM (MFMA) formulation"""
+    from efgh_amd import ops
     from efgh_amd.nets import fn as FN
     from oracle import efgh_oracle as O
     torch.manual_seed(5)
-    cam = torch.randn(1, 16, 9, 21, requires_grad=True)
-    rng = torch.randn(1, 16, 9, 85, requires_grad=True)
-    c = cam / (cam.max() - cam.min())
-    r = rng / (rng.max() - rng.min())
-    ref = torch.sigmoid(F.conv2d(O.circular_assign(r, int(85 / 8)), c).view(1, -1) / 16)
+    cam = torch.randn(2, 16, h, wc, requires_grad=True)
+    rng = torch.randn(2, 16, h, wr, requires_grad=True)
+    refs = []
+    for b in range(2):                                 # B independent evaluations (SURVEY 8a-0)
+        c = cam[b:b + 1] / (cam[b].max() - cam[b].min())
+        r = rng[b:b + 1] / (rng[b].max() - rng[b].min())
+        refs.append(torch.sigmoid(F.conv2d(O.circular_assign(r, int(wr / 8)), c).view(1, -1) / 16))
+    ref = torch.cat(refs, 0)
     g = torch.randn_like(ref)
     ref.backward(g)
     cg, rg = _nhwc(cam.detach()).cuda().requires_grad_(True), _nhwc(rng.detach()).cuda().requires_grad_(True)
-    s = FN.CorrHeadFn.apply(cg, rg)
-    s.backward(g.cuda())
+    old = ops.USE_MFMA_CORR
+    ops.USE_MFMA_CORR = mfma
+    try:
+        s = FN.CorrHeadFn.apply(cg, rg)
+        s.backward(g.cuda())
+    finally:
+        ops.USE_MFMA_CORR = old
     assert _relerr(s.detach().cpu(), ref.detach()) < 1e-5
     assert _relerr(cg.grad.permute(0, 3, 1, 2).cpu(), cam.grad) < 2e-4
     assert _relerr(rg.grad.permute(0, 3, 1, 2).cpu(), rng.grad) < 2e-4
