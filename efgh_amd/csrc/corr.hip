@@ -233,6 +233,59 @@ __global__ void k_corr_toeplitz(const float *__restrict__ dl, int nj, int rows, 
     }
 }
 
+
+// ---- backward of x_n = x / (max(x) - min(x)) per sample (fnet.py:57,64) -------------------------------------------
+// dx = dxn/d - [x == max] * S/(d^2 k_max) + [x == min] * S/(d^2 k_min),  S = sum(dxn * x), d = max - min,
+// k_* = number of elements attaining the extremum (torch's max()/min() backward splits the gradient evenly among ties)
+__global__ void __launch_bounds__(TPB)
+k_norm_bwd_part(const float *__restrict__ x, const float *__restrict__ dxn, const float *__restrict__ mm, long long n,
+                int G, float *__restrict__ part) {
+    const int b = blockIdx.y, g = blockIdx.x;
+    const float *px = x + (long long)b * n, *pd = dxn + (long long)b * n;
+    const float mn = mm[b * 2], mx = mm[b * 2 + 1];
+    float s = 0.f, kmx = 0.f, kmn = 0.f;
+    for (long long i = (long long)g * TPB + threadIdx.x; i < n; i += (long long)G * TPB) {
+        const float v = px[i];
+        s += pd[i] * v;
+        kmx += v == mx ? 1.f : 0.f;
+        kmn += v == mn ? 1.f : 0.f;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); kmx += __shfl_xor(kmx, o); kmn += __shfl_xor(kmn, o); }
+    __shared__ float sh[3][TPB / 64];
+    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = s; sh[1][threadIdx.x >> 6] = kmx; sh[2][threadIdx.x >> 6] = kmn; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < TPB / 64; ++i) { s += sh[0][i]; kmx += sh[1][i]; kmn += sh[2][i]; }
+        float *o = part + ((long long)b * G + g) * 3;
+        o[0] = s; o[1] = kmx; o[2] = kmn;
+    }
+}
+
+__global__ void __launch_bounds__(TPB)
+k_norm_bwd_apply(const float *__restrict__ x, const float *__restrict__ dxn, const float *__restrict__ mm,
+                 const float *__restrict__ part, long long n, int G, float *__restrict__ dx) {
+    const int b = blockIdx.y;
+    __shared__ float tot[3];
+    if (threadIdx.x < 3) {
+        double a = 0.0;
+        for (int g = 0; g < G; ++g) a += part[((long long)b * G + g) * 3 + threadIdx.x];
+        tot[threadIdx.x] = (float)a;
+    }
+    __syncthreads();
+    const float mn = mm[b * 2], mx = mm[b * 2 + 1], d = mx - mn;
+    const float cmx = tot[0] / (d * d) / tot[1], cmn = tot[0] / (d * d) / tot[2];
+    const float *px = x + (long long)b * n, *pd = dxn + (long long)b * n;
+    float *po = dx + (long long)b * n;
+    for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < n; i += (long long)gridDim.x * TPB) {
+        const float v = px[i];
+        float r = pd[i] / d;
+        if (v == mx) r -= cmx;
+        if (v == mn) r += cmn;
+        po[i] = r;
+    }
+}
+
 }  // namespace
 
 extern "C" int32_t efgh_minmax_groups(int64_t n) {
@@ -316,6 +369,18 @@ extern "C" int efgh_corr_toeplitz(const float *dl, int32_t B, int32_t nj, int32_
     long long g = (total + TPB - 1) / TPB;
     k_corr_toeplitz<<<dim3((unsigned)(g > 4096 ? 4096 : g), B), TPB, 0, (hipStream_t)stream_>>>(dl, nj, rows, cols, colsP,
                                                                                                transpose, T);
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}
+
+extern "C" int efgh_norm_bwd(const float *x, const float *dxn, const float *mm, int32_t B, int64_t n, float *part,
+                             float *dx, void *stream_) {
+    hipStream_t st = (hipStream_t)stream_;
+    EFGH_CHECK_ARG(x && dxn && mm && part && dx && B > 0 && n > 0);
+    const int G = efgh_minmax_groups(n);
+    k_norm_bwd_part<<<dim3(G, B), TPB, 0, st>>>(x, dxn, mm, n, G, part);
+    long long g = (n + TPB - 1) / TPB;
+    k_norm_bwd_apply<<<dim3((unsigned)(g > 2048 ? 2048 : g), B), TPB, 0, st>>>(x, dxn, mm, part, n, G, dx);
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
 }

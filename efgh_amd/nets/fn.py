@@ -358,17 +358,4 @@ class CorrHeadFn(torch.autograd.Function):
         dcam_n, drp = ops.corr1d_bwd(rp, cam, cam_mm, dl, B, h, wc, wr + 2 * off)
         drng_n = ops.corr_unpad(drp, B, h, wr, C, off)
 
-        def norm_bwd(x, mm, dxn):
-            # x_n = x / (max - min): dx = dxn/d, d(max) -= S/d^2, d(min) += S/d^2 with S = sum(dxn*x)
-            d = (mm[:, 1] - mm[:, 0]).view(B, 1, 1, 1)
-            S = (dxn * x).flatten(1).sum(1)
-            dx = dxn / d
-            flat = x.flatten(1)
-            imax, imin = flat.argmax(1), flat.argmin(1)
-            corr = S / (d.view(B) ** 2)
-            dxf = dx.flatten(1)
-            ar = torch.arange(B, device=x.device)
-            dxf[ar, imax] -= corr
-            dxf[ar, imin] += corr
-            return dxf.view_as(x)
-        return norm_bwd(cam, cam_mm, dcam_n), norm_bwd(rng, rng_mm, drng_n)
+        return ops.norm_bwd(cam, dcam_n.contiguous(), cam_mm), ops.norm_bwd(rng, drng_n.contiguous(), rng_mm)

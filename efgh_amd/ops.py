@@ -564,6 +564,17 @@ def corr1d_bwd(rp, cam, cam_mm, dl, B, h, wc, wp):
     return dcam, drp
 
 
+def norm_bwd(x, dxn, mm):
+    """gradient of x / (max(x) - min(x)) per sample given d/d(x_n); x, dxn [B][...] contiguous"""
+    B = x.shape[0]
+    n = x.numel() // B
+    G = _L().efgh_minmax_groups(c_int64(n))
+    part = torch.empty((B, G, 3), dtype=torch.float32, device=x.device)
+    dx = torch.empty_like(x)
+    _C.check(_L().efgh_norm_bwd(ptr(x), ptr(dxn), ptr(mm), c_int32(B), c_int64(n), ptr(part), ptr(dx), _st()))
+    return dx
+
+
 def corr_unpad(drp, B, h, w, C, off):
     dx = torch.empty((B, h, w, C), dtype=torch.float32, device=drp.device)
     _C.check(_L().efgh_corr_unpad(ptr(drp), c_int32(B), c_int32(h), c_int32(w), c_int32(C), c_int32(off), ptr(dx),

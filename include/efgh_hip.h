@@ -308,6 +308,9 @@ int efgh_corr_fold(const float *P, int32_t B, int32_t nsplit, int64_t Mv, int32_
  * planes [(y,c)][position] (efgh_corr_planes; `mm` != NULL also applies the 1/(max-min) normalisation) and the Toeplitz matrix
  * of d(logit) (efgh_corr_toeplitz: T[r][c] = dl[c-r], or dl[r-c] when transpose), both gradients are batched mode-0
  * efgh_gather_gemm products; efgh_corr_unplanes restores the [y][position][c] layout.                                          */
+/* backward of the per-sample normalisation x/(max-min) (fnet.py:57,64): dx = dxn/d -/+ S/(d^2 k) at the elements attaining
+ * max / min (S = sum dxn*x, k = number of ties, as torch's max()/min() backward); part has 3*efgh_minmax_groups(n) floats per sample */
+int efgh_norm_bwd(const float *x, const float *dxn, const float *mm, int32_t B, int64_t n, float *part, float *dx, void *stream);
 int efgh_corr_planes(const float *x, const float *mm, int32_t B, int32_t h, int32_t w, int32_t w_in_pitch, int32_t wP,
                      float *out, void *stream);
 int efgh_corr_unplanes(const float *in, int32_t B, int32_t h, int32_t w, int32_t wP, float *out, void *stream);
