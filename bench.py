@@ -87,12 +87,14 @@ def dump_shapes(prof, path):
             fh.write('%s | %d %.2f %.1f\n' % (' '.join(map(str, key)), n, ms, f / (ms * 1e-3) / 1e12 if ms > 0 else 0))
 
 
-def committed_traffic():
-    """HBM bytes per k_gather_gemm launch from the committed rocprofv3 PMC passes (FETCH_SIZE doubled as
-    MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE); collected offline on the forward workload,
-    see profiles/README.md.  PMC collection cannot run inside the timed region."""
+def committed_traffic(family, workload='train'):
+    """HBM-side bytes per launch of one kernel family from the committed rocprofv3 PMC passes (FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE; tools/collect_traffic.py), collected offline on the same
+    bench command, see profiles/README.md.  PMC collection cannot run inside the timed region."""
     try:
-        return json.load(open(os.path.join(ROOT, 'profiles', 'r01_gemm_hbm_traffic.json')))['per_launch']['traffic_bytes']
+        f = 'r01_hbm_traffic_train.json' if workload == 'train' else 'r01_gemm_hbm_traffic.json'
+        d = json.load(open(os.path.join(ROOT, 'profiles', f)))['per_launch']
+        return d[family]['traffic_bytes'] if workload == 'train' else (d['traffic_bytes'] if family == 'gemm' else None)
     except Exception:
         return None
 
@@ -105,8 +107,8 @@ def gemm_roofline(prof, steps, kernel):
     n = len(prof)
     ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     return {'bound': 'mfma', 'kernel': kernel, 'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-            'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': committed_traffic() if 'wgrad' not in kernel else None,
-            'traffic_unit': 'bytes per launch (committed PMC pass on the forward workload)',
+            'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
+            'traffic_unit': 'HBM-side bytes per launch (committed rocprofv3 PMC passes of this bench command, profiles/)',
             'launches_per_step': n / max(1, steps),
             'avg_launch_ms': ms / max(1, n), 'algorithmic_gflop_per_launch': fl / max(1, n) / 1e9,
             'kernel_ms_per_step': ms / max(1, steps)}
@@ -120,7 +122,7 @@ KERNELS = {
 }
 
 
-def rooflines(prof, steps):
+def rooflines(prof, steps, workload='train'):
     """`roofline` = the kernel with the most time in the timed region; the other MFMA kernels as roofline_<name>.
     For k_wino43 `achieved` counts the ALGORITHMIC (direct-form, 2*M*N*9*C) FLOPs as the contract asks; the kernel
     executes half of them on the MFMA pipe, reported as `mfma_executed_frac`."""
@@ -128,8 +130,7 @@ def rooflines(prof, steps):
     for name, lst in prof.items():
         if lst:
             r = gemm_roofline(lst, steps, KERNELS[name])
-            if name != 'gemm':
-                r['traffic'] = None
+            r['traffic'] = committed_traffic(name, workload)
             if name.startswith('wino'):
                 r['mfma_executed_tflops'] = r['achieved'] / 2
                 r['mfma_executed_frac'] = r['frac'] / 2
@@ -222,7 +223,7 @@ def main():
                'value': world * Bf * a.steps / dt, 'unit': 'frame-pairs/s', 'ms_per_step': dt / a.steps * 1e3,
                'workload': 'BASELINE.json configs[1]: EFGHNet forward only (eval), batch=%d per GPU' % Bf,
                }
-        fwd.update(rooflines(prof, a.steps))
+        fwd.update(rooflines(prof, a.steps, 'fwd'))
         # opt-in fast math (NOT the default; `value` above is exact fp32 MFMA): split MFMA with fp32 accumulation.
         #   f16x3 : x = hi + lo*2^-11 in fp16, 3 fp16 MFMAs per fp32 product, ~2^-22 per product (fp32-equivalent,
         #           |x| < 65504);  bf16x3: x = hi + lo in bf16, ~2^-17 per product.  Both keep the pose logits

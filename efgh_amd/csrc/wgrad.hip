@@ -31,6 +31,7 @@ struct WArgs {
     int N;
     long long M; int mchunk;
     float *dW;                       // [N][K], pre-zeroed
+    unsigned kt, nt;
 };
 
 // TN = 128: waves 2(n) x 2(k), each 64x64;  TN = 64 (layers with <= 64 outputs): waves 1 x 4, each 64(n) x 32(k)
@@ -44,8 +45,13 @@ k_gather_wgrad(const WArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = TN == 128 ? (wave >> 1) : 0, wk = TN == 128 ? (wave & 1) : wave;
     const int l31 = lane & 31, lh = lane >> 5;
-    const int k0 = blockIdx.x * TK, n0 = blockIdx.y * TN;
-    const long long mbeg = (long long)blockIdx.z * p.mchunk;
+    // XCD-aware order (see k_wino_wgrad): all (k, n) blocks of one m-chunk run back to back on one XCD and share its L2
+    const unsigned nblk = gridDim.x, q8 = nblk >> 3, r8 = nblk & 7, xcd = blockIdx.x & 7, within = blockIdx.x >> 3;
+    const unsigned lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + within;
+    const unsigned per_z = p.kt * p.nt, bz = lin / per_z, rem = lin - bz * per_z;
+    const unsigned by = rem / p.kt, bx = rem - by * p.kt;
+    const int k0 = bx * TK, n0 = by * TN;
+    const long long mbeg = (long long)bz * p.mchunk;
     long long mend = mbeg + p.mchunk;
     if (mend > p.M) mend = p.M;
     if (mbeg >= mend) return;
@@ -236,12 +242,13 @@ extern "C" int efgh_gather_wgrad(const efgh_gemm_desc *d, const float *G, int64_
     if (chunk < 256) chunk = 256;
     a.mchunk = (int)chunk;
     long long zs = (d->M + chunk - 1) / chunk;
-    EFGH_CHECK_ARG(zs <= 65535);
+    EFGH_CHECK_ARG(zs * kt * nt < 0x7fffffffLL);
+    a.kt = (unsigned)kt; a.nt = (unsigned)nt;
     if (hipMemsetAsync(dWp, 0, (size_t)a.N * a.K * 4, st) != hipSuccess) {
         efgh_set_error("wgrad: memset failed");
         return EFGH_E_LAUNCH;
     }
-    dim3 grid(kt, nt, (unsigned)zs);
+    const unsigned grid = (unsigned)(zs * kt * nt);
     if (TN == 128) {
         if (d->mode == 0) k_gather_wgrad<0, 128><<<grid, 256, 0, st>>>(a);
         else if (d->mode == 1) k_gather_wgrad<1, 128><<<grid, 256, 0, st>>>(a);

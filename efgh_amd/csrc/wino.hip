@@ -266,6 +266,7 @@ struct WinoWArgs {
     int B, H, W, TW;
     long long Mt; long long tchunk;
     float *S;                      // [6][N][3C], pre-zeroed
+    unsigned kt, nt;               // column / row blocks of S
 };
 
 __global__ void __launch_bounds__(256, 2) k_wino_wgrad(const WinoWArgs p) {
@@ -273,10 +274,17 @@ __global__ void __launch_bounds__(256, 2) k_wino_wgrad(const WinoWArgs p) {
     __shared__ __attribute__((aligned(16))) float Vs[6 * TT * 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave >> 1, wc = wave & 1, l31 = lane & 31, lh = lane >> 5;
-    const int k0 = blockIdx.x * 64;                   // column block inside [3][C]
+    // XCD-aware order: consecutive workgroups are dealt round-robin over the 8 XCDs; give every XCD one contiguous band of
+    // tile ranges and run all (n, kh, c) blocks of a range back to back on it, so that the x / dy rows they share are
+    // fetched from HBM once (measured before: 4.3 GB fetched per launch for ~0.9 GB of operands)
+    const unsigned nblk = gridDim.x, q8 = nblk >> 3, r8 = nblk & 7, xcd = blockIdx.x & 7, within = blockIdx.x >> 3;
+    const unsigned lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + within;
+    const unsigned per_z = p.kt * p.nt, bz = lin / per_z, rem = lin - bz * per_z;
+    const unsigned by = rem / p.kt, bx = rem - by * p.kt;
+    const int k0 = bx * 64;                           // column block inside [3][C]
     const int kh = k0 / p.C, c0 = k0 - kh * p.C;
-    const int n0 = blockIdx.y * 64;
-    const long long tbeg = (long long)blockIdx.z * p.tchunk;
+    const int n0 = by * 64;
+    const long long tbeg = (long long)bz * p.tchunk;
     long long tend = tbeg + p.tchunk;
     if (tend > p.Mt) tend = p.Mt;
     if (tbeg >= tend) return;
@@ -481,13 +489,14 @@ extern "C" int efgh_wino_wgrad(const efgh_gemm_desc *d, const float *G, int64_t 
     if (chunk < 8 * TT) chunk = 8 * TT;
     a.tchunk = chunk;
     const long long zs = (a.Mt + chunk - 1) / chunk;
-    EFGH_CHECK_ARG(zs <= 65535);
+    EFGH_CHECK_ARG(zs * kt * nt < 0x7fffffffLL);
+    a.kt = (unsigned)kt; a.nt = (unsigned)nt;
     const size_t sbytes = (size_t)6 * d->N * 3 * d->C * 4;
     if (hipMemsetAsync(S, 0, sbytes, st) != hipSuccess) {
         efgh_set_error("wino wgrad: memset failed");
         return EFGH_E_LAUNCH;
     }
-    k_wino_wgrad<<<dim3(kt, nt, (unsigned)zs), 256, 0, st>>>(a);
+    k_wino_wgrad<<<(unsigned)(zs * kt * nt), 256, 0, st>>>(a);
     EFGH_CHECK_LAUNCH();
     const long long total = (long long)d->N * 3 * d->C;
     long long g = (total + 255) / 256;
