@@ -62,6 +62,108 @@ k_splat_bwd(const float *__restrict__ gsplat, const float *__restrict__ wsum, in
     }
 }
 
+
+// ---- CSR form of the splat (no floating-point atomics) ---------------------------------------------------------
+// The scatter-add above spends its time in same-address fp32 atomics (17 points per vertex on level 0).  Inverting
+// `off` once per level - count per vertex, exclusive scan, fill - turns the splat into a gather: one lane group per
+// vertex walks its (point, remainder) list, sums bary * feat rows in registers and writes the normalised row once.
+__global__ void __launch_bounds__(TPB)
+k_csr_count(const int *__restrict__ off, long long n4, int *__restrict__ cnt) {
+    for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < n4; i += (long long)gridDim.x * TPB)
+        atomicAdd(&cnt[off[i]], 1);
+}
+
+// exclusive scan of cnt[0..H) in three phases (1024 elements per block)
+__global__ void __launch_bounds__(TPB)
+k_scan_local(const int *__restrict__ in, int H, int *__restrict__ out, int *__restrict__ block_sum) {
+    __shared__ int wsum_[TPB / 64];
+    const int base = blockIdx.x * 1024 + threadIdx.x * 4;
+    int v[4], s = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { v[q] = base + q < H ? in[base + q] : 0; s += v[q]; }
+    int incl = s;                                  // inclusive scan of the per-thread sums across the block
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(incl, o); if ((threadIdx.x & 63) >= o) incl += t; }
+    if ((threadIdx.x & 63) == 63) wsum_[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) woff += wsum_[w];
+    int run = woff + incl - s;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { if (base + q < H) out[base + q] = run; run += v[q]; }
+    if (threadIdx.x == TPB - 1) block_sum[blockIdx.x] = woff + incl;
+}
+
+__global__ void __launch_bounds__(TPB)
+k_scan_blocksums(int *__restrict__ block_sum, int nb, int *__restrict__ total) {
+    __shared__ int buf[TPB];
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < nb; base += TPB) {
+        const int i = base + threadIdx.x;
+        const int v = i < nb ? block_sum[i] : 0;
+        buf[threadIdx.x] = v;
+        __syncthreads();
+        for (int o = 1; o < TPB; o <<= 1) {
+            int t = threadIdx.x >= o ? buf[threadIdx.x - o] : 0;
+            __syncthreads();
+            buf[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < nb) block_sum[i] = carry + buf[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == TPB - 1) carry += buf[TPB - 1];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+
+__global__ void __launch_bounds__(TPB)
+k_scan_add(int *__restrict__ out, int H, const int *__restrict__ block_sum, const int *__restrict__ total) {
+    const int i = blockIdx.x * TPB + threadIdx.x;
+    if (i < H) out[i] += block_sum[i >> 10];
+    if (i == 0) out[H] = *total;
+}
+
+__global__ void __launch_bounds__(TPB)
+k_csr_fill(const int *__restrict__ off, long long n4, const int *__restrict__ start, int *__restrict__ fill,
+           int *__restrict__ list) {
+    for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < n4; i += (long long)gridDim.x * TPB) {
+        const int h = off[i];
+        list[start[h] + atomicAdd(&fill[h], 1)] = (int)i;           // entry id = r*n + p
+    }
+}
+
+// G lanes per vertex (G = power of two >= C/4, <= 64): lane g owns channels 4g.. (+ 4G.. when C/4 > G)
+template <int G>
+__global__ void __launch_bounds__(TPB)
+k_splat_gather(const float *__restrict__ feat, long long ldf, int C, const float *__restrict__ bary, int n,
+               const int *__restrict__ start, const int *__restrict__ list, int H, float *__restrict__ splat,
+               float *__restrict__ wsum) {
+    const int c4n = C >> 2;
+    const int g = threadIdx.x % G;
+    const long long h = ((long long)blockIdx.x * TPB + threadIdx.x) / G;
+    if (h >= H) return;
+    const int e0 = start[h], e1 = start[h + 1];
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+    float w = 0.f;
+    for (int e = e0; e < e1; ++e) {
+        const int id = list[e];
+        const int p = id % n;
+        const float b = bary[id];
+        w += b;
+        const float4 *row = reinterpret_cast<const float4 *>(feat + (long long)p * ldf);
+        if (g < c4n) { float4 f = row[g]; a0.x += b * f.x; a0.y += b * f.y; a0.z += b * f.z; a0.w += b * f.w; }
+        if (g + G < c4n) { float4 f = row[g + G]; a1.x += b * f.x; a1.y += b * f.y; a1.z += b * f.z; a1.w += b * f.w; }
+    }
+    const float nrm = 1.0f / (w + 1e-5f);
+    float4 *dst = reinterpret_cast<float4 *>(splat + h * C);
+    if (g < c4n) dst[g] = make_float4(a0.x * nrm, a0.y * nrm, a0.z * nrm, a0.w * nrm);
+    if (g + G < c4n) dst[g + G] = make_float4(a1.x * nrm, a1.y * nrm, a1.z * nrm, a1.w * nrm);
+    if (g == 0) wsum[h] = w;
+}
+
 int grid_for(long long total) {
     long long g = (total + TPB - 1) / TPB;
     return (int)(g > 16384 ? 16384 : (g < 1 ? 1 : g));
@@ -88,6 +190,48 @@ extern "C" int efgh_splat_bwd(const float *gsplat, const float *wsum, int32_t C,
     hipStream_t st = (hipStream_t)stream_;
     EFGH_CHECK_ARG(gsplat && wsum && bary && off && gfeat && n > 0 && H > 0 && C % 4 == 0 && ldg % 4 == 0);
     k_splat_bwd<<<grid_for((long long)n * (C / 4)), TPB, 0, st>>>(gsplat, wsum, C, bary, off, n, gfeat, ldg);
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}
+
+extern "C" int64_t efgh_splat_csr_workspace_ints(int32_t n, int32_t H) {
+    return (int64_t)H + 1 /*start*/ + H /*fill*/ + 4LL * n /*list*/ + (H + 1023) / 1024 + 2 /*block sums, total*/;
+}
+
+// off [4][n] (vertex of every (remainder, point)) -> CSR: start [H+1], list [4n] (entry ids r*n + p grouped by vertex)
+extern "C" int efgh_splat_csr_build(const int32_t *off, int32_t n, int32_t H, int32_t *ws, void *stream_) {
+    hipStream_t st = (hipStream_t)stream_;
+    EFGH_CHECK_ARG(off && ws && n > 0 && H > 0);
+    int *start = ws, *fill = ws + H + 1, *list = fill + H, *bsum = list + 4LL * n;
+    const int nb = (H + 1023) / 1024;
+    int *total = bsum + nb;
+    if (hipMemsetAsync(start, 0, (size_t)(2 * (long long)H + 1) * 4, st) != hipSuccess) {
+        efgh_set_error("splat csr: memset failed");
+        return EFGH_E_LAUNCH;
+    }
+    const long long n4 = 4LL * n;
+    k_csr_count<<<grid_for(n4), TPB, 0, st>>>(off, n4, fill);           // counts into `fill`, scanned into `start`
+    k_scan_local<<<nb, TPB, 0, st>>>(fill, H, start, bsum);
+    k_scan_blocksums<<<1, TPB, 0, st>>>(bsum, nb, total);
+    k_scan_add<<<cdiv(H, TPB), TPB, 0, st>>>(start, H, bsum, total);
+    if (hipMemsetAsync(fill, 0, (size_t)H * 4, st) != hipSuccess) {
+        efgh_set_error("splat csr: memset failed");
+        return EFGH_E_LAUNCH;
+    }
+    k_csr_fill<<<grid_for(n4), TPB, 0, st>>>(off, n4, start, fill, list);
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}
+
+extern "C" int efgh_splat_gather(const float *feat, int64_t ldf, int32_t C, const float *bary, int32_t n, int32_t H,
+                                 const int32_t *ws, float *splat, float *wsum, void *stream_) {
+    hipStream_t st = (hipStream_t)stream_;
+    EFGH_CHECK_ARG(feat && bary && ws && splat && wsum && n > 0 && H > 0 && C > 0 && C % 4 == 0 && C <= 512 && ldf % 4 == 0);
+    const int *start = ws, *list = ws + 2LL * H + 1;
+    const int c4n = C / 4;
+    if (c4n <= 16) k_splat_gather<16><<<cdiv((long long)H * 16, TPB), TPB, 0, st>>>(feat, ldf, C, bary, n, start, list, H, splat, wsum);
+    else if (c4n <= 32) k_splat_gather<32><<<cdiv((long long)H * 32, TPB), TPB, 0, st>>>(feat, ldf, C, bary, n, start, list, H, splat, wsum);
+    else k_splat_gather<64><<<cdiv((long long)H * 64, TPB), TPB, 0, st>>>(feat, ldf, C, bary, n, start, list, H, splat, wsum);
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
 }

@@ -299,10 +299,27 @@ def softmax2_to_nchw(x):
 # ----------------------------------------------------------------------------------------------
 # BCL splat
 # ----------------------------------------------------------------------------------------------
+USE_CSR_SPLAT = _os.environ.get('EFGH_CSR_SPLAT', '1') != '0'
+
+
+def splat_csr(off, n, H):
+    """vertex -> (remainder, point) lists of one lattice level (efgh_splat_csr_build), cached on the `off` tensor"""
+    def make():
+        ws = torch.empty(_L().efgh_splat_csr_workspace_ints(c_int32(n), c_int32(H)), dtype=torch.int32, device=off.device)
+        _C.check(_L().efgh_splat_csr_build(ptr(off), c_int32(n), c_int32(H), ptr(ws), _st()))
+        return ws
+    return _cached(off, ('csr', n, H), (off._version, off.data_ptr()), make)
+
+
 def splat_fwd(feat, C, bary, off, H):
     n = feat.shape[0]
     splat = torch.empty((H, C), dtype=torch.float32, device=feat.device)
     wsum = torch.empty((H,), dtype=torch.float32, device=feat.device)
+    if USE_CSR_SPLAT and C <= 512 and off.is_contiguous() and bary.is_contiguous():
+        ws = splat_csr(off, n, H)
+        _C.check(_L().efgh_splat_gather(ptr(feat), c_int64(feat.stride(0)), c_int32(C), ptr(bary), c_int32(n), c_int32(H),
+                                        ptr(ws), ptr(splat), ptr(wsum), _st()))
+        return splat, wsum
     _C.check(_L().efgh_splat_fwd(ptr(feat), c_int64(feat.stride(0)), c_int32(C), ptr(bary), ptr(off), c_int32(n),
                                  c_int32(H), ptr(splat), ptr(wsum), _st()))
     return splat, wsum

@@ -253,3 +253,30 @@ def test_winograd_conv3x3_vs_direct_and_fp64(L, cin, cout, hw, B):
         yb = L.conv2d(L.Ctx(True), xg, cg, bng, L.ACT_RELU, 0.0)
     assert _rel(yb.permute(0, 3, 1, 2).cpu(), refb) < 2e-5
     assert _rel(bng.running_var.cpu(), bn.running_var) < 1e-5 and _rel(bng.running_mean.cpu(), bn.running_mean) < 1e-4
+
+
+@pytest.mark.parametrize('C', [36, 68, 132, 260, 4])
+def test_splat_csr_equals_atomic_and_reference_sum(C):
+    """CSR gather splat (no fp32 atomics) == the atomic scatter form == a float64 scatter-add, incl. empty vertices"""
+    from efgh_amd import lattice, ops, synthetic as syn
+    pc = syn.lidar_sweep(4096, 3)
+    lv = lattice.build_pyramid(torch.from_numpy(pc).cuda(), (1.0,))[0]
+    n, H = 4096, lv.H + 5                                # 5 vertices nobody splats onto
+    feat = torch.randn(n, C, device='cuda')
+    out = {}
+    for csr in (True, False):
+        ops.USE_CSR_SPLAT = csr
+        try:
+            out[csr] = ops.splat_fwd(feat, C, lv.bary, lv.off, H)
+        finally:
+            ops.USE_CSR_SPLAT = True
+    ref = torch.zeros((H, C), dtype=torch.float64)
+    w = torch.zeros(H, dtype=torch.float64)
+    off, bary = lv.off.cpu().long(), lv.bary.cpu().double()
+    for r in range(4):
+        ref.index_add_(0, off[r], bary[r][:, None] * feat.cpu().double())
+        w.index_add_(0, off[r], bary[r])
+    ref = ref / (w[:, None] + 1e-5)
+    for csr in (True, False):
+        assert _rel(out[csr][0].cpu().double(), ref) < 2e-6 and _rel(out[csr][1].cpu().double(), w) < 2e-6, (C, csr)
+    assert float(out[True][0][lv.H:].abs().max()) == 0.0 and float(out[True][1][lv.H:].abs().max()) == 0.0
