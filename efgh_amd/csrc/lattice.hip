@@ -113,9 +113,12 @@ k_point_keys(const float *__restrict__ pts, int64_t cstride, int n, float scale3
         for (int j = 0; j < 5; ++j) b5[j] = __fmul_rn(b5[j], 0.25f);
         b5[0] = __fadd_rn(b5[0], __fadd_rn(1.0f, b5[4]));
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            bary[(int64_t)r * n + p] = b5[r];
-            emg_out[(int64_t)p * emg_ps + r * emg_rs] = emg[r];
+        for (int r = 0; r < 4; ++r) bary[(int64_t)r * n + p] = b5[r];
+        if (emg_rs == 1 && (emg_ps & 3) == 0)       // channels 0..3 of the level's feature row: one 16-B store
+            *reinterpret_cast<float4 *>(emg_out + (int64_t)p * emg_ps) = make_float4(emg[0], emg[1], emg[2], emg[3]);
+        else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) emg_out[(int64_t)p * emg_ps + r * emg_rs] = emg[r];
         }
         int g[4];
 #pragma unroll
@@ -137,8 +140,31 @@ k_point_keys(const float *__restrict__ pts, int64_t cstride, int n, float scale3
     }
     if (sid) {      // several samples in one launch: per-sample extrema
         const int b = p < n ? sid[p] : -1;
+        // the usual case - the whole block belongs to one sample: LDS reduction, 8 atomics per block (the per-wave
+        // form put 8 atomics per wave on the same 8 words per sample: ~65k serialised atomics at level 0, batch 4)
+        const int bb = sid[(long long)blockIdx.x * TPB < n ? (long long)blockIdx.x * TPB : 0];
+        if (__syncthreads_and(b == bb || b < 0)) {
+            __shared__ int bmin[4][TPB / 64], bmax[4][TPB / 64];
+            const int lane_ = threadIdx.x & 63, w_ = threadIdx.x >> 6;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                int a = kmin[c], z = kmax[c];
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) { a = min(a, __shfl_xor(a, o)); z = max(z, __shfl_xor(z, o)); }
+                if (lane_ == 0) { bmin[c][w_] = a; bmax[c][w_] = z; }
+            }
+            __syncthreads();
+            if (threadIdx.x < 4) {
+                const int c = threadIdx.x;
+                int a = bmin[c][0], z = bmax[c][0];
+                for (int i = 1; i < TPB / 64; ++i) { a = min(a, bmin[c][i]); z = max(z, bmax[c][i]); }
+                atomicMin(&mm[8 * bb + c], a);
+                atomicMax(&mm[8 * bb + 4 + c], z);
+            }
+            return;
+        }
         const int b0 = __shfl(b, 0);
-        if (__all(b == b0 || b < 0)) {           // the usual case: the whole wave belongs to one sample
+        if (__all(b == b0 || b < 0)) {           // a block straddling two samples: per-wave reduction
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 int a = kmin[c], z = kmax[c];
