@@ -135,28 +135,46 @@ k_csr_fill(const int *__restrict__ off, long long n4, const int *__restrict__ st
     }
 }
 
-// G lanes per vertex (G = power of two >= C/4, <= 64): lane g owns channels 4g.. (+ 4G.. when C/4 > G)
+// One wave per vertex: G lanes across the channels (lane g owns channels 4g.. and 4(g+G)..) x S = 64/G entry slots, so
+// S list entries of the vertex are in flight at once (the walk is a chain of dependent loads: list -> bary, feat row);
+// the S partial sums are folded with shuffles at the end.
 template <int G>
 __global__ void __launch_bounds__(TPB)
 k_splat_gather(const float *__restrict__ feat, long long ldf, int C, const float *__restrict__ bary, int n,
                const int *__restrict__ start, const int *__restrict__ list, int H, float *__restrict__ splat,
                float *__restrict__ wsum) {
+    constexpr int S = 64 / G;
     const int c4n = C >> 2;
-    const int g = threadIdx.x % G;
-    const long long h = ((long long)blockIdx.x * TPB + threadIdx.x) / G;
+    const int lane = threadIdx.x & 63, g = lane % G, sl = lane / G;
+    const long long h = (long long)blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
     if (h >= H) return;
     const int e0 = start[h], e1 = start[h + 1];
     float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
     float w = 0.f;
-    for (int e = e0; e < e1; ++e) {
-        const int id = list[e];
-        const int p = id % n;
-        const float b = bary[id];
-        w += b;
-        const float4 *row = reinterpret_cast<const float4 *>(feat + (long long)p * ldf);
-        if (g < c4n) { float4 f = row[g]; a0.x += b * f.x; a0.y += b * f.y; a0.z += b * f.z; a0.w += b * f.w; }
-        if (g + G < c4n) { float4 f = row[g + G]; a1.x += b * f.x; a1.y += b * f.y; a1.z += b * f.z; a1.w += b * f.w; }
+    // two entries per slot and trip (both ids first, then both rows): halves the dependent-load chain
+    for (int e = e0 + sl; e < e1; e += 2 * S) {
+        const bool two = e + S < e1;
+        const int id0 = list[e], id1 = two ? list[e + S] : id0;
+        const float b0 = bary[id0], b1 = two ? bary[id1] : 0.f;
+        const float4 *r0 = reinterpret_cast<const float4 *>(feat + (long long)(id0 % n) * ldf);
+        const float4 *r1 = reinterpret_cast<const float4 *>(feat + (long long)(id1 % n) * ldf);
+        w += b0 + b1;
+        if (g < c4n) {
+            const float4 f0 = r0[g], f1 = r1[g];
+            a0.x += b0 * f0.x + b1 * f1.x; a0.y += b0 * f0.y + b1 * f1.y; a0.z += b0 * f0.z + b1 * f1.z; a0.w += b0 * f0.w + b1 * f1.w;
+        }
+        if (g + G < c4n) {
+            const float4 f0 = r0[g + G], f1 = r1[g + G];
+            a1.x += b0 * f0.x + b1 * f1.x; a1.y += b0 * f0.y + b1 * f1.y; a1.z += b0 * f0.z + b1 * f1.z; a1.w += b0 * f0.w + b1 * f1.w;
+        }
     }
+#pragma unroll
+    for (int o = G; o < 64; o <<= 1) {
+        w += __shfl_xor(w, o);
+        a0.x += __shfl_xor(a0.x, o); a0.y += __shfl_xor(a0.y, o); a0.z += __shfl_xor(a0.z, o); a0.w += __shfl_xor(a0.w, o);
+        a1.x += __shfl_xor(a1.x, o); a1.y += __shfl_xor(a1.y, o); a1.z += __shfl_xor(a1.z, o); a1.w += __shfl_xor(a1.w, o);
+    }
+    if (sl != 0) return;
     const float nrm = 1.0f / (w + 1e-5f);
     float4 *dst = reinterpret_cast<float4 *>(splat + h * C);
     if (g < c4n) dst[g] = make_float4(a0.x * nrm, a0.y * nrm, a0.z * nrm, a0.w * nrm);
@@ -229,9 +247,10 @@ extern "C" int efgh_splat_gather(const float *feat, int64_t ldf, int32_t C, cons
     EFGH_CHECK_ARG(feat && bary && ws && splat && wsum && n > 0 && H > 0 && C > 0 && C % 4 == 0 && C <= 512 && ldf % 4 == 0);
     const int *start = ws, *list = ws + 2LL * H + 1;
     const int c4n = C / 4;
-    if (c4n <= 16) k_splat_gather<16><<<cdiv((long long)H * 16, TPB), TPB, 0, st>>>(feat, ldf, C, bary, n, start, list, H, splat, wsum);
-    else if (c4n <= 32) k_splat_gather<32><<<cdiv((long long)H * 32, TPB), TPB, 0, st>>>(feat, ldf, C, bary, n, start, list, H, splat, wsum);
-    else k_splat_gather<64><<<cdiv((long long)H * 64, TPB), TPB, 0, st>>>(feat, ldf, C, bary, n, start, list, H, splat, wsum);
+    const int grid = cdiv(H, TPB / 64);
+    if (c4n <= 16) k_splat_gather<16><<<grid, TPB, 0, st>>>(feat, ldf, C, bary, n, start, list, H, splat, wsum);
+    else if (c4n <= 32) k_splat_gather<32><<<grid, TPB, 0, st>>>(feat, ldf, C, bary, n, start, list, H, splat, wsum);
+    else k_splat_gather<64><<<grid, TPB, 0, st>>>(feat, ldf, C, bary, n, start, list, H, splat, wsum);
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
 }
