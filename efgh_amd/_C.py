@@ -47,6 +47,8 @@ def lib():
             getattr(_lib, name).restype = c_int64
             getattr(_lib, name).argtypes = [c_int32]
         _lib.efgh_splat_csr_workspace_ints.restype = c_int64
+        _lib.efgh_table_csr_workspace_ints.restype = c_int64
+        _lib.efgh_table_csr_workspace_ints.argtypes = [c_int64]
         _lib.efgh_splat_csr_workspace_ints.argtypes = [c_int32, c_int32]
     return _lib
 

@@ -182,6 +182,55 @@ k_splat_gather(const float *__restrict__ feat, long long ldf, int C, const float
     if (g == 0) wsum[h] = w;
 }
 
+
+// ---- adjoint of the neighbour gather (bilateralNN.py:240-242) as a CSR gather: dst[h][c] = sum over (m, t) with
+// table[m][t] == h of src[m][t*C + c].  Same inversion as the splat, over the [M][16] neighbour table (entries < 0 skipped).
+__global__ void __launch_bounds__(TPB)
+k_tcsr_count(const int *__restrict__ table, long long total, int T, int *__restrict__ cnt) {
+    for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
+        const int h = table[i];
+        if ((int)(i & 15) < T && h >= 0) atomicAdd(&cnt[h], 1);
+    }
+}
+
+__global__ void __launch_bounds__(TPB)
+k_tcsr_fill(const int *__restrict__ table, long long total, int T, const int *__restrict__ start, int *__restrict__ fill,
+            int *__restrict__ list) {
+    for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
+        const int h = table[i];
+        if ((int)(i & 15) < T && h >= 0) list[start[h] + atomicAdd(&fill[h], 1)] = (int)i;      // entry id = m*16 + t
+    }
+}
+
+template <int G>
+__global__ void __launch_bounds__(TPB)
+k_table_gather_add(const float *__restrict__ src, int T, int C, const int *__restrict__ start,
+                   const int *__restrict__ list, int H, float *__restrict__ dst) {
+    constexpr int S = 64 / G;
+    const int c4n = C >> 2;
+    const int lane = threadIdx.x & 63, g = lane % G, sl = lane / G;
+    const long long h = (long long)blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
+    if (h >= H) return;
+    const int e0 = start[h], e1 = start[h + 1];
+    const long long ld = (long long)T * C;
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+    for (int e = e0 + sl; e < e1; e += S) {
+        const int id = list[e];
+        const float4 *row = reinterpret_cast<const float4 *>(src + (long long)(id >> 4) * ld + (long long)(id & 15) * C);
+        if (g < c4n) { float4 f = row[g]; a0.x += f.x; a0.y += f.y; a0.z += f.z; a0.w += f.w; }
+        if (g + G < c4n) { float4 f = row[g + G]; a1.x += f.x; a1.y += f.y; a1.z += f.z; a1.w += f.w; }
+    }
+#pragma unroll
+    for (int o = G; o < 64; o <<= 1) {
+        a0.x += __shfl_xor(a0.x, o); a0.y += __shfl_xor(a0.y, o); a0.z += __shfl_xor(a0.z, o); a0.w += __shfl_xor(a0.w, o);
+        a1.x += __shfl_xor(a1.x, o); a1.y += __shfl_xor(a1.y, o); a1.z += __shfl_xor(a1.z, o); a1.w += __shfl_xor(a1.w, o);
+    }
+    if (sl != 0) return;
+    float4 *d = reinterpret_cast<float4 *>(dst + h * C);
+    if (g < c4n) d[g] = a0;
+    if (g + G < c4n) d[g + G] = a1;
+}
+
 int grid_for(long long total) {
     long long g = (total + TPB - 1) / TPB;
     return (int)(g > 16384 ? 16384 : (g < 1 ? 1 : g));
@@ -251,6 +300,41 @@ extern "C" int efgh_splat_gather(const float *feat, int64_t ldf, int32_t C, cons
     if (c4n <= 16) k_splat_gather<16><<<grid, TPB, 0, st>>>(feat, ldf, C, bary, n, start, list, H, splat, wsum);
     else if (c4n <= 32) k_splat_gather<32><<<grid, TPB, 0, st>>>(feat, ldf, C, bary, n, start, list, H, splat, wsum);
     else k_splat_gather<64><<<grid, TPB, 0, st>>>(feat, ldf, C, bary, n, start, list, H, splat, wsum);
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}
+
+extern "C" int64_t efgh_table_csr_workspace_ints(int64_t M) {
+    return 2 * M + 1 + 16 * M + (M + 1023) / 1024 + 2;
+}
+
+// dst [M][C] = adjoint of the gather through table [M][16] (first T columns) applied to src [M][T*C]; ws as above
+extern "C" int efgh_table_gather_add(const float *src, const int32_t *table, int64_t M, int32_t T, int32_t C, int32_t *ws,
+                                     float *dst, void *stream_) {
+    hipStream_t st = (hipStream_t)stream_;
+    EFGH_CHECK_ARG(src && table && ws && dst && M > 0 && M < (1 << 27) && T > 0 && T <= 16 && C > 0 && C % 4 == 0 && C <= 512);
+    const int H = (int)M;
+    int *start = ws, *fill = ws + H + 1, *list = fill + H, *bsum = list + 16LL * M;
+    const int nb = (H + 1023) / 1024;
+    int *total = bsum + nb;
+    if (hipMemsetAsync(start, 0, (size_t)(2 * (long long)H + 1) * 4, st) != hipSuccess) {
+        efgh_set_error("table csr: memset failed");
+        return EFGH_E_LAUNCH;
+    }
+    const long long tot = 16LL * M;
+    k_tcsr_count<<<grid_for(tot), TPB, 0, st>>>(table, tot, T, fill);
+    k_scan_local<<<nb, TPB, 0, st>>>(fill, H, start, bsum);
+    k_scan_blocksums<<<1, TPB, 0, st>>>(bsum, nb, total);
+    k_scan_add<<<cdiv(H, TPB), TPB, 0, st>>>(start, H, bsum, total);
+    if (hipMemsetAsync(fill, 0, (size_t)H * 4, st) != hipSuccess) {
+        efgh_set_error("table csr: memset failed");
+        return EFGH_E_LAUNCH;
+    }
+    k_tcsr_fill<<<grid_for(tot), TPB, 0, st>>>(table, tot, T, start, fill, list);
+    const int c4n = C / 4, grid = cdiv(H, TPB / 64);
+    if (c4n <= 16) k_table_gather_add<16><<<grid, TPB, 0, st>>>(src, T, C, start, list, H, dst);
+    else if (c4n <= 32) k_table_gather_add<32><<<grid, TPB, 0, st>>>(src, T, C, start, list, H, dst);
+    else k_table_gather_add<64><<<grid, TPB, 0, st>>>(src, T, C, start, list, H, dst);
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
 }

@@ -485,6 +485,11 @@ def unpack_weight(Wp, W, N, T, C, Cp, sn, sc, st, taps, accumulate=False):
 
 
 def table_scatter_add(src, table, M, T, C, dst):
+    """dst[table[m][t]][c] += src[m][t*C+c]; with USE_CSR_SPLAT the CSR gather form (dst is overwritten: callers pass zeros)"""
+    if USE_CSR_SPLAT and C <= 512 and dst.shape[0] == M:
+        ws = torch.empty(_L().efgh_table_csr_workspace_ints(c_int64(M)), dtype=torch.int32, device=src.device)
+        _C.check(_L().efgh_table_gather_add(ptr(src), ptr(table), c_int64(M), c_int32(T), c_int32(C), ptr(ws), ptr(dst), _st()))
+        return
     _C.check(_L().efgh_table_scatter_add(ptr(src), ptr(table), c_int64(M), c_int32(T), c_int32(C), ptr(dst), _st()))
 
 

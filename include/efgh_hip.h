@@ -232,6 +232,11 @@ int efgh_unpack_weight(const float *Wp, float *W, int32_t N, int32_t T, int32_t 
 /* dst[table[m*16+t]][c] += src[m][t*C+c]  (adjoint of the neighbour gather, bilateralNN.py:240-242) */
 int efgh_table_scatter_add(const float *src, const int32_t *table, int64_t M, int32_t T, int32_t C,
                            float *dst, void *stream);
+/* the same adjoint without floating-point atomics: the table is inverted into a CSR (ws: efgh_table_csr_workspace_ints(M)
+ * int32) and every destination row is summed by one wave; dst is fully written (no pre-zeroing).  C <= 512.            */
+int64_t efgh_table_csr_workspace_ints(int64_t M);
+int efgh_table_gather_add(const float *src, const int32_t *table, int64_t M, int32_t T, int32_t C, int32_t *ws, float *dst,
+                          void *stream);
 /* BatchNorm(+residual)+activation backward, two passes.
  * reduce: dpre = dy*act'(y); sum_dpre[c], sum_dpre_xhat[c] (= dbeta, dgamma) and their means;
  *         mean/invstd/raw NULL -> only sum_dpre (bias gradient).  part: [efgh_bwd_groups(M)][2][C].
