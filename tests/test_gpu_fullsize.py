@@ -118,3 +118,34 @@ def test_fullsize_lattice_invariants(full):
             src = torch.nonzero(nbr[:, t] >= 0)[:, 0]
             back = nbr[nbr[src, t], inv[t]]
             assert float((back == src).float().mean()) > 0.999
+
+
+def test_kitti_odom_geometry_forward_vs_oracle(manifest):
+    """BASELINE configs[4] geometry: KITTI-odometry frames (1241x376 -> raw_cam_img_size [352, 1216], 64-beam sweep
+    sub-sampled to 65 536 points): whole eval forward, E/H logits against the oracle, output shapes and invariants"""
+    from efgh_amd.nets import EFGHBackbone
+    from oracle import efgh_oracle as O
+    raw, npts = (352, 1216), 65536
+    m = EFGHBackbone(syn.default_args(raw, 'cuda'))
+    P = syn.synthetic_state_dict(manifest['state_dict'], 1)
+    m.load_state_dict(P, strict=True)
+    m = m.cuda().eval()
+    b = syn.make_batch(raw, npts, 2)
+    inp = [torch.from_numpy(b[k]).cuda() for k in ('pc', 'img', 'calib', 'A')]
+    with torch.no_grad():
+        out = m(*inp)
+    assert out['f_score'].dim() == 2 and out['f_score'].shape[0] == 2
+    assert out['g_depth'].shape == (2, 1, 352, 1216) and out['g_mask'].shape == (2, 2, 352, 1216)
+    assert out['h_img'].shape == (2, 3, 176, 608)
+    for k, v in out.items():
+        if torch.is_tensor(v):
+            assert torch.isfinite(v).all(), k
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    with torch.no_grad():
+        for s in range(2):                               # B independent evaluations (SURVEY 8a-0)
+            pc1, img1 = inp[0][s:s + 1].cpu(), inp[1][s:s + 1].cpu()
+            rete, reth = O.enet(P, pc1, False), O.hnet(P, img1, False)
+            for k in ('e_gn_sgn', 'e_gn_abs'):
+                assert _rel(out[k][s:s + 1].cpu().numpy(), rete[k].numpy()) < 1e-4, (k, s)
+            for k in ('h_hrzn_sgn', 'h_hrzn_abs'):
+                assert _rel(out[k][s:s + 1].cpu().numpy(), reth[k].numpy()) < 1e-4, (k, s)
