@@ -14,6 +14,7 @@ import torch.nn.functional as F
 
 from .. import ops
 from ..common import pose
+from ..nets import fn as FN
 
 
 class EFGHCriterion(nn.Module):
@@ -112,15 +113,13 @@ class EFGHCriterion(nn.Module):
         gt['g_l'] = pose.translation_matrix(gcp)
         rawH, rawW = self.raw_cam_img_size
         with torch.no_grad():
-            gdep, _ = ops.depth_image(pc, f32(gt['cam_T_velo']), rawH, rawW)   # [B][H][W][4]
-            gt['g_depth'] = gdep[..., 3].unsqueeze(1).contiguous()
-            gt['g_mask'] = (gt['g_depth'] > 0).float()
+            gdep, _ = ops.depth_image(pc, f32(gt['cam_T_velo']), rawH, rawW)   # [B][H][W][4], depth = channel 3
         gt['img_mask'] = torch.as_tensor(gt['img_mask']).to(dev)
-        valid = (gt['g_depth'] > 0) & (gt['img_mask'] > 0)
+        imask = gt['img_mask'].to(torch.uint8).contiguous()
         l_trs = F.smooth_l1_loss(gt['g_trs'], pred['g_trs'])
-        diff = (gt['g_depth'] - pred['g_depth']) * valid
-        l_dep = (diff ** 2).sum() / valid.sum()
-        l_msk = F.binary_cross_entropy(pred['g_mask'][:, 0].reshape(B, -1), gt['g_mask'].view(B, -1)) * lam['g_mask']
+        # masked L2 on the depth image + BCE on the mask image: one HIP sweep forward, one backward (loss_utils.py:186-199)
+        l_dep, l_msk_mean, gt['g_depth'], gt['g_mask'] = FN.GImageLossFn.apply(pred['g_depth'], pred['g_mask'], gdep, imask)
+        l_msk = l_msk_mean * lam['g_mask']
         L['g_trs'] = l_trs * lam['g_trs']
         L['g_depth'] = l_dep * lam['g_depth']
         L['g_mask'] = l_msk * lam['g_depth']

@@ -359,3 +359,22 @@ class CorrHeadFn(torch.autograd.Function):
         drng_n = ops.corr_unpad(drp, B, h, wr, C, off)
 
         return ops.norm_bwd(cam, dcam_n.contiguous(), cam_mm), ops.norm_bwd(rng, drng_n.contiguous(), rng_mm)
+
+
+class GImageLossFn(torch.autograd.Function):
+    """(l_depth, l_mask) of Gloss over the full-resolution depth / mask images (loss_utils.py:186-199), one HIP sweep each way"""
+
+    @staticmethod
+    def forward(ctx, pred_depth, pred_mask, gdep4, img_mask):
+        pred_depth, pred_mask = pred_depth.contiguous(), pred_mask.contiguous()
+        out3, gt_depth, gt_mask = ops.gimg_loss_fwd(pred_depth, pred_mask, gdep4, img_mask)
+        ctx.save_for_backward(pred_depth, pred_mask, gt_depth, img_mask, out3)
+        ctx.mark_non_differentiable(gt_depth, gt_mask)
+        return out3[0], out3[1], gt_depth, gt_mask
+
+    @staticmethod
+    def backward(ctx, g_dep, g_msk, _a, _b):
+        pred_depth, pred_mask, gt_depth, img_mask, out3 = ctx.saved_tensors
+        d_depth, d_mask = ops.gimg_loss_bwd(pred_depth, pred_mask, gt_depth, img_mask, out3,
+                                            g_dep.reshape(1).float().contiguous(), g_msk.reshape(1).float().contiguous())
+        return d_depth, d_mask, None, None

@@ -613,3 +613,30 @@ def convt_col2im(Y, B, Hin, Win, Ho, Wo, O, pad, scale, shift, act, slope, out):
 def convt_im2col(G, B, Hin, Win, Ho, Wo, O, pad, Ycol):
     _C.check(_L().efgh_convt_im2col(ptr(G), c_int64(G.shape[-1]), c_int32(B), c_int32(Hin), c_int32(Win), c_int32(Ho),
                                     c_int32(Wo), c_int32(O), c_int32(pad), ptr(Ycol), c_int64(Ycol.shape[-1]), _st()))
+
+
+# ----------------------------------------------------------------------------------------------
+# G image losses (losses/loss_utils.py:186-199)
+# ----------------------------------------------------------------------------------------------
+def gimg_loss_fwd(pred_depth, pred_mask, gdep4, img_mask):
+    """-> (out3 = [l_depth, l_mask, sum(valid)] device tensor, gt_depth (B,1,H,W), gt_mask (B,1,H,W))"""
+    B, _, H, W = pred_depth.shape
+    dev = pred_depth.device
+    gt_depth = torch.empty((B, 1, H, W), dtype=torch.float32, device=dev)
+    gt_mask = torch.empty((B, 1, H, W), dtype=torch.float32, device=dev)
+    G = _L().efgh_gimg_loss_groups(c_int64(B * H * W))
+    part = torch.empty((G, 3), dtype=torch.float64, device=dev)
+    out3 = torch.empty(3, dtype=torch.float32, device=dev)
+    _C.check(_L().efgh_gimg_loss_fwd(ptr(pred_depth), ptr(pred_mask), c_int64(pred_mask.stride(0)), ptr(gdep4), ptr(img_mask),
+                                     c_int32(B), c_int64(H * W), ptr(gt_depth), ptr(gt_mask), ptr(part), ptr(out3), _st()))
+    return out3, gt_depth, gt_mask
+
+
+def gimg_loss_bwd(pred_depth, pred_mask, gt_depth, img_mask, out3, g_depth, g_mask):
+    B, _, H, W = pred_depth.shape
+    d_depth = torch.empty_like(pred_depth)
+    d_mask = torch.zeros_like(pred_mask)                   # channel 1 receives no gradient from this loss
+    _C.check(_L().efgh_gimg_loss_bwd(ptr(pred_depth), ptr(pred_mask), c_int64(pred_mask.stride(0)), ptr(gt_depth), ptr(img_mask),
+                                     c_int32(B), c_int64(H * W), ptr(out3), ptr(g_depth), ptr(g_mask), ptr(d_depth), ptr(d_mask),
+                                     c_int64(d_mask.stride(0)), _st()))
+    return d_depth, d_mask

@@ -386,6 +386,20 @@ int efgh_prep_gather_transform(const float *pcd, const int32_t *keep_idx, const 
 int efgh_pose_errors(const float *gt, const float *pred, int32_t B, int32_t mode, float *rot_err, float *trs_err,
                      void *stream);
 
+/* ------------------------------------------------------------------ G image losses -----------------
+ * losses/loss_utils.py:186-199: l_depth = sum(valid*(gt_depth - pred_depth)^2)/sum(valid), valid = gt_depth > 0 & img_mask > 0;
+ * l_mask = mean BCE(pred_mask[:,0], gt_depth > 0) (torch's -100 log clamp).  gdep4 is efgh_depth_image's [B][H][W][4] output
+ * (depth = channel 3); gt_depth / gt_mask (B,1,H,W) are written for the gt dict; part: 3*efgh_gimg_loss_groups(B*HW) doubles;
+ * out3 = {l_depth, l_mask, sum(valid)} on the device.  The backward call writes both prediction gradients given the two
+ * upstream scalars (device pointers).  *_bstride: batch stride in floats of channel 0 of the (B,2,H,W) mask tensors.        */
+int32_t efgh_gimg_loss_groups(int64_t n);
+int efgh_gimg_loss_fwd(const float *pred_depth, const float *pred_mask, int64_t mask_bstride, const float *gdep4,
+                       const uint8_t *img_mask, int32_t B, int64_t HW, float *gt_depth, float *gt_mask, double *part,
+                       float *out3, void *stream);
+int efgh_gimg_loss_bwd(const float *pred_depth, const float *pred_mask, int64_t mask_bstride, const float *gt_depth,
+                       const uint8_t *img_mask, int32_t B, int64_t HW, const float *sums3, const float *g_depth,
+                       const float *g_mask, float *d_pred_depth, float *d_pred_mask, int64_t dmask_bstride, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -259,3 +259,27 @@ def test_training_step_vs_oracle_and_golden(golden_dir, manifest, monkeypatch):
     med_f = sorted(e for e, _ in errs['F'])[len(errs['F']) // 2]
     assert med_f < 5e-2, (med_f, worst['F'])
     print('grad rel err: ' + ', '.join('%s max %.1e' % (n, worst[n][0]) for n in 'EHFG') + ', F median %.1e' % med_f)
+
+
+def test_g_image_losses_vs_torch_autograd():
+    """GImageLossFn (masked L2 on the depth image + BCE on the mask image) against the torch expressions of loss_utils.py:186-199"""
+    from efgh_amd.nets import fn as FN
+    torch.manual_seed(3)
+    B, H, W = 2, 37, 53
+    pd = torch.randn(B, 1, H, W, requires_grad=True)
+    pm = torch.softmax(torch.randn(B, 2, H, W) * 3, 1).requires_grad_(True)
+    gd = torch.relu(torch.randn(B, 1, H, W)) * 5
+    gd[0, 0, :5] = 0
+    im = (torch.rand(B, 1, H, W) > 0.3).to(torch.uint8)
+    valid = (gd > 0) & (im > 0)
+    l_dep = (((gd - pd) * valid) ** 2).sum() / valid.sum()
+    l_msk = F.binary_cross_entropy(pm[:, 0].reshape(B, -1), (gd > 0).float().view(B, -1))
+    (3.0 * l_dep + 0.5 * l_msk).backward()
+    gdep4 = torch.zeros(B, H, W, 4)
+    gdep4[..., 3] = gd[:, 0]
+    pdg, pmg = pd.detach().cuda().requires_grad_(True), pm.detach().cuda().requires_grad_(True)
+    a, b, gtd, gtm = FN.GImageLossFn.apply(pdg, pmg, gdep4.cuda(), im.cuda())
+    (3.0 * a + 0.5 * b).backward()
+    assert abs(float(a) - float(l_dep)) < 1e-5 * float(l_dep) and abs(float(b) - float(l_msk)) < 1e-5 * float(l_msk)
+    assert torch.equal(gtd.cpu(), gd) and torch.equal(gtm.cpu(), (gd > 0).float())
+    assert _relerr(pdg.grad.cpu(), pd.grad) < 1e-5 and _relerr(pmg.grad.cpu(), pm.grad) < 1e-5
