@@ -39,3 +39,37 @@ def test_trainer_two_steps_match_torch_adam(manifest):
         prev = losses['total'].item()
     assert all(p.data_ptr() >= tr.flat.w.data_ptr() for p in tr.flat.params)
     assert set(m.state_dict().keys()) == {k for k, _, _ in manifest['state_dict']}
+
+
+def test_winograd_and_direct_kernels_give_the_same_first_training_step(manifest):
+    """the 3x3 layers on the Winograd kernels (forward, dgrad, wgrad) vs the same step on the direct kernels: same losses and
+    the same per-sub-net gradients up to the conditioning bands of DESIGN.md §4 (the first step, before the trajectories can
+    diverge through the discontinuous heads)"""
+    from efgh_amd import ops
+    from efgh_amd.losses import EFGHCriterion
+    from efgh_amd.nets import EFGHBackbone
+    from efgh_amd.train import Trainer
+    args = syn.default_args(RAW, 'cuda')
+    b = syn.make_batch(RAW, NPTS, 2)
+    inp = [torch.from_numpy(b[k]).cuda() for k in ('pc', 'img', 'calib', 'A')]
+    gt = {k: torch.from_numpy(v) for k, v in b['gt'].items()}
+    res = {}
+    for wino in (True, False):
+        ops.USE_WINO = ops.USE_WINO_WGRAD = wino
+        try:
+            m = EFGHBackbone(args)
+            m.load_state_dict(syn.synthetic_state_dict(manifest['state_dict'], 1))
+            tr = Trainer(m.cuda(), EFGHCriterion(args), lr=1e-3)
+            losses, _ = tr.step(*inp, gt)
+            names = [n for n, _ in m.named_parameters()]
+            res[wino] = ({k: float(v) for k, v in losses.items()},
+                         {n: p.grad.detach().clone() for n, p in zip(names, tr.flat.params)})
+        finally:
+            ops.USE_WINO = ops.USE_WINO_WGRAD = True
+    for k, v in res[True][0].items():
+        assert abs(v - res[False][0][k]) <= 2e-4 * max(1.0, abs(res[False][0][k])), (k, v, res[False][0][k])
+    band = {'E': 1e-3, 'H': 1e-3, 'F': 0.4, 'G': 3e-2}
+    for net, tol in band.items():
+        num = sum(float((res[True][1][n] - res[False][1][n]).double().pow(2).sum()) for n in res[True][1] if n.startswith(net + '.'))
+        den = sum(float(res[False][1][n].double().pow(2).sum()) for n in res[True][1] if n.startswith(net + '.'))
+        assert (num / max(den, 1e-30)) ** 0.5 < tol, (net, (num / max(den, 1e-30)) ** 0.5)
