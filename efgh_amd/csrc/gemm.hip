@@ -291,8 +291,10 @@ k_gather_gemm(const KArgs p_in) {
         __syncthreads();
         if (ch + 1 < nchunks) load_chunk((ch + 1) * BK);
         if (MATH == 0) {
-#pragma unroll
+            const int kleft = p.K - ch * BK;          // a ragged last chunk (K = 36 for the 4-channel input convs) skips its
+#pragma unroll                                        // all-zero groups of 8
             for (int g = 0; g < 4; ++g) {
+                if (g * 8 >= kleft) continue;
                 float4 a[MI], b[NI];
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
