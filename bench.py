@@ -22,6 +22,7 @@ sys.path.insert(0, ROOT)
 
 RAW = (768, 2560)          # raw camera size -> img 3x384x1280, range image 4x384x5120, depth 4x768x2560
 NPTS = 64 * 2048
+PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s peak (6.3 TB/s measured streaming)
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 
 
@@ -127,7 +128,10 @@ def rooflines(prof, steps, workload='train'):
     For k_wino43 `achieved` counts the ALGORITHMIC (direct-form, 2*M*N*9*C) FLOPs as the contract asks; the kernel
     executes half of them on the MFMA pipe, reported as `mfma_executed_frac`."""
     rl = {}
+    bcl = prof.get('bcl')
     for name, lst in prof.items():
+        if name == 'bcl':
+            continue
         if lst:
             r = gemm_roofline(lst, steps, KERNELS[name])
             r['traffic'] = committed_traffic(name, workload)
@@ -139,6 +143,14 @@ def rooflines(prof, steps, workload='train'):
         return {}
     top = max(rl, key=lambda k: rl[k]['kernel_ms_per_step'])
     out = {'roofline': rl[top]}
+    if bcl:     # the HBM-bound side of the path: BCL splat (CSR inversion + gather), SURVEY 8d algorithmic bytes / event time
+        ms = sum(e0.elapsed_time(e1) for e0, e1, _ in bcl)
+        by = sum(b for _, _, b in bcl)
+        ach = by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        out['roofline_bcl'] = {'bound': 'hbm', 'kernel': 'BCL splat (k_csr_count/scan/fill + k_splat_gather), all five levels',
+                               'achieved': ach, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': ach / PEAK_HBM_GBS, 'traffic': None,
+                               'launches_per_step': len(bcl) / max(1, steps), 'kernel_ms_per_step': ms / max(1, steps),
+                               'algorithmic_mb_per_step': by / max(1, steps) / 1e6}
     for k, v in rl.items():
         if k != top:
             out['roofline_' + k] = v
@@ -197,15 +209,15 @@ def main():
         for _ in range(warmup):
             fn()
         barrier()
-        ops.PROFILE, ops.PROFILE_WGRAD, ops.PROFILE_WINO, ops.PROFILE_WINO_WGRAD = [], [], [], []
+        ops.PROFILE, ops.PROFILE_WGRAD, ops.PROFILE_WINO, ops.PROFILE_WINO_WGRAD, ops.PROFILE_BCL = [], [], [], [], []
         t0 = time.perf_counter()
         for _ in range(steps):
             fn()
         barrier()
         dt = max_over_ranks(time.perf_counter() - t0)
         prof = {'gemm': ops.PROFILE, 'wgrad': ops.PROFILE_WGRAD, 'wino': ops.PROFILE_WINO,
-                'wino_wgrad': ops.PROFILE_WINO_WGRAD}
-        ops.PROFILE = ops.PROFILE_WGRAD = ops.PROFILE_WINO = ops.PROFILE_WINO_WGRAD = None
+                'wino_wgrad': ops.PROFILE_WINO_WGRAD, 'bcl': ops.PROFILE_BCL}
+        ops.PROFILE = ops.PROFILE_WGRAD = ops.PROFILE_WINO = ops.PROFILE_WINO_WGRAD = ops.PROFILE_BCL = None
         return dt, prof
 
     out = None

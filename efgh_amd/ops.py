@@ -311,14 +311,23 @@ def splat_csr(off, n, H):
     return _cached(off, ('csr', n, H), (off._version, off.data_ptr()), make)
 
 
+PROFILE_BCL = None      # bench.py: (start_event, end_event, algorithmic_bytes) per splat (CSR inversion included)
+
+
 def splat_fwd(feat, C, bary, off, H):
     n = feat.shape[0]
     splat = torch.empty((H, C), dtype=torch.float32, device=feat.device)
     wsum = torch.empty((H,), dtype=torch.float32, device=feat.device)
+    if PROFILE_BCL is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     if USE_CSR_SPLAT and C <= 512 and off.is_contiguous() and bary.is_contiguous():
         ws = splat_csr(off, n, H)
         _C.check(_L().efgh_splat_gather(ptr(feat), c_int64(feat.stride(0)), c_int32(C), ptr(bary), c_int32(n), c_int32(H),
                                         ptr(ws), ptr(splat), ptr(wsum), _st()))
+        if PROFILE_BCL is not None:
+            e1.record()
+            PROFILE_BCL.append((e0, e1, float(n) * (4 * C + 48) + float(H) * (4 * C + 4)))      # SURVEY 8d bytes
         return splat, wsum
     _C.check(_L().efgh_splat_fwd(ptr(feat), c_int64(feat.stride(0)), c_int32(C), ptr(bary), ptr(off), c_int32(n),
                                  c_int32(H), ptr(splat), ptr(wsum), _st()))
