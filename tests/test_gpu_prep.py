@@ -91,3 +91,23 @@ def test_cpu_tensors_are_refused_by_prep():
     from efgh_amd.data import prepare as P
     with pytest.raises(EfghError):
         P.preproc_img(np.zeros((8, 8, 3), np.uint8), P.preproc_gt(0, 0, 0, 0, 0, 0, 0.1), (8, 8), device='cpu')
+
+
+def test_points_edge_cases():
+    """no survivor of the radius box; exactly num_points survivors; lidar-line reduction with python's negative indexing"""
+    from efgh_amd.data import prepare as P
+    from oracle import prep_oracle as PO
+    gts = P.preproc_gt(0.2, 0.1, -0.3, 1.0, -2.0, 0.5, 0.0)
+    far = np.full((300, 4), 80.0, np.float32)
+    out = P.preproc_pcd(far, gts, 128).cpu().numpy()
+    assert np.allclose(out, gts['rand_init_l'][:3, 3:4].astype(np.float32))             # all columns = T @ (0,0,0,1)
+    rng = np.random.default_rng(0)
+    pts = rng.uniform(-40, 40, (256, 4)).astype(np.float32)
+    got = P.preproc_pcd(pts, gts, 256).cpu().numpy()                                     # n_keep == num_points: no sampling
+    ref = PO.preproc_pcd(pts, gts, 256)[:3].astype(np.float32)
+    assert np.abs(got - ref).max() <= 1e-5
+    sweep = rng.uniform(-45, 45, (64 * 50 + 7, 4)).astype(np.float32)
+    idx = np.arange(1000)
+    got = P.preproc_pcd(sweep, gts, 1000, lidar_line=16, sampled_indices=idx).cpu().numpy()
+    ref = PO.preproc_pcd(sweep, gts, 1000, lidar_line=16, sampled_indices=idx)[:3].astype(np.float32)
+    assert np.abs(got - ref).max() <= 1e-5
