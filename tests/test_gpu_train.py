@@ -73,3 +73,15 @@ def test_winograd_and_direct_kernels_give_the_same_first_training_step(manifest)
         num = sum(float((res[True][1][n] - res[False][1][n]).double().pow(2).sum()) for n in res[True][1] if n.startswith(net + '.'))
         den = sum(float(res[False][1][n].double().pow(2).sum()) for n in res[True][1] if n.startswith(net + '.'))
         assert (num / max(den, 1e-30)) ** 0.5 < tol, (net, (num / max(den, 1e-30)) ** 0.5)
+
+
+def test_example_loop_runs_end_to_end():
+    """GPU sample preparation -> model -> criterion -> Trainer -> device-side Err meter (examples/train_synthetic.py)"""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'examples', 'train_synthetic.py')
+    spec = importlib.util.spec_from_file_location('train_synthetic', path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    hist = mod.main(['--iters', '2', '--batch', '2', '--raw', '128', '256', '--points', '2048'])
+    assert len(hist) == 2 and all(np.isfinite(h) for h in hist)
