@@ -20,13 +20,17 @@ k_act_bn_bwd_reduce(const float *__restrict__ dy, long long lddy, const float *_
                     const float *__restrict__ raw, long long ldraw, const float *__restrict__ mean,
                     const float *__restrict__ invstd, const float *__restrict__ pscale,
                     const float *__restrict__ pshift, long long M, int C, int act, float slope, int rows_per_block,
-                    int CL, float *__restrict__ part) {
-    __shared__ float4 s1s[TPB], s2s[TPB];
+                    int CL, double *__restrict__ part) {
+    // The column sums are accumulated in float64 (as torch's CPU batch-norm backward does, acc_type<float> = double):
+    // mean(dpre) and mean(dpre*xhat) are subtracted from EVERY row, so a 1e-7 relative error in them is a systematic
+    // bias of draw that the following weight gradient multiplies by the channel mean of the layer input - with nearly
+    // constant feature maps (the G translation head at config S) that was a 10-25 % error of the upstream gradients.
+    __shared__ double s1s[TPB][4], s2s[TPB][4];
     const int cl = threadIdx.x % CL, rl = threadIdx.x / CL, RL = TPB / CL;
     const int c = (blockIdx.x * CL + cl) * 4;
     long long r0 = (long long)blockIdx.y * rows_per_block, r1 = r0 + rows_per_block;
     if (r1 > M) r1 = M;
-    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+    double s1[4] = {0., 0., 0., 0.}, s2[4] = {0., 0., 0., 0.};
     if (c < C) {
         float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), is = mu, psc = mu, psh = mu;
         if (mean) { mu = *reinterpret_cast<const float4 *>(mean + c); is = *reinterpret_cast<const float4 *>(invstd + c); }
@@ -40,28 +44,31 @@ k_act_bn_bwd_reduce(const float *__restrict__ dy, long long lddy, const float *_
             else yy = make_float4(rw.x * psc.x + psh.x, rw.y * psc.y + psh.y, rw.z * psc.z + psh.z, rw.w * psc.w + psh.w);
             g.x *= dact(yy.x, act, slope); g.y *= dact(yy.y, act, slope);
             g.z *= dact(yy.z, act, slope); g.w *= dact(yy.w, act, slope);
-            s1.x += g.x; s1.y += g.y; s1.z += g.z; s1.w += g.w;
+            s1[0] += (double)g.x; s1[1] += (double)g.y; s1[2] += (double)g.z; s1[3] += (double)g.w;
             if (mean) {
-                s2.x += g.x * ((rw.x - mu.x) * is.x); s2.y += g.y * ((rw.y - mu.y) * is.y);
-                s2.z += g.z * ((rw.z - mu.z) * is.z); s2.w += g.w * ((rw.w - mu.w) * is.w);
+                s2[0] += (double)g.x * (double)((rw.x - mu.x) * is.x); s2[1] += (double)g.y * (double)((rw.y - mu.y) * is.y);
+                s2[2] += (double)g.z * (double)((rw.z - mu.z) * is.z); s2[3] += (double)g.w * (double)((rw.w - mu.w) * is.w);
             }
         }
     }
-    s1s[threadIdx.x] = s1; s2s[threadIdx.x] = s2;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { s1s[threadIdx.x][q] = s1[q]; s2s[threadIdx.x][q] = s2[q]; }
     __syncthreads();
     if (rl != 0 || c >= C) return;
-    for (int i = 1; i < RL; ++i) {
-        float4 a = s1s[i * CL + cl], b = s2s[i * CL + cl];
-        s1.x += a.x; s1.y += a.y; s1.z += a.z; s1.w += a.w; s2.x += b.x; s2.y += b.y; s2.z += b.z; s2.w += b.w;
+    for (int i = 1; i < RL; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { s1[q] += s1s[i * CL + cl][q]; s2[q] += s2s[i * CL + cl][q]; }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        part[((long long)blockIdx.y * 2) * C + c + q] = s1[q];
+        part[((long long)blockIdx.y * 2 + 1) * C + c + q] = s2[q];
     }
-    *reinterpret_cast<float4 *>(&part[((long long)blockIdx.y * 2) * C + c]) = s1;
-    *reinterpret_cast<float4 *>(&part[((long long)blockIdx.y * 2 + 1) * C + c]) = s2;
 }
 
 __global__ void __launch_bounds__(1024)
-k_bwd_finalize(const float *__restrict__ part, int G, int C, double count,
+k_bwd_finalize(const double *__restrict__ part, int G, int C, double count,
                float *__restrict__ sum_dpre, float *__restrict__ sum_dpre_xhat,
-               float *__restrict__ mean_dpre, float *__restrict__ mean_dpre_xhat) {
+               double *__restrict__ mean_dpre, double *__restrict__ mean_dpre_xhat) {
     __shared__ double sa[32][33], sb[32][33];
     const int tx = threadIdx.x, ty = threadIdx.y;
     const int c = blockIdx.x * 32 + tx;
@@ -73,7 +80,7 @@ k_bwd_finalize(const float *__restrict__ part, int G, int C, double count,
     if (ty != 0 || c >= C) return;
     for (int i = 1; i < 32; ++i) { a += sa[i][tx]; b += sb[i][tx]; }
     sum_dpre[c] = (float)a; sum_dpre_xhat[c] = (float)b;
-    if (mean_dpre) { mean_dpre[c] = (float)(a / count); mean_dpre_xhat[c] = (float)(b / count); }
+    if (mean_dpre) { mean_dpre[c] = a / count; mean_dpre_xhat[c] = b / count; }
 }
 
 // draw = coef[c] * (dpre - m1[c] - xhat*m2[c])   (train BN; coef = gamma*invstd)
@@ -83,7 +90,7 @@ __global__ void __launch_bounds__(TPB)
 k_act_bn_bwd_apply(const float *__restrict__ dy, long long lddy, const float *__restrict__ y, long long ldy,
                    const float *__restrict__ raw, long long ldraw, const float *__restrict__ mean,
                    const float *__restrict__ invstd, const float *__restrict__ coef,
-                   const float *__restrict__ m1, const float *__restrict__ m2, const float *__restrict__ pscale,
+                   const double *__restrict__ m1, const double *__restrict__ m2, const float *__restrict__ pscale,
                    const float *__restrict__ pshift, long long M, int C, int act,
                    float slope, float *__restrict__ draw, long long lddraw, float *__restrict__ dres,
                    long long lddres) {
@@ -106,8 +113,9 @@ k_act_bn_bwd_apply(const float *__restrict__ dy, long long lddy, const float *__
             float rv[4] = {rw.x, rw.y, rw.z, rw.w};
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                float xh = (rv[q] - mean[c + q]) * invstd[c + q];
-                o[q] = coef[c + q] * (gv[q] - m1[c + q] - xh * m2[c + q]);
+                // float64 like torch's CPU kernel: the two means are common to all rows, their rounding must not bias draw
+                const double xh = ((double)rv[q] - (double)mean[c + q]) * (double)invstd[c + q];
+                o[q] = (float)((double)coef[c + q] * ((double)gv[q] - m1[c + q] - xh * m2[c + q]));
             }
         } else {
 #pragma unroll
@@ -274,8 +282,8 @@ extern "C" int32_t efgh_bwd_groups(int64_t M) {
 extern "C" int efgh_act_bn_bwd_reduce(const float *dy, int64_t lddy, const float *y, int64_t ldy, const float *raw,
                                       int64_t ldraw, const float *mean, const float *invstd, const float *pscale,
                                       const float *pshift, int64_t M, int32_t C,
-                                      int32_t act, float slope, float *part, float *sum_dpre, float *sum_dpre_xhat,
-                                      float *mean_dpre, float *mean_dpre_xhat, void *stream_) {
+                                      int32_t act, float slope, double *part, float *sum_dpre, float *sum_dpre_xhat,
+                                      double *mean_dpre, double *mean_dpre_xhat, void *stream_) {
     hipStream_t st = (hipStream_t)stream_;
     EFGH_CHECK_ARG(dy && part && sum_dpre && sum_dpre_xhat && M > 0 && C > 0 && C % 4 == 0);
     EFGH_CHECK_ARG(y || (raw && pscale && pshift));
@@ -294,7 +302,7 @@ extern "C" int efgh_act_bn_bwd_reduce(const float *dy, int64_t lddy, const float
 
 extern "C" int efgh_act_bn_bwd_apply(const float *dy, int64_t lddy, const float *y, int64_t ldy, const float *raw,
                                      int64_t ldraw, const float *mean, const float *invstd, const float *coef,
-                                     const float *m1, const float *m2, const float *pscale, const float *pshift,
+                                     const double *m1, const double *m2, const float *pscale, const float *pshift,
                                      int64_t M, int32_t C, int32_t act, float slope,
                                      float *draw, int64_t lddraw, float *dres, int64_t lddres, void *stream_) {
     EFGH_CHECK_ARG(dy && (draw || dres) && M > 0 && C > 0 && C % 4 == 0);

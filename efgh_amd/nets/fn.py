@@ -141,12 +141,12 @@ class GemmLayerFn(torch.autograd.Function):
             draw = dy
         else:
             G = ops.bwd_groups(M)
-            part = torch.empty((G, 2, Np), dtype=torch.float32, device=dev)
+            part = torch.empty((G, 2, Np), dtype=torch.float64, device=dev)      # float64 column sums (see backward.hip)
             s1 = torch.empty(Np, dtype=torch.float32, device=dev)
             s2 = torch.empty(Np, dtype=torch.float32, device=dev)
             train_bn = has_bn and spec.train
-            m1 = torch.empty(Np, dtype=torch.float32, device=dev) if train_bn else None
-            m2 = torch.empty(Np, dtype=torch.float32, device=dev) if train_bn else None
+            m1 = torch.empty(Np, dtype=torch.float64, device=dev) if train_bn else None
+            m2 = torch.empty(Np, dtype=torch.float64, device=dev) if train_bn else None
             ops.act_bn_bwd_reduce(dy, ld_of(dy), ymask, Np, raw, Np, mean if has_bn else None,
                                   invstd if has_bn else None, M, Np, spec.act, spec.slope, part, s1, s2, m1, m2,
                                   pscale=psc, pshift=psh)

@@ -239,19 +239,19 @@ int efgh_table_gather_add(const float *src, const int32_t *table, int64_t M, int
                           void *stream);
 /* BatchNorm(+residual)+activation backward, two passes.
  * reduce: dpre = dy*act'(y); sum_dpre[c], sum_dpre_xhat[c] (= dbeta, dgamma) and their means;
- *         mean/invstd/raw NULL -> only sum_dpre (bias gradient).  part: [efgh_bwd_groups(M)][2][C].
+ *         mean/invstd/raw NULL -> only sum_dpre (bias gradient).  part: [efgh_bwd_groups(M)][2][C] float64 (the column sums and the two means are kept in double, as torch's CPU kernel does).
  *         y == NULL: the activation mask is recomputed from raw*pscale + pshift (layers without a
  *         residual), which saves one full read of the activation in both passes.              */
 int32_t efgh_bwd_groups(int64_t M);
 int efgh_act_bn_bwd_reduce(const float *dy, int64_t lddy, const float *y, int64_t ldy, const float *raw,
                            int64_t ldraw, const float *mean, const float *invstd, const float *pscale,
                            const float *pshift, int64_t M, int32_t C,
-                           int32_t act, float slope, float *part, float *sum_dpre, float *sum_dpre_xhat,
-                           float *mean_dpre, float *mean_dpre_xhat, void *stream);
+                           int32_t act, float slope, double *part, float *sum_dpre, float *sum_dpre_xhat,
+                           double *mean_dpre, double *mean_dpre_xhat, void *stream);
 /* apply: draw = coef*(dpre - m1 - xhat*m2)  (train BN)  |  coef*dpre (eval BN / none); dres = dpre */
 int efgh_act_bn_bwd_apply(const float *dy, int64_t lddy, const float *y, int64_t ldy, const float *raw,
                           int64_t ldraw, const float *mean, const float *invstd, const float *coef,
-                          const float *m1, const float *m2, const float *pscale, const float *pshift,
+                          const double *m1, const double *m2, const float *pscale, const float *pshift,
                           int64_t M, int32_t C, int32_t act, float slope,
                           float *draw, int64_t lddraw, float *dres, int64_t lddres, void *stream);
 int efgh_maxpool2_bwd(const float *x, const float *dy, float *dx, int32_t B, int32_t H, int32_t W, int32_t C,

@@ -26,8 +26,8 @@ for M, C in [(8 * 384 * 5119, 64), (8 * 384 * 1280, 64), (8 * 96 * 1279, 256), (
     t = timeit(lambda: ops.scale_shift_act(x, C, sc, sh, y, C, M, C, ops.ACT_RELU))
     gb = M * C * 4 / 1e9
     G = ops.bwd_groups(M)
-    part = torch.empty((G, 2, C), device='cuda'); s1 = torch.empty(C, device='cuda'); s2 = torch.empty(C, device='cuda')
-    m1 = torch.empty(C, device='cuda'); m2 = torch.empty(C, device='cuda')
+    part = torch.empty((G, 2, C), device='cuda', dtype=torch.float64); s1 = torch.empty(C, device='cuda'); s2 = torch.empty(C, device='cuda')
+    m1 = torch.empty(C, device='cuda', dtype=torch.float64); m2 = torch.empty(C, device='cuda', dtype=torch.float64)
     tr = timeit(lambda: ops.act_bn_bwd_reduce(dy, C, None, C, x, C, mean, invstd, M, C, ops.ACT_RELU, 0.0, part, s1, s2, m1, m2,
                                               pscale=sc, pshift=sh))
     draw = torch.empty_like(x)
