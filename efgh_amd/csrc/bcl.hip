@@ -135,6 +135,23 @@ k_csr_fill(const int *__restrict__ off, long long n4, const int *__restrict__ st
     }
 }
 
+// The fill above places the entries of a vertex in arrival order (int atomics), which varies run to run.  Sorting every
+// segment by entry id (one wave per vertex, rank = number of smaller ids) fixes the summation order of the gather, so the
+// whole E branch - and with it the forward pass - is bit-reproducible.
+__global__ void __launch_bounds__(TPB)
+k_csr_sort(const int *__restrict__ start, const int *__restrict__ list, int H, int *__restrict__ sorted) {
+    const int lane = threadIdx.x & 63;
+    const long long h = (long long)blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
+    if (h >= H) return;
+    const int e0 = start[h], n = start[h + 1] - e0;
+    for (int i = lane; i < n; i += 64) {
+        const int id = list[e0 + i];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) rank += list[e0 + j] < id ? 1 : 0;      // ids are distinct
+        sorted[e0 + rank] = id;
+    }
+}
+
 // One wave per vertex: G lanes across the channels (lane g owns channels 4g.. and 4(g+G)..) x S = 64/G entry slots, so
 // S list entries of the vertex are in flight at once (the walk is a chain of dependent loads: list -> bary, feat row);
 // the S partial sums are folded with shuffles at the end.
@@ -262,14 +279,14 @@ extern "C" int efgh_splat_bwd(const float *gsplat, const float *wsum, int32_t C,
 }
 
 extern "C" int64_t efgh_splat_csr_workspace_ints(int32_t n, int32_t H) {
-    return (int64_t)H + 1 /*start*/ + H /*fill*/ + 4LL * n /*list*/ + (H + 1023) / 1024 + 2 /*block sums, total*/;
+    return (int64_t)H + 1 /*start*/ + H /*fill*/ + 8LL * n /*list, sorted list*/ + (H + 1023) / 1024 + 2 /*block sums, total*/;
 }
 
 // off [4][n] (vertex of every (remainder, point)) -> CSR: start [H+1], list [4n] (entry ids r*n + p grouped by vertex)
 extern "C" int efgh_splat_csr_build(const int32_t *off, int32_t n, int32_t H, int32_t *ws, void *stream_) {
     hipStream_t st = (hipStream_t)stream_;
     EFGH_CHECK_ARG(off && ws && n > 0 && H > 0);
-    int *start = ws, *fill = ws + H + 1, *list = fill + H, *bsum = list + 4LL * n;
+    int *start = ws, *fill = ws + H + 1, *list = fill + H, *sorted = list + 4LL * n, *bsum = sorted + 4LL * n;
     const int nb = (H + 1023) / 1024;
     int *total = bsum + nb;
     if (hipMemsetAsync(start, 0, (size_t)(2 * (long long)H + 1) * 4, st) != hipSuccess) {
@@ -286,6 +303,7 @@ extern "C" int efgh_splat_csr_build(const int32_t *off, int32_t n, int32_t H, in
         return EFGH_E_LAUNCH;
     }
     k_csr_fill<<<grid_for(n4), TPB, 0, st>>>(off, n4, start, fill, list);
+    k_csr_sort<<<cdiv(H, TPB / 64), TPB, 0, st>>>(start, list, H, sorted);
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
 }
@@ -294,7 +312,7 @@ extern "C" int efgh_splat_gather(const float *feat, int64_t ldf, int32_t C, cons
                                  const int32_t *ws, float *splat, float *wsum, void *stream_) {
     hipStream_t st = (hipStream_t)stream_;
     EFGH_CHECK_ARG(feat && bary && ws && splat && wsum && n > 0 && H > 0 && C > 0 && C % 4 == 0 && C <= 512 && ldf % 4 == 0);
-    const int *start = ws, *list = ws + 2LL * H + 1;
+    const int *start = ws, *list = ws + 2LL * H + 1 + 4LL * n;      // the sorted copy
     const int c4n = C / 4;
     const int grid = cdiv(H, TPB / 64);
     if (c4n <= 16) k_splat_gather<16><<<grid, TPB, 0, st>>>(feat, ldf, C, bary, n, start, list, H, splat, wsum);

@@ -98,7 +98,7 @@ int efgh_splat_bwd(const float *gsplat, const float *wsum, int32_t C, const floa
                    void *stream);
 /* CSR form of efgh_splat_fwd (same result up to fp32 summation order, no floating-point atomics): efgh_splat_csr_build
  * inverts off [4][n] once per level into ws (efgh_splat_csr_workspace_ints(n, H) int32: start [H+1], scratch [H],
- * list [4n], scan scratch); efgh_splat_gather then sums bary*feat per vertex in registers and writes the normalised
+ * list [4n] + the same list sorted per vertex (fixed summation order: reproducible), scan scratch); efgh_splat_gather then sums bary*feat per vertex in registers and writes the normalised
  * row and wsum once.  C <= 512.                                                                                        */
 int64_t efgh_splat_csr_workspace_ints(int32_t n, int32_t H);
 int efgh_splat_csr_build(const int32_t *off, int32_t n, int32_t H, int32_t *ws, void *stream);

@@ -97,10 +97,10 @@ def test_fullsize_output_invariants(full):
     assert set(vals.tolist()) <= set(torch.unique(inp[1]).tolist()) | {0.0}
     with torch.no_grad():
         out2 = m(*inp)
-    assert torch.equal(out['h_hrzn_sgn'], out2['h_hrzn_sgn']) and torch.equal(out['h_img'], out2['h_img'])
-    for k in ('e_gn_sgn', 'e_gn_abs'):       # float atomics in the splat: summation order varies run to run
-        assert _rel(out2[k].cpu().numpy(), out[k].cpu().numpy()) < 1e-5, k
-    # (F and G sit behind the pixel-truncating rasterisers, so a 1e-7 change of e_l may flip pixels: not compared)
+    # the eval forward is bit-reproducible: no floating-point atomics on the path (CSR splat with per-vertex sorted lists)
+    for k, v in out.items():
+        if torch.is_tensor(v):
+            assert torch.equal(v, out2[k]), k
 
 
 def test_fullsize_lattice_invariants(full):
