@@ -2,8 +2,8 @@
 forward -> efghloss -> backward -> gradient all-reduce over RCCL -> fused Adam.
 
 One process per GPU.  All parameters (and their gradients) are views into ONE flat fp32 buffer each,
-so the data-parallel exchange is a single all-reduce of 191 MB issued in buckets while the tail of
-the buffer is still being produced, and the optimizer is one kernel launch instead of 353.
+so the data-parallel exchange is a bucketed all-reduce of 191 MB whose buckets are launched from
+parameter hooks while backward is still running, and the optimizer is one kernel launch instead of 353.
 `DataParallel` semantics (one loss over the global batch, batch-mean terms) == mean of the per-rank
 gradients for equal per-rank batches."""
 import torch
@@ -52,6 +52,59 @@ def allreduce_mean_(flat_g, world, bucket_elems=8 * 1024 * 1024):
     return works
 
 
+class OverlappedAllReduce:
+    """Gradient all-reduce overlapped with backward: the flat gradient buffer is cut into ~32 MB buckets of
+    whole parameters; a post-accumulate hook on every parameter counts its bucket down and launches the bucket's asynchronous
+    sum all-reduce (RCCL on its own stream) as soon as the last gradient of the bucket has been written - backward produces
+    the gradients back to front, so the tail buckets are on the wire while the front of the network is still being
+    differentiated.  `finish()` launches whatever is left (parameters without a gradient) and waits."""
+
+    def __init__(self, flat, world, bucket_elems=8 * 1024 * 1024):
+        self.flat, self.world = flat, world
+        self.buckets = []                 # [start, end) element ranges of the flat buffer
+        self.bucket_of = []               # parameter index -> bucket index
+        s = 0
+        for i, (off, k) in enumerate(flat.offsets):
+            if off + k - s > bucket_elems and off > s:
+                self.buckets.append((s, off))
+                s = off
+            self.bucket_of.append(len(self.buckets))
+        self.buckets.append((s, flat.n))
+        self.sizes = [0] * len(self.buckets)
+        for b in self.bucket_of:
+            self.sizes[b] += 1
+        self.pending, self.works, self.launched = list(self.sizes), [], [False] * len(self.buckets)
+        if world > 1:
+            for i, p in enumerate(flat.params):
+                p.register_post_accumulate_grad_hook(self._make_hook(i))
+
+    def _make_hook(self, i):
+        def hook(param):
+            b = self.bucket_of[i]
+            self.pending[b] -= 1
+            if self.pending[b] == 0:
+                self._launch(b)
+        return hook
+
+    def _launch(self, b):
+        if self.launched[b]:
+            return
+        self.launched[b] = True
+        s, e = self.buckets[b]
+        self.works.append(dist.all_reduce(self.flat.g[s:e], op=dist.ReduceOp.SUM, async_op=True))
+
+    def start_step(self):
+        self.pending, self.works, self.launched = list(self.sizes), [], [False] * len(self.buckets)
+
+    def finish(self):
+        if self.world <= 1:
+            return
+        for b in range(len(self.buckets)):
+            self._launch(b)
+        for w in self.works:
+            w.wait()
+
+
 class FusedAdam:
     """torch.optim.Adam(lr, betas=(0.9,0.999), eps=1e-8, weight_decay) on a FlatParams, one HIP launch."""
 
@@ -89,6 +142,7 @@ class Trainer:
             for b in model.buffers():
                 dist.broadcast(b, 0)
         self.opt = FusedAdam(self.flat, lr=lr, weight_decay=weight_decay)
+        self.comm = OverlappedAllReduce(self.flat, self.world)
         self.base_lr, self.it = lr, 0
 
     def step(self, pc, img, calib, A, gt):
@@ -97,8 +151,9 @@ class Trainer:
         pred = self.model(pc, img, calib, A)
         losses, gt = self.criterion.compute_loss(pc, img, calib, A, gt, pred)
         self.flat.zero_grad()
-        losses['total'].backward()
-        allreduce_mean_(self.flat.g, self.world)
+        self.comm.start_step()
+        losses['total'].backward()            # bucket all-reduces start from the parameter hooks during this call
+        self.comm.finish()
         self.opt.step(grad_scale=1.0 / self.world)
         self.it += 1
         return losses, pred

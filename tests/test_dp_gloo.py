@@ -38,6 +38,21 @@ def _worker(rank, world, port, q):
     # every parameter's .grad still aliases the flat buffer; names unchanged
     ok = ok and all(p.grad.data_ptr() == flat.g.data_ptr() + 4 * off for p, (off, _) in zip(flat.params, flat.offsets))
     ok = ok and names_before == list(model.state_dict().keys())
+    # the overlapped form (hooks launch the bucket all-reduces during backward) gives the same averaged gradient
+    from efgh_amd.train import OverlappedAllReduce
+    torch.manual_seed(0)
+    model2 = torch.nn.Sequential(torch.nn.Linear(37, 19), torch.nn.ReLU(), torch.nn.Linear(19, 5))
+    flat2 = FlatParams(model2)
+    comm = OverlappedAllReduce(flat2, world, bucket_elems=300)
+    assert len(comm.buckets) >= 2 and sum(e - s for s, e in comm.buckets) == flat2.n
+    for step in range(2):                                # hooks re-arm every step
+        flat2.zero_grad()
+        comm.start_step()
+        model2(x).pow(2).mean().backward()
+        comm.finish()
+        flat2.g.div_(world)
+        ok = ok and torch.allclose(flat2.g, flat.g, atol=1e-7)
+        ok = ok and all(p.grad.data_ptr() == flat2.g.data_ptr() + 4 * off for p, (off, _) in zip(flat2.params, flat2.offsets))
     q.put((rank, bool(ok), flat.g.sum().item()))
     dist.destroy_process_group()
 
