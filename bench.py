@@ -272,6 +272,7 @@ def main():
                 'forward_only': fwd,
             }
             out.update(rooflines(prof, a.steps))
+            out['peak_hbm_gb_per_gpu'] = torch.cuda.max_memory_allocated() / 1e9      # of 288 GB
     elif rank == 0:
         out = {'metric': fwd['metric'], 'value': fwd['value'], 'unit': 'frame-pairs/s', 'n_gpus': world,
                'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': fwd['ms_per_step'], 'higher_is_better': True,
