@@ -85,3 +85,26 @@ def test_example_loop_runs_end_to_end():
     spec.loader.exec_module(mod)
     hist = mod.main(['--iters', '2', '--batch', '2', '--raw', '128', '256', '--points', '2048'])
     assert len(hist) == 2 and all(np.isfinite(h) for h in hist)
+
+
+def test_overfitting_one_small_batch_reduces_every_loss_group(manifest):
+    """20 fused-Adam steps on one batch: the whole stack (forward, efghloss, hand-written backward, optimizer, weight-cache
+    invalidation, BatchNorm running statistics) must actually learn"""
+    from efgh_amd.losses import EFGHCriterion
+    from efgh_amd.nets import EFGHBackbone
+    from efgh_amd.train import Trainer
+    args = syn.default_args(RAW, 'cuda')
+    m = EFGHBackbone(args)
+    m.load_state_dict(syn.synthetic_state_dict(manifest['state_dict'], 1))
+    tr = Trainer(m.cuda(), EFGHCriterion(args), lr=1e-3)
+    b = syn.make_batch(RAW, NPTS, 2)
+    inp = [torch.from_numpy(b[k]).cuda() for k in ('pc', 'img', 'calib', 'A')]
+    gt = {k: torch.from_numpy(v) for k, v in b['gt'].items()}
+    hist = []
+    for _ in range(20):
+        L, _ = tr.step(*inp, gt)
+        hist.append({k: float(v.detach()) for k, v in L.items()})
+    assert hist[-1]['total'] < 0.25 * hist[0]['total'], (hist[0]['total'], hist[-1]['total'])
+    for k in ('e_gn', 'h_hrzn', 'fov', 'g_trs'):
+        assert hist[-1][k] < hist[0][k], (k, hist[0][k], hist[-1][k])
+    assert int(m.H.vgg.features[1].num_batches_tracked) == 20
