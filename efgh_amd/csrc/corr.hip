@@ -262,17 +262,25 @@ k_norm_bwd_part(const float *__restrict__ x, const float *__restrict__ dxn, cons
     }
 }
 
+// one block per sample: part[b][0][0..2] = sum over the G partial rows (in double)
+__global__ void k_norm_bwd_fold(float *__restrict__ part, int G) {
+    const int b = blockIdx.x;
+    __shared__ double sh[3][64];
+    double a[3] = {0.0, 0.0, 0.0};
+    for (int g = threadIdx.x; g < G; g += 64)
+        for (int q = 0; q < 3; ++q) a[q] += part[((long long)b * G + g) * 3 + q];
+    for (int q = 0; q < 3; ++q) sh[q][threadIdx.x] = a[q];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int q = 0; q < 3; ++q) { double t = 0.0; for (int i = 0; i < 64; ++i) t += sh[q][i]; part[(long long)b * G * 3 + q] = (float)t; }
+    }
+}
+
 __global__ void __launch_bounds__(TPB)
 k_norm_bwd_apply(const float *__restrict__ x, const float *__restrict__ dxn, const float *__restrict__ mm,
                  const float *__restrict__ part, long long n, int G, float *__restrict__ dx) {
     const int b = blockIdx.y;
-    __shared__ float tot[3];
-    if (threadIdx.x < 3) {
-        double a = 0.0;
-        for (int g = 0; g < G; ++g) a += part[((long long)b * G + g) * 3 + threadIdx.x];
-        tot[threadIdx.x] = (float)a;
-    }
-    __syncthreads();
+    const float *tot = part + (long long)b * G * 3;            // folded by k_norm_bwd_fold into row 0 of the sample
     const float mn = mm[b * 2], mx = mm[b * 2 + 1], d = mx - mn;
     const float cmx = tot[0] / (d * d) / tot[1], cmn = tot[0] / (d * d) / tot[2];
     const float *px = x + (long long)b * n, *pd = dxn + (long long)b * n;
@@ -379,6 +387,7 @@ extern "C" int efgh_norm_bwd(const float *x, const float *dxn, const float *mm, 
     EFGH_CHECK_ARG(x && dxn && mm && part && dx && B > 0 && n > 0);
     const int G = efgh_minmax_groups(n);
     k_norm_bwd_part<<<dim3(G, B), TPB, 0, st>>>(x, dxn, mm, n, G, part);
+    k_norm_bwd_fold<<<B, 64, 0, st>>>(part, G);
     long long g = (n + TPB - 1) / TPB;
     k_norm_bwd_apply<<<dim3((unsigned)(g > 2048 ? 2048 : g), B), TPB, 0, st>>>(x, dxn, mm, part, n, G, dx);
     EFGH_CHECK_LAUNCH();
