@@ -41,7 +41,7 @@ class LayerSpec:
 
     def __init__(self, N, C, T, mode, launches, M, out_shape, pack_fwd, dgrad, wgrad_unpack, bn=None,
                  train=False, act=ACT_NONE, slope=0.0, table=None, c_real=None, custom_forward=None,
-                 custom_wgrad=None):
+                 custom_wgrad=None, passthrough=False):
         self.N, self.C, self.T, self.mode, self.M = N, C, T, mode, M
         self.launches, self.out_shape = launches, out_shape
         self.pack_fwd, self.dgrad, self.wgrad_unpack = pack_fwd, dgrad, wgrad_unpack
@@ -49,6 +49,9 @@ class LayerSpec:
         self.c_real = c_real if c_real is not None else C
         # optional replacements of the launch loop / weight gradient (e.g. transposed conv as GEMM + col2im)
         self.custom_forward, self.custom_wgrad = custom_forward, custom_wgrad
+        # passthrough: forward also returns an alias of x for a skip connection; the gradient arriving on that alias is added
+        # in the dgrad kernel's epilogue (`dgrad(..., add=)`) instead of by a separate elementwise pass
+        self.passthrough = passthrough
 
 
 class GemmLayerFn(torch.autograd.Function):
@@ -124,10 +127,12 @@ class GemmLayerFn(torch.autograd.Function):
         # layers without a residual re-derive the activation mask from raw*scale+shift in backward
         psc, psh = (scale, shift) if (bn is not None and residual is None) else (None, None)
         ctx.save_for_backward(x, weight, y, raw, mean, invstd, None if gamma is None else gamma.detach(), psc, psh)
+        if spec.passthrough:
+            return y, x.view_as(x)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dskip=None):
         spec = ctx.spec
         x, weight, y, raw, mean, invstd, gamma, psc, psh = ctx.saved_tensors
         ymask = None if psc is not None else y
@@ -167,7 +172,10 @@ class GemmLayerFn(torch.autograd.Function):
         # ---- dgrad
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = spec.dgrad(spec, weight, draw, x)
+            if dskip is not None:
+                dx = spec.dgrad(spec, weight, draw, x, add=as_rows(dskip))
+            else:
+                dx = spec.dgrad(spec, weight, draw, x)
         # ---- wgrad
         dW = None
         if ctx.needs_input_grad[1] and spec.custom_wgrad is not None:

@@ -125,7 +125,7 @@ def _run(ctx, x, lda, C, T, Wp, N, M, mode, geoms, out_t, ldo, coff, bias, bn, a
 
 
 # ----------------------------------------------------------------------------------------------
-def conv2d(ctx, x, conv, bn=None, act=ACT_NONE, slope=0.0, residual=None, out=None, in_ch=None):
+def conv2d(ctx, x, conv, bn=None, act=ACT_NONE, slope=0.0, residual=None, out=None, in_ch=None, skip_out=False):
     """nn.Conv2d (+BatchNorm2d) (+residual) (+activation) on [B][H][W][Cx].
     in_ch: (coff, C) selects a channel slice of x.  Returns the output buffer [B][Ho][Wo][ld]."""
     B, H, W, ldx = x.shape
@@ -147,7 +147,7 @@ def conv2d(ctx, x, conv, bn=None, act=ACT_NONE, slope=0.0, residual=None, out=No
     if ctx.grad:
         assert out is None
         xs = x if in_ch is None else x[..., a_off:a_off + Cx]
-        return _conv2d_grad(ctx, xs, conv, bn, act, slope, residual, geom, (B, H, W, Ho, Wo), Cp)
+        return _conv2d_grad(ctx, xs, conv, bn, act, slope, residual, geom, (B, H, W, Ho, Wo), Cp, passthrough=skip_out)
     out_t, ldo, coff = _alloc_out(x, (B, Ho, Wo), O, out)
     res_ld = residual.shape[-1] if residual is not None else 0
     _run(ctx, x, ldx, Cp, T, Wp, O, M, 1, [(geom, Wp, M)], out_t, ldo, coff, conv.bias, bn, act, slope,
@@ -301,11 +301,13 @@ def run_convt_bn_relu(ctx, seq, x, out=None):
 
 def run_basic_block(ctx, blk, x, out=None):
     """nets/resnet.py:55-71."""
-    y = conv2d(ctx, x, blk.conv1, blk.bn1, ACT_RELU)
-    if blk.downsample is not None:
-        idt = conv2d(ctx, x, blk.downsample[0], blk.downsample[1], ACT_NONE)
+    if ctx.grad and blk.downsample is None:
+        # the identity branch takes an alias of x handed out by conv1's Function: its gradient is added in conv1's dgrad
+        # epilogue instead of by autograd's elementwise accumulation (one read-read-write pass over the activation)
+        y, idt = conv2d(ctx, x, blk.conv1, blk.bn1, ACT_RELU, skip_out=True)
     else:
-        idt = x
+        y = conv2d(ctx, x, blk.conv1, blk.bn1, ACT_RELU)
+        idt = conv2d(ctx, x, blk.downsample[0], blk.downsample[1], ACT_NONE) if blk.downsample is not None else x
     return conv2d(ctx, y, blk.conv2, blk.bn2, ACT_RELU, residual=idt, out=None if ctx.grad else out)
 
 
@@ -323,7 +325,7 @@ def _bn_args(bn):
     return (None, None) if bn is None else (bn.weight, bn.bias)
 
 
-def _conv2d_grad(ctx, x, conv, bn, act, slope, residual, geom, dims, Cp):
+def _conv2d_grad(ctx, x, conv, bn, act, slope, residual, geom, dims, Cp, passthrough=False):
     B, H, W, Ho, Wo = dims
     Cw, O = conv.in_channels, conv.out_channels
     kh, kw = conv.kernel_size
@@ -337,8 +339,10 @@ def _conv2d_grad(ctx, x, conv, bn, act, slope, residual, geom, dims, Cp):
     def unpack(dWp, i, dW):
         ops.unpack_weight(dWp, dW, O, T, Cw, Cp, Cw * T, T, 1, list(range(T)))
 
-    def dgrad(spec, w, draw, xin):
+    def dgrad(spec, w, draw, xin, add=None):
         dev = draw.device
+        if add is not None and not (sh == 1 and sw == 1):
+            return dgrad(spec, w, draw, xin) + add
         if sh == 1 and sw == 1:
             # taps in ascending (dh, dw) order = the canonical 3x3 order the Winograd kernel recognises
             order = sorted(range(T), key=lambda i: (ph - i // kw, pw - i % kw))
@@ -348,7 +352,7 @@ def _conv2d_grad(ctx, x, conv, bn, act, slope, residual, geom, dims, Cp):
             dx = torch.empty((B, H, W, Cp), dtype=torch.float32, device=dev)
             g = (B, Ho, Wo, H, W, 1, 1, dhs, dws, H, W, 1, 1, 0, 0)
             ops.gather_gemm(draw, Np, Np, T, Wd, Cp, B * H * W, dx, Cp, mode=1, geom=g,
-                            flops=2.0 * B * H * W * Cw * T * O)
+                            residual=add, ldr=0 if add is None else FN.ld_of(add), flops=2.0 * B * H * W * Cw * T * O)
             return dx
         assert sh == 2 and sw == 2
         classes = []
@@ -375,9 +379,13 @@ def _conv2d_grad(ctx, x, conv, bn, act, slope, residual, geom, dims, Cp):
         return dx
 
     spec = FN.LayerSpec(O, Cp, T, 1, [(geom, B * Ho * Wo)], B * Ho * Wo, (B, Ho, Wo), pack_fwd, dgrad, unpack,
-                        bn=bn, train=ctx.train, act=act, slope=slope, c_real=Cw)
+                        bn=bn, train=ctx.train, act=act, slope=slope, c_real=Cw,
+                        passthrough=passthrough and x.requires_grad and x.shape[-1] == Cp)
     g_, b_ = _bn_args(bn)
-    return FN.GemmLayerFn.apply(x, conv.weight, conv.bias, g_, b_, residual, spec)
+    out = FN.GemmLayerFn.apply(x, conv.weight, conv.bias, g_, b_, residual, spec)
+    if passthrough and not spec.passthrough:
+        return out, x
+    return out
 
 
 def _convt_grad(ctx, x, convt, bn, act, slope, geoms, dims):
