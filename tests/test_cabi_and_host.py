@@ -112,3 +112,11 @@ def test_lr_schedule_and_flat_params_cpu():
         assert torch.equal(v, before[k])
     m(torch.randn(4, 5)).sum().backward()
     assert float(f.g.abs().sum()) > 0 and all(p.grad.data_ptr() >= f.g.data_ptr() for p in f.params)
+
+
+def test_header_is_plain_c():
+    """the boundary is a C ABI: include/efgh_hip.h must compile as C99 (no C++ or torch types in the signatures)"""
+    import os
+    import subprocess
+    hdr = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'include', 'efgh_hip.h')
+    subprocess.check_call(['gcc', '-std=c99', '-Wall', '-Werror', '-fsyntax-only', '-x', 'c', hdr])
