@@ -57,7 +57,7 @@ def test_fullsize_stagewise_vs_oracle(full, manifest):
     assert (out['h_img'].cpu() != reth['h_img']).float().mean() < 5e-3
     # f_score saturates at this size with these weights, so compare the pre-sigmoid correlation as well.
     # Each logit sums ~1e6 non-negative products: torch's fp32 CPU conv2d is itself 3.8e-4 away from the
-    # exact sum at this size (tools/debug_fullsize_f.py), so the yardstick is the float64 correlation of the
+    # exact sum at this size (tests/tools/debug_fullsize_f.py), so the yardstick is the float64 correlation of the
     # ORACLE's features; the HIP kernel (fp32 MFMA, split-K) is within 1e-5 of it.
     import torch.nn.functional as F
     camf, rngf = keep_o['cam_feat'][0].double(), keep_o['rng_feat'][0].double()

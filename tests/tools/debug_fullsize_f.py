@@ -1,7 +1,7 @@
 """Diagnose the full-size F-net logit difference between the HIP path and the oracle."""
 import json, os, sys
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from efgh_amd import synthetic as syn
 from efgh_amd.nets import EFGHBackbone
 from oracle import efgh_oracle as O

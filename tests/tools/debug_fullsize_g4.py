@@ -1,6 +1,6 @@
 """is d(sum g_trs)/d(G weights) well defined in fp32?  oracle gnet in float32 vs float64 on the same inputs (CPU only)"""
 import json, os, re, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from efgh_amd import synthetic as syn
 from oracle import efgh_oracle as O

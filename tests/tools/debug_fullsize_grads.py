@@ -1,6 +1,6 @@
 """full-size (config S, B=1) gradient comparison: HIP (Winograd on/off) vs oracle, and the oracle against itself with another thread count"""
 import json, os, re, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from efgh_amd import ops, synthetic as syn
 from efgh_amd.losses import EFGHCriterion
