@@ -125,6 +125,47 @@ k_act_bn_bwd_apply(const float *__restrict__ dy, long long lddy, const float *__
     }
 }
 
+// backward of the fused BatchNorm + activation + max pool (elementwise.hip:k_maxpool2_affine): the four activated values of a
+// window are recomputed from the raw conv output, the gradient goes to the first maximal one (scan order), the others get 0
+__global__ void __launch_bounds__(TPB)
+k_maxpool2_bwd_affine(const float *__restrict__ x, const float *__restrict__ scale, const float *__restrict__ shift, int act,
+                      float slope, const float *__restrict__ dy, float *__restrict__ dx, int B, int H, int W, int C) {
+    const int Ho = H / 2, Wo = W / 2, c4 = C >> 2;
+    long long total = (long long)B * Ho * Wo * c4;
+    for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
+        int c = (int)(i % c4) * 4; long long r = i / c4;
+        int ow = (int)(r % Wo); r /= Wo;
+        int oh = (int)(r % Ho); long long b = r / Ho;
+        long long base = (((b * H + oh * 2) * W) + ow * 2) * (long long)C + c;
+        const long long offs[4] = {0, C, (long long)W * C, (long long)W * C + C};
+        const float4 sc = *reinterpret_cast<const float4 *>(scale + c), sf = *reinterpret_cast<const float4 *>(shift + c);
+        const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, sfv[4] = {sf.x, sf.y, sf.z, sf.w};
+        float4 v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const float4 *>(x + base + offs[q]);
+        float4 g = *reinterpret_cast<const float4 *>(dy + (((b * Ho + oh) * Wo) + ow) * (long long)C + c);
+        float o[4][4];
+        const float gg[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) {
+            float e[4] = {((float *)&v[0])[ch], ((float *)&v[1])[ch], ((float *)&v[2])[ch], ((float *)&v[3])[ch]};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float t = e[q] * scv[ch] + sfv[ch];
+                e[q] = act == 1 ? (t > 0.f ? t : 0.f) : (act == 2 ? (t > 0.f ? t : t * slope) : t);
+            }
+            int best = 0;
+#pragma unroll
+            for (int q = 1; q < 4; ++q) if (e[q] > e[best]) best = q;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q][ch] = (q == best) ? gg[ch] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4 *>(dx + base + offs[q]) = make_float4(o[q][0], o[q][1], o[q][2], o[q][3]);
+    }
+}
+
 // MaxPool2d(2,2) backward: gradient goes to the first maximal element in (h,w) scan order
 __global__ void __launch_bounds__(TPB)
 k_maxpool2_bwd(const float *__restrict__ x, const float *__restrict__ dy, float *__restrict__ dx, int B, int H,
@@ -321,6 +362,15 @@ extern "C" int efgh_maxpool2_bwd(const float *x, const float *dy, float *dx, int
     EFGH_CHECK_ARG(x && dy && dx && B > 0 && H >= 2 && W >= 2 && C % 4 == 0);
     k_maxpool2_bwd<<<grid_for((long long)B * (H / 2) * (W / 2) * (C / 4)), TPB, 0, (hipStream_t)stream_>>>(x, dy, dx, B, H,
                                                                                                        W, C);
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}
+
+extern "C" int efgh_maxpool2_bwd_affine(const float *x, const float *scale, const float *shift, int32_t act, float slope,
+                                        const float *dy, float *dx, int32_t B, int32_t H, int32_t W, int32_t C, void *stream_) {
+    EFGH_CHECK_ARG(x && scale && shift && dy && dx && B > 0 && H >= 2 && W >= 2 && C % 4 == 0);
+    k_maxpool2_bwd_affine<<<grid_for((long long)B * (H / 2) * (W / 2) * (C / 4)), TPB, 0, (hipStream_t)stream_>>>(
+        x, scale, shift, act, slope, dy, dx, B, H, W, C);
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
 }

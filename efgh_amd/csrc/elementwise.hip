@@ -151,6 +151,31 @@ k_maxpool2(const float *__restrict__ x, float *__restrict__ y, int B, int H, int
     }
 }
 
+// BatchNorm + activation + 2x2/2 max pool in one pass over the raw conv output (training path of the VGG trunks):
+// y[b][oh][ow][c] = max over the window of act(raw*scale[c] + shift[c]); the full-resolution activation is never stored.
+__global__ void __launch_bounds__(TPB)
+k_maxpool2_affine(const float *__restrict__ x, const float *__restrict__ scale, const float *__restrict__ shift, int act,
+                  float slope, float *__restrict__ y, int B, int H, int W, int C) {
+    const int Ho = H / 2, Wo = W / 2, c4 = C >> 2;
+    long long total = (long long)B * Ho * Wo * c4;
+    for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
+        int c = (int)(i % c4) * 4; long long r = i / c4;
+        int ow = (int)(r % Wo); r /= Wo;
+        int oh = (int)(r % Ho); long long b = r / Ho;
+        const float *p = x + (((b * H + oh * 2) * W) + ow * 2) * (long long)C + c;
+        const float4 sc = *reinterpret_cast<const float4 *>(scale + c), sf = *reinterpret_cast<const float4 *>(shift + c);
+        const long long offs[4] = {0, C, (long long)W * C, (long long)W * C + C};
+        float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 v = *reinterpret_cast<const float4 *>(p + offs[q]);
+            m.x = fmaxf(m.x, act_f(v.x * sc.x + sf.x, act, slope)); m.y = fmaxf(m.y, act_f(v.y * sc.y + sf.y, act, slope));
+            m.z = fmaxf(m.z, act_f(v.z * sc.z + sf.z, act, slope)); m.w = fmaxf(m.w, act_f(v.w * sc.w + sf.w, act, slope));
+        }
+        *reinterpret_cast<float4 *>(y + (((b * Ho + oh) * Wo) + ow) * (long long)C + c) = m;
+    }
+}
+
 // (B,Cs,H,W) planar -> [B][H][W][Cd] channels-last, Cd >= Cs, extra channels zero
 __global__ void __launch_bounds__(TPB)
 k_nchw_to_nhwc(const float *__restrict__ x, float *__restrict__ y, int B, int Cs, long long HW, int Cd) {
@@ -270,6 +295,15 @@ extern "C" int efgh_scale_shift_act(const float *x, int64_t ldx, const float *sc
 extern "C" int efgh_maxpool2(const float *x, float *y, int32_t B, int32_t H, int32_t W, int32_t C, void *stream) {
     EFGH_CHECK_ARG(x && y && B > 0 && H >= 2 && W >= 2 && C % 4 == 0);
     k_maxpool2<<<grid_for((long long)B * (H / 2) * (W / 2) * (C / 4)), TPB, 0, (hipStream_t)stream>>>(x, y, B, H, W, C);
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}
+
+extern "C" int efgh_maxpool2_affine(const float *x, const float *scale, const float *shift, int32_t act, float slope,
+                                    float *y, int32_t B, int32_t H, int32_t W, int32_t C, void *stream) {
+    EFGH_CHECK_ARG(x && scale && shift && y && B > 0 && H >= 2 && W >= 2 && C % 4 == 0);
+    k_maxpool2_affine<<<grid_for((long long)B * (H / 2) * (W / 2) * (C / 4)), TPB, 0, (hipStream_t)stream>>>(x, scale, shift, act,
+                                                                                                          slope, y, B, H, W, C);
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
 }

@@ -41,7 +41,7 @@ class LayerSpec:
 
     def __init__(self, N, C, T, mode, launches, M, out_shape, pack_fwd, dgrad, wgrad_unpack, bn=None,
                  train=False, act=ACT_NONE, slope=0.0, table=None, c_real=None, custom_forward=None,
-                 custom_wgrad=None, passthrough=False):
+                 custom_wgrad=None, passthrough=False, pool=False):
         self.N, self.C, self.T, self.mode, self.M = N, C, T, mode, M
         self.launches, self.out_shape = launches, out_shape
         self.pack_fwd, self.dgrad, self.wgrad_unpack = pack_fwd, dgrad, wgrad_unpack
@@ -52,6 +52,9 @@ class LayerSpec:
         # passthrough: forward also returns an alias of x for a skip connection; the gradient arriving on that alias is added
         # in the dgrad kernel's epilogue (`dgrad(..., add=)`) instead of by a separate elementwise pass
         self.passthrough = passthrough
+        # pool: the layer is followed by MaxPool2d(2,2); BatchNorm + activation + pooling run as one pass over the raw output and
+        # the full-resolution activation is never stored (backward recomputes the window from raw)
+        self.pool = pool
 
 
 class GemmLayerFn(torch.autograd.Function):
@@ -119,9 +122,13 @@ class GemmLayerFn(torch.autograd.Function):
                     mean = ops.pad_vec(bn.running_mean.clone(), Np)
                     scale = ops.pad_vec(gamma.detach(), Np) * invstd
                     shift = ops.pad_vec(beta.detach(), Np) - mean * scale
-            y = torch.empty_like(raw)
-            ops.scale_shift_act(raw, Np, scale, shift, y, Np, M, Np, spec.act, spec.slope, res=res,
-                                ldr=0 if res is None else ld_of(res))
+            if spec.pool:
+                assert res is None
+                y = ops.maxpool2_affine(raw, scale, shift, spec.act, spec.slope)
+            else:
+                y = torch.empty_like(raw)
+                ops.scale_shift_act(raw, Np, scale, shift, y, Np, M, Np, spec.act, spec.slope, res=res,
+                                    ldr=0 if res is None else ld_of(res))
         ctx.spec = spec
         ctx.has = (bias is not None, gamma is not None, residual is not None)
         # layers without a residual re-derive the activation mask from raw*scale+shift in backward
@@ -139,6 +146,8 @@ class GemmLayerFn(torch.autograd.Function):
         has_bias, has_bn, has_res = ctx.has
         N, Np, M = spec.N, ceil4(spec.N), spec.M
         dev = x.device
+        if spec.pool:           # pooled gradient -> full resolution (window recomputed from raw*scale+shift)
+            dy = ops.maxpool2_bwd_affine(raw, psc, psh, spec.act, spec.slope, dy.contiguous())
         dy = as_rows(dy)
         dbias = dgamma = dbeta = dres = None
         need_pre = spec.act != ACT_NONE or has_bn or has_res or has_bias

@@ -125,7 +125,7 @@ def _run(ctx, x, lda, C, T, Wp, N, M, mode, geoms, out_t, ldo, coff, bias, bn, a
 
 
 # ----------------------------------------------------------------------------------------------
-def conv2d(ctx, x, conv, bn=None, act=ACT_NONE, slope=0.0, residual=None, out=None, in_ch=None, skip_out=False):
+def conv2d(ctx, x, conv, bn=None, act=ACT_NONE, slope=0.0, residual=None, out=None, in_ch=None, skip_out=False, pool=False):
     """nn.Conv2d (+BatchNorm2d) (+residual) (+activation) on [B][H][W][Cx].
     in_ch: (coff, C) selects a channel slice of x.  Returns the output buffer [B][Ho][Wo][ld]."""
     B, H, W, ldx = x.shape
@@ -147,7 +147,7 @@ def conv2d(ctx, x, conv, bn=None, act=ACT_NONE, slope=0.0, residual=None, out=No
     if ctx.grad:
         assert out is None
         xs = x if in_ch is None else x[..., a_off:a_off + Cx]
-        return _conv2d_grad(ctx, xs, conv, bn, act, slope, residual, geom, (B, H, W, Ho, Wo), Cp, passthrough=skip_out)
+        return _conv2d_grad(ctx, xs, conv, bn, act, slope, residual, geom, (B, H, W, Ho, Wo), Cp, passthrough=skip_out, pool=pool)
     out_t, ldo, coff = _alloc_out(x, (B, Ho, Wo), O, out)
     res_ld = residual.shape[-1] if residual is not None else 0
     _run(ctx, x, ldx, Cp, T, Wp, O, M, 1, [(geom, Wp, M)], out_t, ldo, coff, conv.bias, bn, act, slope,
@@ -283,8 +283,10 @@ def run_vgg(ctx, features, x):
             i += 1
         else:
             assert isinstance(m, nn.Conv2d) and isinstance(mods[i + 1], nn.BatchNorm2d)
-            x = conv2d(ctx, x, m, mods[i + 1], ACT_RELU)
-            i += 3
+            # training path: a following MaxPool2d is folded into the layer (BatchNorm + ReLU + pool in one pass over raw)
+            fuse = ctx.grad and i + 3 < len(mods) and isinstance(mods[i + 3], nn.MaxPool2d) and m.out_channels % 4 == 0
+            x = conv2d(ctx, x, m, mods[i + 1], ACT_RELU, pool=fuse)
+            i += 4 if fuse else 3
     return x
 
 
@@ -325,7 +327,7 @@ def _bn_args(bn):
     return (None, None) if bn is None else (bn.weight, bn.bias)
 
 
-def _conv2d_grad(ctx, x, conv, bn, act, slope, residual, geom, dims, Cp, passthrough=False):
+def _conv2d_grad(ctx, x, conv, bn, act, slope, residual, geom, dims, Cp, passthrough=False, pool=False):
     B, H, W, Ho, Wo = dims
     Cw, O = conv.in_channels, conv.out_channels
     kh, kw = conv.kernel_size
@@ -380,7 +382,7 @@ def _conv2d_grad(ctx, x, conv, bn, act, slope, residual, geom, dims, Cp, passthr
 
     spec = FN.LayerSpec(O, Cp, T, 1, [(geom, B * Ho * Wo)], B * Ho * Wo, (B, Ho, Wo), pack_fwd, dgrad, unpack,
                         bn=bn, train=ctx.train, act=act, slope=slope, c_real=Cw,
-                        passthrough=passthrough and x.requires_grad and x.shape[-1] == Cp)
+                        passthrough=passthrough and x.requires_grad and x.shape[-1] == Cp, pool=pool)
     g_, b_ = _bn_args(bn)
     out = FN.GemmLayerFn.apply(x, conv.weight, conv.bias, g_, b_, residual, spec)
     if passthrough and not spec.passthrough:

@@ -248,6 +248,23 @@ def maxpool2(x):
     return y
 
 
+def maxpool2_affine(raw, scale, shift, act, slope=0.0):
+    """max pool of act(raw*scale + shift) without materialising the activation; raw [B][H][W][C]"""
+    B, H, W, C = raw.shape
+    y = torch.empty((B, H // 2, W // 2, C), dtype=torch.float32, device=raw.device)
+    _C.check(_L().efgh_maxpool2_affine(ptr(raw), ptr(scale), ptr(shift), c_int32(act), c_float(slope), ptr(y), c_int32(B),
+                                       c_int32(H), c_int32(W), c_int32(C), _st()))
+    return y
+
+
+def maxpool2_bwd_affine(raw, scale, shift, act, slope, dy):
+    B, H, W, C = raw.shape
+    dx = torch.zeros_like(raw) if (H % 2 or W % 2) else torch.empty_like(raw)
+    _C.check(_L().efgh_maxpool2_bwd_affine(ptr(raw), ptr(scale), ptr(shift), c_int32(act), c_float(slope), ptr(dy), ptr(dx),
+                                           c_int32(B), c_int32(H), c_int32(W), c_int32(C), _st()))
+    return dx
+
+
 def nchw_to_nhwc(x, Cd=None):
     _C.require_cuda(x)
     x = x.contiguous()

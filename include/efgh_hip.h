@@ -256,6 +256,13 @@ int efgh_act_bn_bwd_apply(const float *dy, int64_t lddy, const float *y, int64_t
                           float *draw, int64_t lddraw, float *dres, int64_t lddres, void *stream);
 int efgh_maxpool2_bwd(const float *x, const float *dy, float *dx, int32_t B, int32_t H, int32_t W, int32_t C,
                       void *stream);
+/* BatchNorm + activation + MaxPool2d(2,2) fused over the raw conv output (training path of the VGG trunks, nets/vgg.py:69-83):
+ * y = max over the window of act(x*scale + shift); the backward recomputes the activated window and routes dy to its first
+ * maximum (rows / columns beyond 2*floor(H/2), 2*floor(W/2) are not written: zero dx beforehand when H or W is odd).        */
+int efgh_maxpool2_affine(const float *x, const float *scale, const float *shift, int32_t act, float slope, float *y,
+                         int32_t B, int32_t H, int32_t W, int32_t C, void *stream);
+int efgh_maxpool2_bwd_affine(const float *x, const float *scale, const float *shift, int32_t act, float slope,
+                             const float *dy, float *dx, int32_t B, int32_t H, int32_t W, int32_t C, void *stream);
 int efgh_segment_colmax_bwd(const float *dy, const int32_t *argrow, int32_t nseg, int32_t C, float *dx,
                             int64_t ld, void *stream);
 int efgh_segment_colmean_bwd(const float *dy, int32_t P, int32_t nseg, int32_t C, float *dx, int64_t ld,

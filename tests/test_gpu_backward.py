@@ -283,3 +283,38 @@ def test_g_image_losses_vs_torch_autograd():
     assert abs(float(a) - float(l_dep)) < 1e-5 * float(l_dep) and abs(float(b) - float(l_msk)) < 1e-5 * float(l_msk)
     assert torch.equal(gtd.cpu(), gd) and torch.equal(gtm.cpu(), (gd > 0).float())
     assert _relerr(pdg.grad.cpu(), pd.grad) < 1e-5 and _relerr(pmg.grad.cpu(), pm.grad) < 1e-5
+
+
+@pytest.mark.parametrize('hw', [(12, 20), (9, 13)])
+def test_vgg_block_with_fused_bn_relu_pool_backward(hw):
+    """conv3x3 + train-mode BatchNorm + ReLU + MaxPool2d(2,2) on the training path (BatchNorm/ReLU/pool fused over the raw conv
+    output, the full-resolution activation is never stored) against torch autograd; odd sizes leave the last row/column unpooled"""
+    from efgh_amd import ops
+    from efgh_amd.nets import layers as L
+    import copy
+    torch.manual_seed(2)
+    feats = nn.Sequential(nn.Conv2d(64, 64, 3, padding=1), nn.BatchNorm2d(64), nn.ReLU(), nn.MaxPool2d(2, 2),
+                          nn.Conv2d(64, 128, 3, padding=1), nn.BatchNorm2d(128), nn.ReLU())
+    for mod in feats:
+        if isinstance(mod, nn.BatchNorm2d):
+            with torch.no_grad():
+                mod.weight.uniform_(0.5, 1.5); mod.bias.normal_(0, 0.2)
+    feats.train()
+    x = torch.randn(2, 64, *hw, requires_grad=True)
+    y = feats(x)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    fg = copy.deepcopy(feats).cuda()
+    for p_ in fg.parameters():
+        p_.grad = None
+    fg.train()
+    xg = _nhwc(x.detach()).cuda().requires_grad_(True)
+    yg = L.run_vgg(L.Ctx(True), fg, xg)
+    yg.backward(_nhwc(gy).cuda())
+    assert yg.shape[1:3] == (hw[0] // 2, hw[1] // 2)
+    assert _relerr(yg.permute(0, 3, 1, 2).detach().cpu(), y.detach()) < 1e-5
+    assert _relerr(xg.grad.permute(0, 3, 1, 2).cpu(), x.grad) < 3e-4
+    for (n, p_), (_, q_) in zip(fg.named_parameters(), feats.named_parameters()):
+        if n.endswith('0.bias') or n.endswith('4.bias'):
+            continue                                      # conv bias in front of a train-mode BatchNorm: rounding noise
+        assert _relerr(p_.grad.cpu(), q_.grad) < 3e-4, n
