@@ -125,6 +125,126 @@ k_act_bn_bwd_apply(const float *__restrict__ dy, long long lddy, const float *__
     }
 }
 
+// ---- BatchNorm backward of a layer whose activation went straight into MaxPool2d(2,2) (k_maxpool2_affine) -----------------
+// One thread = one 2x2 cell (b, i, j) x one channel quad; the cell's activated values are recomputed from raw, the pooled gradient
+// goes to the first maximum, every other element has dpre = 0.  Cells of an odd last row / column have no pooled gradient at all.
+// Replaces pool-backward + reduce (4 activation passes) by 1.25 and pool-backward + apply (3) by 2.25.
+__device__ __forceinline__ void pool_cell_dpre(const float4 v[4], const bool ok[4], bool pooled, const float4 g, const float sc[4],
+                                               const float sf[4], int act, float slope, float dpre[4][4]) {
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch) {
+        float e[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float t = ((const float *)&v[q])[ch] * sc[ch] + sf[ch];
+            e[q] = act == 1 ? (t > 0.f ? t : 0.f) : (act == 2 ? (t > 0.f ? t : t * slope) : t);
+        }
+        int best = 0;
+#pragma unroll
+        for (int q = 1; q < 4; ++q) if (e[q] > e[best]) best = q;
+        const float gg = ((const float *)&g)[ch];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            // d act / d pre at the winning element, from its pre-activation sign (as dact() does on y = act(pre))
+            const float t = ((const float *)&v[q])[ch] * sc[ch] + sf[ch];
+            const float da = act == 1 ? (t > 0.f ? 1.f : 0.f) : (act == 2 ? (t > 0.f ? 1.f : slope) : 1.f);
+            dpre[q][ch] = (pooled && q == best && ok[q]) ? gg * da : 0.f;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(TPB)
+k_pool_bn_bwd_reduce(const float *__restrict__ dyp, const float *__restrict__ raw, const float *__restrict__ mean,
+                     const float *__restrict__ invstd, const float *__restrict__ pscale, const float *__restrict__ pshift,
+                     int B, int H, int W, int C, int act, float slope, int cells_per_block, int CL, double *__restrict__ part) {
+    __shared__ double s1s[TPB][4], s2s[TPB][4];
+    const int Hc = (H + 1) / 2, Wc = (W + 1) / 2, Ho = H / 2, Wo = W / 2;
+    const long long ncell = (long long)B * Hc * Wc;
+    const int cl = threadIdx.x % CL, rl = threadIdx.x / CL, RL = TPB / CL;
+    const int c = (blockIdx.x * CL + cl) * 4;
+    long long r0 = (long long)blockIdx.y * cells_per_block, r1 = r0 + cells_per_block;
+    if (r1 > ncell) r1 = ncell;
+    double s1[4] = {0., 0., 0., 0.}, s2[4] = {0., 0., 0., 0.};
+    if (c < C) {
+        const float4 mu = *reinterpret_cast<const float4 *>(mean + c), is = *reinterpret_cast<const float4 *>(invstd + c);
+        const float4 psc = *reinterpret_cast<const float4 *>(pscale + c), psh = *reinterpret_cast<const float4 *>(pshift + c);
+        const float sc[4] = {psc.x, psc.y, psc.z, psc.w}, sf[4] = {psh.x, psh.y, psh.z, psh.w};
+        const float muv[4] = {mu.x, mu.y, mu.z, mu.w}, isv[4] = {is.x, is.y, is.z, is.w};
+        for (long long r = r0 + rl; r < r1; r += RL) {
+            const int j = (int)(r % Wc); const long long t = r / Wc;
+            const int i = (int)(t % Hc); const long long b = t / Hc;
+            if (i >= Ho || j >= Wo) continue;                       // no pooled gradient: dpre = 0 everywhere in the cell
+            const long long base = (((b * H + 2 * i) * W) + 2 * j) * (long long)C + c;
+            const long long offs[4] = {0, C, (long long)W * C, (long long)W * C + C};
+            float4 v[4];
+            const bool ok[4] = {true, true, true, true};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const float4 *>(raw + base + offs[q]);
+            const float4 g = *reinterpret_cast<const float4 *>(dyp + (((b * Ho + i) * Wo) + j) * (long long)C + c);
+            float dpre[4][4];
+            pool_cell_dpre(v, ok, true, g, sc, sf, act, slope, dpre);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int ch = 0; ch < 4; ++ch) {
+                    const float d = dpre[q][ch];
+                    s1[ch] += (double)d;
+                    s2[ch] += (double)d * (double)((((const float *)&v[q])[ch] - muv[ch]) * isv[ch]);
+                }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { s1s[threadIdx.x][q] = s1[q]; s2s[threadIdx.x][q] = s2[q]; }
+    __syncthreads();
+    if (rl != 0 || c >= C) return;
+    for (int k = 1; k < RL; ++k)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { s1[q] += s1s[k * CL + cl][q]; s2[q] += s2s[k * CL + cl][q]; }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        part[((long long)blockIdx.y * 2) * C + c + q] = s1[q];
+        part[((long long)blockIdx.y * 2 + 1) * C + c + q] = s2[q];
+    }
+}
+
+__global__ void __launch_bounds__(TPB)
+k_pool_bn_bwd_apply(const float *__restrict__ dyp, const float *__restrict__ raw, const float *__restrict__ mean,
+                    const float *__restrict__ invstd, const float *__restrict__ coef, const double *__restrict__ m1,
+                    const double *__restrict__ m2, const float *__restrict__ pscale, const float *__restrict__ pshift, int B,
+                    int H, int W, int C, int act, float slope, float *__restrict__ draw) {
+    const int Hc = (H + 1) / 2, Wc = (W + 1) / 2, Ho = H / 2, Wo = W / 2, c4n = C >> 2;
+    const long long total = (long long)B * Hc * Wc * c4n;
+    for (long long idx = (long long)blockIdx.x * TPB + threadIdx.x; idx < total; idx += (long long)gridDim.x * TPB) {
+        const int c = (int)(idx % c4n) * 4; long long r = idx / c4n;
+        const int j = (int)(r % Wc); r /= Wc;
+        const int i = (int)(r % Hc); const long long b = r / Hc;
+        const bool pooled = i < Ho && j < Wo;
+        const long long base = (((b * H + 2 * i) * W) + 2 * j) * (long long)C + c;
+        const long long offs[4] = {0, C, (long long)W * C, (long long)W * C + C};
+        const bool ok[4] = {true, 2 * j + 1 < W, 2 * i + 1 < H, (2 * j + 1 < W) && (2 * i + 1 < H)};
+        float4 v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = ok[q] ? *reinterpret_cast<const float4 *>(raw + base + offs[q]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (pooled) g = *reinterpret_cast<const float4 *>(dyp + (((b * Ho + i) * Wo) + j) * (long long)C + c);
+        const float4 psc = *reinterpret_cast<const float4 *>(pscale + c), psh = *reinterpret_cast<const float4 *>(pshift + c);
+        const float sc[4] = {psc.x, psc.y, psc.z, psc.w}, sf[4] = {psh.x, psh.y, psh.z, psh.w};
+        float dpre[4][4];
+        pool_cell_dpre(v, ok, pooled, g, sc, sf, act, slope, dpre);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (!ok[q]) continue;
+            float o[4];
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch) {
+                const double xh = ((double)((const float *)&v[q])[ch] - (double)mean[c + ch]) * (double)invstd[c + ch];
+                o[ch] = (float)((double)coef[c + ch] * ((double)dpre[q][ch] - m1[c + ch] - xh * m2[c + ch]));
+            }
+            *reinterpret_cast<float4 *>(draw + base + offs[q]) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
 // backward of the fused BatchNorm + activation + max pool (elementwise.hip:k_maxpool2_affine): the four activated values of a
 // window are recomputed from the raw conv output, the gradient goes to the first maximal one (scan order), the others get 0
 __global__ void __launch_bounds__(TPB)
@@ -416,6 +536,45 @@ extern "C" int efgh_corr_unpad(const float *drp, int32_t B, int32_t h, int32_t w
                                void *stream_) {
     EFGH_CHECK_ARG(drp && dx && B > 0 && h > 0 && w > 0 && C % 4 == 0 && off >= 0 && off <= w);
     k_corr_unpad<<<grid_for((long long)B * h * w * (C / 4)), TPB, 0, (hipStream_t)stream_>>>(drp, B, h, w, C, off, dx);
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}
+
+extern "C" int32_t efgh_pool_bwd_groups(int32_t B, int32_t H, int32_t W) {
+    const long long ncell = (long long)B * ((H + 1) / 2) * ((W + 1) / 2);
+    const long long rows = bwd_rows_per_block(ncell);
+    return (int32_t)((ncell + rows - 1) / rows);
+}
+
+extern "C" int efgh_pool_bn_bwd_reduce(const float *dy_pool, const float *raw, const float *mean, const float *invstd,
+                                       const float *pscale, const float *pshift, int32_t B, int32_t H, int32_t W, int32_t C,
+                                       int32_t act, float slope, double *part, float *sum_dpre, float *sum_dpre_xhat,
+                                       double *mean_dpre, double *mean_dpre_xhat, void *stream_) {
+    hipStream_t st = (hipStream_t)stream_;
+    EFGH_CHECK_ARG(dy_pool && raw && mean && invstd && pscale && pshift && part && sum_dpre && sum_dpre_xhat && mean_dpre &&
+                   mean_dpre_xhat);
+    EFGH_CHECK_ARG(B > 0 && H >= 2 && W >= 2 && C > 0 && C % 4 == 0);
+    const long long ncell = (long long)B * ((H + 1) / 2) * ((W + 1) / 2);
+    const int G = efgh_pool_bwd_groups(B, H, W);
+    int CL = 1;
+    while (CL < 64 && CL * 4 < C) CL <<= 1;
+    k_pool_bn_bwd_reduce<<<dim3(cdiv(C / 4, CL), G), TPB, 0, st>>>(dy_pool, raw, mean, invstd, pscale, pshift, B, H, W, C, act,
+                                                                  slope, (int)bwd_rows_per_block(ncell), CL, part);
+    k_bwd_finalize<<<cdiv(C, 32), dim3(32, 32), 0, st>>>(part, G, C, (double)B * H * W, sum_dpre, sum_dpre_xhat, mean_dpre,
+                                                         mean_dpre_xhat);
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}
+
+extern "C" int efgh_pool_bn_bwd_apply(const float *dy_pool, const float *raw, const float *mean, const float *invstd,
+                                      const float *coef, const double *m1, const double *m2, const float *pscale,
+                                      const float *pshift, int32_t B, int32_t H, int32_t W, int32_t C, int32_t act,
+                                      float slope, float *draw, void *stream_) {
+    EFGH_CHECK_ARG(dy_pool && raw && mean && invstd && coef && m1 && m2 && pscale && pshift && draw);
+    EFGH_CHECK_ARG(B > 0 && H >= 2 && W >= 2 && C > 0 && C % 4 == 0);
+    const long long total = (long long)B * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4);
+    k_pool_bn_bwd_apply<<<grid_for(total), TPB, 0, (hipStream_t)stream_>>>(dy_pool, raw, mean, invstd, coef, m1, m2, pscale,
+                                                                          pshift, B, H, W, C, act, slope, draw);
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
 }

@@ -146,12 +146,20 @@ class GemmLayerFn(torch.autograd.Function):
         has_bias, has_bn, has_res = ctx.has
         N, Np, M = spec.N, ceil4(spec.N), spec.M
         dev = x.device
-        if spec.pool:           # pooled gradient -> full resolution (window recomputed from raw*scale+shift)
+        fused_pool = spec.pool and has_bn and spec.train and not has_res and Np == N
+        if spec.pool and not fused_pool:    # pooled gradient -> full resolution (window recomputed from raw*scale+shift)
             dy = ops.maxpool2_bwd_affine(raw, psc, psh, spec.act, spec.slope, dy.contiguous())
         dy = as_rows(dy)
         dbias = dgamma = dbeta = dres = None
         need_pre = spec.act != ACT_NONE or has_bn or has_res or has_bias
-        if not need_pre:
+        if fused_pool:
+            # BatchNorm backward straight from the pooled gradient (no full-resolution dy is ever written)
+            coef = gamma * invstd
+            draw, s1, s2 = ops.pool_bn_bwd(dy.contiguous(), raw, mean, invstd, coef, psc, psh, spec.act, spec.slope)
+            dbeta, dgamma = s1, s2
+            if has_bias:
+                dbias = ops.col_sum(draw, M, Np)
+        elif not need_pre:
             draw = dy
         else:
             G = ops.bwd_groups(M)

@@ -263,6 +263,17 @@ int efgh_maxpool2_affine(const float *x, const float *scale, const float *shift,
                          int32_t B, int32_t H, int32_t W, int32_t C, void *stream);
 int efgh_maxpool2_bwd_affine(const float *x, const float *scale, const float *shift, int32_t act, float slope,
                              const float *dy, float *dx, int32_t B, int32_t H, int32_t W, int32_t C, void *stream);
+/* BatchNorm backward of such a fused layer straight from the POOLED gradient dy_pool [B][H/2][W/2][C] (train-mode BN): the 2x2
+ * window is recomputed from raw, the pooled gradient goes to its first maximum, all other elements have dpre = 0.  Same outputs
+ * as efgh_act_bn_bwd_reduce / _apply (means over all B*H*W positions); part: [efgh_pool_bwd_groups(B,H,W)][2][C] float64.      */
+int32_t efgh_pool_bwd_groups(int32_t B, int32_t H, int32_t W);
+int efgh_pool_bn_bwd_reduce(const float *dy_pool, const float *raw, const float *mean, const float *invstd, const float *pscale,
+                            const float *pshift, int32_t B, int32_t H, int32_t W, int32_t C, int32_t act, float slope,
+                            double *part, float *sum_dpre, float *sum_dpre_xhat, double *mean_dpre, double *mean_dpre_xhat,
+                            void *stream);
+int efgh_pool_bn_bwd_apply(const float *dy_pool, const float *raw, const float *mean, const float *invstd, const float *coef,
+                           const double *m1, const double *m2, const float *pscale, const float *pshift, int32_t B, int32_t H,
+                           int32_t W, int32_t C, int32_t act, float slope, float *draw, void *stream);
 int efgh_segment_colmax_bwd(const float *dy, const int32_t *argrow, int32_t nseg, int32_t C, float *dx,
                             int64_t ld, void *stream);
 int efgh_segment_colmean_bwd(const float *dy, int32_t P, int32_t nseg, int32_t C, float *dx, int64_t ld,
