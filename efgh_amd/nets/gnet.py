@@ -46,9 +46,22 @@ class Gnet(nn.Module):
             """torch.cat / concat_tensors of gnet.py:117-121: channel slices of one buffer (inference) or an
             explicit concatenation (training, so that autograd sees it)"""
             return torch.cat(parts, -1) if ctx.grad else b
-        assert H % 8 == 0 and W % 8 == 0, 'reference needs (W/2)%8==0 (SURVEY 8a-17); H likewise here'
-        cat3 = buf(H // 4, W // 4, 512)       # [conv_img4 | convt_img4]
-        cat2 = buf(H // 2, W // 2, 256)       # [conv_img3 | convt_img3]
+        # widths must halve exactly three times (the reference's torch.cat fails otherwise, SURVEY 8a-17); heights only need
+        # H even: a stride-2 layer gives ceil(h/2) rows, the transposed convolution 2*ceil(h/2), and concat_tensors
+        # (common/torch_utils.py:309-319) crops the surplus row: p1 = int((2*ceil(h/2) - h) / 2) = 0, i.e. the first h rows
+        assert H % 2 == 0 and W % 8 == 0, 'reference needs raw H % 4 == 0 and (W/2) % 8 == 0 (SURVEY 8a-17)'
+        h2, h3 = (H + 1) // 2, ((H + 1) // 2 + 1) // 2
+
+        def crop(t, h, b, off):
+            """concat_tensors' crop of a decoder output to the skip connection's height"""
+            if t.shape[1] == h:
+                return t
+            t = t[:, :h]
+            if not ctx.grad:
+                b[..., off:off + t.shape[-1]].copy_(t)
+            return t
+        cat3 = buf(h3, W // 4, 512)           # [conv_img4 | convt_img4]
+        cat2 = buf(h2, W // 2, 256)           # [conv_img3 | convt_img3]
         cat1 = buf(H, W, 128)                 # [convt_img2 | conv_img2]
         c1 = L.run_conv_bn_relu(ctx, self.conv_i0, x)                              # gnet.py:103
         c2 = L.run_resnet_layer(ctx, self.conv_img2, c1, out=tgt(cat1, 64))
@@ -60,8 +73,10 @@ class Gnet(nn.Module):
             c3 = _layer_from_slice(ctx, self.conv_img3, cat1, 64, 64, out=(cat2, 0))
             c4 = _layer_from_slice(ctx, self.conv_img4, cat2, 0, 128, out=(cat3, 0))
             c5 = _layer_from_slice(ctx, self.conv_img5, cat3, 0, 256, out=None)
-        t4 = L.run_convt_bn_relu(ctx, self.convt_img4, c5, out=tgt(cat3, 256))     # :116
-        t3 = L.run_convt_bn_relu(ctx, self.convt_img3, cat(cat3, [c4, t4]), out=tgt(cat2, 128))
+        t4 = L.run_convt_bn_relu(ctx, self.convt_img4, c5, out=tgt(cat3, 256) if 2 * c5.shape[1] == h3 else None)     # :116
+        t4 = crop(t4, h3, cat3, 256)
+        t3 = L.run_convt_bn_relu(ctx, self.convt_img3, cat(cat3, [c4, t4]), out=tgt(cat2, 128) if 2 * h3 == h2 else None)
+        t3 = crop(t3, h2, cat2, 128)
         t2 = L.run_convt_bn_relu(ctx, self.convt_img2, cat(cat2, [c3, t3]), out=tgt(cat1, 0))
         cv = cat(cat1, [t2, c2])
         dimg = L.run_convt_bn_relu(ctx, self.convt_dimg, cv)                       # (B,2H,2W,4) ch0

@@ -16,13 +16,12 @@ def _rel(got, ref):
     return float(np.abs(got - ref).max() / (np.abs(ref).max() + 1e-12))
 
 
-@pytest.fixture(scope='module')
-def full(manifest):
+def _eval_forward(manifest, raw, npts):
     from efgh_amd.nets import EFGHBackbone
-    m = EFGHBackbone(syn.default_args(RAW, 'cuda'))
+    m = EFGHBackbone(syn.default_args(raw, 'cuda'))
     m.load_state_dict(syn.synthetic_state_dict(manifest['state_dict'], 1), strict=True)
     m = m.cuda().eval()
-    b = syn.make_batch(RAW, NPTS, 1)
+    b = syn.make_batch(raw, npts, 1)
     inp = [torch.from_numpy(b[k]).cuda() for k in ('pc', 'img', 'calib', 'A')]
     keep = {}
     with torch.no_grad():
@@ -30,12 +29,32 @@ def full(manifest):
     return m, inp, out, keep
 
 
+@pytest.fixture(scope='module')
+def full(manifest):
+    return _eval_forward(manifest, RAW, NPTS)
+
+
 def test_fullsize_stagewise_vs_oracle(full, manifest):
+    _stagewise(full, manifest, RAW)
+
+
+def test_rellis_config_stagewise_vs_oracle(manifest):
+    """BASELINE configs[0]: the shipped RELLIS-3D configuration (configs/train_rellis.yaml:19-22: raw_cam_img_size [900, 1600],
+    65 536 points, batch 1).  Odd sizes all the way down (450x800 network input, 225 / 113 / 57 / 29 / 15-row feature maps, ragged
+    Winograd tiles, odd pooling edges) at the real scale."""
+    raw, npts = (900, 1600), 65536
+    st = _eval_forward(manifest, raw, npts)
+    out = st[2]
+    assert out['g_depth'].shape == (1, 1, 900, 1600) and out['h_img'].shape == (1, 3, 450, 800)
+    _stagewise(st, manifest, raw)
+
+
+def _stagewise(full, manifest, raw):
     from oracle import efgh_oracle as O
     m, inp, out, _ = full
     torch.set_num_threads(min(32, os.cpu_count() or 1))
     P = syn.synthetic_state_dict(manifest['state_dict'], 1)
-    args = syn.default_args(RAW, 'cpu')
+    args = syn.default_args(raw, 'cpu')
     cpu = [t.cpu() for t in inp]
     with torch.no_grad():
         rete = O.enet(P, cpu[0], False)
@@ -152,6 +171,20 @@ def test_kitti_odom_geometry_forward_vs_oracle(manifest):
 
 
 def test_fullsize_training_step_vs_oracle(manifest, monkeypatch):
+    rel, relg = _training_step(manifest, monkeypatch, RAW, NPTS)
+    assert rel['E'] < 2e-3 and rel['H'] < 1e-2 and rel['F'] == 0.0, rel
+    assert relg < 2e-2
+
+
+def test_rellis_config_training_step_vs_oracle(manifest, monkeypatch):
+    """the same at BASELINE configs[0] (900x1600 raw, 65 536 points): train-mode BatchNorm over the uncropped decoder outputs,
+    the concat_tensors crop and its backward, odd feature-map sizes in every dgrad / wgrad"""
+    rel, relg = _training_step(manifest, monkeypatch, (900, 1600), 65536)
+    assert rel['E'] < 2e-3 and rel['H'] < 1e-2 and rel['F'] < 2e-2, rel
+    assert relg < 2e-2
+
+
+def _training_step(manifest, monkeypatch, RAW, NPTS):
     """forward + efghloss + backward at config S (B = 1) against the oracle.
     Pass A - the whole pipeline (only the uint8 rotate teacher-forced, as in test_gpu_backward): every loss term, and the E / H
     gradients.  Pass B - the G net on the oracle's inputs (E/H/F outputs and the rasterised depth image teacher-forced): the
@@ -212,7 +245,6 @@ def test_fullsize_training_step_vs_oracle(manifest, monkeypatch):
     params = dict(m.named_parameters())
     rel = rel_by_net(lambda k: params[k].grad, 'EHF')
     print('pass A, gradient rel err:', {n: '%.2e' % v for n, v in rel.items()})
-    assert rel['E'] < 2e-3 and rel['H'] < 1e-2 and rel['F'] == 0.0, rel
     # ---- pass B: G on the oracle's inputs
     f_depth_o = keep_o['f_depth'].detach().permute(0, 2, 3, 1).contiguous().cuda()          # (B,4,H,W) -> [B][H][W][4]
     monkeypatch.setattr(FN.DepthImageFn, 'apply', staticmethod(lambda pc, T_, h, w: f_depth_o))
@@ -228,4 +260,4 @@ def test_fullsize_training_step_vs_oracle(manifest, monkeypatch):
     num = sum(float((a.cpu().double() - c.double()).pow(2).sum()) for a, c in zip(g_b, g_o))
     den = sum(float(c.double().pow(2).sum()) for c in g_o)
     print('pass B, G gradient rel err on teacher-forced inputs: %.2e' % ((num / den) ** 0.5))
-    assert (num / den) ** 0.5 < 2e-2
+    return rel, (num / den) ** 0.5
