@@ -41,6 +41,51 @@ def test_trainer_two_steps_match_torch_adam(manifest):
     assert set(m.state_dict().keys()) == {k for k, _, _ in manifest['state_dict']}
 
 
+def test_reference_training_loop_with_stock_torch_adam(manifest):
+    """the reference's own loop (iterater.py:28-43, main.py:181-183) over our modules, unchanged: model(pcd, img, calib, A, check),
+    criterion.compute_loss, torch.optim.Adam(model.parameters()).zero_grad / backward / step.  Must follow the Trainer path
+    (FusedAdam on the flat buffer) step for step - in particular the packed-weight / Winograd / folded-BN caches have to notice the
+    optimizer's in-place updates (they key on the parameter's version counter)."""
+    from efgh_amd.losses import EFGHCriterion
+    from efgh_amd.nets import EFGHBackbone
+    from efgh_amd.train import Trainer
+    args = syn.default_args(RAW, 'cuda')
+    sd = syn.synthetic_state_dict(manifest['state_dict'], 1)
+    m_ref, m_tr = EFGHBackbone(args), EFGHBackbone(args)
+    m_ref.load_state_dict(sd); m_tr.load_state_dict(sd)
+    m_ref, m_tr = m_ref.cuda(), m_tr.cuda()
+    criterion = EFGHCriterion(args)
+    optimizer = torch.optim.Adam(m_ref.parameters(), lr=1e-3, weight_decay=0.0)
+    tr = Trainer(m_tr, EFGHCriterion(args), lr=1e-3)
+    b = syn.make_batch(RAW, NPTS, 2)
+    pcd, img, calib, A = [torch.from_numpy(b[k]).cuda().float() for k in ('pc', 'img', 'calib', 'A')]
+    gt = {k: torch.from_numpy(v) for k, v in b['gt'].items()}
+    w0 = [q.detach().clone() for q in m_tr.parameters()]
+    m_ref.train()
+    seen = []
+    for it in range(2):
+        pred = m_ref(pcd, img, calib, A, it == 0)
+        losses, _ = criterion.compute_loss(pcd, img, calib, A, dict(gt), pred)
+        optimizer.zero_grad()
+        losses['total'].backward()
+        optimizer.step()
+        l_tr, _ = tr.step(pcd, img, calib, A, dict(gt))
+        # the second step runs on weights the stock optimizer updated in place: equal losses <=> every cache was refreshed.
+        # (later steps are not comparable: Adam's first updates are lr * sign(g), so gradient noise on near-zero gradients moves
+        # the trajectory by 0.5 % of the loss within three steps - measured, also between two runs of the same path)
+        assert abs(losses['total'].item() - l_tr['total'].item()) <= 1e-3 * abs(l_tr['total'].item()), (it, losses['total'].item())
+        seen.append(losses['total'].item())
+    assert seen[0] != seen[1]
+    num = den = 0.0
+    for p, q, w in zip(m_ref.parameters(), m_tr.parameters(), w0):
+        num += float(((p.detach() - w) - (q.detach() - w)).double().pow(2).sum())
+        den += float((q.detach() - w).double().pow(2).sum())
+    assert den > 0 and (num / den) ** 0.5 < 0.1, (num / den) ** 0.5      # the two optimizers moved the weights the same way
+    for (k, p), q in zip(m_ref.named_buffers(), m_tr.buffers()):            # BatchNorm running statistics
+        if p.dtype.is_floating_point:
+            assert float((p - q).norm()) <= 1e-2 * float(q.norm()) + 1e-6, k
+
+
 def test_winograd_and_direct_kernels_give_the_same_first_training_step(manifest):
     """the 3x3 layers on the Winograd kernels (forward, dgrad, wgrad) vs the same step on the direct kernels: same losses and
     the same per-sub-net gradients up to the conditioning bands of DESIGN.md §4 (the first step, before the trajectories can
