@@ -153,3 +153,24 @@ def test_overfitting_one_small_batch_reduces_every_loss_group(manifest):
     for k in ('e_gn', 'h_hrzn', 'fov', 'g_trs'):
         assert hist[-1][k] < hist[0][k], (k, hist[0][k], hist[-1][k])
     assert int(m.H.vgg.features[1].num_batches_tracked) == 20
+
+
+def test_dataparallel_wrapper_single_device(manifest):
+    """main.py:127 wraps the model in nn.DataParallel; on one device that must be a transparent wrapper (same outputs, 'module.'-
+    prefixed state_dict that the checkpoint helpers accept)"""
+    from efgh_amd.nets import EFGHBackbone
+    args = syn.default_args(RAW, 'cuda')
+    m = EFGHBackbone(args)
+    m.load_state_dict(syn.synthetic_state_dict(manifest['state_dict'], 1))
+    m = m.cuda().eval()
+    dp = torch.nn.DataParallel(m, device_ids=[0])
+    b = syn.make_batch(RAW, NPTS, 2)
+    inp = [torch.from_numpy(b[k]).cuda() for k in ('pc', 'img', 'calib', 'A')]
+    with torch.no_grad():
+        a, c = m(*inp), dp(*inp, False)
+    assert a.keys() == c.keys() and c['network'] == 'EHFG'
+    for k, v in a.items():
+        if torch.is_tensor(v):
+            assert torch.equal(v, c[k]), k
+    assert all(k.startswith('module.') for k in dp.state_dict())
+    assert {k[len('module.'):] for k in dp.state_dict()} == {k for k, _, _ in manifest['state_dict']}
