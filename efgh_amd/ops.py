@@ -95,8 +95,24 @@ def wino_eligible(mode, C, N, geom, T=None):
             and list(dh) == [t // 3 - 1 for t in range(9)] and list(dw) == [t % 3 - 1 for t in range(9)])
 
 
+USE_C4 = _os.environ.get('EFGH_C4', '1') != '0'       # dedicated MFMA kernels for the 4-channel input layers (c4conv.hip)
+
+
+def c4_eligible(mode, C, N, geom, wgrad=False):
+    """the layers efgh_c4_conv3x3 / efgh_c4_wgrad serve (mirror of efgh_c4_supported): 3x3, pad 1, stride 1 or 2, C == 4"""
+    if not USE_C4 or mode != 1 or geom is None or C != 4:
+        return False
+    if (N % 16 or not 32 <= N <= 128) if wgrad else N not in (32, 64, 128):
+        return False
+    (B, Hin, Win, Hv, Wv, sh, sw, dh, dw, Ho, Wo, osh, osw, oh0, ow0) = geom
+    return (len(dh) == 9 and sh == sw and sh in (1, 2) and (osh, osw, oh0, ow0) == (1, 1, 0, 0) and Hv == Ho and Wv == Wo
+            and list(dh) == [t // 3 - 1 for t in range(9)] and list(dw) == [t % 3 - 1 for t in range(9)])
+
+
 def stats_rows(mode, C, N, geom, M):
     """rows of the per-tile BatchNorm statistics buffer the GEMM launch for this layer writes"""
+    if c4_eligible(mode, C, N, geom):
+        return _L().efgh_c4_stats_rows(c_int32(geom[0]), c_int32(geom[9]), c_int32(geom[10]))
     if wino_eligible(mode, C, N, geom):
         return _L().efgh_wino_grid_m(c_int32(geom[0]), c_int32(geom[1]), c_int32(geom[2]))
     return gemm_grid_m(M, N)
@@ -185,6 +201,9 @@ def gather_gemm(A, lda, C, T, Wp, N, M, out, ldo, mode=0, geom=None, table=None,
     wino = False
     if thin:
         _C.check(_L().efgh_thin_gemm(ctypes.byref(d), _st()))
+    elif M_dev is None and batch is None and c4_eligible(mode, C, N, geom):
+        assert lda % 4 == 0
+        _C.check(_L().efgh_c4_conv3x3(ctypes.byref(d), _st()))
     elif M_dev is None and batch is None and wino_eligible(mode, C, N, geom):
         wino = True
         _C.check(_L().efgh_wino_conv3x3(ctypes.byref(d), ptr(wino_weight(Wp, N, C)), _st()))
@@ -488,6 +507,8 @@ def gather_wgrad(A, lda, C, T, N, M, G, ldg, dWp, mode=0, geom=None, table=None)
     wino = False
     if thin:
         _C.check(_L().efgh_thin_wgrad(ctypes.byref(d), ptr(G), c_int64(ldg), ptr(dWp), _st()))
+    elif c4_eligible(mode, C, N, geom, wgrad=True):
+        _C.check(_L().efgh_c4_wgrad(ctypes.byref(d), ptr(G), c_int64(ldg), ptr(dWp), _st()))
     elif USE_WINO_WGRAD and C % 64 == 0 and wino_eligible(mode, C, N, geom):
         wino = True
         S = torch.empty((6, N, 3 * C), dtype=torch.float32, device=dWp.device)       # zeroed by the C-ABI call

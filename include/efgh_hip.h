@@ -299,6 +299,17 @@ int efgh_thin_supported(const efgh_gemm_desc *d);
 int efgh_thin_gemm(const efgh_gemm_desc *d, void *stream);
 int efgh_thin_wgrad(const efgh_gemm_desc *d, const float *G, int64_t ldg, float *dWp, void *stream);
 
+/* 3x3 convolutions with C == 4 input channels per tap, stride 1 or 2, pad 1, N in {32, 64, 128} on fp32 MFMA (the RGB / range /
+ * depth input layers: nets/vgg.py:77 first conv, nets/gnet.py:21,80; and the data gradient of G's transposed heads): the three
+ * input rows of 128 output pixels are staged in LDS once, the 36 x N weights stay in registers of a persistent workgroup.  Same
+ * descriptor and epilogue as efgh_gather_gemm; `stats` has efgh_c4_stats_rows(B, Ho, Wo) rows.  efgh_c4_wgrad: the weight
+ * gradient dWp [N][9][4] of the same layers (N % 16 == 0, 32 <= N <= 128) on v_mfma_f32_16x16x4_f32, G [M][ldg] read once.      */
+int efgh_c4_supported(const efgh_gemm_desc *d);
+int32_t efgh_c4_stats_rows(int32_t B, int32_t Ho, int32_t Wo);
+int efgh_c4_conv3x3(const efgh_gemm_desc *d, void *stream);
+int efgh_c4_wgrad_supported(const efgh_gemm_desc *d);
+int efgh_c4_wgrad(const efgh_gemm_desc *d, const float *G, int64_t ldg, float *dWp, void *stream);
+
 /* split-bf16 variant of efgh_gather_gemm: every fp32 operand x is used as hi+lo (two bf16 numbers,
  * |x-hi-lo| <= 2^-17|x|) and each product as ah*bh + ah*bl + al*bh on v_mfma_f32_32x32x16_bf16 with fp32
  * accumulation: 3 bf16 MFMAs of K=16 replace 8 fp32 MFMAs of K=2.  Activations are split on the fly

@@ -255,6 +255,53 @@ def test_winograd_conv3x3_vs_direct_and_fp64(L, cin, cout, hw, B):
     assert _rel(bng.running_var.cpu(), bn.running_var) < 1e-5 and _rel(bng.running_mean.cpu(), bn.running_mean) < 1e-4
 
 
+@pytest.mark.parametrize('cin,cout,stride,hw,B', [(3, 64, 1, (24, 40), 2), (4, 32, 2, (37, 301), 1), (1, 128, 2, (18, 26), 2),
+                                                 (3, 64, 1, (9, 263), 1), (2, 128, 1, (5, 131), 2)])
+def test_c4_mfma_conv_vs_generic_and_fp64(L, cin, cout, stride, hw, B):
+    """efgh_c4_conv3x3 / efgh_c4_wgrad (4 input channels per tap: the RGB / range / depth input layers and the data gradient of
+    G's transposed heads) against the generic implicit-GEMM kernels and float64: stride 1 and 2, odd sizes, several 128-pixel
+    units per row with a ragged last one, residual epilogue, train-mode BatchNorm statistics, weight gradient"""
+    from efgh_amd import ops
+    torch.manual_seed(3)
+    conv = nn.Conv2d(cin, cout, 3, stride, 1, bias=True)
+    x = torch.randn(B, cin, *hw)
+    ho, wo = (hw[0] + 2 - 3) // stride + 1, (hw[1] + 2 - 3) // stride + 1
+    res = torch.randn(B, cout, ho, wo)
+    ref = F.leaky_relu(F.conv2d(x.double(), conv.weight.double(), conv.bias.double(), stride=stride, padding=1) + res.double(), 0.2)
+    cg = nn.Conv2d(cin, cout, 3, stride, 1, bias=True).cuda()
+    cg.load_state_dict(conv.state_dict())
+    xg, rg = ops.nchw_to_nhwc(x.cuda(), 4), ops.nchw_to_nhwc(res.cuda(), cout)
+    taps = ([t // 3 - 1 for t in range(9)], [t % 3 - 1 for t in range(9)])
+    geom = (B, hw[0], hw[1], ho, wo, stride, stride, taps[0], taps[1], ho, wo, 1, 1, 0, 0)
+    out = {}
+    for c4 in (True, False):
+        ops.USE_C4 = c4
+        try:
+            assert ops.c4_eligible(1, 4, cout, geom) == c4
+            with torch.no_grad():
+                y = L.conv2d(L.Ctx(False), xg, cg, None, L.ACT_LEAKY, 0.2, residual=rg)
+            out[c4] = y.permute(0, 3, 1, 2).double().cpu()
+        finally:
+            ops.USE_C4 = True
+    assert _rel(out[True], ref) < 2e-6 and _rel(out[False], ref) < 2e-6, (_rel(out[True], ref), _rel(out[False], ref))
+    # train-mode BatchNorm on top (one statistics row per persistent workgroup) + the weight gradient through autograd
+    bn = nn.BatchNorm2d(cout)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.2)
+    bng = nn.BatchNorm2d(cout).cuda()
+    bng.load_state_dict(bn.state_dict())
+    bn.train(); bng.train()
+    gy = torch.randn(B, cout, ho, wo)
+    refb = F.relu(bn(conv(x)))
+    refb.backward(gy)
+    yb = L.conv2d(L.Ctx(True), xg, cg, bng, L.ACT_RELU, 0.0)          # grad mode: the autograd Functions of nets/fn.py
+    yb.backward(ops.nchw_to_nhwc(gy.cuda(), cout))
+    assert _rel(yb.detach().permute(0, 3, 1, 2).cpu(), refb.detach()) < 2e-5
+    assert _rel(bng.running_var.cpu(), bn.running_var) < 1e-5 and _rel(bng.running_mean.cpu(), bn.running_mean) < 1e-4
+    assert _rel(cg.weight.grad.cpu(), conv.weight.grad) < 2e-4, _rel(cg.weight.grad.cpu(), conv.weight.grad)
+    assert _rel(bng.weight.grad.cpu(), bn.weight.grad) < 2e-4 and _rel(bng.bias.grad.cpu(), bn.bias.grad) < 2e-4
+
+
 @pytest.mark.parametrize('C', [36, 68, 132, 260, 4])
 def test_splat_csr_equals_atomic_and_reference_sum(C):
     """CSR gather splat (no fp32 atomics) == the atomic scatter form == a float64 scatter-add, incl. empty vertices"""
