@@ -203,6 +203,7 @@ def gather_gemm(A, lda, C, T, Wp, N, M, out, ldo, mode=0, geom=None, table=None,
         _C.check(_L().efgh_thin_gemm(ctypes.byref(d), _st()))
     elif M_dev is None and batch is None and c4_eligible(mode, C, N, geom):
         assert lda % 4 == 0
+        thin = True             # (for the profile lists: an HBM-bound launch, not part of the MFMA GEMM family)
         _C.check(_L().efgh_c4_conv3x3(ctypes.byref(d), _st()))
     elif M_dev is None and batch is None and wino_eligible(mode, C, N, geom):
         wino = True
@@ -508,6 +509,7 @@ def gather_wgrad(A, lda, C, T, N, M, G, ldg, dWp, mode=0, geom=None, table=None)
     if thin:
         _C.check(_L().efgh_thin_wgrad(ctypes.byref(d), ptr(G), c_int64(ldg), ptr(dWp), _st()))
     elif c4_eligible(mode, C, N, geom, wgrad=True):
+        thin = True             # (profile lists, as above)
         _C.check(_L().efgh_c4_wgrad(ctypes.byref(d), ptr(G), c_int64(ldg), ptr(dWp), _st()))
     elif USE_WINO_WGRAD and C % 64 == 0 and wino_eligible(mode, C, N, geom):
         wino = True
