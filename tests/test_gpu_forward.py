@@ -151,3 +151,32 @@ def test_split_math_forward_logits_within_1e4(golden_dir, manifest, math):
                 assert _rel(got[k].cpu().numpy(), ref[k].numpy()) < 1e-4, k
     finally:
         ops.MATH = old
+
+
+def test_odd_point_count_and_strided_inputs_vs_oracle(manifest):
+    """a sweep whose point count is neither a multiple of 4 nor of 64 (2 045 of the 2 048 points), handed over as a
+    non-contiguous slice of a larger buffer, and an image that is a strided view: E / H logits and the E rasters against the
+    oracle, plus agreement with the contiguous call (no alignment or pitch assumption leaks out of the kernels)"""
+    from oracle import efgh_oracle as O
+    m = _model(manifest, False)
+    b, inp = _inputs(2, 5)
+    n = NPTS - 3
+    pc = inp[0][:, :, :n]                                   # (B, 3, n) view with row pitch NPTS
+    big = torch.zeros((2, 3, RAW[0] // 2 + 2, RAW[1] // 2 + 6), device='cuda')
+    big[:, :, 1:-1, 3:-3] = inp[1]
+    img = big[:, :, 1:-1, 3:-3]                             # strided view of the same pixels
+    assert not pc.is_contiguous() and not img.is_contiguous()
+    with torch.no_grad():
+        o_v = m(pc, img, inp[2], inp[3])
+        o_c = m(pc.contiguous(), img.contiguous(), inp[2], inp[3])
+    for k in LOGITS + ('g_depth', 'cam_T_velo'):
+        assert torch.equal(o_v[k], o_c[k]), k
+    P = syn.synthetic_state_dict(manifest['state_dict'], 1)
+    with torch.no_grad():
+        for s in range(2):
+            rete = O.enet(P, pc[s:s + 1].cpu().contiguous(), False)
+            reth = O.hnet(P, img[s:s + 1].cpu().contiguous(), False)
+            for k in ('e_gn_sgn', 'e_gn_abs'):
+                assert _rel(o_v[k][s:s + 1].cpu().numpy(), rete[k].numpy()) < 1e-4, (k, s)
+            for k in ('h_hrzn_sgn', 'h_hrzn_abs'):
+                assert _rel(o_v[k][s:s + 1].cpu().numpy(), reth[k].numpy()) < 1e-4, (k, s)
