@@ -73,3 +73,12 @@ def require_cuda(*tensors):
         if t is not None and not t.is_cuda:
             raise EfghError('efgh_amd runs on the GPU through libefgh_hip.so only (got a CPU tensor); '
                             'there is no CPU fallback')
+
+
+def require_f32(*tensors):
+    """the kernels read raw float32 memory: anything else would be misread silently (the reference's loop casts its inputs
+    with .float(), iterater.py:29-32)"""
+    import torch
+    for t in tensors:
+        if t is not None and t.dtype != torch.float32:
+            raise EfghError('efgh_amd expects float32 tensors, got %s (cast with .float() as iterater.py:29-32 does)' % t.dtype)

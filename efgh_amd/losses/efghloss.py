@@ -51,7 +51,8 @@ class EFGHCriterion(nn.Module):
 
     def compute_loss(self, pc, img, calib, A, gt, pred):
         dev = pred['f_score'].device
-        ops._C.require_cuda(pred['f_score'])
+        ops._C.require_cuda(pred['f_score'], pc, calib, A)
+        ops._C.require_f32(pc, calib, A)
         lam = self.lam
         gt = dict(gt)
         B = pc.size(0)

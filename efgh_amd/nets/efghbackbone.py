@@ -23,6 +23,7 @@ class EFGHBackbone(nn.Module):
 
     def forward(self, pc, img, calib, A, check=False, keep=None):
         ops._C.require_cuda(pc, img, calib, A)
+        ops._C.require_f32(pc, img, calib, A)
         img_nhwc = ops.nchw_to_nhwc(img, 4)             # shared by H and G
         rete = self.E(pc, check, keep=keep)
         reth = self.H(img, check, img_nhwc=img_nhwc, keep=keep)

@@ -118,6 +118,10 @@ def test_cpu_tensors_are_refused(manifest):
     _, inp = _inputs()
     with pytest.raises(_C.EfghError):
         m(*[t.cpu() for t in inp])
+    with pytest.raises(_C.EfghError):                       # float64 memory must not be read as float32
+        m(inp[0].double(), *inp[1:])
+    with pytest.raises(_C.EfghError):
+        m(inp[0], inp[1].to(torch.uint8), *inp[2:])
 
 
 @pytest.mark.parametrize('math', ['bf16x3', 'f16x3'])
