@@ -174,3 +174,27 @@ def test_dataparallel_wrapper_single_device(manifest):
             assert torch.equal(v, c[k]), k
     assert all(k.startswith('module.') for k in dp.state_dict())
     assert {k[len('module.'):] for k in dp.state_dict()} == {k for k, _, _ in manifest['state_dict']}
+
+
+def test_eval_mode_with_autograd_enabled(manifest):
+    """model.eval() WITHOUT torch.no_grad() (fine-tuning with frozen BatchNorm statistics, or a validation loop that forgets
+    the guard): the autograd path with eval-mode BatchNorm gives bit-identical outputs and a finite gradient for every parameter"""
+    from efgh_amd.losses import EFGHCriterion
+    from efgh_amd.nets import EFGHBackbone
+    args = syn.default_args(RAW, 'cuda')
+    m = EFGHBackbone(args)
+    m.load_state_dict(syn.synthetic_state_dict(manifest['state_dict'], 1))
+    m = m.cuda().eval()
+    b = syn.make_batch(RAW, NPTS, 2)
+    inp = [torch.from_numpy(b[k]).cuda() for k in ('pc', 'img', 'calib', 'A')]
+    gt = {k: torch.from_numpy(v) for k, v in b['gt'].items()}
+    rm = {k: v.clone() for k, v in m.state_dict().items() if 'running_' in k}
+    with torch.no_grad():
+        o0 = m(*inp)
+    o1 = m(*inp)
+    for k in ('e_gn_sgn', 'e_gn_abs', 'h_hrzn_sgn', 'h_hrzn_abs', 'f_score', 'g_trs', 'g_depth', 'g_mask'):
+        assert torch.equal(o0[k], o1[k].detach()), k
+    L, _ = EFGHCriterion(args).compute_loss(*inp, gt, o1)
+    L['total'].backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+    assert all(torch.equal(v, m.state_dict()[k]) for k, v in rm.items())          # running statistics untouched
