@@ -23,6 +23,45 @@ def load_model_state(model, ckpt, strict=True):
     return model.load_state_dict(strip_module_prefix(sd), strict=strict)
 
 
+def update_dict_filter(pretrained_dict, convert_dict, model_dict):
+    """main.py:212-225: rename keys (every `convert_dict` key that occurs as a substring is replaced; a key matched by several
+    entries yields one renamed copy per entry, as in the reference), then keep what the model has"""
+    update = {}
+    for k, v in pretrained_dict.items():
+        converted = False
+        for old, new in convert_dict.items():
+            if old in k:
+                update[k.replace(old, new)] = v
+                converted = True
+        if not converted:
+            update[k] = v
+    return {k: v for k, v in update.items() if k in model_dict}
+
+
+def grad_false_keys_filter(model, grad_false_keys):
+    """main.py:227-235: parameters whose name contains one of the keys are frozen (requires_grad = False)"""
+    for k, p in model.named_parameters():
+        if any(key in k for key in grad_false_keys):
+            p.requires_grad = False
+    return model
+
+
+def load_pretrained(model, ckpt, convert_dict=None, grad_false_keys=None):
+    """the `pretrained_path` branch of main.py:162-176: partial, renamed, non-strict load + freezing.  The optimizer must be
+    built afterwards over the parameters that still require a gradient (main.py:178-183; train.Trainer / FlatParams do)."""
+    if isinstance(ckpt, (str, os.PathLike)):
+        ckpt = torch.load(ckpt, map_location='cpu')
+    sd = ckpt['state_dict'] if isinstance(ckpt, dict) and 'state_dict' in ckpt else ckpt
+    wrapped = all(k.startswith('module.') for k in sd)
+    model_dict = model.state_dict()
+    if wrapped:                                      # a checkpoint of the DataParallel-wrapped reference model
+        model_dict = {'module.' + k: v for k, v in model_dict.items()}
+    update = update_dict_filter(sd, convert_dict or {}, model_dict)
+    res = model.load_state_dict(strip_module_prefix(update) if wrapped else update, strict=False)
+    grad_false_keys_filter(model, grad_false_keys or [])
+    return res
+
+
 def adam_state_dict(opt, lr=None):
     """`torch.optim.Adam.state_dict()`-compatible view of a train.FusedAdam (one entry per parameter)."""
     flat = opt.flat

@@ -198,3 +198,42 @@ def test_eval_mode_with_autograd_enabled(manifest):
     L['total'].backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
     assert all(torch.equal(v, m.state_dict()[k]) for k, v in rm.items())          # running statistics untouched
+
+
+def test_training_with_frozen_subnetworks(manifest):
+    """stage-wise training as main.py:162-183 sets it up: `grad_false_keys` freezes E and H, the optimizer sees the rest.  The
+    frozen parameters get no gradient and do not move; the gradients of F and G equal those of the unfrozen step."""
+    from efgh_amd.io import checkpoint as ck
+    from efgh_amd.losses import EFGHCriterion
+    from efgh_amd.nets import EFGHBackbone
+    from efgh_amd.train import Trainer
+    args = syn.default_args(RAW, 'cuda')
+    sd = syn.synthetic_state_dict(manifest['state_dict'], 1)
+    b = syn.make_batch(RAW, NPTS, 2)
+    inp = [torch.from_numpy(b[k]).cuda() for k in ('pc', 'img', 'calib', 'A')]
+    gt = {k: torch.from_numpy(v) for k, v in b['gt'].items()}
+    grads = {}
+    for frozen in (False, True):
+        m = EFGHBackbone(args)
+        ck.load_pretrained(m, {'state_dict': {'module.' + k: v for k, v in sd.items()}},
+                           grad_false_keys=['E.', 'H.'] if frozen else [])
+        m = m.cuda()
+        w0 = {k: p.detach().clone() for k, p in m.named_parameters()}
+        tr = Trainer(m, EFGHCriterion(args), lr=1e-3)
+        n_train = sum(p.numel() for p in m.parameters() if p.requires_grad)
+        assert tr.flat.n == n_train
+        losses, _ = tr.step(*inp, dict(gt))
+        assert torch.isfinite(losses['total'])
+        grads[frozen] = {k: (None if p.grad is None else p.grad.detach().clone()) for k, p in m.named_parameters()}
+        for k, p in m.named_parameters():
+            moved = not torch.equal(p.detach(), w0[k])
+            if frozen and k[0] in 'EH':
+                assert not p.requires_grad and p.grad is None and not moved, k
+        if frozen:
+            assert any(not torch.equal(p.detach(), w0[k]) for k, p in m.named_parameters() if k[0] in 'FG')
+    num = den = 0.0
+    for k, g in grads[True].items():
+        if g is not None:
+            num += float((g - grads[False][k]).double().pow(2).sum())
+            den += float(grads[False][k].double().pow(2).sum())
+    assert den > 0 and (num / den) ** 0.5 < 1e-3, (num / den) ** 0.5

@@ -71,3 +71,34 @@ def test_checkpoint_interchange_with_torch_adam(tmp_path):
     assert opt2.t == 7 and torch.equal(opt2.m, opt.m) and torch.equal(opt2.v, opt.v) and opt2.lr == 3e-4
     for a, b in zip(m2.parameters(), m.parameters()):
         assert torch.equal(a, b)
+
+
+def test_partial_load_rename_and_freeze(tmp_path):
+    """main.py:162-176,212-235: `convert_dict` renaming, keys the model lacks dropped, `grad_false_keys` freezing; FlatParams /
+    FusedAdam then cover exactly the parameters that still require a gradient (main.py:178-183)"""
+    from efgh_amd.train import FlatParams
+    torch.manual_seed(0)
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.E = torch.nn.Linear(3, 4)
+            self.H = torch.nn.Sequential(torch.nn.Linear(4, 4), torch.nn.BatchNorm1d(4))
+            self.G = torch.nn.Linear(4, 2)
+    src = Net()
+    sd = {('module.' + k).replace('module.G.', 'module.Gold.'): v.clone() + 1.0 for k, v in src.state_dict().items()}
+    sd['module.unknown.weight'] = torch.zeros(1)
+    torch.save({'iter': 5, 'state_dict': sd, 'min_loss': 0.1, 'optimizer': {}}, tmp_path / 'pre.pth.tar')
+    dst = Net()
+    res = ck.load_pretrained(dst, str(tmp_path / 'pre.pth.tar'), convert_dict={'Gold.': 'G.'}, grad_false_keys=['E.', 'H.0'])
+    assert not res.missing_keys and not res.unexpected_keys
+    for k, v in dst.state_dict().items():
+        assert torch.equal(v, src.state_dict()[k] + 1.0), k
+    frozen = {k for k, p in dst.named_parameters() if not p.requires_grad}
+    assert frozen == {'E.weight', 'E.bias', 'H.0.weight', 'H.0.bias'}
+    flat = FlatParams(dst)
+    assert flat.n == sum(p.numel() for k, p in dst.named_parameters() if k not in frozen)
+    # the reference's own functions, restated, on a bare (unwrapped) state_dict and without renaming
+    dst2 = Net()
+    ck.load_pretrained(dst2, {k: v for k, v in src.state_dict().items() if k.startswith('E.')})
+    assert torch.equal(dst2.E.weight, src.E.weight) and not torch.equal(dst2.G.weight, src.G.weight)
