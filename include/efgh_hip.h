@@ -429,6 +429,21 @@ int efgh_gimg_loss_bwd(const float *pred_depth, const float *pred_mask, int64_t 
                        const uint8_t *img_mask, int32_t B, int64_t HW, const float *sums3, const float *g_depth,
                        const float *g_mask, float *d_pred_depth, float *d_pred_mask, int64_t dmask_bstride, void *stream);
 
+/* ---- TensorBoard / evaluation overlay images (common/numpy_utils.py:8-413) -------------------------------
+ * efgh_sum_depth_last / efgh_sum_range_last: the float64 rasterisers of numpy_utils.py:338-358 / :299-336 for ONE sample
+ *   (pc: three rows of N floats, pc_cstride apart; T34: the 3x4 matrix - for the range image the top three rows of the 4x4 -
+ *   as float64): the LAST point of the sweep on a pixel wins.  depth: uint8 [H][W] (float64 -> uint8 wrap as astype does);
+ *   range: float64 [H][W] of sqrt(x^2+y^2+z^2+1).  idx_ws: H*W int32 of scratch.
+ * efgh_sum_paint: minmax_color_img_from_img_numpy's raster-order painting (:384-396) for njobs independent images; jobs_dev is
+ *   a device array of {const double *in (normalised image), double *out (ZEROED by the caller), int32 H, W, px}.
+ * efgh_sum_colorize: matplotlib's look-up (int(x*256), x == 1 -> 255) through a uint8 [256][3] table, plus the != 0 mask. */
+int efgh_sum_depth_last(const float *pc, int64_t pc_cstride, int32_t N, const double *T34, int32_t H, int32_t W, int32_t *idx_ws,
+                        uint8_t *out, void *stream);
+int efgh_sum_range_last(const float *pc, int64_t pc_cstride, int32_t N, const double *T34, int32_t H, int32_t W, double fov_up,
+                        double fov_down, int32_t *idx_ws, double *out, void *stream);
+int efgh_sum_paint(const void *jobs_dev, int32_t njobs, void *stream);
+int efgh_sum_colorize(const double *minmax, int64_t n, const uint8_t *lut, uint8_t *rgb, uint8_t *mask, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
