@@ -7,6 +7,24 @@ import math
 
 import torch
 
+_CONST = {}
+
+
+def const(values, device, dtype=torch.float32):
+    """small constant tensors, uploaded once per device: `torch.tensor(..., device=cuda)` is a blocking host-to-device copy,
+    i.e. a stream synchronisation in the middle of the forward"""
+    key = (tuple(values), str(device), dtype)
+    t = _CONST.get(key)
+    if t is None:
+        t = _CONST[key] = torch.tensor(list(values), device=device, dtype=dtype)
+    return t
+
+
+def inv(m):
+    """batched matrix inverse WITHOUT torch.inverse's host-side singularity check (a device-to-host copy and a stream
+    synchronisation per call): same LU factorisation, same values"""
+    return torch.linalg.inv_ex(m)[0]
+
 
 def softmax_l2(x):
     """softmax(dim=1) then L2-normalise (enet.py:161-164, hnet.py:59-63) -> (B,C,1)"""
@@ -71,7 +89,7 @@ def compute_cam_T_velo(c_T, l_T, calib, A):
     m = torch.bmm(calib, l_T)
     m = torch.bmm(A, m)
     m = torch.bmm(c_T, m)
-    return torch.bmm(torch.inverse(A), m)
+    return torch.bmm(inv(A), m)
 
 
 def yaw_rotation_from_scores(f_score):
@@ -81,5 +99,5 @@ def yaw_rotation_from_scores(f_score):
     f_rad = -(f_idx / (n - 1)) * 2 * math.pi + math.pi
     rad = f_rad[:, 0].double()                       # python math.cos/sin operate in double
     f_fwd = torch.stack([torch.cos(rad), torch.sin(rad), torch.zeros_like(rad)], 1).float()[:, :, None]
-    e1 = torch.tensor([1., 0., 0.], device=f_score.device)
+    e1 = const((1., 0., 0.), f_score.device)
     return rotation_between(f_fwd, e1)

@@ -34,7 +34,7 @@ class EFGHCriterion(nn.Module):
         gt_abs = torch.abs(gt_vec)[:, :nd, :]
         s = torch.sign(gt_vec)[:, :, 0]
         s = torch.where(s == -1, torch.zeros_like(s), s)
-        w = torch.tensor([2 ** (nd - 1 - i) for i in range(nd)], device=s.device, dtype=s.dtype)
+        w = pose.const(tuple(float(2 ** (nd - 1 - i)) for i in range(nd)), s.device, s.dtype)
         cls = (s[:, :nd] * w[None]).sum(1).long()
         cos = F.cosine_similarity(pred_abs, gt_abs, dim=1)
         l_abs = torch.mean(1 - cos) * 10.0
@@ -57,9 +57,7 @@ class EFGHCriterion(nn.Module):
         gt = dict(gt)
         B = pc.size(0)
         f32 = lambda t: torch.as_tensor(t).to(dev).float()
-        e1 = torch.tensor([1., 0., 0.], device=dev)
-        e2 = torch.tensor([0., 1., 0.], device=dev)
-        e3 = torch.tensor([0., 0., 1.], device=dev)
+        e1, e2, e3 = pose.const((1., 0., 0.), dev), pose.const((0., 1., 0.), dev), pose.const((0., 0., 1.), dev)
         L = {}
         # ---- E
         R = f32(gt['rand_init_l'])[:, :3, :3]
@@ -83,14 +81,14 @@ class EFGHCriterion(nn.Module):
         L['h_hrzn_sgn'] = ls * lam['h_hrzn']
         # ---- F (loss_utils.py:77-117)
         T4 = f32(gt['sensor2_T_sensor1'])
-        Tinv = torch.inverse(T4[:, :3, :3])
+        Tinv = pose.inv(T4[:, :3, :3])
         pe = pred['e_l'][:, :3, :3].detach()
         axis = torch.bmm(torch.bmm(pe, Tinv), e1[None, :, None].expand(B, -1, -1))
         W = pred['f_score'].size(-1)
         gt['f_score'] = self._gt_fov(axis, W)
         ge = gt['e_l'][:, :3, :3].detach()
         fl = torch.zeros((B, 4, 4), device=dev)
-        fl[:, :3, :3] = torch.inverse(torch.bmm(ge, Tinv))
+        fl[:, :3, :3] = pose.inv(torch.bmm(ge, Tinv))
         fl[:, 3, 3] = 1
         gt['f_l'] = fl
         pos = gt['f_score'] > 0
@@ -106,11 +104,11 @@ class EFGHCriterion(nn.Module):
         lf = F.binary_cross_entropy(pred['f_score'], gt['f_score'], reduction='none')
         L['fov'] = (lf * wsel).sum() / wsel.sum() * lam['fov']
         # ---- G (loss_utils.py:165-207)
-        origin = torch.tensor([0., 0., 0., 1.], device=dev)[None, :, None].expand(B, -1, -1)
+        origin = pose.const((0., 0., 0., 1.), dev)[None, :, None].expand(B, -1, -1)
         pef = torch.bmm(pred['f_l'], pred['e_l'])
-        gt['g_trs'] = torch.bmm(torch.bmm(T4, torch.inverse(pef)), origin)[:, :3, :]
+        gt['g_trs'] = torch.bmm(torch.bmm(T4, pose.inv(pef)), origin)[:, :3, :]
         gef = torch.bmm(gt['f_l'], gt['e_l'])
-        gcp = torch.bmm(torch.bmm(T4, torch.inverse(gef)), origin)
+        gcp = torch.bmm(torch.bmm(T4, pose.inv(gef)), origin)
         gt['g_l'] = pose.translation_matrix(gcp)
         rawH, rawW = self.raw_cam_img_size
         with torch.no_grad():

@@ -82,7 +82,7 @@ class Enet(nn.Module):
         for conv, bn in ((self.conv_gn_1, self.bn_gn_1), (self.conv_gn_2, self.bn_gn_2),
                          (self.conv_gn_3, self.bn_gn_3)):
             x = L.linear_rows(ctx, x, M, conv.in_channels, conv.weight, conv.bias, bn=bn, act=ACT_RELU)
-        seg = torch.tensor(segs, dtype=torch.int32, device=dev)
+        seg = torch.tensor(segs, dtype=torch.int32).pin_memory().to(dev, non_blocking=True)      # (no stream synchronisation)
         if ctx.grad:
             x = FN.SegmentColMaxFn.apply(x, seg, B, 128)
         else:
@@ -93,6 +93,6 @@ class Enet(nn.Module):
         gn_abs0 = L.linear_rows(ctx, x, B, 32, self.lin_gn_abs.weight, self.lin_gn_abs.bias)[:, :3]
         gn_abs = pose.softmax_l2(gn_abs0)
         e_gn = pose.normal_from_abs_sign(gn_abs, gn_sgn, 3)
-        e_T = pose.rotation_between(e_gn, torch.tensor([0., 0., 1.], device=dev))
+        e_T = pose.rotation_between(e_gn, pose.const((0., 0., 1.), dev))
         return {'e_gn_abs': gn_abs, 'e_gn_sgn': gn_sgn.contiguous(), 'e_gn': e_gn, 'e_l': e_T,
                 'sensor2_T_sensor1': e_T, 'network': 'E'}

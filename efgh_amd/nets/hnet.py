@@ -52,7 +52,7 @@ class Hnet(nn.Module):
         habs = pose.softmax_l2(abs0)
         h = pose.normal_from_abs_sign(habs, sgn, 2)
         h3 = torch.cat([h, torch.zeros(B, 1, 1, device=dev)], 1)
-        h_T = pose.rotation_between(h3, torch.tensor([0., 1., 0.], device=dev))[:, :3, :3]
+        h_T = pose.rotation_between(h3, pose.const((0., 1., 0.), dev))[:, :3, :3]
         rot_deg = torch.rad2deg(torch.atan2(h_T[:, 1, 0], h_T[:, 0, 0])).detach()      # torch_utils.py:245
         h_img, h_img_nhwc = ops.rotate_nearest_u8(img, rot_deg)
         if keep is not None:
