@@ -9,7 +9,7 @@ LIBDIR = os.path.join(HERE, 'lib')
 SO = os.path.join(LIBDIR, 'libefgh_hip.so')
 
 # per-file extra flags: the lattice float recipe must not be contracted / reassociated
-EXTRA = {'lattice.hip': ['-ffp-contract=off']}
+EXTRA = {'lattice.hip': ['-ffp-contract=off'], 'pose.hip': ['-ffp-contract=off']}
 COMMON = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function']
 
 

@@ -3,11 +3,42 @@ with .item()/.tolist() of common/torch_utils.py:105-146, 170-233, 256-296).  The
 formulas on (B,3)/(B,4,4) tensors; they stay as device tensor expressions (no kernel of their own).
 Differentiability mirrors the reference: the skew matrix K is built from detached values, only
 (1-c)/s^2 carries gradient (torch_utils.py:184,194); translation matrices are detached (:229)."""
+import ctypes
 import math
+import os
 
 import torch
 
+from .. import _C
+
 _CONST = {}
+USE_KERNELS = os.environ.get('EFGH_POSE_KERNELS', '1') != '0'    # fused heads (csrc/pose.hip) whenever autograd is off
+
+
+def _fused():
+    return USE_KERNELS and not torch.is_grad_enabled()
+
+
+def head_normal(abs_logits, sgn_logits, dest):
+    """softmax_l2 + normal_from_abs_sign + rotation_between in ONE launch (inference path): abs_logits (B,nd) and sgn_logits
+    (B,2^nd) row views -> (abs (B,nd,1), normal (B,nd,1), R (B,4,4))"""
+    B, nd = abs_logits.shape
+    if not _fused():
+        a = softmax_l2(abs_logits)
+        n = normal_from_abs_sign(a, sgn_logits, nd)
+        n3 = n if nd == 3 else torch.cat([n, torch.zeros(B, 1, 1, device=n.device)], 1)
+        return a, n, rotation_between(n3, const(dest, n.device))
+    _C.require_cuda(abs_logits, sgn_logits)
+    assert abs_logits.stride(1) == 1 and sgn_logits.stride(1) == 1 and sgn_logits.shape[1] == 1 << nd
+    dev = abs_logits.device
+    a = torch.empty((B, nd, 1), dtype=torch.float32, device=dev)
+    n = torch.empty((B, nd, 1), dtype=torch.float32, device=dev)
+    R = torch.empty((B, 4, 4), dtype=torch.float32, device=dev)
+    _C.check(_C.lib().efgh_pose_head_normal(_C.ptr(abs_logits), ctypes.c_int64(abs_logits.stride(0)), _C.ptr(sgn_logits),
+                                            ctypes.c_int64(sgn_logits.stride(0)), ctypes.c_int32(B), ctypes.c_int32(nd),
+                                            ctypes.c_float(dest[0]), ctypes.c_float(dest[1]), ctypes.c_float(dest[2]),
+                                            _C.ptr(a), _C.ptr(n), _C.ptr(R), _C.stream_ptr()))
+    return a, n, R
 
 
 def const(values, device, dtype=torch.float32):
@@ -86,6 +117,14 @@ def translation_matrix(vec):
 
 def compute_cam_T_velo(c_T, l_T, calib, A):
     """torch_utils.py:256-269"""
+    if _fused():
+        _C.require_cuda(c_T, l_T, calib, A)
+        B = l_T.shape[0]
+        c = c_T.contiguous()
+        out = torch.empty((B, 3, 4), dtype=torch.float32, device=l_T.device)
+        _C.check(_C.lib().efgh_pose_cam_T_velo(_C.ptr(c), ctypes.c_int64(9), _C.ptr(l_T.contiguous()), _C.ptr(calib.contiguous()),
+                                               _C.ptr(A.contiguous()), ctypes.c_int32(B), _C.ptr(out), _C.stream_ptr()))
+        return out
     m = torch.bmm(calib, l_T)
     m = torch.bmm(A, m)
     m = torch.bmm(c_T, m)
@@ -95,6 +134,13 @@ def compute_cam_T_velo(c_T, l_T, calib, A):
 def yaw_rotation_from_scores(f_score):
     """fnet.py:87-91: argmax -> yaw -> (cos,sin,0) -> rotation onto e1"""
     n = f_score.size(-1)
+    if _fused():
+        _C.require_cuda(f_score)
+        assert f_score.stride(1) == 1
+        R = torch.empty((f_score.shape[0], 4, 4), dtype=torch.float32, device=f_score.device)
+        _C.check(_C.lib().efgh_pose_head_yaw(_C.ptr(f_score), ctypes.c_int64(f_score.stride(0)), ctypes.c_int32(f_score.shape[0]),
+                                             ctypes.c_int32(n), _C.ptr(R), _C.stream_ptr()))
+        return R
     f_idx = torch.argmax(f_score, dim=1, keepdim=True).float()
     f_rad = -(f_idx / (n - 1)) * 2 * math.pi + math.pi
     rad = f_rad[:, 0].double()                       # python math.cos/sin operate in double

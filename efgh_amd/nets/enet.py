@@ -91,8 +91,6 @@ class Enet(nn.Module):
             x = L.linear_rows(ctx, x, B, lin.in_features, lin.weight, lin.bias, act=ACT_RELU)
         gn_sgn = L.linear_rows(ctx, x, B, 32, self.lin_gn_sgn.weight, self.lin_gn_sgn.bias)[:, :8]
         gn_abs0 = L.linear_rows(ctx, x, B, 32, self.lin_gn_abs.weight, self.lin_gn_abs.bias)[:, :3]
-        gn_abs = pose.softmax_l2(gn_abs0)
-        e_gn = pose.normal_from_abs_sign(gn_abs, gn_sgn, 3)
-        e_T = pose.rotation_between(e_gn, pose.const((0., 0., 1.), dev))
+        gn_abs, e_gn, e_T = pose.head_normal(gn_abs0, gn_sgn, (0., 0., 1.))          # enet.py:161-176
         return {'e_gn_abs': gn_abs, 'e_gn_sgn': gn_sgn.contiguous(), 'e_gn': e_gn, 'e_l': e_T,
                 'sensor2_T_sensor1': e_T, 'network': 'E'}

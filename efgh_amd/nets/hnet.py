@@ -49,10 +49,8 @@ class Hnet(nn.Module):
             x = L.linear_rows(ctx, x, B, lin.in_features, lin.weight, lin.bias, act=ACT_RELU)
         sgn = L.linear_rows(ctx, x, B, 32, self.lin_hrzn_sgn.weight, self.lin_hrzn_sgn.bias)[:, :4]
         abs0 = L.linear_rows(ctx, x, B, 32, self.lin_hrzn_abs.weight, self.lin_hrzn_abs.bias)[:, :2]
-        habs = pose.softmax_l2(abs0)
-        h = pose.normal_from_abs_sign(habs, sgn, 2)
-        h3 = torch.cat([h, torch.zeros(B, 1, 1, device=dev)], 1)
-        h_T = pose.rotation_between(h3, pose.const((0., 1., 0.), dev))[:, :3, :3]
+        habs, h, h_T4 = pose.head_normal(abs0, sgn, (0., 1., 0.))                     # hnet.py:59-77 (z = 0)
+        h_T = h_T4[:, :3, :3]
         rot_deg = torch.rad2deg(torch.atan2(h_T[:, 1, 0], h_T[:, 0, 0])).detach()      # torch_utils.py:245
         h_img, h_img_nhwc = ops.rotate_nearest_u8(img, rot_deg)
         if keep is not None:

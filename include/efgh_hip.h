@@ -444,6 +444,18 @@ int efgh_sum_range_last(const float *pc, int64_t pc_cstride, int32_t N, const do
 int efgh_sum_paint(const void *jobs_dev, int32_t njobs, void *stream);
 int efgh_sum_colorize(const double *minmax, int64_t n, const uint8_t *lut, uint8_t *rgb, uint8_t *mask, void *stream);
 
+/* ---- pose heads, inference path (one launch each; the training path keeps them as tensor expressions for autograd) -----------
+ * efgh_pose_head_normal: softmax + L2 normalisation of the nd (2 or 3) "abs" logits, sign class = first argmax of the 2^nd sign
+ *   logits decoded MSB-first, normal = abs * sign, rotation of the normal onto (dx,dy,dz) as a 4x4 (enet.py:161-176, hnet.py:59-77,
+ *   torch_utils.py:105-146,170-200).  abs_out / normal: [B][nd], R44: [B][16].
+ * efgh_pose_head_yaw: argmax of the n correlation scores -> yaw -> rotation onto e1 (fnet.py:87-91).
+ * efgh_pose_cam_T_velo: A^-1 c_T A calib l_T (torch_utils.py:256-269); c_T rows of 3 with sample pitch ldc, out [B][12].       */
+int efgh_pose_head_normal(const float *abs_logits, int64_t lda, const float *sgn_logits, int64_t lds, int32_t B, int32_t nd,
+                          float dx, float dy, float dz, float *abs_out, float *normal, float *R44, void *stream);
+int efgh_pose_head_yaw(const float *score, int64_t lds, int32_t B, int32_t n, float *R44, void *stream);
+int efgh_pose_cam_T_velo(const float *c_T, int64_t ldc, const float *l_T, const float *calib, const float *A, int32_t B,
+                         float *out34, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -184,3 +184,48 @@ def test_odd_point_count_and_strided_inputs_vs_oracle(manifest):
                 assert _rel(o_v[k][s:s + 1].cpu().numpy(), rete[k].numpy()) < 1e-4, (k, s)
             for k in ('h_hrzn_sgn', 'h_hrzn_abs'):
                 assert _rel(o_v[k][s:s + 1].cpu().numpy(), reth[k].numpy()) < 1e-4, (k, s)
+
+
+def test_fused_pose_heads_equal_the_tensor_expressions():
+    """csrc/pose.hip (inference path) against the tensor expressions the training path keeps (common/pose.py), which are checked
+    against the oracle above: both heads, the yaw head, the calibration chain; incl. the degenerate 'same' / 'opposite' vectors"""
+    from efgh_amd.common import pose
+    torch.manual_seed(0)
+    B = 37
+    dev = 'cuda'
+    with torch.no_grad():
+        for nd, dest in ((3, (0., 0., 1.)), (2, (0., 1., 0.))):
+            row = torch.randn(B, 32, device=dev) * 3
+            sgn = torch.randn(B, 32, device=dev)
+            abs0, sg = row[:, :nd], sgn[:, :1 << nd]
+            if nd == 3:                                      # normal == +-dest exactly: one-hot abs, both signs
+                abs0 = abs0.clone(); abs0[0] = torch.tensor([-200., -200., 50.]); abs0[1] = abs0[0]
+                sg = sg.clone(); sg[0] = 0; sg[0, 0b111] = 9; sg[1] = 0; sg[1, 0b110] = 9
+            out = {}
+            for fused in (True, False):
+                pose.USE_KERNELS = fused
+                try:
+                    out[fused] = pose.head_normal(abs0, sg, dest)
+                finally:
+                    pose.USE_KERNELS = True
+            for a, b in zip(out[True], out[False]):
+                assert a.shape == b.shape and torch.allclose(a, b, rtol=2e-6, atol=2e-7), (nd, (a - b).abs().max())
+            if nd == 3:
+                assert torch.equal(out[True][2][0], torch.eye(4, device=dev))                     # same
+                # opposite: -I with [3][3] = -1 too, and [0][0] flipped back because both x components vanish (torch_utils.py:186-196)
+                assert torch.equal(out[True][2][1], torch.diag(torch.tensor([1., -1., -1., -1.], device=dev)))
+        score = torch.rand(B, 509, device=dev)
+        c_T = torch.linalg.qr(torch.randn(B, 3, 3, device=dev))[0]
+        l_T = torch.eye(4, device=dev).repeat(B, 1, 1); l_T[:, :3, :] = torch.randn(B, 3, 4, device=dev)
+        calib = torch.randn(B, 3, 4, device=dev) * 100
+        A = torch.tensor([[1., 0., -640.], [0., 1., -192.], [0., 0., 1.]], device=dev).repeat(B, 1, 1)
+        res = {}
+        for fused in (True, False):
+            pose.USE_KERNELS = fused
+            try:
+                res[fused] = (pose.yaw_rotation_from_scores(score), pose.compute_cam_T_velo(c_T, l_T, calib, A))
+            finally:
+                pose.USE_KERNELS = True
+        assert torch.allclose(res[True][0], res[False][0], rtol=2e-6, atol=2e-7)
+        d = (res[True][1] - res[False][1]).abs().amax(dim=(1, 2)) / res[False][1].abs().amax(dim=(1, 2))
+        assert float(d.max()) < 2e-6, float(d.max())              # summation order of float32 products only
