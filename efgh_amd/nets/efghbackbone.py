@@ -12,30 +12,34 @@ from .hnet import Hnet
 __all__ = ['EFGHBackbone']
 
 
+def _stamp_pose(state, key, calib, A):
+    """`<key>_cam_T_velo` = A^-1 * intrinsic_sensor2 * A * calib * sensor2_T_sensor1 for the poses accumulated so far
+    (common/torch_utils.py:256-269)"""
+    state[key + '_cam_T_velo'] = pose.compute_cam_T_velo(state['intrinsic_sensor2'], state['sensor2_T_sensor1'], calib, A)
+    return state
+
+
 class EFGHBackbone(nn.Module):
+    """The four stages are sub-modules named E, H, F, G (the checkpoint keys depend on that).  E (point cloud) and H (image) are
+    independent; F refines the yaw from their outputs, G the translation; after each refinement the camera-from-LiDAR
+    projection is re-derived and kept under its own key."""
+
     def __init__(self, args):
         super().__init__()
-        self.E = Enet(args)
-        self.H = Hnet(args)
-        self.F = Fnet(args)
-        self.G = Gnet(args)
+        for name, cls in (('E', Enet), ('H', Hnet), ('F', Fnet), ('G', Gnet)):
+            setattr(self, name, cls(args))
         self.device = args['DEVICE']
 
     def forward(self, pc, img, calib, A, check=False, keep=None):
         ops._C.require_cuda(pc, img, calib, A)
         ops._C.require_f32(pc, img, calib, A)
-        img_nhwc = ops.nchw_to_nhwc(img, 4)             # shared by H and G
-        rete = self.E(pc, check, keep=keep)
-        reth = self.H(img, check, img_nhwc=img_nhwc, keep=keep)
-        ret = {}
-        ret.update(rete)
-        ret.update(reth)
-        ret['network'] = rete['network'] + reth['network']
-        ret['eh_cam_T_velo'] = pose.compute_cam_T_velo(ret['intrinsic_sensor2'], ret['sensor2_T_sensor1'], calib, A)
-        ret = self.F(pc, ret, check, keep=keep)
-        ret['efh_cam_T_velo'] = pose.compute_cam_T_velo(ret['intrinsic_sensor2'], ret['sensor2_T_sensor1'], calib, A)
-        ret = self.G(pc, img, ret, check, img_nhwc=img_nhwc, keep=keep)
-        ret['efgh_cam_T_velo'] = pose.compute_cam_T_velo(ret['intrinsic_sensor2'], ret['sensor2_T_sensor1'], calib, A)
-        ret['cam_T_velo'] = ret['efgh_cam_T_velo']
-        ret.pop('_h_img_nhwc', None)
-        return ret
+        shared_img = ops.nchw_to_nhwc(img, 4)                # channels-last copy used by both H and G
+        point_part = self.E(pc, check, keep=keep)
+        image_part = self.H(img, check, img_nhwc=shared_img, keep=keep)
+        state = {**point_part, **image_part, 'network': point_part['network'] + image_part['network']}
+        _stamp_pose(state, 'eh', calib, A)
+        state = _stamp_pose(self.F(pc, state, check, keep=keep), 'efh', calib, A)
+        state = _stamp_pose(self.G(pc, img, state, check, img_nhwc=shared_img, keep=keep), 'efgh', calib, A)
+        state['cam_T_velo'] = state['efgh_cam_T_velo']
+        state.pop('_h_img_nhwc', None)
+        return state
