@@ -237,3 +237,36 @@ def test_training_with_frozen_subnetworks(manifest):
             num += float((g - grads[False][k]).double().pow(2).sum())
             den += float(grads[False][k].double().pow(2).sum())
     assert den > 0 and (num / den) ** 0.5 < 1e-3, (num / den) ** 0.5
+
+
+def test_odd_batch_training_step_matches_per_sample_gradient_sum(manifest):
+    """B = 3 (odd, ragged lattices of three different sweeps) in EVAL-mode BatchNorm so that the samples do not couple: the batch
+    loss is the mean of the per-sample losses and its gradient the mean of the per-sample gradients"""
+    from efgh_amd.losses import EFGHCriterion
+    from efgh_amd.nets import EFGHBackbone
+    args = syn.default_args(RAW, 'cuda')
+    m = EFGHBackbone(args)
+    m.load_state_dict(syn.synthetic_state_dict(manifest['state_dict'], 1))
+    m = m.cuda().eval()
+    crit = EFGHCriterion(args)
+    b = syn.make_batch(RAW, NPTS - 5, 3, first_seed=11)
+    inp = [torch.from_numpy(b[k]).cuda() for k in ('pc', 'img', 'calib', 'A')]
+    gt = {k: torch.from_numpy(v) for k, v in b['gt'].items()}
+    names = [k for k, _ in m.named_parameters() if k.startswith(('E.', 'H.'))]
+    params = dict(m.named_parameters())
+
+    def grads(sl):
+        for p in m.parameters():
+            p.grad = None
+        pred = m(*[t[sl] for t in inp])
+        L, _ = crit.compute_loss(*[t[sl] for t in inp], {k: v[sl] for k, v in gt.items()}, pred)
+        (L['e_gn'] + L['h_hrzn']).backward()             # the two terms that are plain batch means of per-sample values
+        return float(L['e_gn'] + L['h_hrzn']), {k: params[k].grad.detach().clone() for k in names}
+    l_all, g_all = grads(slice(0, 3))
+    parts = [grads(slice(i, i + 1)) for i in range(3)]
+    assert abs(l_all - sum(p[0] for p in parts) / 3) <= 1e-5 * abs(l_all)
+    num = den = 0.0
+    for k in names:
+        ref = sum(p[1][k] for p in parts) / 3
+        num += float((g_all[k] - ref).double().pow(2).sum()); den += float(ref.double().pow(2).sum())
+    assert den > 0 and (num / den) ** 0.5 < 1e-4, (num / den) ** 0.5
