@@ -4,7 +4,6 @@ import torch.nn as nn
 
 from .. import ops
 from ..common import pose
-from ..ops import ACT_LEAKY
 from . import fn as FN
 from . import layers as L
 from .builders import conv_bn_relu, convt_bn_relu, resnet18_layers

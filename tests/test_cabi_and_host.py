@@ -1,7 +1,6 @@
 """CPU-side checks: the C-ABI library loads and exports every symbol include/efgh_hip.h declares,
 the host mirror reproduces the reference's module API, and the product refuses to run without a GPU."""
 import ctypes
-import json
 import os
 import re
 

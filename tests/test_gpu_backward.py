@@ -1,6 +1,5 @@
 """Backward kernels (through the C-ABI + autograd shims) vs torch autograd on CPU, and the whole
 training step (forward + efghloss + backward) vs the oracle and the reference's golden gradients."""
-import json
 import os
 import re
 

@@ -1,6 +1,5 @@
 """End-to-end EFGHNet forward on the HIP path vs (a) the reference's golden outputs and (b) the
 oracle run on the same inputs.  Tolerance: 1e-4 relative on the pose logits (north star)."""
-import json
 import os
 
 import numpy as np

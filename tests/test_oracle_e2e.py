@@ -4,7 +4,6 @@ import os
 import re
 
 import numpy as np
-import pytest
 import torch
 
 from efgh_amd import synthetic as syn
