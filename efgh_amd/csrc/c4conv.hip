@@ -61,9 +61,12 @@ template <int NT, bool RES>
 __global__ void __launch_bounds__(64 * WAVES, 2) k_c4_conv(const C4Args p) {
     __shared__ float2 Pw[WAVES][3][2][LWMAX + 1];
     __shared__ float red[2][WAVES][NT * 32];
+    constexpr int TPITCH = 40;                       // floats per row of the transpose tile (h = 0 / 1 rows land on disjoint banks)
+    __shared__ __attribute__((aligned(16))) float Tw[WAVES][32 * TPITCH];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
     const int LW = (TP - 1) * p.s + 3;
     float2 (*P)[2][LWMAX + 1] = Pw[wave];
+    float *T = Tw[wave];
 
     float2 bw[9][NT];
     float bi[NT], sc[NT], sf[NT], s1[NT], s2[NT];
@@ -143,25 +146,30 @@ __global__ void __launch_bounds__(64 * WAVES, 2) k_c4_conv(const C4Args p) {
             EFGH_STAGE()
             if (unit + 2 * nwaves < p.units) EFGH_FETCH(unit + 2 * nwaves)
         }
-        // branch-free epilogue: act(v) = max(v, 0) + neg * min(v, 0) with neg = 0 (ReLU) / slope (leaky) / 1 (none)
+        // branch-free epilogue: act(v) = max(v, 0) + neg * min(v, 0) with neg = 0 (ReLU) / slope (leaky) / 1 (none).  The accumulator
+        // layout has one output channel per lane (4-byte stores); every 32 x 32 block goes through a wave-private LDS tile
+        // [pixel][channel] and leaves as 16-byte stores, eight lanes per pixel row (128 contiguous bytes)
+        const bool full = oj0 + TP <= p.Wo;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int jx = oj0 + (q & 3) + 8 * (q >> 2) + 4 * h;
-            if (jx >= p.Wo) continue;
-            const long long orow = orow0 * p.Wo + jx;
-            float *o = p.out + orow * p.ldo + r;
-            float rv[NT];
-            if (RES) {
+        for (int j = 0; j < NT; ++j) {
+            wave_lds_sync();                         // the tile's previous readers are done
 #pragma unroll
-                for (int j = 0; j < NT; ++j) rv[j] = p.residual[orow * p.ldr + 32 * j + r];
-            }
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
+            for (int q = 0; q < 16; ++q) {
+                const int pl = (q & 3) + 8 * (q >> 2) + 4 * h;
+                const bool ok = full || oj0 + pl < p.Wo;
                 float v = acc[j][q] + bi[j];
-                s1[j] += v; s2[j] = fmaf(v, v, s2[j]);
+                if (ok) { s1[j] += v; s2[j] = fmaf(v, v, s2[j]); }
                 v = fmaf(v, sc[j], sf[j]);
-                if (RES) v += rv[j];
-                o[32 * j] = fmaxf(v, 0.f) + neg * fminf(v, 0.f);
+                if (RES) { if (ok) v += p.residual[(orow0 * p.Wo + oj0 + pl) * p.ldr + 32 * j + r]; }
+                T[pl * TPITCH + r] = fmaxf(v, 0.f) + neg * fminf(v, 0.f);
+            }
+            wave_lds_sync();
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                const int pl = 8 * pass + (lane >> 3), c4 = (lane & 7) * 4;
+                const float4 v = *reinterpret_cast<const float4 *>(&T[pl * TPITCH + c4]);
+                if (full || oj0 + pl < p.Wo)
+                    *reinterpret_cast<float4 *>(p.out + (orow0 * p.Wo + oj0 + pl) * p.ldo + 32 * j + c4) = v;
             }
         }
     }
@@ -307,6 +315,7 @@ extern "C" int32_t efgh_c4_stats_rows(int32_t B, int32_t Ho, int32_t Wo) {
 extern "C" int efgh_c4_conv3x3(const efgh_gemm_desc *d, void *stream_) {
     hipStream_t st = (hipStream_t)stream_;
     EFGH_CHECK_ARG(efgh_c4_supported(d) && d->W && d->out && (((uintptr_t)d->W) & 7) == 0);
+    EFGH_CHECK_ARG(d->ldo % 4 == 0 && (((uintptr_t)d->out) & 15) == 0);           // 16-byte output stores
     C4Args a;
     fill(a, d);
     const int grid = grid_of(a.units);
