@@ -88,3 +88,51 @@ def test_update_summary_feeds_a_writer():
     assert set(w.im) == {'train_image/' + k for k in draw}
     assert all(a.shape[0] == 3 and a.dtype == np.uint8 for a in w.im.values())
     assert np.array_equal(np.transpose(w.im['train_image/depth'], (1, 2, 0)), draw['depth'])
+
+
+def test_image_draw_on_real_network_outputs_vs_oracle(manifest):
+    """the whole chain on one synthetic frame: GPU sample preparation -> EFGHBackbone (eval) -> EFGHCriterion (its gt dict) ->
+    image_draw / eval_image_draw, against the oracle on the same tensors (dense float32 g_depth / g_mask predictions included)"""
+    import sys
+    sys.path.insert(0, os.path.join(HERE, '..'))
+    from examples.train_synthetic import collate, raw_frame
+    from efgh_amd import synthetic as syn
+    from efgh_amd.common import summary as S
+    from efgh_amd.data import ProcessKITTIODOM
+    from efgh_amd.losses import EFGHCriterion
+    from efgh_amd.nets import EFGHBackbone
+    from oracle import summary_oracle as SO
+    raw, npts = (128, 256), 2048
+    args = syn.default_args(raw, 'cuda')
+    args.update({'lidar_line': None, 'num_points': npts, 'test': False,
+                 'dclb': {'l_rot_range': 1 / 12., 'l_trs_range': 1.0, 'c_rot_range': 1 / 12.}})
+    m = EFGHBackbone(args)
+    m.load_state_dict(syn.synthetic_state_dict(manifest['state_dict'], 1))
+    m = m.cuda().eval()
+    calib0, _ = syn.calib_and_A(raw)
+    P2 = np.eye(4); P2[:3] = calib0
+    sweep = np.concatenate([syn.lidar_sweep(npts * 2, 5).T, np.ones((npts * 2, 1), np.float32)], 1)
+    sample = ProcessKITTIODOM(args)(sweep, raw_frame(raw, 5), {'P2': P2, 'Tr': np.eye(4)}, np.eye(4), 'f5')[:5]
+    pc, img, calib, A, gt = collate([sample], 'cuda')
+    with torch.no_grad():
+        pred = m(pc, img, calib, A)
+        _, gt2 = EFGHCriterion(args).compute_loss(pc, img, calib, A, gt, pred)
+    fov = args['lidar_fov_rad']
+    luts = np.load(os.path.join(HERE, '..', 'efgh_amd', 'common', 'colormaps.npz'))
+    n0 = lambda d: {k: (v[0].detach().cpu().numpy() if torch.is_tensor(v) else v) for k, v in d.items()}
+    gtn, prn = n0(gt2), n0(pred)
+    prn['network'] = pred['network']
+    a = [t[0].cpu().numpy() for t in (pc, img, calib, A)]
+    got = S.image_draw(pc, img, calib, A, gt2, pred, raw, fov)
+    ref = SO.image_draw(a[0], a[1], a[2], a[3], gtn, prn, raw, fov, luts['plasma'])
+    assert set(got) == set(ref) == {'cam', 'score', 'dimage', 'mask', 'range', 'depth'}
+    for k in ref:
+        g = got[k].cpu().numpy()
+        assert g.shape == ref[k].shape, k
+        # rasters: libm vs device asin / atan2 can move a point across a pixel edge; everything else is byte-exact
+        assert (g != ref[k]).any(-1).mean() < (2e-3 if k in ('range', 'depth') else 1e-12), (k, float((g != ref[k]).any(-1).mean()))
+    got_e = S.eval_image_draw(pc, img, calib, A, gt2, pred, raw, fov, 2)
+    ref_e = SO.eval_image_draw(a[0], a[1], a[2], a[3], gtn, prn, raw, fov, 2, luts['jet'])
+    for k in ref_e:
+        g = got_e[k].cpu().numpy()
+        assert g.shape == ref_e[k].shape and (g != ref_e[k]).any(-1).mean() < 2e-3, k
