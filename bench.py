@@ -2,7 +2,9 @@
 
     python bench.py --gpus N --steps K --warmup W [--mode train|fwd] [--batch B]
 
-One process per GPU (the driver launches N>1 through torch.distributed.run).
+One process per GPU.  The driver launches N>1 through torch.distributed.run; run bare (`python bench.py --gpus N`, no
+WORLD_SIZE in the environment) the parent starts that launcher itself as a child process BEFORE anything touches the GPU,
+and rank 0 of the children prints the JSON line.
 
 * default `--mode train` = BASELINE.json's metric: frame-pairs/s of EFGHNet fwd+bwd (efghloss, gradient
   all-reduce, fused Adam) on synthetic 384x1280 RGB + 64x2048-point sweeps, batch 8 per GPU
@@ -39,14 +41,25 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(raw, npts, mode):
-    """the oracle (CPU restatement of the reference) timed on the host cores on a BOUNDED sample: ONE
-    frame-pair of the same workload (same sizes, same mode), ~10-30 s."""
+def cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def cpu_baseline(raw, npts, mode, timed=3):
+    """the oracle (CPU restatement of the reference) timed on the host cores on a BOUNDED sample: ONE frame-pair of the
+    same workload (same sizes, same mode) per iteration, 1 warm-up + `timed` timed iterations."""
     import torch
     from efgh_amd import synthetic as syn
     from efgh_amd.nets import EFGHBackbone
     from oracle import efgh_oracle as O
-    cores = min(os.cpu_count() or 1, 32)        # torch CPU ops stop scaling (and regress badly) far below 256 threads
+    host = os.cpu_count() or 1
+    cores = min(host, 32)        # torch CPU ops stop scaling (and regress badly) far below 256 threads: 256 threads took 412 s
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     m = EFGHBackbone(syn.default_args(raw, 'cpu'))      # parameter container only; never executed on CPU
@@ -56,23 +69,33 @@ def cpu_baseline(raw, npts, mode):
     T = torch.from_numpy
     args = syn.default_args(raw, 'cpu')
     inp = [T(b[k]) for k in ('pc', 'img', 'calib', 'A')]
+
+    def one():
+        if mode == 'train':
+            for k in names:
+                P[k].requires_grad_(True)
+                P[k].grad = None
+            pred = O.forward(P, *inp, args, train=True)
+            L, _ = O.compute_loss(inp[0], {k: T(v) for k, v in b['gt'].items()}, pred, args)
+            L['total'].backward()
+        else:
+            with torch.no_grad():
+                O.forward(P, *inp, args, train=False)
+    what = 'train fwd+loss+bwd' if mode == 'train' else 'eval forward'
     t0 = time.time()
-    if mode == 'train':
-        for k in names:
-            P[k].requires_grad_(True)
-        pred = O.forward(P, *inp, args, train=True)
-        L, _ = O.compute_loss(inp[0], {k: T(v) for k, v in b['gt'].items()}, pred, args)
-        L['total'].backward()
-        what = 'train fwd+loss+bwd'
-    else:
-        with torch.no_grad():
-            O.forward(P, *inp, args, train=False)
-        what = 'eval forward'
-    dt = time.time() - t0
+    one()                                               # warm-up (thread pool, oneDNN primitives, page faults)
+    warm = time.time() - t0
+    ts = []
+    for _ in range(timed):
+        t0 = time.time()
+        one()
+        ts.append(time.time() - t0)
+    dt = sum(ts) / len(ts)
     return {'value': 1.0 / dt, 'unit': 'frame-pairs/s', 'cores': cores, 'kind': 'port',
-            'sample': '1 frame-pair of the same workload (%dx%d RGB, %d points; %s, B=1) through '
-                      'oracle/efgh_oracle.py + oracle/lattice_oracle.c, torch CPU fp32, %d threads, %.1f s' %
-                      (raw[0] // 2, raw[1] // 2, npts, what, cores, dt)}
+            'host_cpus': host, 'cpu_model': cpu_model(), 'iterations_s': [round(t, 2) for t in ts], 'warmup_s': round(warm, 2),
+            'sample': '%d timed iterations after 1 warm-up, each ONE frame-pair of the same workload (%dx%d RGB, %d points; %s, '
+                      'B=1) through oracle/efgh_oracle.py + oracle/lattice_oracle.c, torch CPU fp32, %d of %d host threads, '
+                      'mean %.1f s' % (timed, raw[0] // 2, raw[1] // 2, npts, what, cores, host, dt)}
 
 
 def dump_shapes(prof, path):
@@ -124,9 +147,9 @@ KERNELS = {
 
 
 def rooflines(prof, steps, workload='train'):
-    """`roofline` = the kernel with the most time in the timed region; the other MFMA kernels as roofline_<name>.
-    For k_wino43 `achieved` counts the ALGORITHMIC (direct-form, 2*M*N*9*C) FLOPs as the contract asks; the kernel
-    executes half of them on the MFMA pipe, reported as `mfma_executed_frac`."""
+    """`roofline` = the MFMA kernel with the most time in the timed region; the other kernels as roofline_<name>.
+    `achieved` / `frac` count the MFMA FLOPs the kernel EXECUTES (so frac <= 1): for the Winograd kernels that is half of the
+    direct-form count 2*M*N*9*C, which is kept as `algorithmic_tflops` (the rate a direct kernel would need for the same time)."""
     rl = {}
     bcl = prof.get('bcl')
     for name, lst in prof.items():
@@ -135,33 +158,63 @@ def rooflines(prof, steps, workload='train'):
         if lst:
             r = gemm_roofline(lst, steps, KERNELS[name])
             r['traffic'] = committed_traffic(name, workload)
+            r['algorithmic_tflops'] = r['achieved']
             if name.startswith('wino'):
-                r['mfma_executed_tflops'] = r['achieved'] / 2
-                r['mfma_executed_frac'] = r['frac'] / 2
+                r['achieved'] = r['achieved'] / 2
+                r['frac'] = r['frac'] / 2
+                r['executed_gflop_per_launch'] = r['algorithmic_gflop_per_launch'] / 2
             rl[name] = r
     if not rl:
         return {}
     top = max(rl, key=lambda k: rl[k]['kernel_ms_per_step'])
     out = {'roofline': rl[top]}
-    if bcl:     # the HBM-bound side of the path: BCL splat (CSR inversion + gather), SURVEY 8d algorithmic bytes / event time
-        ms = sum(e0.elapsed_time(e1) for e0, e1, _ in bcl)
-        by = sum(b for _, _, b in bcl)
+    if bcl:     # the HBM-bound side of the path: lattice build + BCL splat, SURVEY 8d algorithmic bytes / event time
+        ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in bcl)
+        by = sum(b for _, _, b, _ in bcl)
         ach = by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        out['roofline_bcl'] = {'bound': 'hbm', 'kernel': 'BCL splat (k_csr_count/scan/fill + k_splat_gather), all five levels',
-                               'achieved': ach, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': ach / PEAK_HBM_GBS, 'traffic': None,
+        parts = {}
+        for e0, e1, b, what in bcl:
+            a = parts.setdefault(what, [0.0, 0.0])
+            a[0] += e0.elapsed_time(e1); a[1] += b
+        out['roofline_bcl'] = {'bound': 'hbm', 'kernel': 'BCL index + splat pipeline, all five levels and all samples of the batch: '
+                               'lattice build (keys, hash, first-seen numbering, neighbours, vertex lists) and splat gather'
+                               + (' + splat / neighbour-gather adjoints' if any(k.endswith('bwd') for k in parts) else ''),
+                               'achieved': ach, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': ach / PEAK_HBM_GBS,
+                               'traffic': committed_traffic('bcl', workload),
                                'launches_per_step': len(bcl) / max(1, steps), 'kernel_ms_per_step': ms / max(1, steps),
-                               'algorithmic_mb_per_step': by / max(1, steps) / 1e6}
+                               'algorithmic_mb_per_step': by / max(1, steps) / 1e6,
+                               'parts': {k: {'ms_per_step': v[0] / max(1, steps), 'algorithmic_mb_per_step': v[1] / max(1, steps) / 1e6,
+                                             'gbs': (v[1] / (v[0] * 1e-3) / 1e9 if v[0] > 0 else 0.0)} for k, v in parts.items()}}
     for k, v in rl.items():
         if k != top:
             out['roofline_' + k] = v
     return out
 
 
+def spawn_ranks(a):
+    """`python bench.py --gpus N` outside a launcher: start `torch.distributed.run` with N ranks as a CHILD process and hand its
+    exit code on.  Nothing in this process has touched the GPU (no torch import yet), so no initialised process is replaced."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=%d' % a.gpus,
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')        # dmabuf IPC only on this pool (RCCL needs it)
+    env.setdefault('OMP_NUM_THREADS', '8')
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(spawn_ranks(a))
     import torch
     import torch.distributed as dist
-    from efgh_amd import ops, synthetic as syn
+    from efgh_amd import lattice, ops, synthetic as syn
     from efgh_amd.losses import EFGHCriterion
     from efgh_amd.nets import EFGHBackbone
     from efgh_amd.train import Trainer
@@ -169,15 +222,24 @@ def main():
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
-    assert world == a.gpus, (world, a.gpus)
-    local = local % max(1, torch.cuda.device_count())
+    if world != a.gpus:
+        sys.exit('bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks (use --nproc-per-node %d, or run '
+                 '`python bench.py --gpus %d` bare and let it start the ranks itself)' % (a.gpus, world, a.gpus, a.gpus))
+    ndev = torch.cuda.device_count()          # (does not initialise the GPU)
+    if ndev < 1:
+        sys.exit('bench.py: no GPU visible')
+    shared = world > ndev                     # more ranks than devices: ranks share GPUs (plumbing test on a 1-GPU box)
+    local = local % ndev
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
+    backend, rccl_ranks = None, None
     if world > 1:
-        # RCCL over xGMI ('nccl' is RCCL on ROCm); EFGH_DIST_BACKEND=gloo only for single-GPU plumbing tests
-        backend = os.environ.get('EFGH_DIST_BACKEND', 'nccl')
+        # RCCL over xGMI ('nccl' is RCCL on ROCm).  RCCL cannot put two ranks on one device, so ranks that SHARE a GPU
+        # (or EFGH_DIST_BACKEND=gloo) rendezvous over gloo: same code path above the backend, no scaling claim.
+        backend = os.environ.get('EFGH_DIST_BACKEND', 'gloo' if shared else 'nccl')
         if backend == 'nccl':
             dist.init_process_group('nccl', device_id=dev)
+            rccl_ranks = dist.get_world_size()
         else:
             dist.init_process_group(backend)
     raw, npts = ((128, 256), 2048) if a.small else (RAW, NPTS)
@@ -210,6 +272,7 @@ def main():
             fn()
         barrier()
         ops.PROFILE, ops.PROFILE_WGRAD, ops.PROFILE_WINO, ops.PROFILE_WINO_WGRAD, ops.PROFILE_BCL = [], [], [], [], []
+        lattice.PROFILE = ops.PROFILE_BCL
         t0 = time.perf_counter()
         for _ in range(steps):
             fn()
@@ -217,7 +280,7 @@ def main():
         dt = max_over_ranks(time.perf_counter() - t0)
         prof = {'gemm': ops.PROFILE, 'wgrad': ops.PROFILE_WGRAD, 'wino': ops.PROFILE_WINO,
                 'wino_wgrad': ops.PROFILE_WINO_WGRAD, 'bcl': ops.PROFILE_BCL}
-        ops.PROFILE = ops.PROFILE_WGRAD = ops.PROFILE_WINO = ops.PROFILE_WINO_WGRAD = ops.PROFILE_BCL = None
+        ops.PROFILE = ops.PROFILE_WGRAD = ops.PROFILE_WINO = ops.PROFILE_WINO_WGRAD = ops.PROFILE_BCL = lattice.PROFILE = None
         return dt, prof
 
     out = None
@@ -269,6 +332,7 @@ def main():
                                        'fused Adam, synthetic %dx%d RGB + %d-point sweep, batch=%d per GPU, random-init '
                                        'weights' % (raw[0] // 2, raw[1] // 2, npts, Bt),
                            'global_batch': world * Bt, 'points': npts, 'parallelism': 'dp%d' % world},
+                'rccl_ranks': rccl_ranks, 'dist_backend': backend, 'visible_gpus': ndev,
                 'forward_only': fwd,
             }
             out.update(rooflines(prof, a.steps))
@@ -280,6 +344,7 @@ def main():
                'config': {'workload': fwd['workload'] + ', synthetic %dx%d RGB + %d-point sweep, random-init weights'
                                       % (raw[0] // 2, raw[1] // 2, npts),
                           'global_batch': world * (a.batch or 4), 'points': npts, 'parallelism': 'dp%d' % world},
+               'rccl_ranks': rccl_ranks, 'dist_backend': backend, 'visible_gpus': ndev,
                }
         out.update({k: v for k, v in fwd.items() if k.startswith('roofline')})
     if rank == 0:

@@ -43,13 +43,10 @@ def lib():
         import torch  # noqa: F401  (load torch's HIP runtime first so both share one runtime)
         _lib = ctypes.CDLL(SO_PATH)
         _lib.efgh_last_error.restype = ctypes.c_char_p
-        for name in ('efgh_lattice_workspace_bytes', 'efgh_lattice_hash_capacity'):
-            getattr(_lib, name).restype = c_int64
-            getattr(_lib, name).argtypes = [c_int32]
-        _lib.efgh_splat_csr_workspace_ints.restype = c_int64
-        _lib.efgh_table_csr_workspace_ints.restype = c_int64
-        _lib.efgh_table_csr_workspace_ints.argtypes = [c_int64]
-        _lib.efgh_splat_csr_workspace_ints.argtypes = [c_int32, c_int32]
+        _lib.efgh_lattice_hash_capacity.restype = c_int64
+        _lib.efgh_lattice_hash_capacity.argtypes = [c_int32]
+        _lib.efgh_lattice_workspace_bytes.restype = c_int64
+        _lib.efgh_lattice_workspace_bytes.argtypes = [c_int32, c_int32, c_int32]
     return _lib
 
 

@@ -1,13 +1,30 @@
-// Permutohedral lattice build for one pyramid level on gfx950 (K1 + K2 of SURVEY.md §2a).
+// Permutohedral lattice build for one pyramid level, all samples of a batch, on gfx950 (K1 + K2 of SURVEY.md §2a).
 //
 // Reference behaviour reproduced bit-for-bit:
-//   get_keys_and_barycentric   nets/generate_data.py:56-112   -> k_point_keys
+//   get_keys_and_barycentric   nets/generate_data.py:56-112   -> point_keys()  (k_point_keys, k_insert, k_assign)
 //   key2int                    nets/transforms.py:62-77       -> key2int()
-//   build_it (i)  first-seen numbering   transforms.py:153-166 -> k_insert / k_flag_count /
-//                                                                k_scan_sums / k_assign / k_offsets
+//   build_it (i)  first-seen numbering   transforms.py:153-166 -> k_insert / k_seg_* / k_place / k_sortmin /
+//                                                                k_flag_count / k_scan_sums / k_assign / k_offsets
 //   build_it (ii) blur neighbours        transforms.py:168-180 -> k_neighbors
-// The sequential "first seen" numbering is restated as: index(v) = rank of v among distinct
-// key integers ordered by their smallest flat position 4*p+rem (atomicMin + flag prefix sum).
+// The sequential "first seen" numbering is restated as: index(v) = rank of v among the distinct key integers ordered by
+// their smallest flat position f = 4*p + rem.
+//
+// What is different from a line-by-line GPU version (round 1), and why (tools/probes/probe_atomics.hip, profiles/r02_probes.txt):
+// every global atomic on gfx950 executes at the memory side at ~26 G operations/s chip-wide whatever its scope, width or
+// table size, so the cost of this build is its number of atomics per (point, remainder) entry.  Round 1 paid four (hash CAS,
+// atomicMin of the position, and a count + a fill atomic to invert `off` for the splat); this version pays ONE:
+//   * the key is looked up with an ordinary load first (a key never changes once written, so a match is final) and claimed
+//     by CAS only when the slot is still empty (one CAS per vertex, not per entry);
+//   * the one atomic per entry is `rank = atomicAdd(cnt[slot], 1)`.  It yields the entry's place in its vertex's list, so
+//     the inverse of `off` (vertex -> its entries: what the splat gather walks) falls out of the build: one list segment
+//     per occupied slot (exclusive scan of cnt, which also compacts the occupied slots), entries placed with plain stores,
+//     every list sorted by a half-wave (fixed summation order: the forward stays bit-reproducible); its head IS the
+//     smallest position;
+//   * same-ADDRESS atomics serialise at ~20-70 ns each (a per-wave cursor bump measured 1.3 ms for 110 k waves), so nothing
+//     funnels through one counter: key extrema leave k_point_keys as per-wave records, segments come from a scan;
+//   * keys are recomputed from the point where they are needed instead of stored (64 B per point never written).
+// Sizes that depend on the data (n of levels >= 1, H) are read from DEVICE memory, launch sizes come from capacities, so
+// a whole pyramid can be enqueued without a host read-back between levels (efgh_amd/lattice.py).
 //
 // This file is compiled with -ffp-contract=off: the float recipe must round exactly like the
 // reference's MKL sgemm (FMA chain in column order).
@@ -17,6 +34,7 @@
 namespace {
 
 constexpr int TPB = 256;
+constexpr unsigned long long EMPTY = ~0ULL;
 
 __constant__ uint32_t c_elev[4][3] = {{0x3F3504F3u, 0x3ED105EBu, 0x3E93CD3Au},
                                       {0xBF3504F3u, 0x3ED105EBu, 0x3E93CD3Au},
@@ -47,177 +65,395 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x) {
     return x;
 }
 
-__global__ void k_init_minmax(int *mm, int nsamples, int *seg_first) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < nsamples * 8) mm[i] = (i & 7) < 4 ? INT32_MAX : INT32_MIN;
-    if (seg_first && i < nsamples) seg_first[i] = INT32_MAX;
+__device__ __forceinline__ int n_of(const int *n_dev, int n_cap) {
+    if (!n_dev) return n_cap;
+    int n = *n_dev;
+    return n < n_cap ? n : n_cap;
 }
 
-// ---- K1: one thread per point ------------------------------------------------------------
+__device__ __forceinline__ int sample_of(const int *sid, int pps, int p) { return sid ? sid[p] : p / pps; }
+
+// generate_data.py:56-112 for one point: greedy lattice point g, rank, el_minus_gr, barycentric weights
+struct PointKeys { float bary[4], emg[4]; int g[4], rank[4]; };
+
+__device__ __forceinline__ void point_keys(float x, float y, float z, float scale32, float std32, PointKeys &o) {
+    float pos[3] = {__fmul_rn(x, scale32), __fmul_rn(y, scale32), __fmul_rn(z, scale32)};
+    float el[4], gr[4], emg[4];
+    int rank[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float acc = __fmul_rn(elev(r, 0), pos[0]);
+        acc = __fmaf_rn(elev(r, 1), pos[1], acc);
+        acc = __fmaf_rn(elev(r, 2), pos[2], acc);
+        el[r] = __fmul_rn(acc, std32);
+        gr[r] = __fmul_rn(rintf(__fmul_rn(el[r], 0.25f)), 4.0f);
+        emg[r] = __fsub_rn(el[r], gr[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        int c = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c += (emg[j] > emg[r] || (emg[j] == emg[r] && j < r)) ? 1 : 0;
+        rank[r] = c;
+    }
+    float rs = __fmul_rn(__fadd_rn(__fadd_rn(__fadd_rn(gr[0], gr[1]), gr[2]), gr[3]), 0.25f);
+    float sign = (rs > 0.0f) ? -1.0f : ((rs < 0.0f) ? 1.0f : 0.0f);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float rf = (float)rank[r];
+        bool cond = ((rf >= __fsub_rn(4.0f, rs)) && (rs > 0.0f)) || ((rf < -rs) && (rs < 0.0f));
+        float adj = cond ? __fmul_rn(4.0f, sign) : 0.0f;
+        gr[r] = __fadd_rn(gr[r], adj);
+        rank[r] += (int)adj;
+        rank[r] += (int)rs;
+    }
+    float b5[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) emg[r] = __fsub_rn(el[r], gr[r]);
+    // barycentric[d0 - rank] += e ; barycentric[d1 - rank] -= e   (:99-100); rank is a
+    // permutation of 0..3, so every slot gets at most one += and then one -=
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int j = 0; j < 5; ++j) if (3 - rank[r] == j) b5[j] = __fadd_rn(b5[j], emg[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int j = 0; j < 5; ++j) if (4 - rank[r] == j) b5[j] = __fsub_rn(b5[j], emg[r]);
+    }
+#pragma unroll
+    for (int j = 0; j < 5; ++j) b5[j] = __fmul_rn(b5[j], 0.25f);
+    b5[0] = __fadd_rn(b5[0], __fadd_rn(1.0f, b5[4]));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { o.bary[r] = b5[r]; o.emg[r] = emg[r]; o.g[r] = (int)gr[r]; o.rank[r] = rank[r]; }
+}
+
+// key of simplex vertex `rem` (generate_data.py:106): greedy + canonical[rank][rem]
+__device__ __forceinline__ void entry_key(const PointKeys &pk, int rem, int k[4]) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        int cv = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) if (pk.rank[c] == q) cv = c_canon[q][rem];
+        k[c] = pk.g[c] + cv;
+    }
+}
+
+// ---- K0: clear the tables of this level ------------------------------------------------------------
 __global__ void __launch_bounds__(TPB)
-k_point_keys(const float *__restrict__ pts, int64_t cstride, int n, float scale32, float std32,
-             float *__restrict__ bary, float *__restrict__ emg_out, int64_t emg_ps, int64_t emg_rs,
-             int4 *__restrict__ keys, int *__restrict__ mm, const int *__restrict__ sid) {
-    int p = blockIdx.x * TPB + threadIdx.x;
+k_level_init(unsigned long long *__restrict__ hkeys, int *__restrict__ cnt, int64_t hcap, int *__restrict__ flags,
+             int n_cap, int *__restrict__ mm, int nsamples, int *__restrict__ info, int ninfo) {
+    const int64_t i0 = (int64_t)blockIdx.x * TPB + threadIdx.x, stride = (int64_t)gridDim.x * TPB;
+    for (int64_t i = i0; i < hcap; i += stride) { hkeys[i] = EMPTY; cnt[i] = 0; }
+    for (int64_t i = i0; i < n_cap; i += stride) flags[i] = 0;
+    if (i0 < nsamples * 8) mm[i0] = (i0 & 7) < 4 ? INT32_MAX : INT32_MIN;
+    if (i0 < ninfo) info[i0] = 0;
+}
+
+// per-sample extrema of a wave whose lanes belong to more than one sample: one shuffle reduction per distinct sample, then
+// eight atomics by one lane (not eight per lane: same-address atomics serialise)
+__device__ __forceinline__ void wave_minmax_by_sample(int b, const int kmin[4], const int kmax[4], int *__restrict__ mm) {
+    unsigned long long todo = __ballot(b >= 0);
+    const int lane = threadIdx.x & 63;
+    while (todo) {
+        const int l = __ffsll((long long)todo) - 1;
+        const int bs = __shfl(b, l);
+        const bool mine = b == bs;
+        int lo[4], hi[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            lo[c] = mine ? kmin[c] : INT32_MAX;
+            hi[c] = mine ? kmax[c] : INT32_MIN;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { lo[c] = min(lo[c], __shfl_xor(lo[c], o)); hi[c] = max(hi[c], __shfl_xor(hi[c], o)); }
+        }
+        if (lane == l) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { atomicMin(&mm[8 * bs + c], lo[c]); atomicMax(&mm[8 * bs + 4 + c], hi[c]); }
+        }
+        todo &= ~__ballot(mine);
+    }
+}
+
+// ---- K1: one thread per point: barycentric weights, el_minus_gr, per-sample key extrema.  Same-address atomics serialise
+// at the memory side (~20-70 ns each), so the extrema leave the kernel as one plain 48-byte record per WAVE (part[wave] =
+// sample, mins, maxs) and k_minmax_finalize folds the records; only a wave that straddles two samples (at most one per sample
+// boundary) falls back to atomics.
+__global__ void __launch_bounds__(TPB)
+k_point_keys(const float *__restrict__ pts, int64_t cstride, const int *__restrict__ n_dev, int n_cap, float scale32,
+             float std32, float4 *__restrict__ bary, float4 *__restrict__ emg, int *__restrict__ mm,
+             int *__restrict__ part, const int *__restrict__ sid, int pps) {
+    const int n = n_of(n_dev, n_cap);
+    const int p = blockIdx.x * TPB + threadIdx.x;
+    const int wave = p >> 6, lane = threadIdx.x & 63;
+    if ((p & ~63) >= n) {                       // wave past the end: an empty record
+        if (lane == 0) part[12 * wave] = -1;
+        return;
+    }
     int kmin[4] = {INT32_MAX, INT32_MAX, INT32_MAX, INT32_MAX};
     int kmax[4] = {INT32_MIN, INT32_MIN, INT32_MIN, INT32_MIN};
+    int b = -1;
     if (p < n) {
-        float pos[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) pos[c] = __fmul_rn(pts[c * cstride + p], scale32);
-        float el[4], gr[4], emg[4];
-        int rank[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float acc = __fmul_rn(elev(r, 0), pos[0]);
-            acc = __fmaf_rn(elev(r, 1), pos[1], acc);
-            acc = __fmaf_rn(elev(r, 2), pos[2], acc);
-            el[r] = __fmul_rn(acc, std32);
-            gr[r] = __fmul_rn(rintf(__fmul_rn(el[r], 0.25f)), 4.0f);
-            emg[r] = __fsub_rn(el[r], gr[r]);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            int c = 0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) c += (emg[j] > emg[r] || (emg[j] == emg[r] && j < r)) ? 1 : 0;
-            rank[r] = c;
-        }
-        float rs = __fmul_rn(__fadd_rn(__fadd_rn(__fadd_rn(gr[0], gr[1]), gr[2]), gr[3]), 0.25f);
-        float sign = (rs > 0.0f) ? -1.0f : ((rs < 0.0f) ? 1.0f : 0.0f);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float rf = (float)rank[r];
-            bool cond = ((rf >= __fsub_rn(4.0f, rs)) && (rs > 0.0f)) || ((rf < -rs) && (rs < 0.0f));
-            float adj = cond ? __fmul_rn(4.0f, sign) : 0.0f;
-            gr[r] = __fadd_rn(gr[r], adj);
-            rank[r] += (int)adj;
-            rank[r] += (int)rs;
-        }
-        float b5[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int r = 0; r < 4; ++r) emg[r] = __fsub_rn(el[r], gr[r]);
-        // barycentric[d0 - rank] += e ; barycentric[d1 - rank] -= e   (:99-100); rank is a
-        // permutation of 0..3, so every slot gets at most one += and then one -=
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-#pragma unroll
-            for (int j = 0; j < 5; ++j) if (3 - rank[r] == j) b5[j] = __fadd_rn(b5[j], emg[r]);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-#pragma unroll
-            for (int j = 0; j < 5; ++j) if (4 - rank[r] == j) b5[j] = __fsub_rn(b5[j], emg[r]);
-        }
-#pragma unroll
-        for (int j = 0; j < 5; ++j) b5[j] = __fmul_rn(b5[j], 0.25f);
-        b5[0] = __fadd_rn(b5[0], __fadd_rn(1.0f, b5[4]));
-#pragma unroll
-        for (int r = 0; r < 4; ++r) bary[(int64_t)r * n + p] = b5[r];
-        if (emg_rs == 1 && (emg_ps & 3) == 0)       // channels 0..3 of the level's feature row: one 16-B store
-            *reinterpret_cast<float4 *>(emg_out + (int64_t)p * emg_ps) = make_float4(emg[0], emg[1], emg[2], emg[3]);
-        else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) emg_out[(int64_t)p * emg_ps + r * emg_rs] = emg[r];
-        }
-        int g[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) g[c] = (int)gr[c];
+        PointKeys pk;
+        point_keys(pts[p], pts[cstride + p], pts[2 * cstride + p], scale32, std32, pk);
+        bary[p] = make_float4(pk.bary[0], pk.bary[1], pk.bary[2], pk.bary[3]);
+        emg[p] = make_float4(pk.emg[0], pk.emg[1], pk.emg[2], pk.emg[3]);
 #pragma unroll
         for (int rem = 0; rem < 4; ++rem) {
             int k[4];
+            entry_key(pk, rem, k);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                int cv = 0;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) if (rank[c] == q) cv = c_canon[q][rem];
-                k[c] = g[c] + cv;
-                kmin[c] = min(kmin[c], k[c]);
-                kmax[c] = max(kmax[c], k[c]);
-            }
-            keys[(int64_t)p * 4 + rem] = make_int4(k[0], k[1], k[2], k[3]);
+            for (int c = 0; c < 4; ++c) { kmin[c] = min(kmin[c], k[c]); kmax[c] = max(kmax[c], k[c]); }
         }
+        b = sample_of(sid, pps, p);
     }
-    if (sid) {      // several samples in one launch: per-sample extrema
-        const int b = p < n ? sid[p] : -1;
-        // the usual case - the whole block belongs to one sample: LDS reduction, 8 atomics per block (the per-wave
-        // form put 8 atomics per wave on the same 8 words per sample: ~65k serialised atomics at level 0, batch 4)
-        const int bb = sid[(long long)blockIdx.x * TPB < n ? (long long)blockIdx.x * TPB : 0];
-        if (__syncthreads_and(b == bb || b < 0)) {
-            __shared__ int bmin[4][TPB / 64], bmax[4][TPB / 64];
-            const int lane_ = threadIdx.x & 63, w_ = threadIdx.x >> 6;
+    const int b0 = __shfl(b, 0);                // lane 0 is a valid point here
+    if (__all(b == b0 || b < 0)) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                int a = kmin[c], z = kmax[c];
+        for (int c = 0; c < 4; ++c) {
 #pragma unroll
-                for (int o = 32; o > 0; o >>= 1) { a = min(a, __shfl_xor(a, o)); z = max(z, __shfl_xor(z, o)); }
-                if (lane_ == 0) { bmin[c][w_] = a; bmax[c][w_] = z; }
+            for (int o = 32; o > 0; o >>= 1) {
+                kmin[c] = min(kmin[c], __shfl_xor(kmin[c], o));
+                kmax[c] = max(kmax[c], __shfl_xor(kmax[c], o));
             }
-            __syncthreads();
-            if (threadIdx.x < 4) {
-                const int c = threadIdx.x;
-                int a = bmin[c][0], z = bmax[c][0];
-                for (int i = 1; i < TPB / 64; ++i) { a = min(a, bmin[c][i]); z = max(z, bmax[c][i]); }
-                atomicMin(&mm[8 * bb + c], a);
-                atomicMax(&mm[8 * bb + 4 + c], z);
-            }
-            return;
         }
-        const int b0 = __shfl(b, 0);
-        if (__all(b == b0 || b < 0)) {           // a block straddling two samples: per-wave reduction
+        if (lane == 0) {
+            int *q = part + 12 * wave;
+            q[0] = b0;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                int a = kmin[c], z = kmax[c];
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) { a = min(a, __shfl_xor(a, o)); z = max(z, __shfl_xor(z, o)); }
-                if ((threadIdx.x & 63) == 0 && b0 >= 0) { atomicMin(&mm[8 * b0 + c], a); atomicMax(&mm[8 * b0 + 4 + c], z); }
-            }
-        } else if (b >= 0) {                     // a wave straddling two samples: per-lane atomics
-#pragma unroll
-            for (int c = 0; c < 4; ++c) { atomicMin(&mm[8 * b + c], kmin[c]); atomicMax(&mm[8 * b + 4 + c], kmax[c]); }
+            for (int c = 0; c < 4; ++c) { q[1 + c] = kmin[c]; q[5 + c] = kmax[c]; }
         }
-        return;
-    }
-    // block reduce min / max, one atomic per block and coordinate
-    __shared__ int smin[4][TPB / 64], smax[4][TPB / 64];
-    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        int a = kmin[c], b = kmax[c];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { a = min(a, __shfl_xor(a, o)); b = max(b, __shfl_xor(b, o)); }
-        if (lane == 0) { smin[c][w] = a; smax[c][w] = b; }
-    }
-    __syncthreads();
-    if (threadIdx.x < 4) {
-        int c = threadIdx.x, a = smin[c][0], b = smax[c][0];
-        for (int i = 1; i < TPB / 64; ++i) { a = min(a, smin[c][i]); b = max(b, smax[c][i]); }
-        atomicMin(&mm[c], a);
-        atomicMax(&mm[4 + c], b);
+    } else {
+        if (lane == 0) part[12 * wave] = -1;
+        wave_minmax_by_sample(b, kmin, kmax, mm);
     }
 }
 
-// ---- K2a: hash insert, remember the smallest flat position per distinct key -----------------
+// fold the per-wave records: one thread per record, a shuffle reduction per wave of records and distinct sample (records are
+// sample-major, so almost every wave holds one sample), eight atomics per wave
 __global__ void __launch_bounds__(TPB)
-k_insert(const int4 *__restrict__ keys, int n4, const int *__restrict__ mm,
-         unsigned long long *__restrict__ hkeys, int *__restrict__ minpos, int64_t hmask,
-         int *__restrict__ slot, const int *__restrict__ sid, int nsamples) {
-    int f = blockIdx.x * TPB + threadIdx.x;
-    if (f >= n4) return;
-    int4 kk = keys[f];
-    int k[4] = {kk.x, kk.y, kk.z, kk.w};
-    const int b = sid ? sid[f >> 2] : 0;
-    // the map key is (key integer of the sample, sample): vertices of different samples never merge
-    unsigned long long ki = (unsigned long long)(key2int(k, mm + 8 * b) * nsamples + b);
-    uint64_t h = mix64(ki) & (uint64_t)hmask;
-    const unsigned long long EMPTY = ~0ULL;
-    while (true) {
-        unsigned long long prev = atomicCAS(&hkeys[h], EMPTY, ki);
-        if (prev == EMPTY || prev == ki) break;
-        h = (h + 1) & (uint64_t)hmask;
+k_minmax_finalize(const int *__restrict__ part, int nwaves, int *__restrict__ mm) {
+    const int w = blockIdx.x * TPB + threadIdx.x;
+    int b = -1;
+    int kmin[4] = {INT32_MAX, INT32_MAX, INT32_MAX, INT32_MAX};
+    int kmax[4] = {INT32_MIN, INT32_MIN, INT32_MIN, INT32_MIN};
+    if (w < nwaves) {
+        const int4 *q = reinterpret_cast<const int4 *>(part + 12 * w);
+        const int4 q0 = q[0], q1 = q[1], q2 = q[2];
+        b = q0.x;
+        kmin[0] = q0.y; kmin[1] = q0.z; kmin[2] = q0.w; kmin[3] = q1.x;
+        kmax[0] = q1.y; kmax[1] = q1.z; kmax[2] = q1.w; kmax[3] = q2.x;
     }
-    atomicMin(&minpos[h], f);
-    slot[f] = (int)h;
+    wave_minmax_by_sample(b, kmin, kmax, mm);
+}
+
+// ---- K2a: hash insert.  One thread per point, its four entries in flight together.  Per entry: a load of the home slot
+// (a hit for all but the first entries of a vertex), CAS only on an empty slot, then the ONE atomic of the build,
+// rank = atomicAdd(cnt[slot], 1).
+__device__ __forceinline__ unsigned long long load_slot(const unsigned long long *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // sc1: served by the memory side, as the CAS is
+}
+
+__device__ __forceinline__ int claim_slot(unsigned long long *__restrict__ hkeys, uint64_t hmask, unsigned long long ki,
+                                          uint64_t h, unsigned long long cur) {
+    for (;;) {
+        if (cur == ki) return (int)h;
+        if (cur == EMPTY) {
+            const unsigned long long prev = atomicCAS(&hkeys[h], EMPTY, ki);
+            if (prev == EMPTY || prev == ki) return (int)h;
+        }
+        h = (h + 1) & hmask;
+        cur = load_slot(&hkeys[h]);
+    }
+}
+
+__global__ void __launch_bounds__(TPB)
+k_insert(const float *__restrict__ pts, int64_t cstride, const int *__restrict__ n_dev, int n_cap, float scale32,
+         float std32, const int *__restrict__ mm, unsigned long long *__restrict__ hkeys, int *__restrict__ cnt,
+         int64_t hmask, int4 *__restrict__ slot, int4 *__restrict__ rnk, const int *__restrict__ sid, int pps,
+         int nsamples) {
+    const int n = n_of(n_dev, n_cap);
+    const int p = blockIdx.x * TPB + threadIdx.x;
+    if (p >= n) return;
+    PointKeys pk;
+    point_keys(pts[p], pts[cstride + p], pts[2 * cstride + p], scale32, std32, pk);
+    const int b = sample_of(sid, pps, p);
+    unsigned long long ki[4], cur[4];
+    uint64_t h[4];
+    int s[4], r[4];
+#pragma unroll
+    for (int rem = 0; rem < 4; ++rem) {
+        int k[4];
+        entry_key(pk, rem, k);
+        // the map key is (key integer of the sample, sample): vertices of different samples never merge
+        ki[rem] = (unsigned long long)(key2int(k, mm + 8 * b) * nsamples + b);
+        h[rem] = mix64(ki[rem]) & (uint64_t)hmask;
+    }
+    // first look with an ordinary (cacheable) load: a key never changes once written, so a match is final; anything else
+    // (empty, another key, or a stale cached line) goes through the memory-side load / CAS of claim_slot
+#pragma unroll
+    for (int rem = 0; rem < 4; ++rem) cur[rem] = hkeys[h[rem]];
+#pragma unroll
+    for (int rem = 0; rem < 4; ++rem)
+        s[rem] = cur[rem] == ki[rem] ? (int)h[rem] : claim_slot(hkeys, (uint64_t)hmask, ki[rem], h[rem], load_slot(&hkeys[h[rem]]));
+#pragma unroll
+    for (int rem = 0; rem < 4; ++rem) r[rem] = atomicAdd(&cnt[s[rem]], 1);
+    slot[p] = make_int4(s[0], s[1], s[2], s[3]);
+    rnk[p] = make_int4(r[0], r[1], r[2], r[3]);
+}
+
+// ---- K2b: one list segment per occupied slot: exclusive scan of cnt over the slots (block sums, one-block scan, assign) which
+// also compacts the occupied slots into `occ` (their number is the number of vertices).
+constexpr int SEG_Q = 4;            // int4 per thread in the slot scan: 4096 slots per block
+
+__global__ void __launch_bounds__(TPB)
+k_seg_count(const int4 *__restrict__ cnt4, int2 *__restrict__ bsum2) {
+    int sum = 0, occ = 0;
+#pragma unroll
+    for (int q = 0; q < SEG_Q; ++q) {
+        const int4 c = cnt4[((int64_t)blockIdx.x * SEG_Q + q) * TPB + threadIdx.x];
+        sum += c.x + c.y + c.z + c.w;
+        occ += (c.x > 0) + (c.y > 0) + (c.z > 0) + (c.w > 0);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { sum += __shfl_xor(sum, o); occ += __shfl_xor(occ, o); }
+    __shared__ int2 ws_[TPB / 64];
+    if ((threadIdx.x & 63) == 0) ws_[threadIdx.x >> 6] = make_int2(sum, occ);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int2 t = ws_[0];
+        for (int i = 1; i < TPB / 64; ++i) { t.x += ws_[i].x; t.y += ws_[i].y; }
+        bsum2[blockIdx.x] = t;
+    }
+}
+
+__device__ __forceinline__ int2 block_exclusive_scan2(int2 v, int2 *total) {
+    __shared__ int2 wsum2[TPB / 64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int2 x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int y0 = __shfl_up(x.x, o), y1 = __shfl_up(x.y, o);
+        if (lane >= o) { x.x += y0; x.y += y1; }
+    }
+    if (lane == 63) wsum2[w] = x;
+    __syncthreads();
+    int2 base = make_int2(0, 0), tot = make_int2(0, 0);
+#pragma unroll
+    for (int i = 0; i < TPB / 64; ++i) {
+        if (i < w) { base.x += wsum2[i].x; base.y += wsum2[i].y; }
+        tot.x += wsum2[i].x; tot.y += wsum2[i].y;
+    }
+    __syncthreads();
+    *total = tot;
+    return make_int2(base.x + x.x - v.x, base.y + x.y - v.y);
+}
+
+__global__ void __launch_bounds__(TPB)
+k_seg_scan(int2 *__restrict__ bsum2, int nb, int *__restrict__ n_occ) {
+    __shared__ int2 carry_s;
+    if (threadIdx.x == 0) carry_s = make_int2(0, 0);
+    __syncthreads();
+    for (int s = 0; s < nb; s += TPB) {
+        const int i = s + threadIdx.x;
+        const int2 v = i < nb ? bsum2[i] : make_int2(0, 0);
+        int2 tot;
+        const int2 ex = block_exclusive_scan2(v, &tot);
+        const int2 carry = carry_s;
+        if (i < nb) bsum2[i] = make_int2(carry.x + ex.x, carry.y + ex.y);
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s = make_int2(carry.x + tot.x, carry.y + tot.y);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *n_occ = carry_s.y;
+}
+
+// occ[k] = (slot, start, length) of the k-th occupied slot
+__global__ void __launch_bounds__(TPB)
+k_seg_assign(const int4 *__restrict__ cnt4, const int2 *__restrict__ bsum2, int4 *__restrict__ sstart4, int4 *__restrict__ occ) {
+    int2 run = bsum2[blockIdx.x];
+#pragma unroll
+    for (int q = 0; q < SEG_Q; ++q) {
+        const int64_t i = ((int64_t)blockIdx.x * SEG_Q + q) * TPB + threadIdx.x;
+        const int4 c = cnt4[i];
+        const int2 mine = make_int2(c.x + c.y + c.z + c.w, (c.x > 0) + (c.y > 0) + (c.z > 0) + (c.w > 0));
+        int2 tot;
+        const int2 ex = block_exclusive_scan2(mine, &tot);
+        int st = run.x + ex.x, k = run.y + ex.y;
+        run.x += tot.x; run.y += tot.y;
+        const int s0 = (int)(i * 4);
+        int4 o;
+        o.x = st; if (c.x > 0) occ[k++] = make_int4(s0, st, c.x, 0);
+        st += c.x;
+        o.y = st; if (c.y > 0) occ[k++] = make_int4(s0 + 1, st, c.y, 0);
+        st += c.y;
+        o.z = st; if (c.z > 0) occ[k++] = make_int4(s0 + 2, st, c.z, 0);
+        st += c.z;
+        o.w = st; if (c.w > 0) occ[k++] = make_int4(s0 + 3, st, c.w, 0);
+        sstart4[i] = o;
+    }
+}
+
+// ---- K2c: entries into their vertex's segment, in arrival order ------------------------------------------------
+__global__ void __launch_bounds__(TPB)
+k_place(const int4 *__restrict__ slot, const int4 *__restrict__ rnk, const int *__restrict__ n_dev, int n_cap,
+        const int *__restrict__ sstart, int *__restrict__ list0) {
+    const int n = n_of(n_dev, n_cap);
+    const int p = blockIdx.x * TPB + threadIdx.x;
+    if (p >= n) return;
+    const int4 s = slot[p], r = rnk[p];
+    list0[sstart[s.x] + r.x] = 4 * p;
+    list0[sstart[s.y] + r.y] = 4 * p + 1;
+    list0[sstart[s.z] + r.z] = 4 * p + 2;
+    list0[sstart[s.w] + r.w] = 4 * p + 3;
+}
+
+// ---- K2d: every list sorted by flat position (rank = number of smaller ids, ids are distinct): a 32-lane half-wave per
+// occupied slot.  The head of the sorted list is the position where the vertex is first seen: flag it.
+__global__ void __launch_bounds__(TPB)
+k_sortmin(const int4 *__restrict__ occ, const int *__restrict__ n_occ, const int *__restrict__ list0,
+          int *__restrict__ list, unsigned char *__restrict__ flags) {
+    const int nocc = *n_occ;
+    const int lane = threadIdx.x & 63, sub = lane & 31, half = lane & 32;
+    for (int64_t v0 = ((int64_t)blockIdx.x * TPB + threadIdx.x) >> 5; (v0 & ~1LL) < nocc; v0 += ((int64_t)gridDim.x * TPB) >> 5) {
+        const bool have = v0 < nocc;
+        const int4 rec = have ? occ[v0] : make_int4(0, 0, 0, 0);
+        const int len = rec.z, s0 = rec.y;
+        const int lmax = max(len, __shfl_xor(len, 32));          // both halves run the same number of shuffle rounds
+        if (lmax <= 64) {                          // up to two ids per lane, ranks by shuffles only
+            const int id0 = sub < len ? list0[s0 + sub] : INT32_MAX;
+            const int id1 = sub + 32 < len ? list0[s0 + 32 + sub] : INT32_MAX;
+            int r0 = 0, r1 = 0;
+            const int n0 = min(lmax, 32);
+            for (int q = 0; q < n0; ++q) {
+                const int x = __shfl(id0, half + q);
+                r0 += x < id0 ? 1 : 0;
+                r1 += x < id1 ? 1 : 0;
+            }
+            for (int q = 0; q < lmax - 32; ++q) {
+                const int x = __shfl(id1, half + q);
+                r0 += x < id0 ? 1 : 0;
+                r1 += x < id1 ? 1 : 0;
+            }
+            if (sub < len) {
+                list[s0 + r0] = id0;
+                if (r0 == 0) flags[id0] = 1;
+            }
+            if (sub + 32 < len) {
+                list[s0 + r1] = id1;
+                if (r1 == 0) flags[id1] = 1;
+            }
+        } else {                                   // long lists (many points in one cell): O(len^2 / 32)
+            for (int e = sub; e < len; e += 32) {
+                const int id = list0[s0 + e];
+                int rank = 0;
+                for (int q = 0; q < len; ++q) rank += list0[s0 + q] < id ? 1 : 0;
+                list[s0 + rank] = id;
+                if (rank == 0) flags[id] = 1;
+            }
+        }
+    }
 }
 
 __device__ __forceinline__ int block_exclusive_scan(int v, int *total) {
@@ -237,20 +473,21 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int *total) {
     return base + x - v;
 }
 
-// ---- K2b: count first-seen positions per block of 1024 flat positions ----------------------
+__device__ __forceinline__ int flag_count(unsigned w) { return __popc(w & 0x01010101u); }
+
+// ---- K2e: count first-seen positions per block of 256 points (1024 flat positions) -------------------------
 __global__ void __launch_bounds__(TPB)
-k_flag_count(const int *__restrict__ slot, const int *__restrict__ minpos, int n4,
-             int *__restrict__ bsum) {
-    int base = blockIdx.x * (TPB * 4) + threadIdx.x * 4, c = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { int f = base + j; if (f < n4 && minpos[slot[f]] == f) ++c; }
-    int tot; block_exclusive_scan(c, &tot);
+k_flag_count(const unsigned *__restrict__ flags, const int *__restrict__ n_dev, int n_cap, int *__restrict__ bsum) {
+    const int n = n_of(n_dev, n_cap);
+    const int p = blockIdx.x * TPB + threadIdx.x;
+    int tot;
+    block_exclusive_scan(p < n ? flag_count(flags[p]) : 0, &tot);
     if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
 }
 
-// ---- K2c: exclusive scan of the block sums (single block), writes H -------------------------
+// ---- K2f: exclusive scan of the block sums (single block), writes H -------------------------
 __global__ void __launch_bounds__(TPB)
-k_scan_sums(int *__restrict__ bsum, int nb, int *__restrict__ H_out) {
+k_scan_sums(int *__restrict__ bsum, int nb, int *__restrict__ info, int h_cap) {
     __shared__ int carry_s;
     if (threadIdx.x == 0) carry_s = 0;
     __syncthreads();
@@ -263,201 +500,228 @@ k_scan_sums(int *__restrict__ bsum, int nb, int *__restrict__ H_out) {
         if (threadIdx.x == 0) carry_s = carry + tot;
         __syncthreads();
     }
-    if (threadIdx.x == 0) *H_out = carry_s;
+    if (threadIdx.x == 0) {
+        info[EFGH_LATTICE_INFO_H] = carry_s;
+        if (carry_s > h_cap) atomicOr(&info[EFGH_LATTICE_INFO_ERR], 1);
+    }
 }
 
-// ---- K2d: number the vertices, emit their keys and the next level's points ------------------
+// ---- K2g: number the vertices, emit their keys, list segments and the next level's points ------------------
 __global__ void __launch_bounds__(TPB)
-k_assign(const int4 *__restrict__ keys, const int *__restrict__ slot, const int *__restrict__ minpos,
-         int n4, const int *__restrict__ bsum, int *__restrict__ hvals, int4 *__restrict__ vkeys,
-         float *__restrict__ pts_next, int64_t cap, float div32, const int *__restrict__ sid,
-         int *__restrict__ vsid, int *__restrict__ seg_first) {
-    int base = blockIdx.x * (TPB * 4) + threadIdx.x * 4, c = 0;
-    bool fl[4];
-    int sl[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        int f = base + j;
-        fl[j] = false;
-        if (f < n4) { sl[j] = slot[f]; fl[j] = (minpos[sl[j]] == f); }
-        c += fl[j] ? 1 : 0;
-    }
+k_assign(const float *__restrict__ pts, int64_t cstride, const int *__restrict__ n_dev, int n_cap, float scale32,
+         float std32, const unsigned *__restrict__ flags, const int4 *__restrict__ slot, const int *__restrict__ bsum,
+         const int *__restrict__ cnt, const int *__restrict__ sstart, int *__restrict__ hvals, int4 *__restrict__ vkeys,
+         int2 *__restrict__ vseg, float *__restrict__ pts_next, int h_cap, float div32, const int *__restrict__ sid,
+         int pps, int *__restrict__ vsid, int *__restrict__ info) {
+    const int n = n_of(n_dev, n_cap);
+    const int p = blockIdx.x * TPB + threadIdx.x;
+    const unsigned fw = p < n ? (flags[p] & 0x01010101u) : 0u;
     int tot;
-    int idx = bsum[blockIdx.x] + block_exclusive_scan(c, &tot);
+    int idx = bsum[blockIdx.x] + block_exclusive_scan(__popc(fw), &tot);
+    if (!fw) return;
+    PointKeys pk;
+    point_keys(pts[p], pts[cstride + p], pts[2 * cstride + p], scale32, std32, pk);
+    const int b = sample_of(sid, pps, p);
+    const int4 s4 = slot[p];
+    const int sl[4] = {s4.x, s4.y, s4.z, s4.w};
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        if (!fl[j]) continue;
-        int4 kk = keys[base + j];
-        hvals[sl[j]] = idx;
-        vkeys[idx] = kk;
-        if (sid) {
-            const int f = base + j, pp = f >> 2, b = sid[pp];
+    for (int rem = 0; rem < 4; ++rem) {
+        if (!(fw >> (8 * rem) & 1u)) continue;
+        const int h = sl[rem];
+        hvals[h] = idx;
+        if (idx < h_cap) {
+            int k[4];
+            entry_key(pk, rem, k);
+            vkeys[idx] = make_int4(k[0], k[1], k[2], k[3]);
+            vseg[idx] = make_int2(sstart[h], cnt[h]);
             vsid[idx] = b;
             // vertices are numbered sample-major, and the very first key of a sample is always new:
             // its index is the sample's first vertex index
-            if ((f & 3) == 0 && (pp == 0 || sid[pp - 1] != b)) seg_first[b] = idx;
-        }
-        // generate_data.py:176-178: key (as fp32) / float32(std*scale), then E^T . (4-term fma chain)
-        float kf[4] = {__fdiv_rn((float)kk.x, div32), __fdiv_rn((float)kk.y, div32),
-                       __fdiv_rn((float)kk.z, div32), __fdiv_rn((float)kk.w, div32)};
+            if (rem == 0 && (p == 0 || sample_of(sid, pps, p - 1) != b)) info[EFGH_LATTICE_INFO_SEG + b] = idx;
+            // generate_data.py:176-178: key (as fp32) / float32(std*scale), then E^T . (4-term fma chain)
+            float kf[4] = {__fdiv_rn((float)k[0], div32), __fdiv_rn((float)k[1], div32),
+                           __fdiv_rn((float)k[2], div32), __fdiv_rn((float)k[3], div32)};
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            float acc = __fmul_rn(elev(0, q), kf[0]);
-            acc = __fmaf_rn(elev(1, q), kf[1], acc);
-            acc = __fmaf_rn(elev(2, q), kf[2], acc);
-            acc = __fmaf_rn(elev(3, q), kf[3], acc);
-            pts_next[q * cap + idx] = acc;
+            for (int q = 0; q < 3; ++q) {
+                float acc = __fmul_rn(elev(0, q), kf[0]);
+                acc = __fmaf_rn(elev(1, q), kf[1], acc);
+                acc = __fmaf_rn(elev(2, q), kf[2], acc);
+                acc = __fmaf_rn(elev(3, q), kf[3], acc);
+                pts_next[(int64_t)q * h_cap + idx] = acc;
+            }
         }
         ++idx;
     }
 }
 
-// ---- K2e: lattice_offset[rem][p] ----------------------------------------------------------------
+// ---- K2h: lattice_offset[p][rem] ----------------------------------------------------------------
 __global__ void __launch_bounds__(TPB)
-k_offsets(const int *__restrict__ slot, const int *__restrict__ hvals, int n, int *__restrict__ off) {
-    int p = blockIdx.x * TPB + threadIdx.x;
+k_offsets(const int4 *__restrict__ slot, const int *__restrict__ hvals, const int *__restrict__ n_dev, int n_cap,
+          int4 *__restrict__ off) {
+    const int n = n_of(n_dev, n_cap);
+    const int p = blockIdx.x * TPB + threadIdx.x;
     if (p >= n) return;
-    int4 s = reinterpret_cast<const int4 *>(slot)[p];
-    off[p] = hvals[s.x];
-    off[(int64_t)n + p] = hvals[s.y];
-    off[(int64_t)2 * n + p] = hvals[s.z];
-    off[(int64_t)3 * n + p] = hvals[s.w];
+    const int4 s = slot[p];
+    off[p] = make_int4(hvals[s.x], hvals[s.y], hvals[s.z], hvals[s.w]);
 }
 
-// ---- K2f: 15 blur neighbours per vertex, one thread per (vertex, offset) -----------------------
+// ---- K2i: 15 blur neighbours per vertex, one thread per (vertex, offset).  key2int has no range check
+// (transforms.py:173-180): a neighbour key outside the sample's [mins, maxs] box in coordinates 1..3 aliases to the integer
+// of another lattice point and may "find" that vertex.  Such hits are kept (reference behaviour) and marked: bit t of column
+// 15 of the row, and an (entry, target) record in `alist` - everything else in the table is an exact, hence symmetric,
+// neighbour relation, which is what lets the adjoint of the blur gather run as a gather (bcl.hip).
 __global__ void __launch_bounds__(TPB)
-k_neighbors(const int4 *__restrict__ vkeys, const int *__restrict__ mm,
-            const unsigned long long *__restrict__ hkeys, const int *__restrict__ hvals, int64_t hmask,
-            const int *__restrict__ H_dev, int *__restrict__ nbr, const int *__restrict__ vsid, int nsamples) {
-    int H = *H_dev;
-    for (int64_t g = (int64_t)blockIdx.x * TPB + threadIdx.x; g < (int64_t)H * 16;
-         g += (int64_t)gridDim.x * TPB) {
-        int h = (int)(g >> 4), t = (int)(g & 15);
+k_neighbors(const int4 *__restrict__ vkeys, const int *__restrict__ mm, const unsigned long long *__restrict__ hkeys,
+            const int *__restrict__ hvals, int64_t hmask, int *__restrict__ info, int h_cap, int *__restrict__ nbr,
+            const int *__restrict__ vsid, int nsamples, int2 *__restrict__ alist, int alias_cap) {
+    int H = info[EFGH_LATTICE_INFO_H];
+    if (H > h_cap) H = h_cap;
+    const int lane = threadIdx.x & 63;
+    for (int64_t g0 = (int64_t)blockIdx.x * TPB; g0 < (int64_t)H * 16; g0 += (int64_t)gridDim.x * TPB) {
+        const int64_t g = g0 + threadIdx.x;
+        const int h = (int)(g >> 4), t = (int)(g & 15);
         int res = -1;
-        if (t < 15) {
+        bool aliased = false;
+        if (h < H && t < 15) {
             int4 kk = vkeys[h];
             int k[4] = {kk.x + c_nbr[t][0], kk.y + c_nbr[t][1], kk.z + c_nbr[t][2], kk.w + c_nbr[t][3]};
-            const int b = vsid ? vsid[h] : 0;
-            int64_t ki = key2int(k, mm + 8 * b);
+            const int b = vsid[h];
+            const int *m8 = mm + 8 * b;
+            int64_t ki = key2int(k, m8);
             if (ki >= 0) {   // every inserted key integer is >= 0
                 ki = ki * nsamples + b;
                 uint64_t s = mix64((uint64_t)ki) & (uint64_t)hmask;
-                while (true) {
+                for (int64_t probe = 0; probe <= hmask; ++probe) {
                     unsigned long long cur = hkeys[s];
-                    if (cur == ~0ULL) break;
+                    if (cur == EMPTY) break;
                     if (cur == (unsigned long long)ki) { res = hvals[s]; break; }
                     s = (s + 1) & (uint64_t)hmask;
                 }
             }
+            aliased = res >= 0 && (k[1] < m8[1] || k[1] > m8[5] || k[2] < m8[2] || k[2] > m8[6] || k[3] < m8[3] || k[3] > m8[7]);
         }
-        nbr[g] = res;
+        const unsigned long long am = __ballot(aliased);
+        if (h < H) {
+            if (t < 15) nbr[g] = res;
+            else nbr[g] = (int)((am >> (lane & 48)) & 0x7FFFu);
+        }
+        if (am) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&info[EFGH_LATTICE_INFO_ALIAS], __popcll(am));
+            base = __shfl(base, 0);
+            if (aliased) {
+                const int k_ = base + __popcll(am & ((1ULL << lane) - 1ULL));
+                if (k_ < alias_cap) alist[k_] = make_int2((int)g, res);
+                else atomicOr(&info[EFGH_LATTICE_INFO_ERR], 2);
+            }
+        }
     }
+}
+
+int64_t align256(int64_t x) { return (x + 255) / 256 * 256; }
+
+struct WsLayout {
+    int64_t slot, rnk, list0, flags, bsum, hkeys, cnt, sstart, hvals, mm, vkeys, part, bsum2, occ, total;
+};
+
+WsLayout ws_layout(int32_t n_cap, int32_t h_cap, int32_t nsamples, int64_t hcap) {
+    WsLayout w;
+    int64_t o = 0;
+    w.slot = o;   o += align256((int64_t)n_cap * 16);
+    w.rnk = o;    o += align256((int64_t)n_cap * 16);
+    w.list0 = o;  o += align256((int64_t)n_cap * 16);
+    w.flags = o;  o += align256((int64_t)n_cap * 4);
+    w.bsum = o;   o += align256(((int64_t)cdiv(n_cap, TPB) + 64) * 4);
+    w.hkeys = o;  o += align256(hcap * 8);
+    w.cnt = o;    o += align256(hcap * 4);
+    w.sstart = o; o += align256(hcap * 4);
+    w.hvals = o;  o += align256(hcap * 4);
+    w.mm = o;     o += align256((int64_t)nsamples * 32);
+    w.vkeys = o;  o += align256((int64_t)h_cap * 16);
+    w.part = o;   o += align256(((int64_t)cdiv(n_cap, 64) + 4) * 48);
+    w.bsum2 = o;  o += align256((hcap / 1024 + 1) * 8);
+    w.occ = o;    o += align256((int64_t)n_cap * 64);
+    w.total = o;
+    return w;
 }
 
 }  // namespace
 
-static int64_t ws_off_keys(int n) { (void)n; return 0; }
-static int64_t ws_off_slot(int n) { return (int64_t)n * 64; }
-static int64_t ws_off_bsum(int n) { return ws_off_slot(n) + (int64_t)n * 16; }
-static int64_t ws_off_minpos(int n) { return ws_off_bsum(n) + (((int64_t)cdiv((int64_t)n * 4, 1024) + 64) * 4 + 255) / 256 * 256; }
-
 extern "C" int64_t efgh_lattice_hash_capacity(int32_t n_in) {
-    int64_t c = 1024;
+    int64_t c = 4096;
     while (c < (int64_t)n_in * 8) c <<= 1;
     return c;
 }
 
-extern "C" int64_t efgh_lattice_workspace_bytes(int32_t n_in) {
-    return ws_off_minpos(n_in) + efgh_lattice_hash_capacity(n_in) * 4 + 256;
+extern "C" int64_t efgh_lattice_workspace_bytes(int32_t n_cap, int32_t h_cap, int32_t nsamples) {
+    return ws_layout(n_cap, h_cap, nsamples, efgh_lattice_hash_capacity(n_cap)).total;
 }
 
-static int lattice_build_impl(const float *pts, int64_t pts_cstride, int32_t n, float scale32,
-                              float div32, float *bary, float *emg, int64_t emg_ps, int64_t emg_rs,
-                              int32_t *off, int32_t *vkeys, float *pts_next, int32_t *minmax,
-                              int64_t *hash_keys, int32_t *hash_vals, int64_t hcap, int32_t *H_out,
-                              void *workspace, const int32_t *sid, int32_t nsamples, int32_t *vsid,
-                              int32_t *seg_first, void *stream_) {
+extern "C" int efgh_lattice_level_build(const float *pts, int64_t pts_cstride, const int32_t *n_dev, int32_t n_cap,
+                                        const int32_t *sid, int32_t pts_per_sample, int32_t nsamples, float scale32,
+                                        float div32, float *bary, float *emg, int32_t *off, int32_t *list, int32_t h_cap,
+                                        int32_t *vseg, float *pts_next, int32_t *vsid, int32_t *info, void *workspace,
+                                        void *stream_) {
     hipStream_t st = (hipStream_t)stream_;
-    EFGH_CHECK_ARG(n > 0 && n < (1 << 28));
-    EFGH_CHECK_ARG(nsamples >= 1 && (nsamples == 1 || (sid && vsid && seg_first)));
-    if (nsamples == 1) sid = nullptr;
-    EFGH_CHECK_ARG(hcap >= (int64_t)n * 8 && (hcap & (hcap - 1)) == 0);
-    EFGH_CHECK_ARG(pts && bary && emg && off && vkeys && pts_next && minmax && hash_keys && hash_vals && H_out && workspace);
+    EFGH_CHECK_ARG(n_cap > 0 && n_cap < (1 << 27) && h_cap > 0 && nsamples >= 1 && nsamples <= EFGH_LATTICE_MAX_SAMPLES);      // (LDS [nsamples][8] in k_minmax_finalize)
+    EFGH_CHECK_ARG(sid || pts_per_sample > 0);
+    EFGH_CHECK_ARG(pts && bary && emg && off && list && vseg && pts_next && vsid && info && workspace);
+    const int64_t hcap = efgh_lattice_hash_capacity(n_cap);
+    const WsLayout w = ws_layout(n_cap, h_cap, nsamples, hcap);
     char *ws = (char *)workspace;
-    int4 *keys = (int4 *)(ws + ws_off_keys(n));
-    int *slot = (int *)(ws + ws_off_slot(n));
-    int *bsum = (int *)(ws + ws_off_bsum(n));
-    int *minpos = (int *)(ws + ws_off_minpos(n));
+    int4 *slot = (int4 *)(ws + w.slot), *rnk = (int4 *)(ws + w.rnk);
+    int *list0 = (int *)(ws + w.list0), *flags = (int *)(ws + w.flags), *bsum = (int *)(ws + w.bsum);
+    unsigned long long *hkeys = (unsigned long long *)(ws + w.hkeys);
+    int *cnt = (int *)(ws + w.cnt), *sstart = (int *)(ws + w.sstart), *hvals = (int *)(ws + w.hvals), *mm = (int *)(ws + w.mm);
+    int4 *vkeys = (int4 *)(ws + w.vkeys);
+    int *part = (int *)(ws + w.part);
+    int4 *occ = (int4 *)(ws + w.occ);
+    int2 *bsum2 = (int2 *)(ws + w.bsum2);
     const uint32_t std_bits = 0x405105ECu;         // float32(4*sqrt(2/3)), generate_data.py:19
     float std32;
     memcpy(&std32, &std_bits, 4);
-    int n4 = n * 4, nb = cdiv(n4, TPB * 4);
-    hipError_t e1 = hipMemsetAsync(hash_keys, 0xFF, (size_t)hcap * 8, st);
-    hipError_t e2 = hipMemsetAsync(minpos, 0x7F, (size_t)hcap * 4, st);
-    if (e1 != hipSuccess || e2 != hipSuccess) {
-        efgh_set_error("lattice: memset failed: %s / %s (n=%d hcap=%lld)", hipGetErrorString(e1),
-                       hipGetErrorString(e2), n, (long long)hcap);
-        return EFGH_E_LAUNCH;
+    const int nbp = cdiv(n_cap, TPB);
+    const int pps = sid ? 1 : pts_per_sample;
+    int ginit = cdiv(hcap, TPB * 4);
+    if (ginit > 8192) ginit = 8192;
+    k_level_init<<<ginit, TPB, 0, st>>>(hkeys, cnt, hcap, flags, n_cap, mm, nsamples, info, EFGH_LATTICE_INFO_SEG + nsamples);
+    k_point_keys<<<nbp, TPB, 0, st>>>(pts, pts_cstride, n_dev, n_cap, scale32, std32, (float4 *)bary, (float4 *)emg, mm, part, sid,
+                                      pps);
+    k_minmax_finalize<<<cdiv(nbp * (TPB / 64), TPB), TPB, 0, st>>>(part, nbp * (TPB / 64), mm);
+    k_insert<<<nbp, TPB, 0, st>>>(pts, pts_cstride, n_dev, n_cap, scale32, std32, mm, hkeys, cnt, hcap - 1, slot, rnk, sid, pps,
+                                  nsamples);
+    const int nb2 = (int)(hcap / (1024 * SEG_Q)) > 0 ? (int)(hcap / (1024 * SEG_Q)) : 1;      // hcap is a power of two >= 4096
+    k_seg_count<<<nb2, TPB, 0, st>>>((const int4 *)cnt, bsum2);
+    k_seg_scan<<<1, TPB, 0, st>>>(bsum2, nb2, info + EFGH_LATTICE_INFO_CURSOR);
+    k_seg_assign<<<nb2, TPB, 0, st>>>((const int4 *)cnt, bsum2, (int4 *)sstart, occ);
+    k_place<<<nbp, TPB, 0, st>>>(slot, rnk, n_dev, n_cap, sstart, list0);
+    {
+        int g = cdiv((int64_t)n_cap * 4 * 32, TPB);           // at most 4*n_cap occupied slots, a half-wave each
+        if (g > 16384) g = 16384;
+        k_sortmin<<<g, TPB, 0, st>>>(occ, info + EFGH_LATTICE_INFO_CURSOR, list0, list, (unsigned char *)flags);
     }
-    k_init_minmax<<<cdiv(nsamples * 8, 64), 64, 0, st>>>(minmax, nsamples, sid ? seg_first : nullptr);
-    k_point_keys<<<cdiv(n, TPB), TPB, 0, st>>>(pts, pts_cstride, n, scale32, std32, bary, emg, emg_ps,
-                                              emg_rs, keys, minmax, sid);
-    k_insert<<<cdiv(n4, TPB), TPB, 0, st>>>(keys, n4, minmax, (unsigned long long *)hash_keys, minpos,
-                                           hcap - 1, slot, sid, nsamples);
-    k_flag_count<<<nb, TPB, 0, st>>>(slot, minpos, n4, bsum);
-    k_scan_sums<<<1, TPB, 0, st>>>(bsum, nb, H_out);
-    k_assign<<<nb, TPB, 0, st>>>(keys, slot, minpos, n4, bsum, hash_vals, (int4 *)vkeys, pts_next,
-                                 (int64_t)n * 4, div32, sid, vsid, seg_first);
-    k_offsets<<<cdiv(n, TPB), TPB, 0, st>>>(slot, hash_vals, n, off);
+    k_flag_count<<<nbp, TPB, 0, st>>>((const unsigned *)flags, n_dev, n_cap, bsum);
+    k_scan_sums<<<1, TPB, 0, st>>>(bsum, nbp, info, h_cap);
+    k_assign<<<nbp, TPB, 0, st>>>(pts, pts_cstride, n_dev, n_cap, scale32, std32, (const unsigned *)flags, slot, bsum, cnt, sstart,
+                                  hvals, vkeys, (int2 *)vseg, pts_next, h_cap, div32, sid, pps, vsid, info);
+    k_offsets<<<nbp, TPB, 0, st>>>(slot, hvals, n_dev, n_cap, (int4 *)off);
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
 }
 
-extern "C" int efgh_lattice_build(const float *pts, int64_t pts_cstride, int32_t n, float scale32,
-                                  float div32, float *bary, float *emg, int64_t emg_ps, int64_t emg_rs,
-                                  int32_t *off, int32_t *vkeys, float *pts_next, int32_t *minmax,
-                                  int64_t *hash_keys, int32_t *hash_vals, int64_t hcap, int32_t *H_out,
-                                  void *workspace, void *stream_) {
-    return lattice_build_impl(pts, pts_cstride, n, scale32, div32, bary, emg, emg_ps, emg_rs, off, vkeys, pts_next,
-                              minmax, hash_keys, hash_vals, hcap, H_out, workspace, nullptr, 1, nullptr, nullptr,
-                              stream_);
-}
-
-extern "C" int efgh_lattice_build_batched(const float *pts, int64_t pts_cstride, int32_t n, float scale32,
-                                          float div32, float *bary, float *emg, int64_t emg_ps, int64_t emg_rs,
-                                          int32_t *off, int32_t *vkeys, float *pts_next, int32_t *minmax,
-                                          int64_t *hash_keys, int32_t *hash_vals, int64_t hcap, int32_t *H_out,
-                                          void *workspace, const int32_t *sid, int32_t nsamples, int32_t *vsid,
-                                          int32_t *seg_first, void *stream_) {
-    return lattice_build_impl(pts, pts_cstride, n, scale32, div32, bary, emg, emg_ps, emg_rs, off, vkeys, pts_next,
-                              minmax, hash_keys, hash_vals, hcap, H_out, workspace, sid, nsamples, vsid, seg_first,
-                              stream_);
-}
-
-extern "C" int efgh_lattice_neighbors_batched(const int32_t *vkeys, const int32_t *minmax, const int64_t *hash_keys,
-                                              const int32_t *hash_vals, int64_t hcap, const int32_t *H_dev,
-                                              int32_t h_bound, int32_t *nbr, const int32_t *vsid, int32_t nsamples,
-                                              void *stream_) {
+extern "C" int efgh_lattice_level_neighbors(const void *workspace, int32_t n_cap, int32_t h_cap_build, int32_t nsamples,
+                                            int32_t *info, const int32_t *vsid, int32_t h_cap, int32_t *nbr,
+                                            int32_t *alist, int32_t alias_cap, void *stream_) {
     hipStream_t st = (hipStream_t)stream_;
-    EFGH_CHECK_ARG(vkeys && minmax && hash_keys && hash_vals && H_dev && nbr && h_bound > 0 && nsamples >= 1);
-    EFGH_CHECK_ARG(nsamples == 1 || vsid);
-    int grid = cdiv((int64_t)h_bound * 16, TPB);
-    if (grid > 4096) grid = 4096;
-    k_neighbors<<<grid, TPB, 0, st>>>((const int4 *)vkeys, minmax, (const unsigned long long *)hash_keys,
-                                      hash_vals, hcap - 1, H_dev, nbr, nsamples > 1 ? vsid : nullptr, nsamples);
-    EFGH_CHECK_LAUNCH();
-    return EFGH_OK;
-}
-
-extern "C" int efgh_lattice_neighbors(const int32_t *vkeys, const int32_t *minmax,
-                                      const int64_t *hash_keys, const int32_t *hash_vals, int64_t hcap,
-                                      const int32_t *H_dev, int32_t h_bound, int32_t *nbr, void *stream_) {
-    hipStream_t st = (hipStream_t)stream_;
-    EFGH_CHECK_ARG(vkeys && minmax && hash_keys && hash_vals && H_dev && nbr && h_bound > 0);
-    int grid = cdiv((int64_t)h_bound * 16, TPB);
-    if (grid > 4096) grid = 4096;
-    k_neighbors<<<grid, TPB, 0, st>>>((const int4 *)vkeys, minmax, (const unsigned long long *)hash_keys,
-                                      hash_vals, hcap - 1, H_dev, nbr, nullptr, 1);
+    EFGH_CHECK_ARG(workspace && info && vsid && nbr && alist && n_cap > 0 && h_cap > 0 && h_cap <= h_cap_build && alias_cap > 0);
+    const int64_t hcap = efgh_lattice_hash_capacity(n_cap);
+    const WsLayout w = ws_layout(n_cap, h_cap_build, nsamples, hcap);
+    const char *ws = (const char *)workspace;
+    int grid = cdiv((int64_t)h_cap * 16, TPB);
+    if (grid > 8192) grid = 8192;
+    k_neighbors<<<grid, TPB, 0, st>>>((const int4 *)(ws + w.vkeys), (const int *)(ws + w.mm),
+                                      (const unsigned long long *)(ws + w.hkeys), (const int *)(ws + w.hvals), hcap - 1, info,
+                                      h_cap, nbr, vsid, nsamples, (int2 *)alist, alias_cap);
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
 }

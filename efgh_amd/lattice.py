@@ -1,5 +1,12 @@
 """Device-side permutohedral lattice pyramid (replaces GenerateData.__call__,
-nets/generate_data.py:117-193, which the reference runs on the CPU inside forward)."""
+nets/generate_data.py:117-193, which the reference runs on the CPU inside forward).
+
+All samples of a batch are built by ONE launch sequence per level (efgh_lattice_level_build / _neighbors); every sample
+keeps its own lattice (own key ranges, own vertex numbering).  The number of vertices of a level - the number of points of
+the next one - lives in device memory, so when the sizes of a previous call with the same (batch, points, scales) signature
+are known the whole pyramid is enqueued without a host read-back between levels (capacities = previous sizes + 25 %) and
+the five counts come back in ONE read; a count that does not fit its capacity (flagged by the device) falls back to the
+level-by-level path, which reads each count before sizing the next level."""
 import math
 
 import numpy as np
@@ -8,133 +15,162 @@ import torch
 from . import _C
 
 EXPECTED_STD = 4 * math.sqrt(2 / 3)            # generate_data.py:19
+ALIAS_CAP = 4096                               # aliased neighbour hits recorded per level (lattice.hip k_neighbors)
+INFO_H, INFO_ERR, INFO_ALIAS, INFO_SEG = 0, 1, 2, 4          # include/efgh_hip.h EFGH_LATTICE_INFO_*
+
+PROFILE = None          # bench.py: list of (start_event, end_event, algorithmic_bytes, 'lattice build') per pyramid
+_SIZES = {}             # (device, B, N, scales) -> vertex counts of the last build with that signature
 
 
 class LatticeLevel:
-    """one pyramid level; in the batched form the arrays cover all samples (sample-major) and
-    seg_in / seg hold the per-sample offsets of input points / vertices (host lists, len B+1)"""
-    __slots__ = ('n_in', 'H', 'bary', 'off', 'nbr', 'emg', 'pts_next', 'cap', 'H_dev', 'seg_in', 'seg', 'sid')
+    """one pyramid level; the arrays cover all samples (sample-major); seg_in / seg hold the per-sample offsets of input
+    points / vertices (host lists, len B+1).
+
+    point-major device arrays (16 B per point): bary_pm, emg_pm (float32 [n][4]), off_pm (int32 [n][4]);
+    per vertex: nbr [H][16] (15 neighbours + alias mask), vseg [H][2] + list [4n] (vertex -> ascending flat positions
+    4p + r), pts_next [3][H]; info = the level's device counters (INFO_*), alist = aliased neighbour records."""
+    __slots__ = ('n_in', 'H', 'bary_pm', 'emg_pm', 'off_pm', 'nbr', 'vseg', 'list', 'pts_next_buf', 'info', 'alist',
+                 'seg_in', 'seg', 'vsid', '_ws', '_caps')
+
+    # the reference's (4, n) / (3, H) arrays as views
+    @property
+    def bary(self):
+        return self.bary_pm[:self.n_in].t()
+
+    @property
+    def emg(self):
+        return self.emg_pm[:self.n_in].t()
+
+    @property
+    def off(self):
+        return self.off_pm[:self.n_in].t()
+
+    @property
+    def pts_next(self):
+        return self.pts_next_buf[:, :self.H]
 
     def sample(self, b):
         """per-sample view with LOCAL indices, exactly the reference's per-sample arrays"""
         p0, p1, h0, h1 = self.seg_in[b], self.seg_in[b + 1], self.seg[b], self.seg[b + 1]
-        out = LatticeLevel()
+        out = _SampleView()
         out.n_in, out.H = p1 - p0, h1 - h0
         out.bary = self.bary[:, p0:p1]
-        out.emg = self.emg[:, p0:p1] if self.emg.shape[0] == 4 and self.emg.dim() == 2 and self.emg.shape[1] == self.n_in \
-            else self.emg[p0:p1, :4].t()
+        out.emg = self.emg[:, p0:p1]
         out.off = self.off[:, p0:p1] - h0
-        nb = self.nbr[h0:h1]
+        nb = self.nbr[h0:h1, :15]
         out.nbr = torch.where(nb >= 0, nb - h0, nb)
         out.pts_next = self.pts_next[:, h0:h1]
         return out
 
 
-def build_pyramid(pc, scales, feat_bufs=None, sync=True):
-    """pc: (3,N) fp32 CUDA tensor (one sample).  Returns a list of LatticeLevel.
-
-    feat_bufs: optional list of per-level callables / None.  When given, feat_bufs[l](n_in)
-    returns a [n_in][C] fp32 buffer whose channels 0..3 receive el_minus_gr directly."""
-    _C.require_cuda(pc)
-    L = _C.lib()
-    dev = pc.device
-    assert pc.dim() == 2 and pc.size(0) == 3 and pc.dtype == torch.float32
-    pts, cstride, n = pc.contiguous(), pc.size(1), pc.size(1)
-    out = []
-    st = _C.stream_ptr()
-    for l, s in enumerate(scales):
-        s = float(s)
-        cap = 4 * n
-        hcap = L.efgh_lattice_hash_capacity(n)
-        lv = LatticeLevel()
-        lv.n_in, lv.cap = n, cap
-        lv.bary = torch.empty((4, n), dtype=torch.float32, device=dev)
-        if feat_bufs is not None and feat_bufs[l] is not None:
-            fb = feat_bufs[l](n)
-            lv.emg = fb
-            emg_ptr, emg_ps, emg_rs = fb, fb.stride(0), 1
-        else:
-            lv.emg = torch.empty((4, n), dtype=torch.float32, device=dev)
-            emg_ptr, emg_ps, emg_rs = lv.emg, 1, n
-        lv.off = torch.empty((4, n), dtype=torch.int32, device=dev)
-        vkeys = torch.empty((cap, 4), dtype=torch.int32, device=dev)
-        lv.pts_next = torch.empty((3, cap), dtype=torch.float32, device=dev)
-        minmax = torch.empty(8, dtype=torch.int32, device=dev)
-        hkeys = torch.empty(hcap, dtype=torch.int64, device=dev)
-        hvals = torch.empty(hcap, dtype=torch.int32, device=dev)
-        lv.H_dev = torch.empty(1, dtype=torch.int32, device=dev)
-        ws = torch.empty(L.efgh_lattice_workspace_bytes(n), dtype=torch.uint8, device=dev)
-        _C.check(L.efgh_lattice_build(
-            _C.ptr(pts), _C.c_int64(cstride), _C.c_int32(n), _C.c_float(np.float32(s)),
-            _C.c_float(np.float32(EXPECTED_STD * s)), _C.ptr(lv.bary), _C.ptr(emg_ptr),
-            _C.c_int64(emg_ps), _C.c_int64(emg_rs), _C.ptr(lv.off), _C.ptr(vkeys), _C.ptr(lv.pts_next),
-            _C.ptr(minmax), _C.ptr(hkeys), _C.ptr(hvals), _C.c_int64(hcap), _C.ptr(lv.H_dev),
-            _C.ptr(ws), st))
-        H = int(lv.H_dev.item())          # one host sync per level (sizes the next level)
-        lv.H = H
-        lv.nbr = torch.empty((H, 16), dtype=torch.int32, device=dev)
-        _C.check(L.efgh_lattice_neighbors(_C.ptr(vkeys), _C.ptr(minmax), _C.ptr(hkeys), _C.ptr(hvals),
-                                          _C.c_int64(hcap), _C.ptr(lv.H_dev), _C.c_int32(H),
-                                          _C.ptr(lv.nbr), st))
-        out.append(lv)
-        pts, cstride, n = lv.pts_next, cap, H
-    return out
+class _SampleView:
+    __slots__ = ('n_in', 'H', 'bary', 'emg', 'off', 'nbr', 'pts_next')
 
 
-def build_pyramid_batched(pc, scales, feat_bufs=None):
-    """pc: (B,3,N) fp32 CUDA tensor.  One launch sequence and ONE host read-back per level for the whole
-    batch; every sample keeps its own lattice (own key ranges, own vertex numbering)."""
+def _level_arrays(L, dev, n_cap, h_cap, B):
+    lv = LatticeLevel()
+    lv.bary_pm = torch.empty((n_cap, 4), dtype=torch.float32, device=dev)
+    lv.emg_pm = torch.empty((n_cap, 4), dtype=torch.float32, device=dev)
+    lv.off_pm = torch.empty((n_cap, 4), dtype=torch.int32, device=dev)
+    lv.list = torch.empty(4 * n_cap, dtype=torch.int32, device=dev)
+    lv.vseg = torch.empty((h_cap, 2), dtype=torch.int32, device=dev)
+    lv.pts_next_buf = torch.empty((3, h_cap), dtype=torch.float32, device=dev)
+    lv.vsid = torch.empty(h_cap, dtype=torch.int32, device=dev)
+    lv.info = torch.empty(INFO_SEG + B, dtype=torch.int32, device=dev)
+    lv.alist = torch.empty((ALIAS_CAP, 2), dtype=torch.int32, device=dev)
+    lv._ws = torch.empty(L.efgh_lattice_workspace_bytes(n_cap, h_cap, B), dtype=torch.uint8, device=dev)
+    lv._caps = (n_cap, h_cap)
+    return lv
+
+
+def _launch_build(L, lv, pts, cstride, n_dev, sid, pps, B, s, st):
+    n_cap, h_cap = lv._caps
+    _C.check(L.efgh_lattice_level_build(
+        _C.ptr(pts), _C.c_int64(cstride), _C.ptr(n_dev), _C.c_int32(n_cap), _C.ptr(sid), _C.c_int32(pps), _C.c_int32(B),
+        _C.c_float(np.float32(s)), _C.c_float(np.float32(EXPECTED_STD * s)), _C.ptr(lv.bary_pm), _C.ptr(lv.emg_pm),
+        _C.ptr(lv.off_pm), _C.ptr(lv.list), _C.c_int32(h_cap), _C.ptr(lv.vseg), _C.ptr(lv.pts_next_buf), _C.ptr(lv.vsid),
+        _C.ptr(lv.info), _C.ptr(lv._ws), st))
+
+
+def _launch_neighbors(L, lv, B, h_rows, st):
+    n_cap, h_cap = lv._caps
+    lv.nbr = torch.empty((h_rows, 16), dtype=torch.int32, device=lv.info.device)
+    _C.check(L.efgh_lattice_level_neighbors(_C.ptr(lv._ws), _C.c_int32(n_cap), _C.c_int32(h_cap), _C.c_int32(B),
+                                            _C.ptr(lv.info), _C.ptr(lv.vsid), _C.c_int32(h_rows), _C.ptr(lv.nbr),
+                                            _C.ptr(lv.alist), _C.c_int32(ALIAS_CAP), st))
+
+
+def _finish(lv, host, n_in, seg_in, B):
+    if host[INFO_ERR] & 2:
+        raise _C.EfghError('lattice: more than %d aliased neighbour hits on one level' % ALIAS_CAP)
+    H = host[INFO_H]
+    lv.n_in, lv.H, lv.seg_in = n_in, H, seg_in
+    lv.seg = list(host[INFO_SEG:INFO_SEG + B]) + [H]
+    lv._ws = None                      # scratch no longer needed (the stream orders its reuse)
+    if lv.nbr.shape[0] != H:
+        lv.nbr = lv.nbr[:H]
+
+
+def build_pyramid_batched(pc, scales):
+    """pc: (B,3,N) fp32 CUDA tensor -> list of LatticeLevel (one per scale)."""
     _C.require_cuda(pc)
     L = _C.lib()
     dev = pc.device
     B, _, N = pc.shape
-    assert pc.dtype == torch.float32 and pc.size(1) == 3
-    pts = pc.permute(1, 0, 2).reshape(3, B * N).contiguous()
-    cstride, n = B * N, B * N
-    sid = torch.arange(B, dtype=torch.int32, device=dev).repeat_interleave(N).contiguous() if B > 1 else None
-    seg_in = [b * N for b in range(B + 1)]
-    out = []
+    assert pc.dtype == torch.float32 and pc.size(1) == 3 and B >= 1 and N >= 1
+    pts0 = pc.permute(1, 0, 2).reshape(3, B * N).contiguous()
     st = _C.stream_ptr()
-    for l, s in enumerate(scales):
-        s = float(s)
-        cap = 4 * n
-        hcap = L.efgh_lattice_hash_capacity(n)
-        lv = LatticeLevel()
-        lv.n_in, lv.cap, lv.seg_in, lv.sid = n, cap, seg_in, sid
-        lv.bary = torch.empty((4, n), dtype=torch.float32, device=dev)
-        if feat_bufs is not None and feat_bufs[l] is not None:
-            fb = feat_bufs[l](n)
-            lv.emg = fb
-            emg_ptr, emg_ps, emg_rs = fb, fb.stride(0), 1
-        else:
-            lv.emg = torch.empty((4, n), dtype=torch.float32, device=dev)
-            emg_ptr, emg_ps, emg_rs = lv.emg, 1, n
-        lv.off = torch.empty((4, n), dtype=torch.int32, device=dev)
-        vkeys = torch.empty((cap, 4), dtype=torch.int32, device=dev)
-        lv.pts_next = torch.empty((3, cap), dtype=torch.float32, device=dev)
-        minmax = torch.empty(8 * B, dtype=torch.int32, device=dev)
-        hkeys = torch.empty(hcap, dtype=torch.int64, device=dev)
-        hvals = torch.empty(hcap, dtype=torch.int32, device=dev)
-        info = torch.empty(1 + B, dtype=torch.int32, device=dev)            # [H_total, seg_first[0..B)]
-        vsid = torch.empty(cap, dtype=torch.int32, device=dev) if B > 1 else None
-        ws = torch.empty(L.efgh_lattice_workspace_bytes(n), dtype=torch.uint8, device=dev)
-        _C.check(L.efgh_lattice_build_batched(
-            _C.ptr(pts), _C.c_int64(cstride), _C.c_int32(n), _C.c_float(np.float32(s)),
-            _C.c_float(np.float32(EXPECTED_STD * s)), _C.ptr(lv.bary), _C.ptr(emg_ptr),
-            _C.c_int64(emg_ps), _C.c_int64(emg_rs), _C.ptr(lv.off), _C.ptr(vkeys), _C.ptr(lv.pts_next),
-            _C.ptr(minmax), _C.ptr(hkeys), _C.ptr(hvals), _C.c_int64(hcap), _C.ptr(info),
-            _C.ptr(ws), _C.ptr(sid), _C.c_int32(B), _C.ptr(vsid),
-            _C.c_void_p(info.data_ptr() + 4), st))
-        host = info.cpu().tolist()           # the one host sync of this level (sizes the next level)
-        H = host[0]
-        seg = ([0] if B == 1 else host[1:]) + [H]
-        lv.H, lv.seg = H, seg
-        lv.H_dev = info[:1]
-        lv.nbr = torch.empty((H, 16), dtype=torch.int32, device=dev)
-        _C.check(L.efgh_lattice_neighbors_batched(_C.ptr(vkeys), _C.ptr(minmax), _C.ptr(hkeys), _C.ptr(hvals),
-                                                  _C.c_int64(hcap), _C.ptr(lv.H_dev), _C.c_int32(H), _C.ptr(lv.nbr),
-                                                  _C.ptr(vsid), _C.c_int32(B), st))
-        out.append(lv)
-        pts, cstride, n, seg_in = lv.pts_next, cap, H, seg
-        sid = vsid[:H] if B > 1 else None
+    scales = [float(s) for s in scales]
+    key = (dev.index, B, N, tuple(scales))
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    out = lvs = None
+    prev = _SIZES.get(key)
+    if prev is not None:
+        # speculative path: capacities from the previous build of this signature, no read-back between levels
+        lvs, pts, cstride, n_dev, sid, n_cap = [], pts0, B * N, None, None, B * N
+        for s, hp in zip(scales, prev):
+            h_cap = min(4 * n_cap, hp + hp // 4 + 1024)
+            lv = _level_arrays(L, dev, n_cap, h_cap, B)
+            _launch_build(L, lv, pts, cstride, n_dev, sid, N, B, s, st)
+            _launch_neighbors(L, lv, B, h_cap, st)
+            lvs.append(lv)
+            pts, cstride, n_dev, sid, n_cap = lv.pts_next_buf, h_cap, lv.info[INFO_H:], lv.vsid, h_cap
+        if PROFILE is not None:
+            e1.record()              # (before the read-back: the events bracket the launches only)
+        host = torch.stack([lv.info for lv in lvs]).cpu().tolist()           # the one host sync of the pyramid
+        if not any(h[INFO_ERR] & 1 for h in host):
+            n_in, seg_in = B * N, [b * N for b in range(B + 1)]
+            for lv, h in zip(lvs, host):
+                _finish(lv, h, n_in, seg_in, B)
+                n_in, seg_in = lv.H, lv.seg
+            out = lvs
+    if out is None:
+        # level-by-level path: each level's count is read before the next level is sized (exact capacities)
+        out, pts, cstride, sid, n = [], pts0, B * N, None, B * N
+        seg_in = [b * N for b in range(B + 1)]
+        for s in scales:
+            lv = _level_arrays(L, dev, n, 4 * n, B)
+            _launch_build(L, lv, pts, cstride, None, sid, N, B, s, st)
+            H = int(lv.info[INFO_H].item())          # host sync (sizes the next level)
+            _launch_neighbors(L, lv, B, H, st)
+            host = lv.info.cpu().tolist()
+            _finish(lv, host, n, seg_in, B)
+            out.append(lv)
+            pts, cstride, sid, n, seg_in = lv.pts_next_buf, 4 * n, lv.vsid, H, lv.seg
+    _SIZES[key] = [lv.H for lv in out]
+    if PROFILE is not None:
+        if prev is None or out is not lvs:
+            e1.record()
+        by = 0.0
+        for lv in out:          # SURVEY 8d: reads N*3*4, writes N*(4*4 + 4*4 + 4*8) + 15*H*8 + 4*H*4
+            by += lv.n_in * 12.0 + lv.n_in * 64.0 + lv.H * (15 * 8 + 16.0)
+        PROFILE.append((e0, e1, by, 'lattice build'))
     return out
+
+
+def build_pyramid(pc, scales):
+    """pc: (3,N) fp32 CUDA tensor (one sample).  Returns a list of LatticeLevel."""
+    assert pc.dim() == 2 and pc.size(0) == 3
+    return build_pyramid_batched(pc.unsqueeze(0), scales)

@@ -45,37 +45,26 @@ class Enet(nn.Module):
         bcns = [self.bcn1, self.bcn2, self.bcn3, self.bcn4, self.bcn5]
         scales = [s for s, _ in self.scale_map]
         cins = [m.num_input for m in bcns]
-        feats = [None] * 5
-
-        def mk(l):
-            def alloc(n):
-                feats[l] = torch.empty((n, cins[l]), dtype=torch.float32, device=dev)
-                return feats[l]
-            return alloc
-        # all samples in one launch sequence per level (every sample keeps its own lattice)
-        lv = lattice.build_pyramid_batched(pc, scales, feat_bufs=[mk(l) for l in range(5)])
+        # all samples in one launch sequence per level, all five levels enqueued before the one read-back of their sizes
+        # (every sample keeps its own lattice)
+        lv = lattice.build_pyramid_batched(pc, scales)
         if keep is not None:
             keep['lattice'] = lv
-        # conv_in on [B*N][4] (x,y,z,0) -> channels 4..35 of the level-0 feature rows
+        # conv_in on [B*N][4] (x,y,z,0)
         x = ops.nchw_to_nhwc(pc, 4).view(B * N, 4)
         for i in range(3):
             conv = self.conv_in[i][0]
-            last = i == 2 and not ctx.grad
-            x = L.linear_rows(ctx, x, B * N, conv.in_channels, conv.weight, conv.bias, act=ACT_LEAKY, slope=0.1,
-                              out=(feats[0], 4) if last else None)
-        # level-l input rows = [el_minus_gr (4, written by the lattice kernel) | previous features]
-        cur = torch.cat([feats[0][:, :4], x], 1) if ctx.grad else feats[0]
+            x = L.linear_rows(ctx, x, B * N, conv.in_channels, conv.weight, conv.bias, act=ACT_LEAKY, slope=0.1)
+        # level-l input rows = [el_minus_gr (4, in the lattice's own array) | previous features]: read in place by the splat
+        cur = x
         for l in range(5):
             d = lv[l]
+            cf = cins[l] - 4
             if ctx.grad:
-                splat = FN.SplatFn.apply(cur, d.bary, d.off, d.H, cins[l])
+                splat = FN.SplatFn.apply(cur, d, cf)
             else:
-                splat, _ = ops.splat_fwd(cur, cins[l], d.bary, d.off, d.H)
-            tgt = (feats[l + 1], 4) if (l < 4 and not ctx.grad) else None
-            cur = L.blur_conv(ctx, splat, d.H, cins[l], d.nbr, bcns[l].blur_conv[0], bcns[l].blur_conv[2],
-                              out=tgt)
-            if l < 4:
-                cur = torch.cat([feats[l + 1][:, :4], cur], 1) if ctx.grad else feats[l + 1]
+                splat, _ = ops.splat_fwd(d, cur, cf)
+            cur = L.blur_conv(ctx, splat, d.H, cins[l], d, bcns[l].blur_conv[0], bcns[l].blur_conv[2])
         x = cur                                                          # (sum_b H5_b, 256)
         segs = lv[4].seg
         M = x.shape[0]

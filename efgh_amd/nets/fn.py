@@ -261,24 +261,25 @@ class SegmentColMeanFn(torch.autograd.Function):
 
 
 class SplatFn(torch.autograd.Function):
-    """BCL splat + density normalisation; bary/off carry no gradient (generate_data.py:119)."""
+    """BCL splat + density normalisation of one lattice level; the level's rows are [el_minus_gr | feat[:, :Cf]]; the lattice
+    arrays carry no gradient (generate_data.py:119)."""
 
     @staticmethod
-    def forward(ctx, feat, bary, off, H, C):
+    def forward(ctx, feat, lv, Cf, use_emg=True):
         feat = as_rows(feat)
-        splat, wsum = ops.splat_fwd(feat, C, bary, off, H)
-        ctx.save_for_backward(bary, off, wsum)
-        ctx.meta = (feat.shape[0], H, C, feat.shape[-1])
+        splat, wsum = ops.splat_fwd(lv, feat, Cf, use_emg)
+        ctx.save_for_backward(wsum)
+        ctx.meta = (lv, Cf, feat.shape[-1], use_emg)
         return splat
 
     @staticmethod
     def backward(ctx, g):
-        bary, off, wsum = ctx.saved_tensors
-        n, H, C, ldf = ctx.meta
-        gfeat = torch.zeros((n, ldf), dtype=torch.float32, device=g.device) if ldf != C else \
-            torch.empty((n, C), dtype=torch.float32, device=g.device)
-        ops.splat_bwd(g.contiguous(), wsum, C, bary, off, n, H, gfeat)
-        return gfeat, None, None, None, None
+        (wsum,) = ctx.saved_tensors
+        lv, Cf, ldf, use_emg = ctx.meta
+        gfeat = torch.zeros((lv.n_in, ldf), dtype=torch.float32, device=g.device) if ldf != Cf else \
+            torch.empty((lv.n_in, Cf), dtype=torch.float32, device=g.device)
+        ops.splat_bwd(lv, g.contiguous(), wsum, Cf, gfeat, use_emg)
+        return gfeat, None, None, None
 
 
 class Softmax2ToNchwFn(torch.autograd.Function):

@@ -252,11 +252,15 @@ def linear_rows(ctx, x, M, C, weight, bias, bn=None, act=ACT_NONE, slope=0.0, ou
 
 def blur_conv(ctx, splat, H, C, table, conv0, conv1, out=None):
     """BCL blur: gather 15 neighbour rows + Conv2d(C,C0,(15,1)) + ReLU + Conv2d(C0,C1,1)
-    (nets/bilateralNN.py:240-246).  splat [H][C], table [H][16] -> [H][ld]."""
+    (nets/bilateralNN.py:240-246).  splat [H][C]; `table` = the lattice level (efgh_amd.lattice.LatticeLevel: its neighbour
+    table also serves the adjoint of the gather) or a bare [H][16] neighbour table -> [H][ld]."""
     C0, C1 = conv0.out_channels, conv1.out_channels
+    lv = table if hasattr(table, 'nbr') else None
+    if lv is not None:
+        table = lv.nbr
     if ctx.grad:
         assert out is None
-        mid = _blur_grad(ctx, splat, H, C, table, conv0)
+        mid = _blur_grad(ctx, splat, H, C, table, conv0, lv)
         return linear_rows(ctx, mid, H, C0, conv1.weight, conv1.bias)
     Wp0 = ops.pack_weight(conv0.weight, C0, 15, C, C * 15, 15, 1, list(range(15)), key=('blur0',))
     mid = torch.empty((H, C0), dtype=torch.float32, device=splat.device)
@@ -457,7 +461,7 @@ def _linear_grad(ctx, x, M, C, weight, bias, bn, act, slope):
     return FN.GemmLayerFn.apply(x, weight, bias, g_, b_, None, spec)
 
 
-def _blur_grad(ctx, splat, H, C, table, conv0):
+def _blur_grad(ctx, splat, H, C, table, conv0, lv=None):
     C0 = conv0.out_channels
 
     def pack_fwd(w, i):
@@ -471,6 +475,8 @@ def _blur_grad(ctx, splat, H, C, table, conv0):
         Wd = w.detach().squeeze(-1).permute(2, 1, 0).contiguous().view(15 * C, C0)
         tmp = torch.empty((H, 15 * C), dtype=torch.float32, device=draw.device)
         ops.gather_gemm(draw, C0, C0, 1, Wd, 15 * C, H, tmp, 15 * C, mode=0, flops=2.0 * H * 15 * C * C0)
+        if lv is not None:              # through the lattice's own (symmetric) table: a gather, no atomics
+            return ops.neighbor_gather_adjoint(lv, tmp, C)
         dsplat = torch.zeros((H, C), dtype=torch.float32, device=draw.device)
         ops.table_scatter_add(tmp, table, H, 15, C, dsplat)
         return dsplat

@@ -336,44 +336,58 @@ def softmax2_to_nchw(x):
 # ----------------------------------------------------------------------------------------------
 # BCL splat
 # ----------------------------------------------------------------------------------------------
-USE_CSR_SPLAT = _os.environ.get('EFGH_CSR_SPLAT', '1') != '0'
+SPLAT_LANES = int(_os.environ.get('EFGH_SPLAT_LANES', '0'))       # 0 = auto, 32 / 64 = forced lane mapping (tuning)
+PROFILE_BCL = None      # bench.py: (start_event, end_event, algorithmic_bytes, what) per BCL index/splat launch
 
 
-def splat_csr(off, n, H):
-    """vertex -> (remainder, point) lists of one lattice level (efgh_splat_csr_build), cached on the `off` tensor"""
-    def make():
-        ws = torch.empty(_L().efgh_splat_csr_workspace_ints(c_int32(n), c_int32(H)), dtype=torch.int32, device=off.device)
-        _C.check(_L().efgh_splat_csr_build(ptr(off), c_int32(n), c_int32(H), ptr(ws), _st()))
-        return ws
-    return _cached(off, ('csr', n, H), (off._version, off.data_ptr()), make)
+def _bcl_prof(what, nbytes):
+    """context manager: event-time the launches inside it (bench.py only)"""
+    class _P:
+        def __enter__(self_):
+            if PROFILE_BCL is not None:
+                self_.e0, self_.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                self_.e0.record()
+
+        def __exit__(self_, *exc):
+            if PROFILE_BCL is not None:
+                self_.e1.record()
+                PROFILE_BCL.append((self_.e0, self_.e1, float(nbytes), what))
+    return _P()
 
 
-PROFILE_BCL = None      # bench.py: (start_event, end_event, algorithmic_bytes) per splat (CSR inversion included)
-
-
-def splat_fwd(feat, C, bary, off, H):
-    n = feat.shape[0]
+def splat_fwd(lv, feat, Cf, use_emg=True):
+    """BCL splat of one lattice level (efgh_amd.lattice.LatticeLevel): rows [el_minus_gr (4, from the lattice) | feat[:, :Cf]]
+    of the level's n_in points -> splat [H][4 + Cf] (use_emg=False: feat rows only, [H][Cf]), wsum [H]."""
+    _C.require_cuda(feat)
+    n, H = lv.n_in, lv.H
+    assert feat.shape[0] >= n and feat.stride(1) == 1 and feat.stride(0) % 4 == 0 and Cf % 4 == 0
+    C = Cf + (4 if use_emg else 0)
     splat = torch.empty((H, C), dtype=torch.float32, device=feat.device)
     wsum = torch.empty((H,), dtype=torch.float32, device=feat.device)
-    if PROFILE_BCL is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-    if USE_CSR_SPLAT and C <= 512 and off.is_contiguous() and bary.is_contiguous():
-        ws = splat_csr(off, n, H)
-        _C.check(_L().efgh_splat_gather(ptr(feat), c_int64(feat.stride(0)), c_int32(C), ptr(bary), c_int32(n), c_int32(H),
-                                        ptr(ws), ptr(splat), ptr(wsum), _st()))
-        if PROFILE_BCL is not None:
-            e1.record()
-            PROFILE_BCL.append((e0, e1, float(n) * (4 * C + 48) + float(H) * (4 * C + 4)))      # SURVEY 8d bytes
-        return splat, wsum
-    _C.check(_L().efgh_splat_fwd(ptr(feat), c_int64(feat.stride(0)), c_int32(C), ptr(bary), ptr(off), c_int32(n),
-                                 c_int32(H), ptr(splat), ptr(wsum), _st()))
+    with _bcl_prof('splat', float(n) * (4 * C + 48) + float(H) * (4 * C + 4)):                 # SURVEY 8d bytes
+        _C.check(_L().efgh_splat_gather(ptr(lv.emg_pm if use_emg else None), ptr(feat), c_int64(feat.stride(0)), c_int32(Cf),
+                                        ptr(lv.bary_pm), ptr(lv.list), ptr(lv.vseg), c_int32(H), c_int32(max(1, 4 * n // max(H, 1))), c_int32(SPLAT_LANES), ptr(splat),
+                                        ptr(wsum), _st()))
     return splat, wsum
 
 
-def splat_bwd(gsplat, wsum, C, bary, off, n, H, gfeat):
-    _C.check(_L().efgh_splat_bwd(ptr(gsplat), ptr(wsum), c_int32(C), ptr(bary), ptr(off), c_int32(n), c_int32(H),
-                                 ptr(gfeat), c_int64(gfeat.stride(0)), _st()))
+def splat_bwd(lv, gsplat, wsum, Cf, gfeat, use_emg=True):
+    """gradient of splat_fwd w.r.t. feat[:, :Cf] (el_minus_gr carries none) -> gfeat [n][ld]"""
+    C = gsplat.shape[1]
+    with _bcl_prof('splat bwd', float(lv.n_in) * (4 * C + 48) + float(lv.H) * (4 * C + 4)):
+        _C.check(_L().efgh_splat_bwd(ptr(gsplat), c_int32(C), c_int32(4 if use_emg else 0), ptr(wsum), c_int32(Cf), ptr(lv.bary_pm),
+                                     ptr(lv.off_pm), c_int32(lv.n_in), ptr(gfeat), c_int64(gfeat.stride(0)), _st()))
+
+
+def neighbor_gather_adjoint(lv, src, C):
+    """adjoint of the blur's neighbour gather through the level's own table: src [H][15*C] -> [H][C]"""
+    from .lattice import ALIAS_CAP, INFO_ALIAS
+    dst = torch.empty((lv.H, C), dtype=torch.float32, device=src.device)
+    with _bcl_prof('gather bwd', float(lv.H) * (4 * C + 15 * 8 + 4 * C)):
+        _C.check(_L().efgh_table_gather_transposed(ptr(src), ptr(lv.nbr), c_int32(lv.H), c_int32(C), ptr(lv.alist),
+                                                   _C.c_void_p(lv.info.data_ptr() + 4 * INFO_ALIAS), c_int32(ALIAS_CAP), ptr(dst),
+                                                   _st()))
+    return dst
 
 
 # ----------------------------------------------------------------------------------------------
@@ -534,11 +548,7 @@ def unpack_weight(Wp, W, N, T, C, Cp, sn, sc, st, taps, accumulate=False):
 
 
 def table_scatter_add(src, table, M, T, C, dst):
-    """dst[table[m][t]][c] += src[m][t*C+c]; with USE_CSR_SPLAT the CSR gather form (dst is overwritten: callers pass zeros)"""
-    if USE_CSR_SPLAT and C <= 512 and dst.shape[0] == M:
-        ws = torch.empty(_L().efgh_table_csr_workspace_ints(c_int64(M)), dtype=torch.int32, device=src.device)
-        _C.check(_L().efgh_table_gather_add(ptr(src), ptr(table), c_int64(M), c_int32(T), c_int32(C), ptr(ws), ptr(dst), _st()))
-        return
+    """dst[table[m][t]][c] += src[m][t*C+c] (atomic form; the BCL uses neighbor_gather_adjoint)"""
     _C.check(_L().efgh_table_scatter_add(ptr(src), ptr(table), c_int64(M), c_int32(T), c_int32(C), ptr(dst), _st()))
 
 

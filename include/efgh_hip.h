@@ -33,77 +33,80 @@ int efgh_version(void);
  * replaces GenerateData.get_keys_and_barycentric  nets/generate_data.py:56-112,
  *          key2int / build_it                     nets/transforms.py:62-77, 125-184,
  *          the khash map                          lib/khash_int2int.h:8-33
- * for ONE pyramid level.  Bit-exact w.r.t. the reference for bary/emg (fp32 bits),
- * lattice_offset and blur_neighbors (integers).                                             */
+ * for ONE pyramid level and ALL samples of a batch.  Bit-exact w.r.t. the reference for bary/emg (fp32 bits),
+ * lattice_offset and blur_neighbors (integers).
+ *
+ * The points of `nsamples` frame-pairs are concatenated (sample-major); the sample of point p is sid[p], or
+ * p / pts_per_sample when sid is NULL (level 0).  Every sample keeps its own key_mins/maxs and its own hash keys, vertices
+ * are numbered sample-major, so (vertex index - first vertex of the sample) and the neighbour indices are exactly the
+ * per-sample results of the reference.
+ *
+ * Data-dependent sizes live in DEVICE memory: the number of input points is *n_dev (NULL: n_cap is exact), capped by n_cap;
+ * the number of vertices is written to info[EFGH_LATTICE_INFO_H] and must fit h_cap (else bit 0 of
+ * info[EFGH_LATTICE_INFO_ERR] is set and nothing is written out of bounds).  Launch sizes derive from the capacities only,
+ * so the levels of a pyramid can be enqueued back to back (level l+1: pts = pts_next, pts_cstride = h_cap, n_dev =
+ * info + EFGH_LATTICE_INFO_H, n_cap = h_cap, sid = vsid) with one host read-back at the end.                              */
+#define EFGH_LATTICE_INFO_H 0        /* number of vertices (pc1_hash_cnt summed over the samples) */
+#define EFGH_LATTICE_INFO_ERR 1      /* bit 0: H > h_cap; bit 1: more aliased neighbour hits than alias_cap */
+#define EFGH_LATTICE_INFO_ALIAS 2    /* number of aliased neighbour hits (see efgh_lattice_level_neighbors) */
+#define EFGH_LATTICE_INFO_CURSOR 3   /* internal (number of occupied hash slots == H) */
+#define EFGH_LATTICE_INFO_SEG 4      /* info[SEG + b] = first vertex of sample b */
+#define EFGH_LATTICE_MAX_SAMPLES 1024
 
-/* bytes of scratch needed by efgh_lattice_build for n_in points */
-int64_t efgh_lattice_workspace_bytes(int32_t n_in);
-/* entries of hash_keys / hash_vals (power of two >= 8*n_in) */
-int64_t efgh_lattice_hash_capacity(int32_t n_in);
+/* entries of the level's hash table (power of two >= 8*n_cap) */
+int64_t efgh_lattice_hash_capacity(int32_t n_cap);
+/* bytes of scratch for efgh_lattice_level_build; efgh_lattice_level_neighbors reads the same workspace afterwards */
+int64_t efgh_lattice_workspace_bytes(int32_t n_cap, int32_t h_cap, int32_t nsamples);
 
 /* pts: 3 coordinates, pts[c*pts_cstride + p]; positions are multiplied by `scale32` first
  *      (generate_data.py:130), `div32` = float32(expected_std*scale) (:177).
- * out: bary  [4][n_in] f32            (pc1_barycentric)
- *      emg   emg[p*emg_pstride + r*emg_rstride] f32   (pc1_el_minus_gr; strides let the caller
- *            write straight into channels 0..3 of the next BCL input feature rows)
- *      off   [4][n_in] i32            (pc1_lattice_offset, in [0,H))
- *      vkeys [cap][4] i32             (lattice coordinates of vertex h, first-seen order)
- *      pts_next[c*cap + h] f32        (next level's points, generate_data.py:176-178)
- *      minmax[8] i32                  (key_mins[4], key_maxs[4])
- *      hash_keys[hcap] i64, hash_vals[hcap] i32       (open-addressing map key-int -> h; kept
- *            for efgh_lattice_neighbors)
- *      H_out[1] i32                   (pc1_hash_cnt), device memory
- * cap = 4*n_in (upper bound on H); hcap = power of two >= 8*n_in.                          */
-int efgh_lattice_build(const float *pts, int64_t pts_cstride, int32_t n_in, float scale32,
-                       float div32, float *bary, float *emg, int64_t emg_pstride,
-                       int64_t emg_rstride, int32_t *off, int32_t *vkeys, float *pts_next,
-                       int32_t *minmax, int64_t *hash_keys, int32_t *hash_vals, int64_t hcap,
-                       int32_t *H_out, void *workspace, void *stream);
+ * out, per point (point-major, 16 B per point and array):
+ *      bary [n_cap][4] f32   (pc1_barycentric[r][p]  at [p][r])
+ *      emg  [n_cap][4] f32   (pc1_el_minus_gr)
+ *      off  [n_cap][4] i32   (pc1_lattice_offset, in [0,H))
+ * out, per vertex (first-seen order):
+ *      vseg [h_cap][2] i32   (start, length) of the vertex's list in `list`
+ *      list [4*n_cap]  i32   the flat positions f = 4*p + r that splat onto the vertex, ascending (the inverse of `off`,
+ *                            what efgh_splat_gather walks)
+ *      pts_next[c*h_cap + h] f32   (next level's points, generate_data.py:176-178)
+ *      vsid [h_cap]    i32   sample of vertex h (the next level's sid)
+ *      info [EFGH_LATTICE_INFO_SEG + nsamples] i32                                              */
+int efgh_lattice_level_build(const float *pts, int64_t pts_cstride, const int32_t *n_dev, int32_t n_cap,
+                             const int32_t *sid, int32_t pts_per_sample, int32_t nsamples, float scale32,
+                             float div32, float *bary, float *emg, int32_t *off, int32_t *list, int32_t h_cap,
+                             int32_t *vseg, float *pts_next, int32_t *vsid, int32_t *info, void *workspace,
+                             void *stream);
 
-/* blur neighbours (transforms.py:168-180): nbr[h*16 + t] = index of vertex key(h)+offset_t, or
- * -1; t<15, column 15 is padding (-1).  H is read from H_dev on the device; `h_bound` (>= H,
- * e.g. cap) only sizes the grid.                                                            */
-int efgh_lattice_neighbors(const int32_t *vkeys, const int32_t *minmax, const int64_t *hash_keys,
-                           const int32_t *hash_vals, int64_t hcap, const int32_t *H_dev,
-                           int32_t h_bound, int32_t *nbr, void *stream);
-
-/* Batched forms: the points of `nsamples` frame-pairs are concatenated (sample-major); sid[p] is the
- * sample of point p.  Every sample keeps its own key_mins/maxs (minmax [nsamples][8]) and its own hash
- * keys, vertices are numbered sample-major, so vertex index - seg_first[sample] and the neighbour
- * indices are exactly the per-sample results of the reference; vsid[h] = sample of vertex h (the next
- * level's sid).  One launch sequence per level for the whole batch.                            */
-int efgh_lattice_build_batched(const float *pts, int64_t pts_cstride, int32_t n_in, float scale32,
-                               float div32, float *bary, float *emg, int64_t emg_pstride,
-                               int64_t emg_rstride, int32_t *off, int32_t *vkeys, float *pts_next,
-                               int32_t *minmax, int64_t *hash_keys, int32_t *hash_vals, int64_t hcap,
-                               int32_t *H_out, void *workspace, const int32_t *sid, int32_t nsamples,
-                               int32_t *vsid, int32_t *seg_first, void *stream);
-int efgh_lattice_neighbors_batched(const int32_t *vkeys, const int32_t *minmax, const int64_t *hash_keys,
-                                   const int32_t *hash_vals, int64_t hcap, const int32_t *H_dev,
-                                   int32_t h_bound, int32_t *nbr, const int32_t *vsid, int32_t nsamples,
-                                   void *stream);
+/* blur neighbours (transforms.py:168-180): nbr[h*16 + t] = index of vertex key(h)+offset_t, or -1, t < 15.
+ * key2int has no range check (transforms.py:173-180): a neighbour key outside the sample's key box aliases to the integer
+ * of another lattice point and may hit that vertex.  Such hits are reproduced and marked: bit t of nbr[h*16 + 15], one
+ * record (h*16 + t, hit vertex) in alist [alias_cap][2], their number in info[EFGH_LATTICE_INFO_ALIAS]; all unmarked entries
+ * form a symmetric relation (nbr[m][t] == h  <=>  nbr[h][15-t] == m), which efgh_table_gather_transposed relies on.
+ * `workspace`, n_cap, h_cap_build, nsamples: as passed to efgh_lattice_level_build; h_cap (<= h_cap_build) rows of nbr.     */
+int efgh_lattice_level_neighbors(const void *workspace, int32_t n_cap, int32_t h_cap_build, int32_t nsamples,
+                                 int32_t *info, const int32_t *vsid, int32_t h_cap, int32_t *nbr, int32_t *alist,
+                                 int32_t alias_cap, void *stream);
 
 /* ------------------------------------------------------------------ BCL splat (K3) ---------
- * replaces SparseSum + density normalisation, nets/bilateralNN.py:6-40, 179-211.
- * feat [n_in][ldf] (first C columns used), bary [4][n_in], off [4][n_in]  ->
- * splat [H][C]  (row h = reference row h+1; the reference's all-zero row 0 is represented by
- * neighbour index -1), already multiplied by 1/(sum_bary + 1e-5).  wsum [H] holds the density
- * (kept for backward).                                                                     */
-int efgh_splat_fwd(const float *feat, int64_t ldf, int32_t C, const float *bary,
-                   const int32_t *off, int32_t n_in, int32_t H, float *splat, float *wsum,
-                   void *stream);
-/* backward of the above w.r.t. feat: gfeat[p][c] = sum_r bary[r][p]*norm[off]*gsplat[off][c] */
-int efgh_splat_bwd(const float *gsplat, const float *wsum, int32_t C, const float *bary,
-                   const int32_t *off, int32_t n_in, int32_t H, float *gfeat, int64_t ldg,
-                   void *stream);
-/* CSR form of efgh_splat_fwd (same result up to fp32 summation order, no floating-point atomics): efgh_splat_csr_build
- * inverts off [4][n] once per level into ws (efgh_splat_csr_workspace_ints(n, H) int32: start [H+1], scratch [H],
- * list [4n] + the same list sorted per vertex (fixed summation order: reproducible), scan scratch); efgh_splat_gather then sums bary*feat per vertex in registers and writes the normalised
- * row and wsum once.  C <= 512.                                                                                        */
-int64_t efgh_splat_csr_workspace_ints(int32_t n, int32_t H);
-int efgh_splat_csr_build(const int32_t *off, int32_t n, int32_t H, int32_t *ws, void *stream);
-int efgh_splat_gather(const float *feat, int64_t ldf, int32_t C, const float *bary, int32_t n, int32_t H, const int32_t *ws,
+ * replaces SparseSum + density normalisation, nets/bilateralNN.py:6-40, 179-211, as a gather over the vertex lists of the
+ * lattice build (no floating-point atomics, fixed summation order).  The input row of point p is
+ * [emg[p] (4 channels; emg may be NULL: no such channels) | feat[p*ldf .. +Cf)]  ->
+ * splat [H][C], C = (emg ? 4 : 0) + Cf  (row h = reference row h+1; the reference's all-zero row 0 is represented by
+ * neighbour index -1), already multiplied by 1/(sum_bary + 1e-5).  wsum [H] holds the density (kept for backward).
+ * lanes_per_vertex: 64, 32 (two vertices per wave; needs C/4 <= 32) or 0 = chosen from avg_len (entries per vertex,
+ * 4*n_in / H).  The mappings differ in the fp32 summation order only; a given mapping is bit-reproducible.                */
+int efgh_splat_gather(const float *emg, const float *feat, int64_t ldf, int32_t Cf, const float *bary,
+                      const int32_t *list, const int32_t *vseg, int32_t H, int32_t avg_len, int32_t lanes_per_vertex,
                       float *splat, float *wsum, void *stream);
+/* backward w.r.t. feat: gfeat[p][c] = sum_r bary[p][r] / (wsum[off[p][r]] + 1e-5) * gsplat[off[p][r]][coff + c], c < Cf;
+ * gsplat [H][C] */
+int efgh_splat_bwd(const float *gsplat, int32_t C, int32_t coff, const float *wsum, int32_t Cf, const float *bary,
+                   const int32_t *off, int32_t n, float *gfeat, int64_t ldg, void *stream);
+/* adjoint of the blur's neighbour gather (autograd of bilateralNN.py:240-242) through the lattice's own table:
+ * dst[h][c] = sum over (m, t < 15) with nbr[m][t] == h of src[m][t*C + c]; src [H][15*C], dst [H][C] (overwritten).
+ * n_alias = info + EFGH_LATTICE_INFO_ALIAS (device).                                                                */
+int efgh_table_gather_transposed(const float *src, const int32_t *nbr, int32_t H, int32_t C, const int32_t *alist,
+                                 const int32_t *n_alias, int32_t alias_cap, float *dst, void *stream);
 
 /* ------------------------------------------------------------------ gather-GEMM (K4,K6,K8) -
  * One implicit-GEMM kernel family on fp32 MFMA (v_mfma_f32_32x32x2_f32):
@@ -232,11 +235,6 @@ int efgh_unpack_weight(const float *Wp, float *W, int32_t N, int32_t T, int32_t 
 /* dst[table[m*16+t]][c] += src[m][t*C+c]  (adjoint of the neighbour gather, bilateralNN.py:240-242) */
 int efgh_table_scatter_add(const float *src, const int32_t *table, int64_t M, int32_t T, int32_t C,
                            float *dst, void *stream);
-/* the same adjoint without floating-point atomics: the table is inverted into a CSR (ws: efgh_table_csr_workspace_ints(M)
- * int32) and every destination row is summed by one wave; dst is fully written (no pre-zeroing).  C <= 512.            */
-int64_t efgh_table_csr_workspace_ints(int64_t M);
-int efgh_table_gather_add(const float *src, const int32_t *table, int64_t M, int32_t T, int32_t C, int32_t *ws, float *dst,
-                          void *stream);
 /* BatchNorm(+residual)+activation backward, two passes.
  * reduce: dpre = dy*act'(y); sum_dpre[c], sum_dpre_xhat[c] (= dbeta, dgamma) and their means;
  *         mean/invstd/raw NULL -> only sum_dpre (bias gradient).  part: [efgh_bwd_groups(M)][2][C] float64 (the column sums and the two means are kept in double, as torch's CPU kernel does).

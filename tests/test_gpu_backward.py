@@ -157,8 +157,8 @@ def test_bcl_level_backward():
     ref.backward(g)
     m = m.cuda()
     fg = feat.cuda().requires_grad_(True)
-    splat = FN.SplatFn.apply(fg, lv.bary, lv.off, lv.H, C)
-    out = L.blur_conv(L.Ctx(True), splat, lv.H, C, lv.nbr, m.blur_conv[0], m.blur_conv[2])
+    splat = FN.SplatFn.apply(fg, lv, C, False)            # all 36 channels from the feature rows (no el_minus_gr part)
+    out = L.blur_conv(L.Ctx(True), splat, lv.H, C, lv, m.blur_conv[0], m.blur_conv[2])
     out.backward(g.t().contiguous().cuda())
     assert _relerr(fg.grad.t().cpu(), fr.grad) < 2e-4
     assert _relerr(m.blur_conv[0].weight.grad.cpu(), P['b.blur_conv.0.weight'].grad) < 2e-4

@@ -95,3 +95,33 @@ def test_batched_build_equals_per_sample():
             assert np.array_equal(d.bary.cpu().numpy().view(np.uint32), r['bary'].view(np.uint32)), (b, l)
             assert np.array_equal(d.emg.cpu().numpy().view(np.uint32), r['emg'].view(np.uint32)), (b, l)
             assert np.array_equal(d.pts_next.cpu().numpy().view(np.uint32), r['pts_next'].view(np.uint32)), (b, l)
+
+
+def test_speculative_pyramid_equals_level_by_level():
+    """second build of the same (batch, points, scales) signature: all five levels enqueued from the previous sizes with device-side
+    counts and ONE read-back == the level-by-level build; capacities that turn out too small are detected and rebuilt"""
+    from efgh_amd import lattice
+    pcs = [syn.lidar_sweep(4096, 0), syn.lidar_sweep(4096, 7)]
+    pc = torch.from_numpy(np.stack(pcs)).cuda()
+    lattice._SIZES.clear()
+    a = lattice.build_pyramid_batched(pc, SCALES)                  # level by level (no sizes known)
+    key = next(iter(lattice._SIZES))
+    assert lattice._SIZES[key] == [d.H for d in a]
+    b = lattice.build_pyramid_batched(pc, SCALES)                  # speculative
+    lattice._SIZES[key] = [8, 8, 8, 8, 8]                          # far too small: must fall back
+    c = lattice.build_pyramid_batched(pc, SCALES)
+    pc2 = torch.from_numpy(np.stack([syn.lidar_sweep(4096, 3), syn.lidar_sweep(4096, 4)])).cuda()
+    d2 = lattice.build_pyramid_batched(pc2, SCALES)                # speculative with another scene's sizes
+    lattice._SIZES.clear()
+    e2 = lattice.build_pyramid_batched(pc2, SCALES)
+    for x, y in ((a, b), (a, c), (e2, d2)):
+        for l, (u, v) in enumerate(zip(x, y)):
+            assert u.H == v.H and u.seg == v.seg and u.n_in == v.n_in, l
+            for name in ('bary', 'emg', 'off', 'pts_next'):
+                assert torch.equal(getattr(u, name), getattr(v, name)), (l, name)
+            assert torch.equal(u.nbr, v.nbr), l
+            assert torch.equal(u.vseg[:u.H, 1], v.vseg[:v.H, 1]), l
+            # same lists per vertex (the segments may sit at different places)
+            for h in (0, u.H // 3, u.H - 1):
+                su, sv = u.vseg[h].tolist(), v.vseg[h].tolist()
+                assert torch.equal(u.list[su[0]:su[0] + su[1]], v.list[sv[0]:sv[0] + sv[1]]), (l, h)

@@ -142,9 +142,14 @@ def test_splat_and_blur(golden_dir):
     ref = O.bcl(P, 'b', feat.t().contiguous(), torch.from_numpy(ref_lv['bary']), torch.from_numpy(ref_lv['off']),
                 torch.from_numpy(ref_lv['nbr']))
     m = m.cuda()
-    splat, _ = ops.splat_fwd(feat.cuda(), C, lv.bary, lv.off, lv.H)
-    out = L.blur_conv(L.Ctx(False), splat, lv.H, C, lv.nbr, m.blur_conv[0], m.blur_conv[2])
+    splat, _ = ops.splat_fwd(lv, feat.cuda(), C, use_emg=False)
+    out = L.blur_conv(L.Ctx(False), splat, lv.H, C, lv, m.blur_conv[0], m.blur_conv[2])
     assert _rel(out[:, :48].t().cpu(), ref) < 2e-5
+    # the production form: el_minus_gr read from the lattice's own array + 32 feature channels == the concatenated row
+    feat2 = torch.cat([lv.emg.t().cpu(), feat[:, 4:]], 1)
+    s_cat, w_cat = ops.splat_fwd(lv, feat2.cuda(), C, use_emg=False)
+    s_two, w_two = ops.splat_fwd(lv, feat[:, 4:].contiguous().cuda(), C - 4, use_emg=True)
+    assert torch.equal(s_cat, s_two) and torch.equal(w_cat, w_two)
 
 
 def test_rotate_golden(golden_dir):
@@ -302,28 +307,66 @@ def test_c4_mfma_conv_vs_generic_and_fp64(L, cin, cout, stride, hw, B):
     assert _rel(bng.weight.grad.cpu(), bn.weight.grad) < 2e-4 and _rel(bng.bias.grad.cpu(), bn.bias.grad) < 2e-4
 
 
-@pytest.mark.parametrize('C', [36, 68, 132, 260, 4])
-def test_splat_csr_equals_atomic_and_reference_sum(C):
-    """CSR gather splat (no fp32 atomics) == the atomic scatter form == a float64 scatter-add, incl. empty vertices"""
+@pytest.mark.parametrize('C', [36, 68, 132, 260, 4, 256])
+@pytest.mark.parametrize('emg', [False, True])
+def test_splat_gather_vs_float64_scatter_add(C, emg):
+    """splat gather over the lattice's vertex lists (no fp32 atomics) == a float64 scatter-add; the vertex lists are the exact
+    inverse of `off`, ascending; the gradient kernel == the float64 adjoint"""
     from efgh_amd import lattice, ops, synthetic as syn
     pc = syn.lidar_sweep(4096, 3)
     lv = lattice.build_pyramid(torch.from_numpy(pc).cuda(), (1.0,))[0]
-    n, H = 4096, lv.H + 5                                # 5 vertices nobody splats onto
-    feat = torch.randn(n, C, device='cuda')
-    out = {}
-    for csr in (True, False):
-        ops.USE_CSR_SPLAT = csr
-        try:
-            out[csr] = ops.splat_fwd(feat, C, lv.bary, lv.off, H)
-        finally:
-            ops.USE_CSR_SPLAT = True
+    n, H = 4096, lv.H
+    if emg and C <= 4:
+        pytest.skip('no feature channels left')
+    Cf = C - 4 if emg else C
+    feat = torch.randn(n, Cf, device='cuda')
+    splat, wsum = ops.splat_fwd(lv, feat, Cf, use_emg=emg)
+    rows = torch.cat([lv.emg.t(), feat], 1).cpu().double() if emg else feat.cpu().double()
     ref = torch.zeros((H, C), dtype=torch.float64)
     w = torch.zeros(H, dtype=torch.float64)
     off, bary = lv.off.cpu().long(), lv.bary.cpu().double()
     for r in range(4):
-        ref.index_add_(0, off[r], bary[r][:, None] * feat.cpu().double())
+        ref.index_add_(0, off[r], bary[r][:, None] * rows)
         w.index_add_(0, off[r], bary[r])
     ref = ref / (w[:, None] + 1e-5)
-    for csr in (True, False):
-        assert _rel(out[csr][0].cpu().double(), ref) < 2e-6 and _rel(out[csr][1].cpu().double(), w) < 2e-6, (C, csr)
-    assert float(out[True][0][lv.H:].abs().max()) == 0.0 and float(out[True][1][lv.H:].abs().max()) == 0.0
+    assert _rel(splat.cpu().double(), ref) < 2e-6 and _rel(wsum.cpu().double(), w) < 2e-6, C
+    # lists: vertex h <- ascending flat positions f = 4p + r with off[r][p] == h
+    vseg, lst = lv.vseg[:H].cpu().numpy(), lv.list.cpu().numpy()
+    flat_off = lv.off_pm[:n].cpu().numpy().reshape(-1)
+    assert int(vseg[:, 1].sum()) == 4 * n
+    order = np.argsort(flat_off, kind='stable')
+    starts = np.concatenate([[0], np.cumsum(np.bincount(flat_off, minlength=H))])
+    for h in (0, 1, H // 2, H - 1):
+        got = lst[vseg[h, 0]:vseg[h, 0] + vseg[h, 1]]
+        assert np.array_equal(got, order[starts[h]:starts[h + 1]]), h
+    # backward
+    g = torch.randn(H, C, device='cuda')
+    gfeat = torch.empty((n, Cf), device='cuda')
+    ops.splat_bwd(lv, g, wsum, Cf, gfeat, use_emg=emg)
+    gd = g.cpu().double() / (w[:, None] + 1e-5)
+    gref = torch.zeros((n, C), dtype=torch.float64)
+    for r in range(4):
+        gref += bary[r][:, None] * gd[off[r]]
+    assert _rel(gfeat.cpu().double(), gref[:, C - Cf:]) < 2e-6
+
+
+def test_neighbor_gather_adjoint_vs_atomic_scatter():
+    """adjoint of the blur's neighbour gather through the lattice's own table (symmetric part as a gather + the aliased hits
+    of key2int added) == the atomic scatter-add over the table, on a scene whose key box is hit by out-of-range neighbours"""
+    from efgh_amd import lattice, ops
+    rs = np.random.RandomState(11)
+    pc = (rs.randn(3, 6000) * np.array([[3.], [3.], [0.4]])).astype(np.float32)
+    for lv in lattice.build_pyramid(torch.from_numpy(pc).cuda(), (1.0, 0.5)):
+        H, C = lv.H, 36
+        src = torch.randn(H, 15 * C, device='cuda')
+        got = ops.neighbor_gather_adjoint(lv, src, C)
+        ref = torch.zeros((H, C), device='cuda')
+        ops.table_scatter_add(src, lv.nbr, H, 15, C, ref)
+        assert _rel(got.cpu(), ref.cpu()) < 1e-5, int(lv.info[2])
+        # column 15 = alias mask, and the unmarked relation is symmetric
+        nbr = lv.nbr.cpu().numpy()
+        na = int(lv.info[2])
+        assert int(sum(bin(int(v)).count('1') for v in nbr[:, 15])) == na
+        for t in range(1, 15):
+            ok = (nbr[:, t] >= 0) & ((nbr[:, 15] >> t) & 1 == 0)
+            assert np.array_equal(nbr[nbr[ok, t], 15 - t], np.nonzero(ok)[0]), t

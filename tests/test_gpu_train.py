@@ -178,7 +178,8 @@ def test_dataparallel_wrapper_single_device(manifest):
 
 def test_eval_mode_with_autograd_enabled(manifest):
     """model.eval() WITHOUT torch.no_grad() (fine-tuning with frozen BatchNorm statistics, or a validation loop that forgets
-    the guard): the autograd path with eval-mode BatchNorm gives bit-identical outputs and a finite gradient for every parameter"""
+    the guard): the autograd path with eval-mode BatchNorm gives the same outputs (bit-identical network heads) and a finite gradient for
+    every parameter"""
     from efgh_amd.losses import EFGHCriterion
     from efgh_amd.nets import EFGHBackbone
     args = syn.default_args(RAW, 'cuda')
@@ -192,8 +193,12 @@ def test_eval_mode_with_autograd_enabled(manifest):
     with torch.no_grad():
         o0 = m(*inp)
     o1 = m(*inp)
-    for k in ('e_gn_sgn', 'e_gn_abs', 'h_hrzn_sgn', 'h_hrzn_abs', 'f_score', 'g_trs', 'g_depth', 'g_mask'):
+    for k in ('e_gn_sgn', 'e_gn_abs', 'h_hrzn_sgn', 'h_hrzn_abs', 'g_trs', 'g_depth', 'g_mask'):
         assert torch.equal(o0[k], o1[k].detach()), k
+    # e_l comes from the fused pose-head kernel without autograd and from the tensor expressions with it: the two may differ in
+    # the last bit of the rotation (6e-8), which f_score sees through the rotated cloud
+    assert float((o0['e_l'] - o1['e_l'].detach()).abs().max()) < 2e-7
+    assert float((o0['f_score'] - o1['f_score'].detach()).abs().max()) < 2e-6
     L, _ = EFGHCriterion(args).compute_loss(*inp, gt, o1)
     L['total'].backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
