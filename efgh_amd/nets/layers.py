@@ -21,9 +21,12 @@ class Ctx:
 
 
 def _bn_eval_affine(bn, Np):
-    """eval-mode BatchNorm as y = x*scale + shift, cached on the buffers' versions."""
+    """eval-mode BatchNorm as y = x*scale + shift, cached on the buffers' versions.  Train-mode forwards update
+    running_mean / running_var through raw pointers (efgh_bn_finalize), which does not bump their version counters;
+    `num_batches_tracked += 1` (in _bn_train, the only writer) does, so it is part of the key."""
     key = ('bn_eval', Np)
-    vers = ops._ver(bn.weight, bn.bias, bn.running_mean, bn.running_var)
+    vers = ops._ver(bn.weight, bn.bias, bn.running_mean, bn.running_var) + \
+        ((bn.num_batches_tracked._version,) if bn.num_batches_tracked is not None else ())
 
     def make():
         with torch.no_grad():

@@ -16,6 +16,8 @@ class FlatParams:
     """Re-homes every parameter of `model` (and its .grad) inside flat buffers, keeping names/shapes."""
 
     def __init__(self, model):
+        self.frozen = tuple(bool(p.requires_grad) for p in model.parameters())      # checked by Trainer.step
+        self.all_params = list(model.parameters())
         ps = [p for p in model.parameters() if p.requires_grad]
         dev, n = ps[0].device, sum(p.numel() for p in ps)
         self.n = n
@@ -137,15 +139,36 @@ class Trainer:
         self.model, self.criterion = model, criterion
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.flat = FlatParams(model)
-        if self.world > 1:                                  # identical start on every rank
+        if self.world > 1:                                  # identical start on every rank: trainable, FROZEN and buffers
             dist.broadcast(self.flat.w, 0)
-            for b in model.buffers():
-                dist.broadcast(b, 0)
+            flat_ids = {id(p) for p in self.flat.params}
+            for t in list(model.parameters()) + list(model.buffers()):
+                if id(t) not in flat_ids:
+                    dist.broadcast(t.data, 0)
         self.opt = FusedAdam(self.flat, lr=lr, weight_decay=weight_decay)
         self.comm = OverlappedAllReduce(self.flat, self.world)
         self.base_lr, self.it = lr, 0
 
+    def load_checkpoint(self, ckpt):
+        """resume from a checkpoint in the reference's layout (common/helper.py:40-61, main.py:149-160,190-198): model state,
+        Adam moments and the iteration counter, so that the step-wise decay 0.7^(iter // 50000) continues where it stopped.
+        (The reference re-evaluates the schedule once per iterater() call, iterater.py:21, i.e. per epoch; here it is evaluated
+        every step from the same formula - the learning rate changes at iteration 50000*k exactly instead of at the next epoch
+        boundary.)"""
+        from .io import checkpoint as ck
+        if isinstance(ckpt, (str, bytes)) or hasattr(ckpt, '__fspath__'):
+            ckpt = torch.load(ckpt, map_location='cpu')
+        ck.load_model_state(self.model, ckpt)
+        if 'optimizer' in ckpt:
+            ck.load_adam_state(self.opt, ckpt['optimizer'])
+        self.it = int(ckpt.get('iter', -1)) + 1
+        ops.WEIGHT_EPOCH += 1
+        return self.it
+
     def step(self, pc, img, calib, A, gt):
+        if tuple(bool(p.requires_grad) for p in self.flat.all_params) != self.flat.frozen:
+            raise _C.EfghError('the set of trainable parameters changed after the Trainer was built (FlatParams snapshots '
+                               'requires_grad): freeze parameters first, then construct the Trainer')
         self.opt.lr = adjust_learning_rate(self.base_lr, self.it)
         self.model.train()
         pred = self.model(pc, img, calib, A)

@@ -275,3 +275,63 @@ def test_odd_batch_training_step_matches_per_sample_gradient_sum(manifest):
         ref = sum(p[1][k] for p in parts) / 3
         num += float((g_all[k] - ref).double().pow(2).sum()); den += float(ref.double().pow(2).sum())
     assert den > 0 and (num / den) ** 0.5 < 1e-4, (num / den) ** 0.5
+
+
+def test_eval_after_train_forward_uses_fresh_running_statistics():
+    """the folded eval-mode BatchNorm (scale, shift) is cached; a train-mode forward updates the running statistics
+    through a raw pointer, so the cache key must notice it (no optimizer step, no weight change in between)."""
+    import torch.nn as nn
+    from efgh_amd.nets import layers as L
+    from efgh_amd import ops
+    torch.manual_seed(0)
+    conv, bn = nn.Conv2d(8, 16, 3, padding=1, bias=False).cuda(), nn.BatchNorm2d(16).cuda()
+    ref_bn = nn.BatchNorm2d(16).cuda()
+    x = torch.randn(2, 8, 12, 20, device='cuda') * 3 + 1
+    xh = ops.nchw_to_nhwc(x, 8)
+
+    def run(train):
+        with torch.no_grad():
+            y = L.conv2d(L.Ctx(train), xh, conv, bn=bn, act=ops.ACT_NONE)
+        return y.permute(0, 3, 1, 2)[:, :16]
+
+    def ref(train):
+        ref_bn.train(train)
+        with torch.no_grad():
+            return ref_bn(torch.nn.functional.conv2d(x, conv.weight, padding=1))
+    e0 = run(False)
+    assert float((e0 - ref(False)).abs().max()) < 1e-4
+    run(True)                                  # train-mode forward under no_grad: running stats move
+    ref(True)
+    e1 = run(False)
+    assert float((e1 - ref(False)).abs().max()) < 1e-4
+    assert float((e1 - e0).abs().max()) > 1e-3          # and the eval output did change
+
+
+def test_trainer_resume_and_frozen_set(manifest, tmp_path):
+    """Trainer.load_checkpoint restores weights, Adam moments and the iteration (so the LR decay continues); changing
+    requires_grad after construction is refused"""
+    from efgh_amd import _C
+    from efgh_amd.io import checkpoint as ck
+    from efgh_amd.losses import EFGHCriterion
+    from efgh_amd.nets import EFGHBackbone
+    from efgh_amd.train import Trainer, adjust_learning_rate
+    args = syn.default_args(RAW, 'cuda')
+    sd = syn.synthetic_state_dict(manifest['state_dict'], 1)
+    b = syn.make_batch(RAW, NPTS, 1)
+    inp = [torch.from_numpy(b[k]).cuda() for k in ('pc', 'img', 'calib', 'A')]
+    gt = {k: torch.from_numpy(v) for k, v in b['gt'].items()}
+    m = EFGHBackbone(args)
+    m.load_state_dict(sd)
+    tr = Trainer(m.cuda(), EFGHCriterion(args), lr=1e-3)
+    tr.it = 49999
+    tr.step(*inp, gt)
+    path = ck.save_checkpoint(str(tmp_path), m, tr.opt, tr.it - 1, 0.0)
+    m2 = EFGHBackbone(args)
+    tr2 = Trainer(m2.cuda(), EFGHCriterion(args), lr=1e-3)
+    assert tr2.load_checkpoint(path) == 50000
+    assert torch.equal(tr2.flat.w, tr.flat.w) and torch.equal(tr2.opt.m, tr.opt.m) and tr2.opt.t == tr.opt.t
+    tr2.step(*inp, gt)
+    assert abs(tr2.opt.lr - adjust_learning_rate(1e-3, 50000)) < 1e-12 and abs(tr2.opt.lr - 0.7e-3) < 1e-9
+    next(iter(m2.parameters())).requires_grad = False
+    with pytest.raises(_C.EfghError):
+        tr2.step(*inp, gt)
