@@ -139,6 +139,8 @@ def gemm_roofline(prof, steps, kernel):
 
 
 KERNELS = {
+    'wino2d_gemm': 'k_gather_gemm<0> / k_gather_wgrad<0>, batched over the 36 planes of Winograd F(4x4,3x3): the 3x3 / stride-1 '
+                   'convolutions with >= 256 channels, their data gradients and (>= 128 channels) weight gradients',
     'gemm': 'k_gather_gemm (fp32 MFMA implicit GEMM: every contraction that is not a "same" 3x3 convolution)',
     'wino': 'k_wino43 (Winograd F(4,3) on fp32 MFMA: the 3x3 / stride-1 convolutions and their data gradients)',
     'wgrad': 'k_gather_wgrad (fp32 MFMA weight gradient)',
@@ -152,14 +154,15 @@ def rooflines(prof, steps, workload='train'):
     direct-form count 2*M*N*9*C, which is kept as `algorithmic_tflops` (the rate a direct kernel would need for the same time)."""
     rl = {}
     bcl = prof.get('bcl')
+    w2 = prof.get('wino2d')
     for name, lst in prof.items():
-        if name == 'bcl':
+        if name in ('bcl', 'wino2d'):
             continue
         if lst:
             r = gemm_roofline(lst, steps, KERNELS[name])
             r['traffic'] = committed_traffic(name, workload)
             r['algorithmic_tflops'] = r['achieved']
-            if name.startswith('wino'):
+            if name in ('wino', 'wino_wgrad'):
                 r['achieved'] = r['achieved'] / 2
                 r['frac'] = r['frac'] / 2
                 r['executed_gflop_per_launch'] = r['algorithmic_gflop_per_launch'] / 2
@@ -188,6 +191,12 @@ def rooflines(prof, steps, workload='train'):
     for k, v in rl.items():
         if k != top:
             out['roofline_' + k] = v
+    if w2:      # whole F(4x4,3x3) layers (input transform + batched GEMM + output transform), direct-form FLOPs
+        ms = sum(p[0].elapsed_time(p[1]) for p in w2)
+        fl = sum(p[2] for p in w2)
+        out['winograd2d_layers'] = {'launch_groups_per_step': len(w2) / max(1, steps), 'ms_per_step': ms / max(1, steps),
+                                    'algorithmic_tflops': fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
+                                    'note': 'three launches per layer; the GEMM launch alone is in roofline*["wino2d_gemm"]'}
     return out
 
 
@@ -272,6 +281,7 @@ def main():
             fn()
         barrier()
         ops.PROFILE, ops.PROFILE_WGRAD, ops.PROFILE_WINO, ops.PROFILE_WINO_WGRAD, ops.PROFILE_BCL = [], [], [], [], []
+        ops.PROFILE_WINO2D, ops.PROFILE_WINO2D_GEMM = [], []
         lattice.PROFILE = ops.PROFILE_BCL
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -279,8 +289,10 @@ def main():
         barrier()
         dt = max_over_ranks(time.perf_counter() - t0)
         prof = {'gemm': ops.PROFILE, 'wgrad': ops.PROFILE_WGRAD, 'wino': ops.PROFILE_WINO,
-                'wino_wgrad': ops.PROFILE_WINO_WGRAD, 'bcl': ops.PROFILE_BCL}
+                'wino_wgrad': ops.PROFILE_WINO_WGRAD, 'bcl': ops.PROFILE_BCL, 'wino2d': ops.PROFILE_WINO2D,
+                'wino2d_gemm': ops.PROFILE_WINO2D_GEMM}
         ops.PROFILE = ops.PROFILE_WGRAD = ops.PROFILE_WINO = ops.PROFILE_WINO_WGRAD = ops.PROFILE_BCL = lattice.PROFILE = None
+        ops.PROFILE_WINO2D = ops.PROFILE_WINO2D_GEMM = None
         return dt, prof
 
     out = None

@@ -43,6 +43,7 @@ def lib():
         import torch  # noqa: F401  (load torch's HIP runtime first so both share one runtime)
         _lib = ctypes.CDLL(SO_PATH)
         _lib.efgh_last_error.restype = ctypes.c_char_p
+        _lib.efgh_wino2d_tiles.restype = c_int64
         _lib.efgh_lattice_hash_capacity.restype = c_int64
         _lib.efgh_lattice_hash_capacity.argtypes = [c_int32]
         _lib.efgh_lattice_workspace_bytes.restype = c_int64

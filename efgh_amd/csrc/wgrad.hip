@@ -32,12 +32,15 @@ struct WArgs {
     long long M; int mchunk;
     float *dW;                       // [N][K], pre-zeroed
     unsigned kt, nt;
+    long long bsA, bsG, bsD;         // batched launch (gridDim.y): element strides of A, G, dW per batch entry
 };
 
 // TN = 128: waves 2(n) x 2(k), each 64x64;  TN = 64 (layers with <= 64 outputs): waves 1 x 4, each 64(n) x 32(k)
 template <int MODE, int TN>
 __global__ void __launch_bounds__(256)
-k_gather_wgrad(const WArgs p) {
+k_gather_wgrad(const WArgs p0) {
+    WArgs p = p0;
+    p.A += (long long)blockIdx.y * p0.bsA; p.G += (long long)blockIdx.y * p0.bsG; p.dW += (long long)blockIdx.y * p0.bsD;
     constexpr int TJ = TN == 128 ? 2 : 1;        // k tiles per wave
     constexpr int NGQ = TN == 128 ? 4 : 2;       // G float4 slots per thread
     __shared__ __attribute__((aligned(16))) float Gs[TM * TN];
@@ -211,7 +214,24 @@ k_table_scatter_add(const float *__restrict__ src, const int *__restrict__ table
 
 }  // namespace
 
+static int gather_wgrad_impl(const efgh_gemm_desc *d, const float *G, int64_t ldg, float *dWp, int nbatch, int64_t bsG,
+                             int64_t bsD, void *stream_);
+
 extern "C" int efgh_gather_wgrad(const efgh_gemm_desc *d, const float *G, int64_t ldg, float *dWp, void *stream_) {
+    return gather_wgrad_impl(d, G, ldg, dWp, 1, 0, 0, stream_);
+}
+
+/* the same contraction for d->nbatch independent problems in ONE launch (mode 0): problem b reads A + b*d->batch_stride_a and
+ * G + b*batch_stride_g and writes dWp + b*batch_stride_dw  (the 36 alpha planes of the 2-D Winograd weight gradient) */
+extern "C" int efgh_gather_wgrad_batched(const efgh_gemm_desc *d, const float *G, int64_t ldg, int64_t batch_stride_g,
+                                         float *dWp, int64_t batch_stride_dw, void *stream_) {
+    EFGH_CHECK_ARG(d && d->mode == 0 && d->nbatch >= 1 && d->nbatch <= 65535);
+    EFGH_CHECK_ARG(d->batch_stride_a % 4 == 0 && batch_stride_g % 4 == 0 && batch_stride_dw == (int64_t)d->N * d->C);
+    return gather_wgrad_impl(d, G, ldg, dWp, d->nbatch, batch_stride_g, batch_stride_dw, stream_);
+}
+
+static int gather_wgrad_impl(const efgh_gemm_desc *d, const float *G, int64_t ldg, float *dWp, int nbatch, int64_t bsG,
+                             int64_t bsD, void *stream_) {
     hipStream_t st = (hipStream_t)stream_;
     EFGH_CHECK_ARG(d && d->A && G && dWp);
     EFGH_CHECK_ARG(d->C > 0 && d->C % 4 == 0 && d->T >= 1 && d->T <= 16 && d->N >= 1 && d->M >= 1);
@@ -230,12 +250,13 @@ extern "C" int efgh_gather_wgrad(const efgh_gemm_desc *d, const float *G, int64_
     }
     a.Ho = d->Ho; a.Wo = d->Wo; a.osh = d->osh; a.osw = d->osw; a.oh0 = d->oh0; a.ow0 = d->ow0;
     a.table = d->table; a.G = G; a.ldg = ldg; a.N = d->N; a.M = d->M; a.dW = dWp;
+    a.bsA = nbatch > 1 ? d->batch_stride_a : 0; a.bsG = bsG; a.bsD = bsD;
     if (d->mode == 1) EFGH_CHECK_ARG(d->M == (int64_t)d->B * d->Hv * d->Wv && d->osh >= 1 && d->osw >= 1);
     if (d->mode == 2) EFGH_CHECK_ARG(d->table != nullptr);
     const int TN = a.N <= 64 ? 64 : 128;
     const int kt = (a.K + TK - 1) / TK, nt = (a.N + TN - 1) / TN;
     // split m so that the grid has ~2048+ blocks, chunks are multiples of TM
-    long long want = 2048 / (kt * nt);
+    long long want = 2048 / ((long long)kt * nt * nbatch);
     if (want < 1) want = 1;
     long long chunk = (d->M + want - 1) / want;
     chunk = (chunk + TM - 1) / TM * TM;
@@ -244,11 +265,11 @@ extern "C" int efgh_gather_wgrad(const efgh_gemm_desc *d, const float *G, int64_
     long long zs = (d->M + chunk - 1) / chunk;
     EFGH_CHECK_ARG(zs * kt * nt < 0x7fffffffLL);
     a.kt = (unsigned)kt; a.nt = (unsigned)nt;
-    if (hipMemsetAsync(dWp, 0, (size_t)a.N * a.K * 4, st) != hipSuccess) {
+    if (hipMemsetAsync(dWp, 0, (size_t)a.N * a.K * 4 * nbatch, st) != hipSuccess) {
         efgh_set_error("wgrad: memset failed");
         return EFGH_E_LAUNCH;
     }
-    const unsigned grid = (unsigned)(zs * kt * nt);
+    const dim3 grid((unsigned)(zs * kt * nt), (unsigned)nbatch);
     if (TN == 128) {
         if (d->mode == 0) k_gather_wgrad<0, 128><<<grid, 256, 0, st>>>(a);
         else if (d->mode == 1) k_gather_wgrad<1, 128><<<grid, 256, 0, st>>>(a);

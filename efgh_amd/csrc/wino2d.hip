@@ -1,0 +1,410 @@
+// Winograd F(4x4, 3x3) for the 3x3 / stride 1 / pad 1 convolutions with >= 128 channels (gfx950), fp32 throughout.
+//
+// The 1-D kernel of wino.hip (F(4,3) along the image row, 2x fewer MFMAs than the direct form) is held at 63 % of the fp32 matrix
+// pipe by its staging traffic per MFMA (profiles/r02_wino_ablation.txt).  The 2-D form needs 36 products per 4x4 output tile
+// and channel pair instead of 144 - a quarter of the direct MFMA work - and for C >= 128 the transforms are cheap enough to
+// run as separate streaming passes around a plain batched GEMM:
+//     V[tile][a][c] = (B^T d B)_a         k_w2_input     reads x once (tiles overlap: 2.25x from L2), writes 2.25 x |x|
+//                                                         (tile-major: a tile's 36 planes are ONE contiguous block - with
+//                                                         plane-major [a][tile][c] the 36 write streams ran at 1.9 TB/s)
+//     M_a[tile][n] = sum_c V_a[tile][c] U_a[n][c]      36 GEMMs of depth C: k_gather_gemm, mode 0, batched (gemm.hip)
+//     y = A^T M A (+ bias, BatchNorm statistics / affine, residual, activation)     k_w2_output
+// with U_a = (G w G^T)_a packed once per weight version (k_w2_pack), a = 6 i + j.  Layers: every VGG layer of H / F from
+// 128 channels up and the ResNet-18 layers 2-4 of G (nets/vgg.py:77, nets/resnet.py:22-30), their data gradients (same path on
+// the transposed, tap-reversed weights) and their weight gradients:
+//     dW = A3^T [ sum_tiles (G4 dy G4^T)_a (x) (B^T x B)_a ] A3     k_w2_dy, k_w2_input, batched k_gather_wgrad, k_w2_wfinish
+// Rounding: measured 2.8e-6 rms / 1e-5 max relative on C = 256..512 layers (numpy fp32 model of exactly these transforms),
+// 3.4x the 1-D form; the parity suites run at unchanged tolerances.
+#include "common.h"
+
+namespace {
+constexpr int TPB = 256;
+
+struct TileGeo { int B, H, W, TH, TW; long long T; };
+
+// launches are 2-D: blockIdx.y walks the rows of tiles (b, ty) - one scalar division per workgroup - and blockIdx.x the
+// (tile column, channel pair) pairs of a row, split with a shift (the pair count is a power of two): no per-thread division
+// (the first version spent more instructions on 64-bit index divisions than on the transform and ran at 1 TB/s)
+__device__ __forceinline__ int ilog2(int v) { return 31 - __builtin_clz(v); }
+
+// the transform kernels work on channel PAIRS (8 bytes per lane): 36 accumulators of a 6x6 tile are 72 registers, which keeps
+// four waves per SIMD resident; with 16-byte quads the kernels needed 256 registers (+ spills) and ran at 1.1 TB/s
+typedef float2 vec_t;
+constexpr int VW = 2;
+#define F4OP(dst, expr)                                                                              \
+    { dst.x = expr(x); dst.y = expr(y); }
+
+// B^T (6 -> 6), Lavin & Gray F(4,3): points 0, +-1, +-2, inf
+__device__ __forceinline__ void bt6(const vec_t d[6], vec_t v[6]) {
+#define E0(e) (4.f * d[0].e - 5.f * d[2].e + d[4].e)
+#define E1(e) ((d[4].e - 4.f * d[2].e) + (d[3].e - 4.f * d[1].e))
+#define E2(e) ((d[4].e - 4.f * d[2].e) - (d[3].e - 4.f * d[1].e))
+#define E3(e) ((d[4].e - d[2].e) + 2.f * (d[3].e - d[1].e))
+#define E4(e) ((d[4].e - d[2].e) - 2.f * (d[3].e - d[1].e))
+#define E5(e) (4.f * d[1].e - 5.f * d[3].e + d[5].e)
+    F4OP(v[0], E0) F4OP(v[1], E1) F4OP(v[2], E2) F4OP(v[3], E3) F4OP(v[4], E4) F4OP(v[5], E5)
+#undef E0
+#undef E1
+#undef E2
+#undef E3
+#undef E4
+#undef E5
+}
+
+// A^T (6 -> 4)
+__device__ __forceinline__ void at4(const vec_t m[6], vec_t y[4]) {
+#define E0(e) (m[0].e + (m[1].e + m[2].e) + (m[3].e + m[4].e))
+#define E1(e) ((m[1].e - m[2].e) + 2.f * (m[3].e - m[4].e))
+#define E2(e) ((m[1].e + m[2].e) + 4.f * (m[3].e + m[4].e))
+#define E3(e) ((m[1].e - m[2].e) + 8.f * (m[3].e - m[4].e) + m[5].e)
+    F4OP(y[0], E0) F4OP(y[1], E1) F4OP(y[2], E2) F4OP(y[3], E3)
+#undef E0
+#undef E1
+#undef E2
+#undef E3
+}
+
+// G4 (4 -> 6): the gradient-side transform of F(3,4) (wino.hip k_wino_wgrad)
+__device__ __forceinline__ void g46(const vec_t g[4], vec_t u[6]) {
+#define E0(e) (0.25f * g[0].e)
+#define E1(e) (((g[0].e + g[2].e) + (g[1].e + g[3].e)) * (-1.f / 6.f))
+#define E2(e) (((g[0].e + g[2].e) - (g[1].e + g[3].e)) * (-1.f / 6.f))
+#define E3(e) (((g[0].e + 4.f * g[2].e) + (2.f * g[1].e + 8.f * g[3].e)) * (1.f / 24.f))
+#define E4(e) (((g[0].e + 4.f * g[2].e) - (2.f * g[1].e + 8.f * g[3].e)) * (1.f / 24.f))
+#define E5(e) (g[3].e)
+    F4OP(u[0], E0) F4OP(u[1], E1) F4OP(u[2], E2) F4OP(u[3], E3) F4OP(u[4], E4) F4OP(u[5], E5)
+#undef E0
+#undef E1
+#undef E2
+#undef E3
+#undef E4
+#undef E5
+}
+
+__device__ __forceinline__ void axpy4(vec_t &a, float s, const vec_t &v) {
+    a.x += s * v.x; a.y += s * v.y;
+}
+
+// ---- input transform: thread = (tile, channel pair); 36 x 8-byte loads (pixels outside the image are zero), 36 stores
+__global__ void __launch_bounds__(TPB)
+k_w2_input(const float *__restrict__ A, long long lda, int C, const TileGeo g, float *__restrict__ V) {
+    const int q4n = C / VW, sh = ilog2(q4n);
+    const int idx = blockIdx.x * TPB + threadIdx.x;
+    const int tx = idx >> sh, q = idx & (q4n - 1);
+    if (tx >= g.TW) return;
+    const int rowt = blockIdx.y, ty = rowt % g.TH;
+    const long long b = rowt / g.TH;
+    const long long t = (long long)rowt * g.TW + tx;
+    const int y0 = 4 * ty, x0 = 4 * tx;
+    // all 36 loads first (one round trip: the kernel is bound by waves in flight x dependent memory round trips), then the two
+    // 1-D transforms in place
+    const vec_t zero = make_float2(0.f, 0.f);
+    vec_t d[6][6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        const int y = y0 - 1 + r;
+        const bool rok = (unsigned)y < (unsigned)g.H;
+        const float *row = A + ((b * g.H + (rok ? y : 0)) * g.W) * lda + q * VW;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            const int x = x0 - 1 + c;
+            const bool ok = rok && (unsigned)x < (unsigned)g.W;
+            d[r][c] = ok ? *reinterpret_cast<const vec_t *>(row + (long long)x * lda) : zero;
+        }
+    }
+    vec_t acc[6][6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {        // along x
+        vec_t w[6];
+        bt6(d[r], w);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) d[r][j] = w[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {        // along y
+        vec_t col[6], w[6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) col[r] = d[r][j];
+        bt6(col, w);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) acc[i][j] = w[i];
+    }
+    float *vp = V + t * 36 * C + q * VW;           // V [T][36][C]: the 36 planes of a tile are one contiguous block
+    const long long as = C;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) *reinterpret_cast<vec_t *>(vp + (long long)(6 * i + j) * as) = acc[i][j];
+}
+
+// ---- gradient-side transform of the weight gradient: Gy_a[tile][n] = (G4 dy G4^T)_a, dy outside the image is zero
+__global__ void __launch_bounds__(TPB)
+k_w2_dy(const float *__restrict__ G, long long ldg, int N, const TileGeo g, float *__restrict__ Gy) {
+    const int q4n = N / VW, sh = ilog2(q4n);
+    const int idx = blockIdx.x * TPB + threadIdx.x;
+    const int tx = idx >> sh, q = idx & (q4n - 1);
+    if (tx >= g.TW) return;
+    const int rowt = blockIdx.y, ty = rowt % g.TH;
+    const long long b = rowt / g.TH;
+    const long long t = (long long)rowt * g.TW + tx;
+    const int y0 = 4 * ty, x0 = 4 * tx;
+    const vec_t zero = make_float2(0.f, 0.f);
+    vec_t d[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int y = y0 + r;
+        const bool rok = y < g.H;
+        const float *row = G + ((b * g.H + (rok ? y : 0)) * g.W) * ldg + q * VW;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int x = x0 + c;
+            d[r][c] = (rok && x < g.W) ? *reinterpret_cast<const vec_t *>(row + (long long)x * ldg) : zero;
+        }
+    }
+    vec_t wx[4][6], acc[6][6];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) g46(d[r], wx[r]);          // along x
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {                          // along y
+        vec_t col[4], w[6];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) col[r] = wx[r][j];
+        g46(col, w);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) acc[i][j] = w[i];
+    }
+    float *vp = Gy + t * 36 * N + q * VW;
+    const long long as = N;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) *reinterpret_cast<vec_t *>(vp + (long long)(6 * i + j) * as) = acc[i][j];
+}
+
+// ---- output transform + the k_gather_gemm epilogue.  Thread = (tile column, channel pair); a workgroup walks ROWS_PER_BLOCK
+// rows of tiles and leaves one row of BatchNorm statistics (column sums of v and v^2).
+struct W2OutArgs {
+    const float *M; int N; TileGeo g;
+    const float *bias, *scale, *shift, *residual; long long ldr;
+    int act; float slope;
+    float *out; long long ldo;
+    float *stats;
+};
+
+constexpr int ROWS_PER_BLOCK = 4;              // rows of tiles per workgroup of k_w2_output (one statistics row per workgroup)
+
+__global__ void __launch_bounds__(TPB)
+k_w2_output(const W2OutArgs p) {
+    __shared__ float red[2][TPB][VW];
+    const int q4n = p.N / VW, sh = ilog2(q4n);
+    const int idx = blockIdx.x * TPB + threadIdx.x;
+    const int tx = idx >> sh, q = idx & (q4n - 1);
+    const int col = q * VW;
+    const vec_t one = make_float2(1.f, 1.f), zero = make_float2(0.f, 0.f);
+    const vec_t bi = p.bias ? *reinterpret_cast<const vec_t *>(p.bias + col) : zero;
+    const vec_t sc = p.scale ? *reinterpret_cast<const vec_t *>(p.scale + col) : one;
+    const vec_t sf = p.shift ? *reinterpret_cast<const vec_t *>(p.shift + col) : zero;
+    vec_t s1 = zero, s2 = zero;
+    const long long as = p.N;                      // M [T][36][N]
+    const int nrows = p.g.B * p.g.TH;
+    for (int k = 0; k < ROWS_PER_BLOCK; ++k) {
+        const int rowt = blockIdx.y * ROWS_PER_BLOCK + k;
+        if (rowt >= nrows || tx >= p.g.TW) break;
+        const int ty = rowt % p.g.TH;
+        const long long b = rowt / p.g.TH;
+        const long long t = (long long)rowt * p.g.TW + tx;
+        const int y0 = 4 * ty, x0 = 4 * tx;
+        const float *mp = p.M + t * 36 * p.N + col;
+        vec_t m[6][6], wx[6][4], Y[4][4];
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) m[i][j] = *reinterpret_cast<const vec_t *>(mp + (long long)(6 * i + j) * as);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) at4(m[i], wx[i]);           // along x
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {                           // along y
+            vec_t col[6], w[4];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) col[i] = wx[i][x];
+            at4(col, w);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) Y[a][x] = w[a];
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int y = y0 + a;
+            if (y >= p.g.H) continue;
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                const int xx = x0 + x;
+                if (xx >= p.g.W) continue;
+                const long long pix = (b * p.g.H + y) * p.g.W + xx;
+                vec_t v = Y[a][x];
+                v.x += bi.x; v.y += bi.y;
+                s1.x += v.x; s1.y += v.y;
+                s2.x += v.x * v.x; s2.y += v.y * v.y;
+                v.x = v.x * sc.x + sf.x; v.y = v.y * sc.y + sf.y;
+                if (p.residual) {
+                    const vec_t r = *reinterpret_cast<const vec_t *>(p.residual + pix * p.ldr + col);
+                    v.x += r.x; v.y += r.y;
+                }
+                if (p.act == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); }
+                else if (p.act == 2) { v.x = v.x > 0.f ? v.x : v.x * p.slope; v.y = v.y > 0.f ? v.y : v.y * p.slope; }
+                *reinterpret_cast<vec_t *>(p.out + pix * p.ldo + col) = v;
+            }
+        }
+    }
+    if (p.stats) {
+        red[0][threadIdx.x][0] = s1.x; red[0][threadIdx.x][1] = s1.y;
+        red[1][threadIdx.x][0] = s2.x; red[1][threadIdx.x][1] = s2.y;
+        __syncthreads();
+        const int nslots = q4n >= TPB ? 1 : TPB / q4n;          // tile columns per workgroup
+        if (threadIdx.x < q4n) {
+            float a1[VW] = {0, 0}, a2[VW] = {0, 0};
+            for (int s_ = 0; s_ < nslots; ++s_)
+#pragma unroll
+                for (int e = 0; e < VW; ++e) { a1[e] += red[0][s_ * q4n + threadIdx.x][e]; a2[e] += red[1][s_ * q4n + threadIdx.x][e]; }
+            const long long brow = (long long)blockIdx.y * gridDim.x + blockIdx.x;
+            float *o = p.stats + (brow * 2) * p.N + threadIdx.x * VW;
+            *reinterpret_cast<vec_t *>(o) = make_float2(a1[0], a1[1]);
+            *reinterpret_cast<vec_t *>(o + p.N) = make_float2(a2[0], a2[1]);
+        }
+    }
+}
+
+// U[6i + j][n][c] = sum_{kh,kw} G[i][kh] G[j][kw] Wp[n][kh*3 + kw][c]        (Wp: packed [N][9][C])
+__global__ void k_w2_pack(const float *__restrict__ Wp, float *__restrict__ U, int N, int C) {
+    const double G[6][3] = {{0.25, 0., 0.}, {-1. / 6, -1. / 6, -1. / 6}, {-1. / 6, 1. / 6, -1. / 6},
+                            {1. / 24, 1. / 12, 1. / 6}, {1. / 24, -1. / 12, 1. / 6}, {0., 0., 1.}};
+    const long long total = (long long)N * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C); const long long n = i / C;
+        double w[3][3];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) w[t / 3][t % 3] = Wp[(n * 9 + t) * C + c];
+        double gw[6][3];
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) gw[a][kw] = G[a][0] * w[0][kw] + G[a][1] * w[1][kw] + G[a][2] * w[2][kw];
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int b = 0; b < 6; ++b)
+                U[((long long)(6 * a + b) * N + n) * C + c] = (float)(gw[a][0] * G[b][0] + gw[a][1] * G[b][1] + gw[a][2] * G[b][2]);
+    }
+}
+
+// dWp[n][kh*3 + kw][c] = sum_{i,j} A3T[kh][i] A3T[kw][j] S[6i + j][n][c]
+__global__ void k_w2_wfinish(const float *__restrict__ S, float *__restrict__ dWp, int N, int C) {
+    const float A3[3][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}, {0, 1, 1, 4, 4, 1}};
+    const long long total = (long long)N * C, plane = total;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C); const long long n = i / C;
+        float r[6][3];               // r[i][kw] = sum_j A3[kw][j] S[6i + j]
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            float s[6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) s[j] = S[(long long)(6 * a + j) * plane + i];
+            r[a][0] = s[0] + (s[1] + s[2]) + (s[3] + s[4]);
+            r[a][1] = (s[1] - s[2]) + 2.f * (s[3] - s[4]);
+            r[a][2] = (s[1] + s[2]) + 4.f * (s[3] + s[4]) + s[5];
+        }
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                float v = 0.f;
+#pragma unroll
+                for (int a = 0; a < 6; ++a) v += A3[kh][a] * r[a][kw];
+                dWp[(n * 9 + kh * 3 + kw) * C + c] = v;
+            }
+    }
+}
+
+bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+bool supported(const efgh_gemm_desc *d) {
+    if (!d || d->mode != 1 || d->T != 9 || d->M_dev || d->nbatch > 1) return false;
+    if (d->C % 4 || d->N % 4 || !pow2(d->N / VW) || d->N / VW > TPB || !pow2(d->C / VW) || d->C / VW > TPB) return false;
+    if (d->sh != 1 || d->sw != 1 || d->osh != 1 || d->osw != 1 || d->oh0 || d->ow0) return false;
+    if (d->Hv != d->Hin || d->Wv != d->Win || d->Ho != d->Hin || d->Wo != d->Win) return false;
+    for (int t = 0; t < 9; ++t) if (d->dh[t] != t / 3 - 1 || d->dw[t] != t % 3 - 1) return false;
+    return d->lda % 4 == 0;
+}
+
+TileGeo geo(int B, int H, int W) {
+    TileGeo g;
+    g.B = B; g.H = H; g.W = W; g.TH = (H + 3) / 4; g.TW = (W + 3) / 4;
+    g.T = (long long)B * g.TH * g.TW;
+    return g;
+}
+}  // namespace
+
+extern "C" int efgh_wino2d_supported(const efgh_gemm_desc *d) { return supported(d) ? 1 : 0; }
+
+extern "C" int64_t efgh_wino2d_tiles(int32_t B, int32_t H, int32_t W) { return geo(B, H, W).T; }
+
+static dim3 row_grid(const TileGeo &g, int pairs, int rows_per_block) {
+    return dim3((unsigned)(((long long)g.TW * pairs + TPB - 1) / TPB), (unsigned)((g.B * g.TH + rows_per_block - 1) / rows_per_block));
+}
+
+extern "C" int32_t efgh_wino2d_stats_rows(int32_t B, int32_t H, int32_t W, int32_t N) {
+    const dim3 gr = row_grid(geo(B, H, W), N / VW, ROWS_PER_BLOCK);
+    return (int32_t)(gr.x * gr.y);
+}
+
+extern "C" int efgh_wino2d_pack(const float *Wp, float *U, int32_t N, int32_t C, void *stream_) {
+    EFGH_CHECK_ARG(Wp && U && N > 0 && C > 0);
+    const long long total = (long long)N * C;
+    long long g = (total + 255) / 256;
+    k_w2_pack<<<(int)(g > 8192 ? 8192 : g), 256, 0, (hipStream_t)stream_>>>(Wp, U, N, C);
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}
+
+extern "C" int efgh_wino2d_input(const float *A, int64_t lda, int32_t C, int32_t B, int32_t H, int32_t W, float *V,
+                                 void *stream_) {
+    EFGH_CHECK_ARG(A && V && C > 0 && C % 4 == 0 && lda % 4 == 0 && B > 0 && H > 0 && W > 0);
+    EFGH_CHECK_ARG((((uintptr_t)A) & 15) == 0 && (((uintptr_t)V) & 15) == 0);
+    const TileGeo g = geo(B, H, W);
+    EFGH_CHECK_ARG(pow2(C / VW) && (long long)B * g.TH < 65536);
+    k_w2_input<<<row_grid(g, C / VW, 1), TPB, 0, (hipStream_t)stream_>>>(A, lda, C, g, V);
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}
+
+extern "C" int efgh_wino2d_dy(const float *G, int64_t ldg, int32_t N, int32_t B, int32_t H, int32_t W, float *Gy,
+                              void *stream_) {
+    EFGH_CHECK_ARG(G && Gy && N > 0 && N % 4 == 0 && ldg % 4 == 0 && B > 0 && H > 0 && W > 0);
+    EFGH_CHECK_ARG((((uintptr_t)G) & 15) == 0 && (((uintptr_t)Gy) & 15) == 0);
+    const TileGeo g = geo(B, H, W);
+    EFGH_CHECK_ARG(pow2(N / VW) && (long long)B * g.TH < 65536);
+    k_w2_dy<<<row_grid(g, N / VW, 1), TPB, 0, (hipStream_t)stream_>>>(G, ldg, N, g, Gy);
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}
+
+extern "C" int efgh_wino2d_output(const float *M, const efgh_gemm_desc *d, void *stream_) {
+    EFGH_CHECK_ARG(M && supported(d) && d->out && d->B > 0);
+    EFGH_CHECK_ARG((((uintptr_t)M) & 15) == 0 && (((uintptr_t)d->out) & 15) == 0 && d->ldo % 4 == 0);
+    EFGH_CHECK_ARG(!d->residual || (d->ldr % 4 == 0 && (((uintptr_t)d->residual) & 15) == 0));
+    W2OutArgs a;
+    a.M = M; a.N = d->N; a.g = geo(d->B, d->Hin, d->Win);
+    a.bias = d->bias; a.scale = d->scale; a.shift = d->shift; a.residual = d->residual; a.ldr = d->ldr;
+    a.act = d->act; a.slope = d->slope; a.out = d->out; a.ldo = d->ldo; a.stats = d->stats;
+    k_w2_output<<<row_grid(a.g, d->N / VW, ROWS_PER_BLOCK), TPB, 0, (hipStream_t)stream_>>>(a);
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}
+
+extern "C" int efgh_wino2d_wfinish(const float *S, float *dWp, int32_t N, int32_t C, void *stream_) {
+    EFGH_CHECK_ARG(S && dWp && N > 0 && C > 0);
+    const long long total = (long long)N * C;
+    long long g = (total + 255) / 256;
+    k_w2_wfinish<<<(int)(g > 4096 ? 4096 : g), 256, 0, (hipStream_t)stream_>>>(S, dWp, N, C);
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}

@@ -95,6 +95,36 @@ def wino_eligible(mode, C, N, geom, T=None):
             and list(dh) == [t // 3 - 1 for t in range(9)] and list(dw) == [t % 3 - 1 for t in range(9)])
 
 
+USE_WINO2D = _os.environ.get('EFGH_WINO2D', '1') != '0'   # F(4x4,3x3) as transform / batched GEMM / transform (wino2d.hip)
+WINO2D_MIN_C = int(_os.environ.get('EFGH_WINO2D_MIN_C', '256'))            # forward / data gradient
+WINO2D_MIN_C_WGRAD = int(_os.environ.get('EFGH_WINO2D_MIN_C_WGRAD', '128'))  # weight gradient
+
+
+def _pow2(v):
+    return v > 0 and (v & (v - 1)) == 0
+
+
+def wino2d_eligible(mode, C, N, geom, wgrad=False):
+    """the layers the 2-D Winograd path serves (mirror of efgh_wino2d_supported + the channel threshold below which the
+    transform passes cost more than the saved MFMAs, measured with tools/bench_wino.py): 3x3, stride 1, pad 1, C and N powers
+    of two, >= 256 channels (forward / data gradient) or >= 128 (weight gradient)"""
+    if not USE_WINO2D or not wino_eligible(mode, C, N, geom):
+        return False
+    lim = WINO2D_MIN_C_WGRAD if wgrad else WINO2D_MIN_C
+    if geom[1] < 8 or geom[2] < 8:          # maps of fewer than 2 x 2 tiles: mostly padding (and nothing to gain)
+        return False
+    return min(C, N) >= lim and _pow2(C // 4) and _pow2(N // 4) and C <= 512 and N <= 512
+
+
+def wino2d_weight(Wp, N, C):
+    """U = G w G^T of a packed [N][9][C] weight (efgh_wino2d_pack), cached on the packed tensor"""
+    def make():
+        U = torch.empty((36, N, C), dtype=torch.float32, device=Wp.device)
+        _C.check(_L().efgh_wino2d_pack(ptr(Wp), ptr(U), c_int32(N), c_int32(C), _st()))
+        return U
+    return _cached(Wp, ('wino2d',), _ver(Wp), make)
+
+
 USE_C4 = _os.environ.get('EFGH_C4', '1') != '0'       # dedicated MFMA kernels for the 4-channel input layers (c4conv.hip)
 
 
@@ -113,6 +143,8 @@ def stats_rows(mode, C, N, geom, M):
     """rows of the per-tile BatchNorm statistics buffer the GEMM launch for this layer writes"""
     if c4_eligible(mode, C, N, geom):
         return _L().efgh_c4_stats_rows(c_int32(geom[0]), c_int32(geom[9]), c_int32(geom[10]))
+    if wino2d_eligible(mode, C, N, geom):
+        return _L().efgh_wino2d_stats_rows(c_int32(geom[0]), c_int32(geom[1]), c_int32(geom[2]), c_int32(N))
     if wino_eligible(mode, C, N, geom):
         return _L().efgh_wino_grid_m(c_int32(geom[0]), c_int32(geom[1]), c_int32(geom[2]))
     return gemm_grid_m(M, N)
@@ -205,6 +237,9 @@ def gather_gemm(A, lda, C, T, Wp, N, M, out, ldo, mode=0, geom=None, table=None,
         assert lda % 4 == 0
         thin = True             # (for the profile lists: an HBM-bound launch, not part of the MFMA GEMM family)
         _C.check(_L().efgh_c4_conv3x3(ctypes.byref(d), _st()))
+    elif M_dev is None and batch is None and wino2d_eligible(mode, C, N, geom):
+        wino = '2d'
+        _wino2d_forward(d, A, a_off, lda, C, N, geom, Wp)
     elif M_dev is None and batch is None and wino_eligible(mode, C, N, geom):
         wino = True
         _C.check(_L().efgh_wino_conv3x3(ctypes.byref(d), ptr(wino_weight(Wp, N, C)), _st()))
@@ -226,7 +261,43 @@ def gather_gemm(A, lda, C, T, Wp, N, M, out, ldo, mode=0, geom=None, table=None,
     elif PROFILE is not None:
         e1.record()
         rec = (e0, e1, float(flops) if flops is not None else 2.0 * M * N * T * C, (mode, M, N, T, C))
-        (PROFILE_WINO if (wino and PROFILE_WINO is not None) else PROFILE).append(rec)
+        if wino == '2d' and PROFILE_WINO2D is not None:
+            PROFILE_WINO2D.append(rec)
+        else:
+            (PROFILE_WINO if (wino and PROFILE_WINO is not None) else PROFILE).append(rec)
+
+
+PROFILE_WINO2D = None           # bench.py: whole 2-D Winograd layers (three launches), direct-form FLOPs
+PROFILE_WINO2D_GEMM = None      # bench.py: their batched GEMM launches alone, EXECUTED FLOPs (2*36*T*C*N)
+
+
+def _batched_plain_gemm(A3, W3, out3, rows, C, N):
+    """out3[a] = A3[a] @ W3[a]^T for the 36 alpha planes: k_gather_gemm, mode 0, one launch"""
+    g = _C.GemmDesc()
+    g.A, g.lda, g.C, g.T, g.mode = A3.data_ptr(), 36 * C, C, 1, 0          # activations are tile-major [rows][36][C]
+    g.W, g.N, g.M = W3.data_ptr(), N, rows
+    g.out, g.ldo = out3.data_ptr(), 36 * N
+    g.nbatch, g.batch_stride_a, g.batch_stride_w, g.batch_stride_out = 36, C, N * C, N
+    if PROFILE_WINO2D_GEMM is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _C.check(_L().efgh_gather_gemm(ctypes.byref(g), _st()))
+    if PROFILE_WINO2D_GEMM is not None:
+        e1.record()
+        PROFILE_WINO2D_GEMM.append((e0, e1, 2.0 * 36 * rows * C * N, (0, rows, N, 36, C)))
+
+
+def _wino2d_forward(d, A, a_off, lda, C, N, geom, Wp):
+    """input transform -> 36 batched GEMMs -> output transform with the layer's epilogue (descriptor d)"""
+    B, H, W = geom[0], geom[1], geom[2]
+    T = _L().efgh_wino2d_tiles(c_int32(B), c_int32(H), c_int32(W))
+    dev = A.device
+    V = torch.empty((T, 36, C), dtype=torch.float32, device=dev)
+    Mb = torch.empty((T, 36, N), dtype=torch.float32, device=dev)
+    _C.check(_L().efgh_wino2d_input(_C.c_void_p(A.data_ptr() + 4 * a_off), c_int64(lda), c_int32(C), c_int32(B), c_int32(H),
+                                    c_int32(W), ptr(V), _st()))
+    _batched_plain_gemm(V, wino2d_weight(Wp, N, C), Mb, T, C, N)
+    _C.check(_L().efgh_wino2d_output(ptr(Mb), ctypes.byref(d), _st()))
 
 
 # ----------------------------------------------------------------------------------------------
@@ -525,6 +596,28 @@ def gather_wgrad(A, lda, C, T, N, M, G, ldg, dWp, mode=0, geom=None, table=None)
     elif c4_eligible(mode, C, N, geom, wgrad=True):
         thin = True             # (profile lists, as above)
         _C.check(_L().efgh_c4_wgrad(ctypes.byref(d), ptr(G), c_int64(ldg), ptr(dWp), _st()))
+    elif USE_WINO_WGRAD and wino2d_eligible(mode, C, N, geom, wgrad=True):
+        wino = '2d'
+        B, H, W = geom[0], geom[1], geom[2]
+        T2 = _L().efgh_wino2d_tiles(c_int32(B), c_int32(H), c_int32(W))
+        dev = dWp.device
+        V = torch.empty((T2, 36, C), dtype=torch.float32, device=dev)
+        Gy = torch.empty((T2, 36, N), dtype=torch.float32, device=dev)
+        S = torch.empty((36, N, C), dtype=torch.float32, device=dev)               # zeroed by the C-ABI call
+        _C.check(_L().efgh_wino2d_input(ptr(A), c_int64(lda), c_int32(C), c_int32(B), c_int32(H), c_int32(W), ptr(V), _st()))
+        _C.check(_L().efgh_wino2d_dy(ptr(G), c_int64(ldg), c_int32(N), c_int32(B), c_int32(H), c_int32(W), ptr(Gy), _st()))
+        g = _C.GemmDesc()
+        g.A, g.lda, g.C, g.T, g.mode, g.N, g.M = V.data_ptr(), 36 * C, C, 1, 0, N, T2
+        g.nbatch, g.batch_stride_a = 36, C
+        if PROFILE_WINO2D_GEMM is not None:
+            f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            f0.record()
+        _C.check(_L().efgh_gather_wgrad_batched(ctypes.byref(g), ptr(Gy), c_int64(36 * N), c_int64(N), ptr(S), c_int64(N * C),
+                                                _st()))
+        if PROFILE_WINO2D_GEMM is not None:
+            f1.record()
+            PROFILE_WINO2D_GEMM.append((f0, f1, 2.0 * 36 * T2 * C * N, (0, T2, N, 36, C)))
+        _C.check(_L().efgh_wino2d_wfinish(ptr(S), ptr(dWp), c_int32(N), c_int32(C), _st()))
     elif USE_WINO_WGRAD and C % 64 == 0 and wino_eligible(mode, C, N, geom):
         wino = True
         S = torch.empty((6, N, 3 * C), dtype=torch.float32, device=dWp.device)       # zeroed by the C-ABI call
@@ -538,7 +631,10 @@ def gather_wgrad(A, lda, C, T, N, M, G, ldg, dWp, mode=0, geom=None, table=None)
     elif PROFILE_WGRAD is not None:
         e1.record()
         rec = (e0, e1, 2.0 * M * N * T * C, (mode, M, N, T, C))
-        (PROFILE_WINO_WGRAD if (wino and PROFILE_WINO_WGRAD is not None) else PROFILE_WGRAD).append(rec)
+        if wino == '2d' and PROFILE_WINO2D is not None:
+            PROFILE_WINO2D.append(rec)
+        else:
+            (PROFILE_WINO_WGRAD if (wino and PROFILE_WINO_WGRAD is not None) else PROFILE_WGRAD).append(rec)
 
 
 def unpack_weight(Wp, W, N, T, C, Cp, sn, sc, st, taps, accumulate=False):

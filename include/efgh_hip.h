@@ -229,6 +229,27 @@ int efgh_corr1d(const float *rp, const float *cam, const float *cam_mm, int32_t 
  * `d` describes the SAME gather as the forward launch (A, lda, C, T, mode, geometry/table, N, M);
  * G is the gradient w.r.t. the (pre-BatchNorm) GEMM output, rows addressed like `out`.         */
 int efgh_gather_wgrad(const efgh_gemm_desc *d, const float *G, int64_t ldg, float *dWp, void *stream);
+/* the same contraction for d->nbatch independent problems in ONE launch (mode 0 only): problem b reads A + b*d->batch_stride_a
+ * and G + b*batch_stride_g and writes dWp + b*batch_stride_dw (= N*C) */
+int efgh_gather_wgrad_batched(const efgh_gemm_desc *d, const float *G, int64_t ldg, int64_t batch_stride_g, float *dWp,
+                              int64_t batch_stride_dw, void *stream);
+
+/* ------------------------------------------------------------------ Winograd F(4x4,3x3) --------
+ * the 3x3 / stride 1 / pad 1 convolutions with >= 128 channels (nets/vgg.py:77, nets/resnet.py:22-30), their data and weight
+ * gradients, as input transform -> 36 batched GEMMs (efgh_gather_gemm, mode 0) -> output transform; fp32 throughout.
+ * `d` is the mode-1 descriptor of the layer (efgh_wino2d_supported: N/2 and C/2 powers of two <= 256).
+ *   T = efgh_wino2d_tiles(B,H,W) 4x4 output tiles;  V [T][36][C],  U [36][N][C],  M [T][36][N],  Gy [T][36][N],  S [36][N][C]
+ *   (tile-major activations: GEMM a uses rows of length C at stride 36*C, batch stride C).
+ *   efgh_wino2d_output applies d's epilogue (bias, stats [efgh_wino2d_stats_rows][2][N], scale/shift, residual, act) -> d->out. */
+int efgh_wino2d_supported(const efgh_gemm_desc *d);
+int64_t efgh_wino2d_tiles(int32_t B, int32_t H, int32_t W);
+int32_t efgh_wino2d_stats_rows(int32_t B, int32_t H, int32_t W, int32_t N);
+int efgh_wino2d_pack(const float *Wp, float *U, int32_t N, int32_t C, void *stream);          /* U = G w G^T of packed [N][9][C] */
+int efgh_wino2d_input(const float *A, int64_t lda, int32_t C, int32_t B, int32_t H, int32_t W, float *V, void *stream);
+int efgh_wino2d_output(const float *M, const efgh_gemm_desc *d, void *stream);
+int efgh_wino2d_dy(const float *G, int64_t ldg, int32_t N, int32_t B, int32_t H, int32_t W, float *Gy, void *stream);
+int efgh_wino2d_wfinish(const float *S, float *dWp, int32_t N, int32_t C, void *stream);       /* dWp [N][9][C] = A3^T S A3 */
+
 /* W.flat[n*sn + c*sc + tapidx[t]*st] (+)= Wp[n][t][c]  (Wp rows padded to Cp) */
 int efgh_unpack_weight(const float *Wp, float *W, int32_t N, int32_t T, int32_t C, int32_t Cp, int64_t sn,
                        int64_t sc, int64_t st, const int32_t *tapidx_host, int32_t accumulate, void *stream);

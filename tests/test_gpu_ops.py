@@ -233,6 +233,7 @@ def test_winograd_conv3x3_vs_direct_and_fp64(L, cin, cout, hw, B):
     cg.load_state_dict(conv.state_dict())
     xg, rg = ops.nchw_to_nhwc(x.cuda(), cin), ops.nchw_to_nhwc(res.cuda(), cout)
     out = {}
+    old2d, ops.USE_WINO2D = ops.USE_WINO2D, False            # this test is about the 1-D kernel (the 2-D path has its own below)
     for wino in (True, False):
         ops.USE_WINO = wino
         try:
@@ -258,6 +259,60 @@ def test_winograd_conv3x3_vs_direct_and_fp64(L, cin, cout, hw, B):
         yb = L.conv2d(L.Ctx(True), xg, cg, bng, L.ACT_RELU, 0.0)
     assert _rel(yb.permute(0, 3, 1, 2).cpu(), refb) < 2e-5
     assert _rel(bng.running_var.cpu(), bn.running_var) < 1e-5 and _rel(bng.running_mean.cpu(), bn.running_mean) < 1e-4
+    ops.USE_WINO2D = old2d
+
+
+@pytest.mark.parametrize('cin,cout,hw,B', [(128, 256, (9, 13), 2), (256, 128, (8, 11), 1), (128, 128, (17, 262), 1),
+                                           (512, 512, (10, 14), 3), (256, 256, (24, 40), 2)])
+def test_winograd2d_conv3x3_vs_direct_and_fp64(L, cin, cout, hw, B):
+    """F(4x4,3x3) path (input transform, 36 batched GEMMs, output transform; wino2d.hip) against the direct gather-GEMM and
+    float64: ragged heights and widths (H, W % 4 != 0, < 4), residual + ReLU epilogue, train-mode BatchNorm statistics, and the
+    weight gradient + data gradient through autograd"""
+    from efgh_amd import ops
+    torch.manual_seed(1)
+    conv = nn.Conv2d(cin, cout, 3, 1, 1, bias=True)
+    x = torch.randn(B, cin, *hw).clamp_min(-0.5)
+    res = torch.randn(B, cout, *hw)
+    ref = F.relu(F.conv2d(x.double(), conv.weight.double(), conv.bias.double(), padding=1) + res.double())
+    cg = nn.Conv2d(cin, cout, 3, 1, 1, bias=True).cuda()
+    cg.load_state_dict(conv.state_dict())
+    xg, rg = ops.nchw_to_nhwc(x.cuda(), cin), ops.nchw_to_nhwc(res.cuda(), cout)
+    geom = (B, hw[0], hw[1], hw[0], hw[1], 1, 1, [t // 3 - 1 for t in range(9)], [t % 3 - 1 for t in range(9)], hw[0], hw[1],
+            1, 1, 0, 0)
+    out = {}
+    old_min, ops.WINO2D_MIN_C = ops.WINO2D_MIN_C, 128          # also the 128-channel shapes through the forward path
+    for w2 in (True, False):
+        ops.USE_WINO2D = w2
+        ops.USE_WINO = w2
+        try:
+            assert ops.wino2d_eligible(1, cin, cout, geom) == w2
+            with torch.no_grad():
+                y = L.conv2d(L.Ctx(False), xg, cg, None, L.ACT_RELU, 0.0, residual=rg)
+            out[w2] = y.permute(0, 3, 1, 2).double().cpu()
+        finally:
+            ops.USE_WINO2D = ops.USE_WINO = True
+    e_w, e_d = _rel(out[True], ref), _rel(out[False], ref)
+    assert e_w < 3e-5 and e_d < 1e-5, (e_w, e_d)        # 2-D transforms: ~1e-5 max relative (DESIGN.md), direct ~3e-7
+    # train-mode BatchNorm on top (statistics rows of the output-transform kernel) + gradients through autograd
+    bn = nn.BatchNorm2d(cout)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.2)
+    bng = nn.BatchNorm2d(cout).cuda()
+    bng.load_state_dict(bn.state_dict())
+    bn.train(); bng.train()
+    xr = x.clone().requires_grad_(True)
+    refb = F.relu(bn(conv(xr)))
+    gy = torch.randn_like(refb)
+    refb.backward(gy)
+    xq = xg.clone().requires_grad_(True)
+    yb = L.conv2d(L.Ctx(True), xq, cg, bng, L.ACT_RELU, 0.0)
+    yb.backward(ops.nchw_to_nhwc(gy.cuda(), cout))
+    assert _rel(yb.detach().permute(0, 3, 1, 2).cpu(), refb.detach()) < 3e-5
+    assert _rel(bng.running_var.cpu(), bn.running_var) < 1e-5 and _rel(bng.running_mean.cpu(), bn.running_mean) < 1e-4
+    assert _rel(cg.weight.grad.cpu(), conv.weight.grad) < 2e-4, _rel(cg.weight.grad.cpu(), conv.weight.grad)
+    assert _rel(xq.grad.permute(0, 3, 1, 2).cpu(), xr.grad) < 2e-4
+    assert _rel(bng.weight.grad.cpu(), bn.weight.grad) < 2e-4 and _rel(bng.bias.grad.cpu(), bn.bias.grad) < 2e-4
+    ops.WINO2D_MIN_C = old_min
 
 
 @pytest.mark.parametrize('cin,cout,stride,hw,B', [(3, 64, 1, (24, 40), 2), (4, 32, 2, (37, 301), 1), (1, 128, 2, (18, 26), 2),

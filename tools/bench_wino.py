@@ -7,6 +7,8 @@ from efgh_amd import ops
 from efgh_amd.nets import layers as L
 
 torch.set_grad_enabled(False)
+import os
+ops.USE_WINO2D = os.environ.get('EFGH_WINO2D', '1') != '0'
 shapes = [  # (B, H, W, Cin, Cout)
     (4, 384, 1280, 64, 64), (4, 192, 640, 128, 128), (4, 96, 320, 256, 256), (4, 48, 160, 512, 512),
     (4, 24, 80, 512, 512), (1, 384, 5119, 64, 64), (4, 96, 1279, 256, 256), (4, 192, 640, 64, 128),
