@@ -102,3 +102,85 @@ def test_partial_load_rename_and_freeze(tmp_path):
     dst2 = Net()
     ck.load_pretrained(dst2, {k: v for k, v in src.state_dict().items() if k.startswith('E.')})
     assert torch.equal(dst2.E.weight, src.E.weight) and not torch.equal(dst2.G.weight, src.G.weight)
+
+
+# ---- pinned to the reference: fixtures written by tests/golden/make_golden_io.py (the unmodified reference's own readers,
+# ---- prediction writer and save_checkpoint, run in the build container) -----------------------------------------------------------
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'io')
+
+
+def test_readers_equal_the_reference_loader_utils():
+    """loader_utils.py:12-61,206-229: pcd_read, pose_read, calib_read, get_lidar2cam_mtx, get_cam_mtx"""
+    e = np.load(os.path.join(GOLD, 'io_expected.npz'))
+    assert np.array_equal(fm.read_velodyne_bin(os.path.join(GOLD, 'sweep.bin')), e['pcd'])
+    lines = open(os.path.join(GOLD, 'poses.txt')).read().splitlines()
+    assert np.array_equal(np.stack([fm.parse_pose_line(l) for l in lines]), e['poses'])
+    cal = fm.read_kitti_calib(os.path.join(GOLD, 'calib.txt'))
+    for k in ('Tr', 'Tr_inv', 'P2', 'P2_inv'):
+        assert np.array_equal(cal[k], e['calib_' + k]), k
+    assert np.array_equal(fm.read_rellis_camera_info(os.path.join(GOLD, 'camera_info.txt')), e['cam_mtx'])
+    # scipy's Rotation.from_quat vs the closed form: same matrix to the last bits of the inverse
+    assert np.allclose(fm.read_rellis_lidar2cam(os.path.join(GOLD, 'transforms.yaml')), e['lidar2cam'], rtol=0, atol=2e-16)
+
+
+def test_rand_init_csv_equals_the_reference_reader_on_the_shipped_rows():
+    """rellis3d_loader.py:44-48 on the first rows of params/rellis3d_rand_init_30_30.csv"""
+    e = np.load(os.path.join(GOLD, 'io_expected.npz'))
+    d = fm.read_rand_init_csv(os.path.join(GOLD, 'rand_init_head.csv'))
+    assert list(d) == [str(n) for n in e['rand_init_names']]
+    assert np.array_equal(np.array([d[k] for k in d]), e['rand_init_vals'])
+    # facts about the whole file that the configs[4] test draws from: 2413 rows, |angles| <= 30 deg, translations zero
+    assert int(e['rand_init_all_count']) == 2413
+    assert np.all(np.abs(e['rand_init_all_min'][[0, 1, 2, 6]]) <= np.pi / 6 + 1e-9) and np.all(e['rand_init_all_max'][[0, 1, 2, 6]] <= np.pi / 6 + 1e-9)
+    assert np.all(e['rand_init_all_min'][3:6] == 0) and np.all(e['rand_init_all_max'][3:6] == 0)
+
+
+def test_prediction_csv_is_byte_identical_to_the_reference_writer(tmp_path):
+    """test.py:46-53 (run through the reference's own test_odom with a stand-in model): same bytes, and it reads back"""
+    e = np.load(os.path.join(GOLD, 'io_expected.npz'))
+    p = tmp_path / 'pred.csv'
+    for name, T in zip(('000000_000001', '000000_000002'), e['pred_T']):
+        fm.append_prediction_csv(p, name, T)
+    assert p.read_bytes() == open(os.path.join(GOLD, 'pred_toy.csv'), 'rb').read()
+    back = fm.read_prediction_csv(os.path.join(GOLD, 'pred_toy.csv'))
+    assert np.array_equal(back['000000_000001'], e['pred_T'][0][:3]) and np.array_equal(back['000000_000002'], e['pred_T'][1][:3])
+
+
+def test_checkpoint_written_by_the_reference_loads_here_and_back():
+    """common/helper.py:40-61 save_checkpoint of a DataParallel-wrapped model + torch.optim.Adam (main.py:127,181-183): our loader
+    restores weights, buffers, Adam moments and the step; what we save from that state is loadable by the reference's resume code
+    (main.py:149-160,190-198: strict load into the wrapped model, optimizer.load_state_dict) and equal tensor for tensor"""
+    from efgh_amd.train import FlatParams, FusedAdam
+    path = os.path.join(GOLD, 'ckpt', 'checkpoint.pth.tar')
+    ref = torch.load(path, map_location='cpu', weights_only=False)
+    assert set(ref) == {'iter', 'state_dict', 'min_loss', 'optimizer'} and ref['iter'] == 2000
+
+    def toy():
+        return torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3, bias=False), torch.nn.BatchNorm2d(4), torch.nn.Flatten(),
+                                   torch.nn.Linear(16, 2))
+    m = toy()
+    ck.load_model_state(m, path)
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, ref['state_dict']['module.' + k]), k
+    flat = FlatParams(m)
+    opt = FusedAdam(flat, lr=1.0)
+    ck.load_adam_state(opt, ref['optimizer'])
+    assert opt.t == 3 and opt.lr == 1e-4
+    for i, (p, (off, n)) in enumerate(zip(flat.params, flat.offsets)):
+        assert torch.equal(opt.m[off:off + n].view(p.shape), ref['optimizer']['state'][i]['exp_avg'])
+        assert torch.equal(opt.v[off:off + n].view(p.shape), ref['optimizer']['state'][i]['exp_avg_sq'])
+    # and back: the reference's resume path
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        out = ck.save_checkpoint(d, m, opt, it=2000, min_loss=0.75)
+        mine = torch.load(out, map_location='cpu', weights_only=False)
+    wrapped = torch.nn.DataParallel(toy())
+    wrapped.load_state_dict(mine['state_dict'], strict=True)
+    ropt = torch.optim.Adam(filter(lambda p: p.requires_grad, wrapped.parameters()), lr=1e-4, weight_decay=0)
+    ropt.load_state_dict(mine['optimizer'])
+    for k, v in ref['state_dict'].items():
+        assert torch.equal(mine['state_dict'][k], v), k
+    for i in ref['optimizer']['state']:
+        for key in ('exp_avg', 'exp_avg_sq'):
+            assert torch.equal(ropt.state_dict()['state'][i][key], ref['optimizer']['state'][i][key])
+        assert float(ropt.state_dict()['state'][i]['step']) == float(ref['optimizer']['state'][i]['step'])
