@@ -27,12 +27,13 @@ def default_args(raw_hw=(768, 2560), device='cuda'):
     }
 
 
-def lidar_sweep(n_points, seed=0, beams=64):
-    """64-beam organised sweep with random ranges in [5,25) m -> (3,N) float32."""
+def lidar_sweep(n_points, seed=0, beams=64, pitch_range=(-0.12 * np.pi, 0.12 * np.pi)):
+    """64-beam organised sweep with random ranges in [5,25) m -> (3,N) float32.  pitch_range: lowest / highest beam elevation
+    in radians (default: the symmetric fan of SURVEY 8d; an HDL-64E is (-24.8 deg, +2 deg))."""
     rs = np.random.RandomState(seed)
     nb = beams
     na = n_points // nb
-    pitch = np.linspace(-0.12 * np.pi, 0.12 * np.pi, nb)[:, None]
+    pitch = np.linspace(pitch_range[0], pitch_range[1], nb)[:, None]
     yaw = np.linspace(-np.pi, np.pi, na, endpoint=False)[None, :]
     r = 5 + 20 * rs.rand(nb, na)
     x = r * np.cos(pitch) * np.cos(yaw)
@@ -75,6 +76,12 @@ def ground_truth(raw_hw, seed=0, l_rot=1 / 6., l_trs=2., c_rot=1 / 6.):
     rr, rp, ry = u[0] * np.pi * l_rot, u[1] * np.pi * l_rot, u[2] * np.pi * l_rot
     tx, ty, tz = u[3] * l_trs, u[4] * l_trs, u[5] * l_trs
     rt = u[6] * np.pi * c_rot
+    return ground_truth_from_params(raw_hw, rr, rp, ry, tx, ty, tz, rt)
+
+
+def ground_truth_from_params(raw_hw, rr, rp, ry, tx, ty, tz, rt):
+    """GT dict of one mis-calibration given as a row of the reference's rand-init CSV (name, roll, pitch, yaw, tx, ty, tz,
+    cam_roll; rellis3d_loader.py:44-48 -> rand_init_params / preproc_gt, loader_utils.py:63-103)"""
     ltrs = np.eye(4)
     ltrs[:3, 3] = [tx, ty, tz]
     rand_init_l = _rpy(rr, rp, ry) @ ltrs

@@ -275,23 +275,32 @@ def bcl(P, pre, feat, bary, off, nbr):
 
 
 def enet(P, pc, train, lattice=None):
-    """nets/enet.py:103-187.  Only batch element 0 is used (:107)."""
-    if lattice is None:
-        lattice = _lattice.generate_data(pc[0].detach().numpy())
-    x = pc[:1, :3, :]
-    for i in range(3):                                            # conv_in :24-28, LeakyReLU(0.1)
-        x = F.leaky_relu(F.conv1d(x, P[f'E.conv_in.{i}.0.weight'], P[f'E.conv_in.{i}.0.bias']), 0.1)
-    feat = x[0]
-    for l in range(5):                                            # :113-141
-        g = lattice[l]
-        emg = torch.from_numpy(g['emg'])
-        feat = bcl(P, f'E.bcn{l + 1}', torch.cat((emg, feat), 0), torch.from_numpy(g['bary']),
-                   torch.from_numpy(g['off']), torch.from_numpy(g['nbr']))
-    x = feat[None]
+    """nets/enet.py:103-187.  The reference uses batch element 0 only (:107) and is hard-wired to batch 1; for
+    B > 1 every sample gets its own lattice and BCL chain (B independent evaluations) and the only coupling is train-mode
+    BatchNorm1d of the head, whose statistics run over the vertices of ALL samples - the (1, C, sum_b H5_b) tensor the head's
+    Conv1d / BatchNorm1d see when the samples' vertex rows are laid end to end (B = 1: exactly the reference)."""
+    B = pc.size(0)
+    feats = []
+    for b in range(B):
+        lat = lattice if (lattice is not None and B == 1) else _lattice.generate_data(pc[b].detach().numpy())
+        x = pc[b:b + 1, :3, :]
+        for i in range(3):                                        # conv_in :24-28, LeakyReLU(0.1)
+            x = F.leaky_relu(F.conv1d(x, P[f'E.conv_in.{i}.0.weight'], P[f'E.conv_in.{i}.0.bias']), 0.1)
+        feat = x[0]
+        for l in range(5):                                        # :113-141
+            g = lat[l]
+            emg = torch.from_numpy(g['emg'])
+            feat = bcl(P, f'E.bcn{l + 1}', torch.cat((emg, feat), 0), torch.from_numpy(g['bary']),
+                       torch.from_numpy(g['off']), torch.from_numpy(g['nbr']))
+        feats.append(feat)
+    seg = [0]
+    for f_ in feats:
+        seg.append(seg[-1] + f_.size(1))
+    x = torch.cat(feats, 1)[None]
     for i in (1, 2, 3):                                           # :150-152
         x = F.conv1d(x, P[f'E.conv_gn_{i}.weight'], P[f'E.conv_gn_{i}.bias'])
         x = F.relu(_bn(P, f'E.bn_gn_{i}', x, train))
-    x = torch.max(x, 2)[0]                                        # :154-155
+    x = torch.cat([torch.max(x[:, :, seg[b]:seg[b + 1]], 2)[0] for b in range(B)], 0)      # :154-155, per sample
     for i in (1, 2, 3):
         x = F.relu(F.linear(x, P[f'E.lin_gn_{i}.weight'], P[f'E.lin_gn_{i}.bias']))
     sgn = F.linear(x, P['E.lin_gn_sgn.weight'], P['E.lin_gn_sgn.bias'])

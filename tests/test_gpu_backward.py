@@ -260,6 +260,57 @@ def test_training_step_vs_oracle_and_golden(golden_dir, manifest, monkeypatch):
     print('grad rel err: ' + ', '.join('%s max %.1e' % (n, worst[n][0]) for n in 'EHFG') + ', F median %.1e' % med_f)
 
 
+def test_training_step_batch2_vs_batched_oracle(manifest, monkeypatch):
+    """train-mode B = 2: the only place the samples couple is BatchNorm over the per-GPU batch.  The oracle
+    restates that definition on the CPU (per-sample lattices / rasters / correlation, BatchNorm statistics over both samples,
+    E head over the vertices of both) - an external check of what round 1 only tested against itself: every loss term, the
+    BatchNorm running statistics after the step, and the per-net gradients."""
+    from efgh_amd import ops
+    from efgh_amd.losses import EFGHCriterion
+    from efgh_amd.nets import EFGHBackbone
+    from oracle import efgh_oracle as O
+    RAW, NPTS = (128, 256), 2048
+    args_c, args_g = syn.default_args(RAW, 'cpu'), syn.default_args(RAW, 'cuda')
+    b = syn.make_batch(RAW, NPTS, 2)
+    T = torch.from_numpy
+    cpu = [T(b[k]) for k in ('pc', 'img', 'calib', 'A')]
+    P = syn.synthetic_state_dict(manifest['state_dict'], 1)
+    for k in manifest['parameters']:
+        P[k].requires_grad_(True)
+    pred_o = O.forward(P, *cpu, args_c, train=True)
+    L_o, _ = O.compute_loss(cpu[0], {k: T(v) for k, v in b['gt'].items()}, pred_o, args_c)
+    L_o['total'].backward()
+    h_img_o = pred_o['h_img'].detach().cuda()
+    monkeypatch.setattr(ops, 'rotate_nearest_u8', lambda img, rot, **kw: (h_img_o, ops.nchw_to_nhwc(h_img_o, 4)))
+    m = EFGHBackbone(args_g)
+    m.load_state_dict(syn.synthetic_state_dict(manifest['state_dict'], 1))
+    m = m.cuda().train()
+    gpu = [t.cuda() for t in cpu]
+    pred = m(*gpu)
+    L, _ = EFGHCriterion(args_g).compute_loss(gpu[0], gpu[1], gpu[2], gpu[3], {k: T(v) for k, v in b['gt'].items()}, pred)
+    for k in ('e_gn_sgn', 'e_gn_abs', 'h_hrzn_sgn', 'h_hrzn_abs', 'g_trs'):
+        assert _relerr(pred[k].detach().cpu(), pred_o[k].detach()) < 2e-4, k
+    for k in L_o:
+        assert abs(L[k].item() - L_o[k].item()) <= 5e-4 * abs(L_o[k].item()) + 1e-6, (k, L[k].item(), L_o[k].item())
+    # running statistics after one train-mode forward (momentum 0.1, unbiased variance over BOTH samples)
+    sd = m.state_dict()
+    for k in ('H.vgg.features.1.running_mean', 'H.vgg.features.1.running_var', 'E.bn_gn_1.running_mean', 'E.bn_gn_3.running_var',
+              'G.conv_img2.0.bn1.running_var', 'F.vgg_range.features.5.running_mean'):
+        assert _relerr(sd[k].cpu(), P[k].detach()) < 1e-4, k
+    L['total'].backward()
+    params = dict(m.named_parameters())
+    num, den = {n: 0.0 for n in 'EHG'}, {n: 0.0 for n in 'EHG'}
+    for k in manifest['parameters']:
+        if k[0] == 'F' or re.search(r'(features\.\d+|conv_gn_\d|conv_hrzn_\d|E\.bcn5\.blur_conv\.2)\.bias$', k):
+            continue
+        g, ref = params[k].grad.cpu().double(), P[k].grad.double()
+        num[k[0]] += float((g - ref).pow(2).sum())
+        den[k[0]] += float(ref.pow(2).sum())
+    rel = {n: (num[n] / max(den[n], 1e-300)) ** 0.5 for n in num}
+    print('B=2 gradient rel err per net:', {n: '%.2e' % v for n, v in rel.items()})
+    assert rel['E'] < 2e-3 and rel['H'] < 2e-3 and rel['G'] < 5e-2, rel
+
+
 def test_g_image_losses_vs_torch_autograd():
     """GImageLossFn (masked L2 on the depth image + BCE on the mask image) against the torch expressions of loss_utils.py:186-199"""
     from efgh_amd.nets import fn as FN

@@ -16,12 +16,12 @@ def _rel(got, ref):
     return float(np.abs(got - ref).max() / (np.abs(ref).max() + 1e-12))
 
 
-def _eval_forward(manifest, raw, npts):
+def _eval_forward(manifest, raw, npts, args_over=None, batch=None):
     from efgh_amd.nets import EFGHBackbone
-    m = EFGHBackbone(syn.default_args(raw, 'cuda'))
+    m = EFGHBackbone(dict(syn.default_args(raw, 'cuda'), **(args_over or {})))
     m.load_state_dict(syn.synthetic_state_dict(manifest['state_dict'], 1), strict=True)
     m = m.cuda().eval()
-    b = syn.make_batch(raw, npts, 1)
+    b = batch if batch is not None else syn.make_batch(raw, npts, 1)
     inp = [torch.from_numpy(b[k]).cuda() for k in ('pc', 'img', 'calib', 'A')]
     keep = {}
     with torch.no_grad():
@@ -49,12 +49,12 @@ def test_rellis_config_stagewise_vs_oracle(manifest):
     _stagewise(st, manifest, raw)
 
 
-def _stagewise(full, manifest, raw):
+def _stagewise(full, manifest, raw, args_over=None):
     from oracle import efgh_oracle as O
     m, inp, out, _ = full
     torch.set_num_threads(min(32, os.cpu_count() or 1))
     P = syn.synthetic_state_dict(manifest['state_dict'], 1)
-    args = syn.default_args(raw, 'cpu')
+    args = dict(syn.default_args(raw, 'cpu'), **(args_over or {}))
     cpu = [t.cpu() for t in inp]
     with torch.no_grad():
         rete = O.enet(P, cpu[0], False)
@@ -184,7 +184,7 @@ def test_rellis_config_training_step_vs_oracle(manifest, monkeypatch):
     assert relg < 2e-2
 
 
-def _training_step(manifest, monkeypatch, RAW, NPTS):
+def _training_step(manifest, monkeypatch, RAW, NPTS, args_over=None, batch=None):
     """forward + efghloss + backward at config S (B = 1) against the oracle.
     Pass A - the whole pipeline (only the uint8 rotate teacher-forced, as in test_gpu_backward): every loss term, and the E / H
     gradients.  Pass B - the G net on the oracle's inputs (E/H/F outputs and the rasterised depth image teacher-forced): the
@@ -199,8 +199,8 @@ def _training_step(manifest, monkeypatch, RAW, NPTS):
     from efgh_amd.nets import fn as FN
     from oracle import efgh_oracle as O
     torch.set_num_threads(min(32, os.cpu_count() or 1))
-    args_c, args_g = syn.default_args(RAW, 'cpu'), syn.default_args(RAW, 'cuda')
-    b = syn.make_batch(RAW, NPTS, 1)
+    args_c, args_g = dict(syn.default_args(RAW, 'cpu'), **(args_over or {})), dict(syn.default_args(RAW, 'cuda'), **(args_over or {}))
+    b = batch if batch is not None else syn.make_batch(RAW, NPTS, 1)
     T = torch.from_numpy
     cpu = [T(b[k]) for k in ('pc', 'img', 'calib', 'A')]
     gtd = lambda: {k: T(v) for k, v in b['gt'].items()}
@@ -261,3 +261,47 @@ def _training_step(manifest, monkeypatch, RAW, NPTS):
     den = sum(float(c.double().pow(2).sum()) for c in g_o)
     print('pass B, G gradient rel err on teacher-forced inputs: %.2e' % ((num / den) ** 0.5))
     return rel, (num / den) ** 0.5
+
+
+# ---- BASELINE configs[4]: KITTI-odometry loader geometry with the +-30 degree perturbations of the reference's rand-init CSV ----
+KITTI_RAW = (352, 1216)                  # 376 x 1241 frames cropped so that (W/2) % 8 == 0 (gnet.py:144)
+KITTI_NPTS = 65536
+HDL64_FOV = [2.0 / 180.0, -24.8 / 180.0]  # lidar_fov_rad is in units of pi (torch_utils.py:19-20): HDL-64E, +2 .. -24.8 degrees
+                                          # (the reference ships no KITTI yaml; this is the value used here)
+
+
+def _kitti_batch(row):
+    """one frame-pair in the KITTI geometry, perturbed by ROW `row` of the committed excerpt of the reference's own
+    params/rellis3d_rand_init_30_30.csv (name, roll, pitch, yaw, tx, ty, tz, cam_roll; tests/golden/io/rand_init_head.csv)"""
+    from efgh_amd.io import formats as fm
+    here = os.path.dirname(os.path.abspath(__file__))
+    ri = fm.read_rand_init_csv(os.path.join(here, 'golden', 'io', 'rand_init_head.csv'))
+    vals = list(ri.values())[row]
+    assert len(vals) == 7 and all(abs(v) <= np.pi / 6 + 1e-9 for v in vals[:3] + vals[6:]) and vals[3:6] == [0.0, 0.0, 0.0]
+    calib, A = syn.calib_and_A(KITTI_RAW)
+    pc = syn.lidar_sweep(KITTI_NPTS, 11 + row, pitch_range=(-24.8 / 180 * np.pi, 2.0 / 180 * np.pi))
+    gt = syn.ground_truth_from_params(KITTI_RAW, *vals)
+    s = {'pc': pc, 'img': syn.camera_image(KITTI_RAW, 11 + row), 'calib': calib.astype(np.float32), 'A': A.astype(np.float32)}
+    out = {k: v[None] for k, v in s.items()}
+    out['gt'] = {k: np.asarray(v)[None] for k, v in gt.items()}
+    return out
+
+
+def test_kitti_config_all_four_stages_vs_oracle(manifest):
+    """configs[4], eval forward: E / H / F / G stage-wise against the oracle (teacher-forced per stage as at config S) with the
+    HDL-64 field of view and a perturbation row of the reference's CSV"""
+    over = {'lidar_fov_rad': HDL64_FOV, 'dataset': 'KITTI_ODOM'}
+    b = _kitti_batch(0)
+    st = _eval_forward(manifest, KITTI_RAW, KITTI_NPTS, over, b)
+    out = st[2]
+    assert out['g_depth'].shape == (1, 1, 352, 1216) and out['h_img'].shape == (1, 3, 176, 608)
+    assert out['f_score'].shape[0] == 1
+    _stagewise(st, manifest, KITTI_RAW, over)
+
+
+def test_kitti_config_training_step_vs_oracle(manifest, monkeypatch):
+    """configs[4], one training step (forward, efghloss, backward) against the oracle, same checks as at config S"""
+    over = {'lidar_fov_rad': HDL64_FOV, 'dataset': 'KITTI_ODOM'}
+    rel, relg = _training_step(manifest, monkeypatch, KITTI_RAW, KITTI_NPTS, over, _kitti_batch(1))
+    assert rel['E'] < 2e-3 and rel['H'] < 1e-2 and rel['F'] < 2e-2, rel
+    assert relg < 2e-2
