@@ -112,13 +112,13 @@ def dump_shapes(prof, path):
 
 
 def committed_traffic(family, workload='train'):
-    """HBM-side bytes per launch of one kernel family from the committed rocprofv3 PMC passes (FETCH_SIZE doubled as
-    MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE; tools/collect_traffic.py), collected offline on the same
-    bench command, see profiles/README.md.  PMC collection cannot run inside the timed region."""
+    """HBM-side bytes per launch of one kernel family (`bcl`: per step) from the committed rocprofv3 PMC passes (FETCH_SIZE doubled
+    as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE; tools/collect_traffic.py), collected offline on the same bench
+    command, see profiles/README.md.  PMC collection cannot run inside the timed region."""
     try:
-        f = 'r01_hbm_traffic_train.json' if workload == 'train' else 'r01_gemm_hbm_traffic.json'
+        f = 'r02_hbm_traffic_train.json' if workload == 'train' else 'r02_hbm_traffic_fwd.json'
         d = json.load(open(os.path.join(ROOT, 'profiles', f)))['per_launch']
-        return d[family]['traffic_bytes'] if workload == 'train' else (d['traffic_bytes'] if family == 'gemm' else None)
+        return d[family]['traffic_bytes']
     except Exception:
         return None
 
@@ -132,7 +132,7 @@ def gemm_roofline(prof, steps, kernel):
     ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     return {'bound': 'mfma', 'kernel': kernel, 'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
             'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
-            'traffic_unit': 'HBM-side bytes per launch (committed rocprofv3 PMC passes of this bench command, profiles/)',
+            'traffic_unit': 'HBM-side bytes per launch (committed rocprofv3 PMC passes of this bench command, profiles/r02_hbm_traffic_*.json)',
             'launches_per_step': n / max(1, steps),
             'avg_launch_ms': ms / max(1, n), 'algorithmic_gflop_per_launch': fl / max(1, n) / 1e9,
             'kernel_ms_per_step': ms / max(1, steps)}
@@ -184,6 +184,7 @@ def rooflines(prof, steps, workload='train'):
                                + (' + splat / neighbour-gather adjoints' if any(k.endswith('bwd') for k in parts) else ''),
                                'achieved': ach, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': ach / PEAK_HBM_GBS,
                                'traffic': committed_traffic('bcl', workload),
+                               'traffic_unit': 'HBM-side bytes per STEP, all lattice.hip + bcl.hip launches (profiles/r02_hbm_traffic_*.json)',
                                'launches_per_step': len(bcl) / max(1, steps), 'kernel_ms_per_step': ms / max(1, steps),
                                'algorithmic_mb_per_step': by / max(1, steps) / 1e6,
                                'parts': {k: {'ms_per_step': v[0] / max(1, steps), 'algorithmic_mb_per_step': v[1] / max(1, steps) / 1e6,

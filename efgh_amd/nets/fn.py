@@ -83,6 +83,7 @@ class GemmLayerFn(torch.autograd.Function):
         if spec.custom_forward is not None:
             assert bn is not None and bias is None
             spec.custom_forward(x, weight, out)
+        ops.W2V_WANTED = bool(ctx.needs_input_grad[1])
         for li, (geom, m) in enumerate(spec.launches if spec.custom_forward is None else []):
             wp = spec.pack_fwd(weight, li)
             T = spec.T if geom is None else len(geom[7])
@@ -98,6 +99,7 @@ class GemmLayerFn(torch.autograd.Function):
                     g0 += gs[li]
                 ops.gather_gemm(x, ld_of(x), spec.C, T, wp, Np, m, out, Np, mode=spec.mode, geom=geom,
                                 table=spec.table, bias=b, act=ACT_NONE, stats=st, flops=fl)
+        ops.W2V_WANTED = False
         y = out
         if bn is not None:
             raw = out

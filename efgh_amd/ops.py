@@ -287,6 +287,16 @@ def _batched_plain_gemm(A3, W3, out3, rows, C, N):
         PROFILE_WINO2D_GEMM.append((e0, e1, 2.0 * 36 * rows * C * N, (0, rows, N, 36, C)))
 
 
+W2V_CACHE = {}          # training: B^T x B of a layer's input, kept from the forward for the layer's weight gradient
+W2V_KEEP = _os.environ.get('EFGH_WINO2D_KEEP_V', '1') != '0'
+W2V_WANTED = False      # set by GemmLayerFn.forward around its launches when the weight gradient will be asked for
+
+
+def w2v_clear():
+    """drop transformed inputs that no backward came for (train.Trainer calls this at the start of every step)"""
+    W2V_CACHE.clear()
+
+
 def _wino2d_forward(d, A, a_off, lda, C, N, geom, Wp):
     """input transform -> 36 batched GEMMs -> output transform with the layer's epilogue (descriptor d)"""
     B, H, W = geom[0], geom[1], geom[2]
@@ -296,6 +306,11 @@ def _wino2d_forward(d, A, a_off, lda, C, N, geom, Wp):
     Mb = torch.empty((T, 36, N), dtype=torch.float32, device=dev)
     _C.check(_L().efgh_wino2d_input(_C.c_void_p(A.data_ptr() + 4 * a_off), c_int64(lda), c_int32(C), c_int32(B), c_int32(H),
                                     c_int32(W), ptr(V), _st()))
+    if W2V_KEEP and W2V_WANTED and a_off == 0:
+        # 2.25x the activation, ~10 GB over the eligible layers at batch 8 (of 288 GB): saves one transform pass per layer and step
+        if len(W2V_CACHE) > 256:
+            W2V_CACHE.clear()
+        W2V_CACHE[(A.data_ptr(), lda, C, B, H, W)] = (V, A._version)
     _batched_plain_gemm(V, wino2d_weight(Wp, N, C), Mb, T, C, N)
     _C.check(_L().efgh_wino2d_output(ptr(Mb), ctypes.byref(d), _st()))
 
@@ -601,10 +616,14 @@ def gather_wgrad(A, lda, C, T, N, M, G, ldg, dWp, mode=0, geom=None, table=None)
         B, H, W = geom[0], geom[1], geom[2]
         T2 = _L().efgh_wino2d_tiles(c_int32(B), c_int32(H), c_int32(W))
         dev = dWp.device
-        V = torch.empty((T2, 36, C), dtype=torch.float32, device=dev)
+        kept = W2V_CACHE.pop((A.data_ptr(), lda, C, B, H, W), None)
         Gy = torch.empty((T2, 36, N), dtype=torch.float32, device=dev)
         S = torch.empty((36, N, C), dtype=torch.float32, device=dev)               # zeroed by the C-ABI call
-        _C.check(_L().efgh_wino2d_input(ptr(A), c_int64(lda), c_int32(C), c_int32(B), c_int32(H), c_int32(W), ptr(V), _st()))
+        if kept is not None and kept[1] == A._version and kept[0].shape == (T2, 36, C):
+            V = kept[0]                                                            # B^T x B from the forward pass
+        else:
+            V = torch.empty((T2, 36, C), dtype=torch.float32, device=dev)
+            _C.check(_L().efgh_wino2d_input(ptr(A), c_int64(lda), c_int32(C), c_int32(B), c_int32(H), c_int32(W), ptr(V), _st()))
         _C.check(_L().efgh_wino2d_dy(ptr(G), c_int64(ldg), c_int32(N), c_int32(B), c_int32(H), c_int32(W), ptr(Gy), _st()))
         g = _C.GemmDesc()
         g.A, g.lda, g.C, g.T, g.mode, g.N, g.M = V.data_ptr(), 36 * C, C, 1, 0, N, T2

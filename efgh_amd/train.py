@@ -76,6 +76,7 @@ class OverlappedAllReduce:
         for b in self.bucket_of:
             self.sizes[b] += 1
         self.pending, self.works, self.launched = list(self.sizes), [], [False] * len(self.buckets)
+        self.next_b, self.order = len(self.buckets) - 1, []
         if world > 1:
             for i, p in enumerate(flat.params):
                 p.register_post_accumulate_grad_hook(self._make_hook(i))
@@ -84,24 +85,33 @@ class OverlappedAllReduce:
         def hook(param):
             b = self.bucket_of[i]
             self.pending[b] -= 1
-            if self.pending[b] == 0:
-                self._launch(b)
+            self._launch_ready()
         return hook
+
+    def _launch_ready(self):
+        """collectives must be issued in the SAME order on every rank (RCCL matches them by issue order, not by buffer): buckets
+        go out strictly from the last to the first - the order backward completes them in - and a bucket that becomes complete
+        early waits for its successors, so the order cannot depend on how autograd happens to schedule a rank's hooks"""
+        while self.next_b >= 0 and self.pending[self.next_b] <= 0:
+            self._launch(self.next_b)
+            self.next_b -= 1
 
     def _launch(self, b):
         if self.launched[b]:
             return
         self.launched[b] = True
         s, e = self.buckets[b]
+        self.order.append(b)
         self.works.append(dist.all_reduce(self.flat.g[s:e], op=dist.ReduceOp.SUM, async_op=True))
 
     def start_step(self):
         self.pending, self.works, self.launched = list(self.sizes), [], [False] * len(self.buckets)
+        self.next_b, self.order = len(self.buckets) - 1, []
 
     def finish(self):
         if self.world <= 1:
             return
-        for b in range(len(self.buckets)):
+        for b in range(len(self.buckets) - 1, -1, -1):          # whatever is left (parameters without a gradient), same order
             self._launch(b)
         for w in self.works:
             w.wait()
@@ -170,6 +180,7 @@ class Trainer:
             raise _C.EfghError('the set of trainable parameters changed after the Trainer was built (FlatParams snapshots '
                                'requires_grad): freeze parameters first, then construct the Trainer')
         self.opt.lr = adjust_learning_rate(self.base_lr, self.it)
+        ops.w2v_clear()
         self.model.train()
         pred = self.model(pc, img, calib, A)
         losses, gt = self.criterion.compute_loss(pc, img, calib, A, gt, pred)

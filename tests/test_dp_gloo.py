@@ -49,6 +49,7 @@ def _worker(rank, world, port, q):
         comm.start_step()
         model2(x).pow(2).mean().backward()
         comm.finish()
+        assert comm.order == sorted(comm.order, reverse=True) and len(comm.order) == len(comm.buckets)      # fixed issue order
         flat2.g.div_(world)
         ok = ok and torch.allclose(flat2.g, flat.g, atol=1e-7)
         ok = ok and all(p.grad.data_ptr() == flat2.g.data_ptr() + 4 * off for p, (off, _) in zip(flat2.params, flat2.offsets))

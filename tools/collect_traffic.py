@@ -1,9 +1,20 @@
-"""HBM-side bytes per launch of the MFMA kernel families from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE):
-    python tools/collect_traffic.py <fetch_dir> <write_dir> <out.json> "<workload description>"
-FETCH_SIZE / WRITE_SIZE are in KB; FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950."""
+"""HBM-side bytes per launch of the kernel families of bench.py from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE):
+    python tools/collect_traffic.py <fetch_dir> <write_dir> <out.json> "<workload description>" <steps in the trace>
+FETCH_SIZE / WRITE_SIZE are in KB; FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950.
+The `bcl` family (every kernel of lattice.hip and bcl.hip) is reported per STEP, as bench.py's roofline_bcl is."""
 import collections, csv, glob, json, sys
 
-FAMILIES = {'gemm': 'k_gather_gemm', 'wino': 'k_wino43', 'wgrad': 'k_gather_wgrad', 'wino_wgrad': 'k_wino_wgrad('}
+FAMILIES = {
+    'gemm': ['k_gather_gemm<1,', 'k_gather_gemm<2,', 'k_gather_gemm<3,', 'k_gather_gemm<0, 256', 'k_gather_gemm<0, 128, 64'],
+    'wino': ['k_wino43('],
+    'wgrad': ['k_gather_wgrad<1,', 'k_gather_wgrad<2,', 'k_gather_wgrad<0, 64'],
+    'wino_wgrad': ['k_wino_wgrad('],
+    'wino2d_gemm': ['k_gather_gemm<0, 128, 128', 'k_gather_wgrad<0, 128'],
+    'wino2d_transforms': ['k_w2_input', 'k_w2_output', 'k_w2_dy'],
+    'bcl': ['k_level_init', 'k_point_keys', 'k_minmax_finalize', 'k_insert', 'k_seg_count', 'k_seg_scan', 'k_seg_assign', 'k_place',
+            'k_sortmin', 'k_flag_count', 'k_scan_sums', 'k_assign', 'k_offsets', 'k_neighbors', 'k_splat_gather', 'k_splat_bwd',
+            'k_table_gather_t', 'k_table_alias_add'],
+}
 
 
 def per_kernel(d, counter):
@@ -12,21 +23,27 @@ def per_kernel(d, counter):
         for r in csv.DictReader(open(f)):
             if r['Counter_Name'] != counter:
                 continue
-            for fam, pat in FAMILIES.items():
-                if pat in r['Kernel_Name']:
+            for fam, pats in FAMILIES.items():
+                if any(p in r['Kernel_Name'] for p in pats):
                     tot[fam] += float(r['Counter_Value']) * 1024.0
                     n[fam] += 1
+                    break
     return tot, n
 
 
 fetch, nf = per_kernel(sys.argv[1], 'FETCH_SIZE')
 write, nw = per_kernel(sys.argv[2], 'WRITE_SIZE')
-out = {'workload': sys.argv[4], 'note': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes; KB x 1024; '
-       'FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B)', 'per_launch': {}}
+steps = int(sys.argv[5]) if len(sys.argv) > 5 else 1
+out = {'workload': sys.argv[4], 'steps_in_trace': steps,
+       'note': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes; KB x 1024; '
+               'FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B)', 'per_launch': {}}
 for fam in FAMILIES:
     if nf[fam]:
-        fb, wb = fetch[fam] / nf[fam], write[fam] / max(1, nw[fam])
+        div = steps if fam == 'bcl' else nf[fam]
+        divw = steps if fam == 'bcl' else max(1, nw[fam])
+        fb, wb = fetch[fam] / div, write[fam] / divw
         out['per_launch'][fam] = {'fetch_bytes_reported': fb, 'fetch_bytes_corrected_x2': 2 * fb, 'write_bytes': wb,
-                                  'launches': nf[fam], 'traffic_bytes': 2 * fb + wb}
+                                  'launches': nf[fam], 'traffic_bytes': 2 * fb + wb,
+                                  'unit': 'bytes per step (all launches of the family)' if fam == 'bcl' else 'bytes per launch'}
 json.dump(out, open(sys.argv[3], 'w'), indent=1)
 print(json.dumps(out['per_launch'], indent=1))
