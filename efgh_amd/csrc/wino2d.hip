@@ -117,19 +117,23 @@ k_w2_input(const float *__restrict__ A, long long lda, int C, const TileGeo g, f
     const long long t = (long long)rowt * g.TW + tx;
     const int y0 = 4 * ty, x0 = 4 * tx;
     // all 36 loads first (one round trip: the kernel is bound by waves in flight x dependent memory round trips), then the two
-    // 1-D transforms in place
+    // 1-D transforms in place.  No branch around a load: out-of-image taps read a clamped (valid) address and are zeroed by a
+    // select (36 exec-masked branches, one per load, kept the loads from being issued together)
     const vec_t zero = make_float2(0.f, 0.f);
     vec_t d[6][6];
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
         const int y = y0 - 1 + r;
         const bool rok = (unsigned)y < (unsigned)g.H;
-        const float *row = A + ((b * g.H + (rok ? y : 0)) * g.W) * lda + q * VW;
+        const int yc = min(max(y, 0), g.H - 1);
+        const float *row = A + ((b * g.H + yc) * g.W) * lda + q * VW;
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
             const int x = x0 - 1 + c;
             const bool ok = rok && (unsigned)x < (unsigned)g.W;
-            d[r][c] = ok ? *reinterpret_cast<const vec_t *>(row + (long long)x * lda) : zero;
+            const int xc = min(max(x, 0), g.W - 1);
+            const vec_t v = *reinterpret_cast<const vec_t *>(__builtin_assume_aligned(row + (long long)xc * lda, 8));
+            d[r][c] = ok ? v : zero;
         }
     }
     vec_t acc[6][6];
@@ -174,11 +178,12 @@ k_w2_dy(const float *__restrict__ G, long long ldg, int N, const TileGeo g, floa
     for (int r = 0; r < 4; ++r) {
         const int y = y0 + r;
         const bool rok = y < g.H;
-        const float *row = G + ((b * g.H + (rok ? y : 0)) * g.W) * ldg + q * VW;
+        const float *row = G + ((b * g.H + min(y, g.H - 1)) * g.W) * ldg + q * VW;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int x = x0 + c;
-            d[r][c] = (rok && x < g.W) ? *reinterpret_cast<const vec_t *>(row + (long long)x * ldg) : zero;
+            const vec_t v = *reinterpret_cast<const vec_t *>(__builtin_assume_aligned(row + (long long)min(x, g.W - 1) * ldg, 8));
+            d[r][c] = (rok && x < g.W) ? v : zero;
         }
     }
     vec_t wx[4][6], acc[6][6];
@@ -211,7 +216,7 @@ struct W2OutArgs {
     float *stats;
 };
 
-constexpr int ROWS_PER_BLOCK = 4;              // rows of tiles per workgroup of k_w2_output (one statistics row per workgroup)
+constexpr int ROWS_PER_BLOCK = 1;              // rows of tiles per workgroup of k_w2_output (one statistics row per workgroup)
 
 __global__ void __launch_bounds__(TPB)
 k_w2_output(const W2OutArgs p) {
