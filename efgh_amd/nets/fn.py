@@ -57,6 +57,19 @@ class LayerSpec:
         self.pool = pool
 
 
+def claim_grad(p):
+    """(flat gradient view, deliver()) when parameter `p` lives in a train.FlatParams whose slice may be overwritten by this
+    backward, else (None, None): the backward then returns the gradient to autograd as usual."""
+    slot = getattr(p, '_efgh_flat', None) if p is not None else None
+    if slot is None:
+        return None, None
+    flat, i = slot
+    g = flat.claim(p, i)
+    if g is None:
+        return None, None
+    return g, (lambda: flat.deliver(i))
+
+
 class GemmLayerFn(torch.autograd.Function):
     """y = act(BN(gemm(x, W) + bias) + residual)   with hand-written backward."""
 
@@ -133,6 +146,7 @@ class GemmLayerFn(torch.autograd.Function):
                                     ldr=0 if res is None else ld_of(res))
         ctx.spec = spec
         ctx.has = (bias is not None, gamma is not None, residual is not None)
+        ctx.params = (weight, bias, gamma, beta)      # the Parameter objects themselves (claim_grad), not saved copies
         # layers without a residual re-derive the activation mask from raw*scale+shift in backward
         psc, psh = (scale, shift) if (bn is not None and residual is None) else (None, None)
         ctx.save_for_backward(x, weight, y, raw, mean, invstd, None if gamma is None else gamma.detach(), psc, psh)
@@ -154,11 +168,28 @@ class GemmLayerFn(torch.autograd.Function):
         dy = as_rows(dy)
         dbias = dgamma = dbeta = dres = None
         need_pre = spec.act != ACT_NONE or has_bn or has_res or has_bias
+        p_w, p_bias, p_gamma, p_beta = ctx.params
+        delivered = []
+        # per-channel sums go straight into the flat gradient slices when the parameters live in a FlatParams (no padding)
+        gs1 = gs2 = None
+        if Np == N and has_bn and ctx.needs_input_grad[3] and ctx.needs_input_grad[4]:
+            gs1, d1 = claim_grad(p_beta)
+            gs2, d2 = claim_grad(p_gamma) if gs1 is not None else (None, None)
+            if gs2 is None:
+                gs1 = None
+            else:
+                delivered += [d1, d2]
+        elif Np == N and has_bias and not has_bn and ctx.needs_input_grad[2]:
+            gs1, d1 = claim_grad(p_bias)
+            if gs1 is not None:
+                delivered.append(d1)
         if fused_pool:
             # BatchNorm backward straight from the pooled gradient (no full-resolution dy is ever written)
             coef = gamma * invstd
-            draw, s1, s2 = ops.pool_bn_bwd(dy.contiguous(), raw, mean, invstd, coef, psc, psh, spec.act, spec.slope)
-            dbeta, dgamma = s1, s2
+            draw, s1, s2 = ops.pool_bn_bwd(dy.contiguous(), raw, mean, invstd, coef, psc, psh, spec.act, spec.slope,
+                                           s1=gs1, s2=gs2)
+            if gs1 is None:
+                dbeta, dgamma = s1, s2
             if has_bias:
                 dbias = ops.col_sum(draw, M, Np)
         elif not need_pre:
@@ -166,8 +197,8 @@ class GemmLayerFn(torch.autograd.Function):
         else:
             G = ops.bwd_groups(M)
             part = torch.empty((G, 2, Np), dtype=torch.float64, device=dev)      # float64 column sums (see backward.hip)
-            s1 = torch.empty(Np, dtype=torch.float32, device=dev)
-            s2 = torch.empty(Np, dtype=torch.float32, device=dev)
+            s1 = gs1 if gs1 is not None else torch.empty(Np, dtype=torch.float32, device=dev)
+            s2 = gs2 if gs2 is not None else torch.empty(Np, dtype=torch.float32, device=dev)
             train_bn = has_bn and spec.train
             m1 = torch.empty(Np, dtype=torch.float64, device=dev) if train_bn else None
             m2 = torch.empty(Np, dtype=torch.float64, device=dev) if train_bn else None
@@ -176,9 +207,10 @@ class GemmLayerFn(torch.autograd.Function):
                                   pscale=psc, pshift=psh)
             coef = None
             if has_bn:
-                dbeta, dgamma = s1[:N].clone(), s2[:N].clone()
+                if gs1 is None:
+                    dbeta, dgamma = s1[:N].clone(), s2[:N].clone()
                 coef = ops.pad_vec(gamma, Np) * invstd
-            if has_bias and not has_bn:
+            if has_bias and not has_bn and gs1 is None:
                 dbias = s1[:N].clone()
             draw = torch.empty(tuple(spec.out_shape) + (Np,), dtype=torch.float32, device=dev)
             if has_res:
@@ -200,15 +232,21 @@ class GemmLayerFn(torch.autograd.Function):
         if ctx.needs_input_grad[1] and spec.custom_wgrad is not None:
             dW = spec.custom_wgrad(x, weight, draw)
         elif ctx.needs_input_grad[1]:
-            dW = torch.empty_like(weight)
+            gW, dw_done = claim_grad(p_w)
+            dW = gW if gW is not None else torch.empty_like(weight)
             for li, (geom, m) in enumerate(spec.launches):
                 T = spec.T if geom is None else len(geom[7])
                 dWp = torch.empty((Np, T, spec.C), dtype=torch.float32, device=dev)
                 ops.gather_wgrad(x, ld_of(x), spec.C, T, Np, m, draw, Np, dWp, mode=spec.mode, geom=geom,
                                  table=spec.table)
                 spec.wgrad_unpack(dWp, li, dW)
+            if gW is not None:
+                dW = None
+                delivered.append(dw_done)
         if dres is not None and Np != N:
             dres = dres[..., :N]
+        for done in delivered:               # after the writes are enqueued: the all-reduce bucket countdown
+            done()
         return dx, dW, dbias, dgamma, dbeta, dres, None
 
 

@@ -679,15 +679,15 @@ def act_bn_bwd_reduce(dy, lddy, y, ldy, raw, ldraw, mean, invstd, M, C, act, slo
                                          c_float(slope), ptr(part), ptr(s1), ptr(s2), ptr(m1), ptr(m2), _st()))
 
 
-def pool_bn_bwd(dy_pool, raw, mean, invstd, coef, pscale, pshift, act, slope):
+def pool_bn_bwd(dy_pool, raw, mean, invstd, coef, pscale, pshift, act, slope, s1=None, s2=None):
     """BatchNorm backward of a conv+BN+act layer fused with MaxPool2d(2,2), from the pooled gradient; raw [B][H][W][C].
     -> (draw [B][H][W][C], dbeta [C], dgamma [C])"""
     B, H, W, C = raw.shape
     dev = raw.device
     G = _L().efgh_pool_bwd_groups(c_int32(B), c_int32(H), c_int32(W))
     part = torch.empty((G, 2, C), dtype=torch.float64, device=dev)
-    s1 = torch.empty(C, dtype=torch.float32, device=dev)
-    s2 = torch.empty(C, dtype=torch.float32, device=dev)
+    s1 = s1 if s1 is not None else torch.empty(C, dtype=torch.float32, device=dev)
+    s2 = s2 if s2 is not None else torch.empty(C, dtype=torch.float32, device=dev)
     m1 = torch.empty(C, dtype=torch.float64, device=dev)
     m2 = torch.empty(C, dtype=torch.float64, device=dev)
     _C.check(_L().efgh_pool_bn_bwd_reduce(ptr(dy_pool), ptr(raw), ptr(mean), ptr(invstd), ptr(pscale), ptr(pshift), c_int32(B),

@@ -6,6 +6,8 @@ so the data-parallel exchange is a bucketed all-reduce of 191 MB whose buckets a
 parameter hooks while backward is still running, and the optimizer is one kernel launch instead of 353.
 `DataParallel` semantics (one loss over the global batch, batch-mean terms) == mean of the per-rank
 gradients for equal per-rank batches."""
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -33,9 +35,41 @@ class FlatParams:
             self.offsets.append((off, k))
             off += k
         self.params = ps
+        # gradients written straight into the flat slices by the layer backward (nets/fn.py `claim_grad`) instead of handed to
+        # autograd's AccumulateGrad (which costs an allocation, a copy and an `add` launch per parameter).  `arrived[i]` is set
+        # by whichever route delivers parameter i's gradient first; later deliveries in the same step go through autograd and
+        # accumulate, so shared parameters and gradient accumulation over several backward calls keep their meaning.
+        self.direct = os.environ.get('EFGH_DIRECT_GRAD', '1') != '0'
+        self.arrived = [False] * len(ps)
+        self.listeners = []               # callables(index), e.g. the overlapped all-reduce's bucket countdown
+        for i, p in enumerate(ps):
+            p._efgh_flat = (self, i)
+            p.register_post_accumulate_grad_hook(self._make_hook(i))
+
+    def _make_hook(self, i):
+        def hook(param):
+            self.deliver(i)
+        return hook
+
+    def deliver(self, i):
+        """parameter i's gradient for this backward pass is (enqueued to be) in the flat buffer"""
+        first, self.arrived[i] = not self.arrived[i], True
+        if first:
+            for fn in self.listeners:
+                fn(i)
+
+    def claim(self, p, i):
+        """the flat gradient view of parameter i if a backward may overwrite it now (zeroed, nothing delivered yet), else None"""
+        if not self.direct or self.arrived[i]:
+            return None
+        off, k = self.offsets[i]
+        if p.grad is None or p.grad.data_ptr() != self.g.data_ptr() + 4 * off:
+            return None
+        return p.grad
 
     def zero_grad(self):
         self.g.zero_()
+        self.arrived = [False] * len(self.params)
         for p, (off, k) in zip(self.params, self.offsets):      # autograd may have replaced .grad
             if p.grad is None or p.grad.data_ptr() != self.g.data_ptr() + 4 * off:
                 p.grad = self.g[off:off + k].view(p.shape)
@@ -56,7 +90,8 @@ def allreduce_mean_(flat_g, world, bucket_elems=8 * 1024 * 1024):
 
 class OverlappedAllReduce:
     """Gradient all-reduce overlapped with backward: the flat gradient buffer is cut into ~32 MB buckets of
-    whole parameters; a post-accumulate hook on every parameter counts its bucket down and launches the bucket's asynchronous
+    whole parameters; every delivered parameter gradient (FlatParams.deliver: from
+    autograd's post-accumulate hook or from a layer backward that wrote the flat slice itself) counts its bucket down and launches the bucket's asynchronous
     sum all-reduce (RCCL on its own stream) as soon as the last gradient of the bucket has been written - backward produces
     the gradients back to front, so the tail buckets are on the wire while the front of the network is still being
     differentiated.  `finish()` launches whatever is left (parameters without a gradient) and waits."""
@@ -78,15 +113,11 @@ class OverlappedAllReduce:
         self.pending, self.works, self.launched = list(self.sizes), [], [False] * len(self.buckets)
         self.next_b, self.order = len(self.buckets) - 1, []
         if world > 1:
-            for i, p in enumerate(flat.params):
-                p.register_post_accumulate_grad_hook(self._make_hook(i))
+            flat.listeners.append(self._arrived)
 
-    def _make_hook(self, i):
-        def hook(param):
-            b = self.bucket_of[i]
-            self.pending[b] -= 1
-            self._launch_ready()
-        return hook
+    def _arrived(self, i):
+        self.pending[self.bucket_of[i]] -= 1
+        self._launch_ready()
 
     def _launch_ready(self):
         """collectives must be issued in the SAME order on every rank (RCCL matches them by issue order, not by buffer): buckets
