@@ -434,7 +434,7 @@ k_gather_gemm(const KArgs p_in) {
     }
 }
 
-__global__ void k_pack_weight(const float *__restrict__ W, float *__restrict__ Wp, int N, int T, int C,
+__global__ void k_pack_weight(const float *__restrict__ W, float *__restrict__ Wp, int N, int T, int C, int Nw, int Cw,
                               long long sn, long long sc, long long st, const int4 taps0,
                               const int4 taps1, const int4 taps2, const int4 taps3) {
     const int tp[16] = {taps0.x, taps0.y, taps0.z, taps0.w, taps1.x, taps1.y, taps1.z, taps1.w,
@@ -447,8 +447,13 @@ __global__ void k_pack_weight(const float *__restrict__ W, float *__restrict__ W
         int ti = 0;
 #pragma unroll
         for (int q = 0; q < 16; ++q) if (q == t) ti = tp[q];
-        Wp[i] = W[n * sn + c * sc + ti * st];
+        Wp[i] = (n < Nw && c < Cw) ? W[n * sn + c * sc + ti * st] : 0.f;      // (N, C) may be the zero-padded extents of (Nw, Cw)
     }
+}
+
+__global__ void k_pad_vec(const float *__restrict__ v, int n, float *__restrict__ out, int np, float fill) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < np) out[i] = i < n ? v[i] : fill;
 }
 
 __global__ void k_split_f16(const float *__restrict__ w, _Float16 *__restrict__ hi, _Float16 *__restrict__ lo, long long n) {
@@ -610,16 +615,28 @@ extern "C" int efgh_split_bf16(const float *w, void *hi, void *mid, void *lo, in
     return EFGH_OK;
 }
 
+extern "C" int efgh_pad_vec(const float *v, int32_t n, float *out, int32_t np, float fill, void *stream_) {
+    EFGH_CHECK_ARG(v && out && n > 0 && np >= n);
+    k_pad_vec<<<cdiv(np, 256), 256, 0, (hipStream_t)stream_>>>(v, n, out, np, fill);
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}
+
 extern "C" int efgh_pack_weight(const float *W, float *Wp, int32_t N, int32_t T, int32_t C, int64_t sn,
                                 int64_t sc, int64_t stt, const int32_t *tapidx, void *stream_) {
+    return efgh_pack_weight_padded(W, Wp, N, T, C, N, C, sn, sc, stt, tapidx, stream_);
+}
+
+extern "C" int efgh_pack_weight_padded(const float *W, float *Wp, int32_t N, int32_t T, int32_t C, int32_t Np, int32_t Cp,
+                                       int64_t sn, int64_t sc, int64_t stt, const int32_t *tapidx, void *stream_) {
     hipStream_t st = (hipStream_t)stream_;
-    EFGH_CHECK_ARG(W && Wp && N > 0 && T > 0 && T <= 16 && C > 0);
+    EFGH_CHECK_ARG(W && Wp && N > 0 && T > 0 && T <= 16 && C > 0 && Np >= N && Cp >= C);
     int tp[16];
     for (int t = 0; t < 16; ++t) tp[t] = (tapidx && t < T) ? tapidx[t] : (t < T ? t : 0);
-    long long total = (long long)N * T * C;
+    long long total = (long long)Np * T * Cp;
     int grid = (int)((total + 255) / 256);
     if (grid > 8192) grid = 8192;
-    k_pack_weight<<<grid, 256, 0, st>>>(W, Wp, N, T, C, sn, sc, stt, make_int4(tp[0], tp[1], tp[2], tp[3]),
+    k_pack_weight<<<grid, 256, 0, st>>>(W, Wp, Np, T, Cp, N, C, sn, sc, stt, make_int4(tp[0], tp[1], tp[2], tp[3]),
                                         make_int4(tp[4], tp[5], tp[6], tp[7]),
                                         make_int4(tp[8], tp[9], tp[10], tp[11]),
                                         make_int4(tp[12], tp[13], tp[14], tp[15]));

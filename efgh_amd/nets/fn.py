@@ -119,7 +119,11 @@ class GemmLayerFn(torch.autograd.Function):
             if need_stats and thin:
                 stats, _ = ops.col_stats(out, M, Np, Np)
             if need_stats:
-                bn.num_batches_tracked += 1
+                slot = getattr(bn, '_efgh_nbt', None)          # (train.FlatParams, index): counted once per step there
+                if slot is not None and slot[0].collect_ticks:
+                    slot[0].tick(slot[1])
+                else:
+                    bn.num_batches_tracked += 1
                 momentum = bn.momentum if bn.momentum is not None else 0.1
                 g_, b_ = ops.pad_vec(gamma.detach(), Np), ops.pad_vec(beta.detach(), Np)
                 if Np == N:
@@ -149,7 +153,8 @@ class GemmLayerFn(torch.autograd.Function):
         ctx.params = (weight, bias, gamma, beta)      # the Parameter objects themselves (claim_grad), not saved copies
         # layers without a residual re-derive the activation mask from raw*scale+shift in backward
         psc, psh = (scale, shift) if (bn is not None and residual is None) else (None, None)
-        ctx.save_for_backward(x, weight, y, raw, mean, invstd, None if gamma is None else gamma.detach(), psc, psh)
+        # coef = gamma * invstd of the BatchNorm backward is the forward's `scale`
+        ctx.save_for_backward(x, weight, y, raw, mean, invstd, scale if bn is not None else None, psc, psh)
         if spec.passthrough:
             return y, x.view_as(x)
         return y
@@ -157,7 +162,7 @@ class GemmLayerFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, dskip=None):
         spec = ctx.spec
-        x, weight, y, raw, mean, invstd, gamma, psc, psh = ctx.saved_tensors
+        x, weight, y, raw, mean, invstd, coef, psc, psh = ctx.saved_tensors
         ymask = None if psc is not None else y
         has_bias, has_bn, has_res = ctx.has
         N, Np, M = spec.N, ceil4(spec.N), spec.M
@@ -185,7 +190,6 @@ class GemmLayerFn(torch.autograd.Function):
                 delivered.append(d1)
         if fused_pool:
             # BatchNorm backward straight from the pooled gradient (no full-resolution dy is ever written)
-            coef = gamma * invstd
             draw, s1, s2 = ops.pool_bn_bwd(dy.contiguous(), raw, mean, invstd, coef, psc, psh, spec.act, spec.slope,
                                            s1=gs1, s2=gs2)
             if gs1 is None:
@@ -205,11 +209,8 @@ class GemmLayerFn(torch.autograd.Function):
             ops.act_bn_bwd_reduce(dy, ld_of(dy), ymask, Np, raw, Np, mean if has_bn else None,
                                   invstd if has_bn else None, M, Np, spec.act, spec.slope, part, s1, s2, m1, m2,
                                   pscale=psc, pshift=psh)
-            coef = None
-            if has_bn:
-                if gs1 is None:
-                    dbeta, dgamma = s1[:N].clone(), s2[:N].clone()
-                coef = ops.pad_vec(gamma, Np) * invstd
+            if has_bn and gs1 is None:
+                dbeta, dgamma = s1[:N].clone(), s2[:N].clone()
             if has_bias and not has_bn and gs1 is None:
                 dbias = s1[:N].clone()
             draw = torch.empty(tuple(spec.out_shape) + (Np,), dtype=torch.float32, device=dev)

@@ -53,14 +53,10 @@ def pack_weight(w, N, T, C, sn, sc, st, taps=None, Np=None, Cp=None, key=None):
         wd = w.detach()
         _C.require_cuda(wd)
         wd = wd.contiguous()
-        out = torch.empty((N, T, C), dtype=torch.float32, device=wd.device)
+        out = torch.empty((Np, T, Cp), dtype=torch.float32, device=wd.device)
         tp = (ctypes.c_int32 * 16)(*([int(t) for t in taps] + [0] * (16 - len(taps)))) if taps is not None else None
-        _C.check(_L().efgh_pack_weight(ptr(wd), ptr(out), c_int32(N), c_int32(T), c_int32(C), c_int64(sn),
-                                       c_int64(sc), c_int64(st), tp, _st()))
-        if Np != N or Cp != C:
-            full = torch.zeros((Np, T, Cp), dtype=torch.float32, device=wd.device)
-            full[:N, :, :C] = out
-            out = full
+        _C.check(_L().efgh_pack_weight_padded(ptr(wd), ptr(out), c_int32(N), c_int32(T), c_int32(C), c_int32(Np), c_int32(Cp),
+                                              c_int64(sn), c_int64(sc), c_int64(st), tp, _st()))
         return out
 
     if key is None:
@@ -71,8 +67,13 @@ def pack_weight(w, N, T, C, sn, sc, st, taps=None, Np=None, Cp=None, key=None):
 def pad_vec(v, Np, fill=0.0):
     if v is None or v.numel() == Np:
         return v
-    out = torch.full((Np,), fill, dtype=torch.float32, device=v.device)
-    out[:v.numel()] = v.detach()
+    v = v.detach()
+    if not v.is_cuda or v.dtype != torch.float32 or not v.is_contiguous():
+        out = torch.full((Np,), fill, dtype=torch.float32, device=v.device)
+        out[:v.numel()] = v
+        return out
+    out = torch.empty((Np,), dtype=torch.float32, device=v.device)
+    _C.check(_L().efgh_pad_vec(ptr(v), c_int32(v.numel()), ptr(out), c_int32(Np), c_float(fill), _st()))
     return out
 
 

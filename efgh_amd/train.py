@@ -40,6 +40,15 @@ class FlatParams:
         # by whichever route delivers parameter i's gradient first; later deliveries in the same step go through autograd and
         # accumulate, so shared parameters and gradient accumulation over several backward calls keep their meaning.
         self.direct = os.environ.get('EFGH_DIRECT_GRAD', '1') != '0'
+        # BatchNorm's `num_batches_tracked` counters re-homed as views of ONE int64 vector: a training forward notes which layers
+        # ran (GemmLayerFn.forward -> tick) and Trainer.step adds the whole step's counts with one launch instead of one per layer
+        bns = [m for m in model.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm)
+               and m.num_batches_tracked is not None]
+        self.nbt = torch.stack([m.num_batches_tracked.to(dev) for m in bns]).clone() if bns else None
+        self.ticks, self.collect_ticks = [0] * len(bns), False
+        for j, m in enumerate(bns):
+            m.num_batches_tracked = self.nbt[j]
+            m._efgh_nbt = (self, j)
         self.arrived = [False] * len(ps)
         self.listeners = []               # callables(index), e.g. the overlapped all-reduce's bucket countdown
         for i, p in enumerate(ps):
@@ -66,6 +75,19 @@ class FlatParams:
         if p.grad is None or p.grad.data_ptr() != self.g.data_ptr() + 4 * off:
             return None
         return p.grad
+
+    def tick(self, j):
+        self.ticks[j] += 1
+
+    def flush_ticks(self):
+        self.collect_ticks = False
+        if any(self.ticks):
+            k = self.ticks[0]
+            if all(t == k for t in self.ticks):
+                self.nbt += k
+            else:
+                self.nbt += torch.tensor(self.ticks, dtype=self.nbt.dtype).to(self.nbt.device)
+            self.ticks = [0] * len(self.ticks)
 
     def zero_grad(self):
         self.g.zero_()
@@ -213,7 +235,11 @@ class Trainer:
         self.opt.lr = adjust_learning_rate(self.base_lr, self.it)
         ops.w2v_clear()
         self.model.train()
-        pred = self.model(pc, img, calib, A)
+        self.flat.collect_ticks = True
+        try:
+            pred = self.model(pc, img, calib, A)
+        finally:
+            self.flat.flush_ticks()
         losses, gt = self.criterion.compute_loss(pc, img, calib, A, gt, pred)
         self.flat.zero_grad()
         self.comm.start_step()

@@ -156,6 +156,11 @@ int32_t efgh_gather_gemm_grid_m(int64_t M, int32_t N);      /* rows of `stats` *
 /* Wp[n][t][c] = W[n*sn + c*sc + tapidx[t]*st]   (weight re-layout for the kernel above) */
 int efgh_pack_weight(const float *W, float *Wp, int32_t N, int32_t T, int32_t C, int64_t sn,
                      int64_t sc, int64_t st, const int32_t *tapidx_host, void *stream);
+/* same, Wp[Np][T][Cp] with zeros outside [N][.][C] (row / channel counts rounded up for the kernels' vector width) */
+int efgh_pack_weight_padded(const float *W, float *Wp, int32_t N, int32_t T, int32_t C, int32_t Np, int32_t Cp, int64_t sn,
+                            int64_t sc, int64_t st, const int32_t *tapidx_host, void *stream);
+/* out[i] = i < n ? v[i] : fill, i < np   (bias / BatchNorm vectors of layers whose width is not a multiple of 4) */
+int efgh_pad_vec(const float *v, int32_t n, float *out, int32_t np, float fill, void *stream);
 
 /* ------------------------------------------------------------------ BatchNorm / elementwise --
  * replaces nn.BatchNorm1d/2d + ReLU/LeakyReLU + residual add + nn.MaxPool2d(2,2) as composed in

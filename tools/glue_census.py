@@ -1,7 +1,7 @@
 """Which host lines launch the non-HIP-extension kernels of a training step?
     python tools/glue_census.py [--small] [--batch B]
-One training step under torch.profiler (with_stack): every aten op that launches a device kernel is charged to the innermost
-frame inside efgh_amd/ that issued it.  Output: launches per (file:line, aten op), most frequent first, and the total.
+One training step under a TorchDispatchMode: every aten op on device tensors that is not a pure view / allocation is charged to
+the innermost frame inside efgh_amd/ that issued it (ops of autograd's own backward formulas have no such frame).  Output: launches per (file:line, aten op), most frequent first, and the total.
 (The extension's own kernels go through ctypes and do not appear as aten ops.)"""
 import argparse
 import collections
@@ -35,30 +35,37 @@ def main():
     for _ in range(2):
         tr.step(*inp, gt)
     torch.cuda.synchronize()
-    from torch.profiler import ProfilerActivity, profile
-    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
-        tr.step(*inp, gt)
-        torch.cuda.synchronize()
+    import traceback
+    from torch.utils._python_dispatch import TorchDispatchMode
     count = collections.Counter()
-    dur = collections.Counter()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for ev in prof.events():
-        if ev.device_type != torch.autograd.DeviceType.CPU or not ev.kernels:
-            continue
-        if ev.cpu_parent is not None and ev.cpu_parent.kernels:       # count the kernel once, at the outermost aten op
-            continue
-        where = 'autograd engine / outside efgh_amd'
-        for fr in ev.stack:
-            if 'efgh_amd/' in fr or 'bench.py' in fr or 'tools/' in fr:
-                where = fr.replace(root + '/', '').strip()
-                break
-        key = (where, ev.name)
-        count[key] += len(ev.kernels)
-        dur[key] += sum(k.duration for k in ev.kernels)
+    NO_KERNEL = ('view', 'reshape', 'slice', 'select', 'expand', 'permute', 'transpose', 'unsqueeze', 'squeeze', 'detach',
+                 'alias', 'as_strided', 'empty', 'new_empty', 'unbind', 'split', 'narrow', 't.default', 'size', 'stride',
+                 'is_', 'lift_fresh', '_local_scalar_dense', 'unfold', 'chunk', 'diagonal', 'numel', '_version',
+                 'record_stream', 'resize_', 'set_', '_to_copy.default_cpu')
+
+    class Census(TorchDispatchMode):
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            out = func(*args, **(kwargs or {}))
+            name = str(func)
+            flat = [t for t in torch.utils._pytree.tree_leaves((args, kwargs, out)) if isinstance(t, torch.Tensor)]
+            if any(t.is_cuda for t in flat) and not any(k in name for k in NO_KERNEL):
+                where = 'autograd engine / outside efgh_amd'
+                for fr in reversed(traceback.extract_stack()):
+                    if '/efgh_amd/' in fr.filename:
+                        where = '%s:%d %s' % (fr.filename.replace(root + '/', ''), fr.lineno, fr.name)
+                        break
+                count[(where, name)] += 1
+            return out
+
+    with Census():
+        tr.step(*inp, gt)
+    torch.cuda.synchronize()
+    dur = collections.Counter()
     total = sum(count.values())
-    print('torch-launched kernels in one training step: %d  (%.2f ms of device time)' % (total, sum(dur.values()) / 1e3))
+    print('aten ops on device tensors in one training step (about one launch each): %d' % total)
     for (where, name), n in count.most_common(a.top):
-        print('%5d  %8.1f us  %-28s %s' % (n, dur[(where, name)], name, where))
+        print('%5d  %-36s %s' % (n, name.replace('aten.', ''), where))
 
 
 if __name__ == '__main__':
