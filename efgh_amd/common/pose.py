@@ -1,8 +1,9 @@
 """Batched pose-head algebra without host synchronisation (replaces the per-sample python loops
-with .item()/.tolist() of common/torch_utils.py:105-146, 170-233, 256-296).  These are O(B) scalar
-formulas on (B,3)/(B,4,4) tensors; they stay as device tensor expressions (no kernel of their own).
-Differentiability mirrors the reference: the skew matrix K is built from detached values, only
-(1-c)/s^2 carries gradient (torch_utils.py:184,194); translation matrices are detached (:229)."""
+with .item()/.tolist() of common/torch_utils.py:105-146, 170-233, 256-296): one HIP launch per head
+(csrc/pose.hip), forward and - on the training path - a hand-written backward.  The same formulas as
+device tensor expressions are kept below as the EFGH_POSE_KERNELS=0 path (what the kernels are tested
+against).  Differentiability mirrors the reference: the skew matrix K is built from detached values,
+only (1-c)/s^2 carries gradient (torch_utils.py:184,194); translation matrices are detached (:229)."""
 import ctypes
 import math
 import os
@@ -16,18 +17,48 @@ USE_KERNELS = os.environ.get('EFGH_POSE_KERNELS', '1') != '0'    # fused heads (
 
 
 def _fused():
-    return USE_KERNELS and not torch.is_grad_enabled()
+    return USE_KERNELS
+
+
+class PoseHeadFn(torch.autograd.Function):
+    """head_normal with the backward of csrc/pose.hip (k_head_normal_bwd)"""
+
+    @staticmethod
+    def forward(ctx, abs_logits, sgn_logits, dest):
+        ctx.save_for_backward(abs_logits, sgn_logits)
+        ctx.dest = dest
+        return _head_normal_launch(abs_logits, sgn_logits, dest)
+
+    @staticmethod
+    def backward(ctx, ga, gn, gR):
+        abs_logits, sgn_logits = ctx.saved_tensors
+        B, nd = abs_logits.shape
+        d = ctx.dest
+        g = torch.empty((B, nd), dtype=torch.float32, device=abs_logits.device)
+        ga, gn, gR = (None if t is None else t.contiguous() for t in (ga, gn, gR))
+        _C.check(_C.lib().efgh_pose_head_normal_bwd(
+            _C.ptr(abs_logits), ctypes.c_int64(abs_logits.stride(0)), _C.ptr(sgn_logits), ctypes.c_int64(sgn_logits.stride(0)),
+            ctypes.c_int32(B), ctypes.c_int32(nd), ctypes.c_float(d[0]), ctypes.c_float(d[1]), ctypes.c_float(d[2]),
+            _C.ptr(ga), _C.ptr(gn), _C.ptr(gR), _C.ptr(g), _C.stream_ptr()))
+        return g, None, None
 
 
 def head_normal(abs_logits, sgn_logits, dest):
-    """softmax_l2 + normal_from_abs_sign + rotation_between in ONE launch (inference path): abs_logits (B,nd) and sgn_logits
-    (B,2^nd) row views -> (abs (B,nd,1), normal (B,nd,1), R (B,4,4))"""
+    """softmax_l2 + normal_from_abs_sign + rotation_between in ONE launch: abs_logits (B,nd) and sgn_logits (B,2^nd) row views
+    -> (abs (B,nd,1), normal (B,nd,1), R (B,4,4))"""
     B, nd = abs_logits.shape
     if not _fused():
         a = softmax_l2(abs_logits)
         n = normal_from_abs_sign(a, sgn_logits, nd)
         n3 = n if nd == 3 else torch.cat([n, torch.zeros(B, 1, 1, device=n.device)], 1)
         return a, n, rotation_between(n3, const(dest, n.device))
+    if torch.is_grad_enabled() and abs_logits.requires_grad:
+        return PoseHeadFn.apply(abs_logits, sgn_logits, tuple(dest))
+    return _head_normal_launch(abs_logits.detach(), sgn_logits.detach(), dest)
+
+
+def _head_normal_launch(abs_logits, sgn_logits, dest):
+    B, nd = abs_logits.shape
     _C.require_cuda(abs_logits, sgn_logits)
     assert abs_logits.stride(1) == 1 and sgn_logits.stride(1) == 1 and sgn_logits.shape[1] == 1 << nd
     dev = abs_logits.device
@@ -115,16 +146,40 @@ def translation_matrix(vec):
     return t
 
 
+class CamTVeloFn(torch.autograd.Function):
+    """A^-1 c_T A calib l_T with gradients w.r.t. c_T and l_T (csrc/pose.hip k_cam_T_velo / k_cam_T_velo_bwd)"""
+
+    @staticmethod
+    def forward(ctx, c_T, l_T, calib, A):
+        _C.require_cuda(c_T, l_T, calib, A)
+        B = l_T.shape[0]
+        c, l, k, a = c_T.contiguous(), l_T.contiguous(), calib.contiguous(), A.contiguous()
+        out = torch.empty((B, 3, 4), dtype=torch.float32, device=l_T.device)
+        _C.check(_C.lib().efgh_pose_cam_T_velo(_C.ptr(c), ctypes.c_int64(9), _C.ptr(l), _C.ptr(k), _C.ptr(a), ctypes.c_int32(B),
+                                               _C.ptr(out), _C.stream_ptr()))
+        ctx.save_for_backward(c, l, k, a)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        c, l, k, a = ctx.saved_tensors
+        B = l.shape[0]
+        gc = torch.empty((B, 3, 3), dtype=torch.float32, device=l.device) if ctx.needs_input_grad[0] else None
+        gl = torch.empty((B, 4, 4), dtype=torch.float32, device=l.device) if ctx.needs_input_grad[1] else None
+        if gc is not None or gl is not None:
+            _C.check(_C.lib().efgh_pose_cam_T_velo_bwd(_C.ptr(c), ctypes.c_int64(9), _C.ptr(l), _C.ptr(k), _C.ptr(a),
+                                                       _C.ptr(g.contiguous()), ctypes.c_int32(B), _C.ptr(gc), _C.ptr(gl),
+                                                       _C.stream_ptr()))
+        return gc, gl, None, None
+
+
 def compute_cam_T_velo(c_T, l_T, calib, A):
     """torch_utils.py:256-269"""
     if _fused():
-        _C.require_cuda(c_T, l_T, calib, A)
-        B = l_T.shape[0]
-        c = c_T.contiguous()
-        out = torch.empty((B, 3, 4), dtype=torch.float32, device=l_T.device)
-        _C.check(_C.lib().efgh_pose_cam_T_velo(_C.ptr(c), ctypes.c_int64(9), _C.ptr(l_T.contiguous()), _C.ptr(calib.contiguous()),
-                                               _C.ptr(A.contiguous()), ctypes.c_int32(B), _C.ptr(out), _C.stream_ptr()))
-        return out
+        if torch.is_grad_enabled() and (c_T.requires_grad or l_T.requires_grad):
+            return CamTVeloFn.apply(c_T, l_T, calib, A)
+        with torch.no_grad():
+            return CamTVeloFn.apply(c_T, l_T, calib, A)
     m = torch.bmm(calib, l_T)
     m = torch.bmm(A, m)
     m = torch.bmm(c_T, m)

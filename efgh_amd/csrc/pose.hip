@@ -241,7 +241,8 @@ __global__ void k_cam_T_velo_bwd(const float *__restrict__ cT, long long ldc, co
 struct PoseLossArgs {
     const float *e_abs, *e_sgn, *h_abs, *h_sgn, *f_score, *g_trs, *e_l, *f_l;     // predictions
     long long ld_esgn, ld_hsgn, ld_fs;
-    const float *rand_l, *rand_c, *T4;                                              // ground truth 4x4 each
+    const float *rand_l, *rand_c, *T4;                                              // ground truth: rotations (3x3 or 4x4), 4x4
+    int rl_b, rl_r, rc_b, rc_r;                                                     // sample / row pitch of rand_l, rand_c
     int B, W, pos_num;
     float neg_ratio;
 };
@@ -307,9 +308,9 @@ __device__ __forceinline__ void inv3(const float *m, long long ld, float o[3][3]
 struct PoseGt { float e_gn[3], e_l[16], h_hrzn[3], h_c16[16], f_l[16], g_l[16], e_absv[3], h_absv[2]; int cls_e, cls_h, xmin; };
 
 __device__ void pose_gt(const PoseLossArgs &a, int b, PoseGt &o) {
-    const float *L = a.rand_l + (long long)b * 16, *C = a.rand_c + (long long)b * 16, *T4 = a.T4 + (long long)b * 16;
+    const float *L = a.rand_l + (long long)b * a.rl_b, *C = a.rand_c + (long long)b * a.rc_b, *T4 = a.T4 + (long long)b * 16;
     {   // E: third column of R_l, normalised; rotation onto e3
-        float g[3] = {L[2], L[6], L[10]};
+        float g[3] = {L[2], L[a.rl_r + 2], L[2 * a.rl_r + 2]};
         const float n = sqrtf((g[0] * g[0] + g[1] * g[1]) + g[2] * g[2]);
         for (int i = 0; i < 3; ++i) { g[i] = g[i] / n; o.e_gn[i] = g[i]; o.e_absv[i] = fabsf(g[i]); }
         const float e3[3] = {0.f, 0.f, 1.f};
@@ -317,7 +318,7 @@ __device__ void pose_gt(const PoseLossArgs &a, int b, PoseGt &o) {
         o.cls_e = (g[0] > 0.f ? 4 : 0) + (g[1] > 0.f ? 2 : 0) + (g[2] > 0.f ? 1 : 0);
     }
     {   // H: second column of R_c
-        float g[3] = {C[1], C[5], C[9]};
+        float g[3] = {C[1], C[a.rc_r + 1], C[2 * a.rc_r + 1]};
         const float n = sqrtf((g[0] * g[0] + g[1] * g[1]) + g[2] * g[2]);
         for (int i = 0; i < 3; ++i) { g[i] = g[i] / n; o.h_hrzn[i] = g[i]; }
         o.h_absv[0] = fabsf(g[0]); o.h_absv[1] = fabsf(g[1]);
@@ -572,13 +573,15 @@ static PoseLossArgs pose_args(const efgh_pose_loss_desc *d) {
     a.g_trs = d->g_trs; a.e_l = d->e_l; a.f_l = d->f_l;
     a.ld_esgn = d->ld_e_gn_sgn; a.ld_hsgn = d->ld_h_hrzn_sgn; a.ld_fs = d->ld_f_score;
     a.rand_l = d->rand_init_l; a.rand_c = d->rand_init_c; a.T4 = d->sensor2_T_sensor1;
+    a.rl_r = d->rand_init_l_dim; a.rl_b = a.rl_r * a.rl_r; a.rc_r = d->rand_init_c_dim; a.rc_b = a.rc_r * a.rc_r;
     a.B = d->B; a.W = d->W; a.pos_num = d->fov_pos_num; a.neg_ratio = d->fov_neg_ratio;
     return a;
 }
 
 static bool pose_desc_ok(const efgh_pose_loss_desc *d) {
     return d && d->e_gn_abs && d->e_gn_sgn && d->h_hrzn_abs && d->h_hrzn_sgn && d->f_score && d->g_trs && d->e_l && d->f_l &&
-           d->rand_init_l && d->rand_init_c && d->sensor2_T_sensor1 && d->B > 0 && d->W > 1 && d->fov_pos_num > 0 &&
+           d->rand_init_l && d->rand_init_c && d->sensor2_T_sensor1 && (d->rand_init_l_dim == 3 || d->rand_init_l_dim == 4) &&
+           (d->rand_init_c_dim == 3 || d->rand_init_c_dim == 4) && d->B > 0 && d->W > 1 && d->fov_pos_num > 0 &&
            d->ld_e_gn_sgn >= 8 && d->ld_h_hrzn_sgn >= 4 && d->ld_f_score >= d->W;
 }
 

@@ -92,6 +92,66 @@ k_raster_bwd(const int *__restrict__ pix, const float4 *__restrict__ gimg, int B
     }
 }
 
+// backward of both rasters w.r.t. the POSE that transformed the points (the training path of the pose heads): the gradient image
+// is gathered at every rasterised point (as k_raster_bwd) and contracted with the point on the fly, without the [B][N][4]
+// intermediate:   range (mode 0): q = E [p;1], r = |q|;  gq = (g.xyz, 0) + g.w q / r;  gE[i][j] = sum_n gq_i [p;1]_j   (4x4)
+//                 depth (mode 1): only the depth channel depends on the projection's third row:  gP[2][j] = sum_n g.w [p;1]_j
+// float64 accumulation, fixed summation order (partials per workgroup, summed in order by k_pose_grad_finish).
+#define POSE_GRAD_GROUPS 64
+__global__ void __launch_bounds__(TPB)
+k_raster_pose_bwd(const int *__restrict__ pix, const float4 *__restrict__ gimg, const float *__restrict__ pc,
+                  const float *__restrict__ E, int N, long long HW, int mode, double *__restrict__ part) {
+    const int b = blockIdx.y, tid = threadIdx.x;
+    double acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0;
+    float e[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) e[i] = (mode == 0) ? E[(long long)b * 16 + i] : 0.f;
+    const float *px_ = pc + (long long)b * 3 * N;
+    for (int n = blockIdx.x * TPB + tid; n < N; n += gridDim.x * TPB) {
+        const int px = pix[(long long)b * N + n];
+        if (px < 0) continue;
+        const float4 g = gimg[(long long)b * HW + px];
+        const float p[4] = {px_[n], px_[N + n], px_[2 * N + n], 1.f};
+        if (mode == 0) {
+            float q[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) q[i] = ((e[i * 4] * p[0] + e[i * 4 + 1] * p[1]) + e[i * 4 + 2] * p[2]) + e[i * 4 + 3];
+            const float r = sqrtf(((q[0] * q[0] + q[1] * q[1]) + q[2] * q[2]) + q[3] * q[3]);
+            const float gq[4] = {g.x + g.w * (q[0] / r), g.y + g.w * (q[1] / r), g.z + g.w * (q[2] / r), g.w * (q[3] / r)};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i * 4 + j] += (double)(gq[i] * p[j]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[8 + j] += (double)(g.w * p[j]);
+        }
+    }
+    __shared__ double red[TPB / 64][16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        double v = acc[i];
+        for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
+        if ((tid & 63) == 0) red[tid >> 6][i] = v;
+    }
+    __syncthreads();
+    if (tid < 16) {
+        double v = 0.0;
+        for (int w = 0; w < TPB / 64; ++w) v += red[w][tid];
+        part[((long long)b * gridDim.x + blockIdx.x) * 16 + tid] = v;
+    }
+}
+
+__global__ void k_pose_grad_finish(const double *__restrict__ part, int G, int nout, float *__restrict__ out) {
+    const int b = blockIdx.x, i = threadIdx.x;
+    if (i >= nout) return;
+    double v = 0.0;
+    for (int g = 0; g < G; ++g) v += part[((long long)b * G + g) * 16 + i];
+    out[(long long)b * nout + i] = (float)v;
+}
+
 // ---- PIL rotate -------------------------------------------------------------------------------
 __device__ __forceinline__ double round15(double v) {      // python round(v, 15) for |v| <= 1
     return nearbyint(v * 1e15) / 1e15;
@@ -186,6 +246,17 @@ extern "C" int efgh_raster_bwd(const int32_t *pix, const float *gimg, int32_t B,
     EFGH_CHECK_ARG(pix && gimg && gvals && B > 0 && N > 0 && HW > 0);
     k_raster_bwd<<<grid_for((long long)B * N), TPB, 0, (hipStream_t)stream_>>>(pix, (const float4 *)gimg, B, N, HW,
                                                                              (float4 *)gvals);
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}
+
+extern "C" int efgh_raster_pose_bwd(const int32_t *pix, const float *gimg, const float *pc, const float *e_l, int32_t B, int32_t N,
+                                    int64_t HW, int32_t mode, double *partials, float *g_pose, void *stream_) {
+    EFGH_CHECK_ARG(pix && gimg && pc && partials && g_pose && B > 0 && N > 0 && HW > 0 && (mode == 1 || (mode == 0 && e_l)));
+    hipStream_t st = (hipStream_t)stream_;
+    const int G = (int)(cdiv(N, TPB) < POSE_GRAD_GROUPS ? cdiv(N, TPB) : POSE_GRAD_GROUPS);
+    k_raster_pose_bwd<<<dim3(G, B), TPB, 0, st>>>(pix, (const float4 *)gimg, pc, e_l, N, HW, mode, partials);
+    k_pose_grad_finish<<<B, 64, 0, st>>>(partials, G, mode == 0 ? 16 : 12, g_pose);
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
 }

@@ -369,15 +369,7 @@ class RangeImageFn(torch.autograd.Function):
         pc, e_l, pix = ctx.saved_tensors
         H, W = ctx.hw
         B, _, N = pc.shape
-        gv = ops.raster_bwd(pix, g.contiguous(), B, N, H * W)                 # (B,N,4): d/d(x,y,z,r)
-        ones = torch.ones((B, 1, N), dtype=pc.dtype, device=pc.device)
-        p1 = torch.cat([pc, ones], 1)                                         # (B,4,N)
-        q = torch.bmm(e_l.detach(), p1)                                       # transformed (x,y,z,w)
-        r = torch.sqrt(torch.sum(q * q, 1, keepdim=True))
-        gq = torch.zeros_like(q)
-        gq[:, :3] = gv[..., :3].transpose(1, 2)
-        gq = gq + gv[..., 3:4].transpose(1, 2) * (q / r)
-        ge = torch.bmm(gq, p1.transpose(1, 2))                                # (B,4,4)
+        ge = ops.raster_pose_bwd(pix, g.contiguous(), pc, e_l.detach(), B, N, H * W, 0).view(B, 4, 4)
         return None, ge, None, None, None, None
 
 
@@ -396,12 +388,7 @@ class DepthImageFn(torch.autograd.Function):
         pc, pix = ctx.saved_tensors
         H, W = ctx.hw
         B, _, N = pc.shape
-        gv = ops.raster_bwd(pix, g.contiguous(), B, N, H * W)
-        ones = torch.ones((B, 1, N), dtype=pc.dtype, device=pc.device)
-        p1 = torch.cat([pc, ones], 1)
-        gw = gv[..., 3]                                                       # (B,N)
-        gP = torch.zeros((B, 3, 4), dtype=pc.dtype, device=pc.device)
-        gP[:, 2] = torch.bmm(p1, gw[:, :, None])[:, :, 0]
+        gP = ops.raster_pose_bwd(pix, g.contiguous(), pc, None, B, N, H * W, 1).view(B, 3, 4)
         return None, gP, None, None
 
 

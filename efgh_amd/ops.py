@@ -741,6 +741,17 @@ def raster_bwd(pix, gimg, B, N, HW):
     return gv
 
 
+def raster_pose_bwd(pix, gimg, pc, e_l, B, N, HW, mode):
+    """gradient w.r.t. the pose argument of the range (mode 0, -> (B,16)) / depth (mode 1, -> (B,12)) rasteriser"""
+    _C.require_cuda(pix, gimg, pc)
+    pc = pc.contiguous()
+    part = torch.empty((B, 64, 16), dtype=torch.float64, device=gimg.device)
+    out = torch.empty((B, 16 if mode == 0 else 12), dtype=torch.float32, device=gimg.device)
+    _C.check(_L().efgh_raster_pose_bwd(ptr(pix), ptr(gimg), ptr(pc), ptr(None if e_l is None else e_l.contiguous()), c_int32(B),
+                                       c_int32(N), c_int64(HW), c_int32(mode), ptr(part), ptr(out), _st()))
+    return out
+
+
 def corr1d_bwd_mfma(rp, cam, cam_mm, dl, B, h, wc, wp, rp_pitch=None):
     """the two correlation gradients as Toeplitz GEMMs on the MFMA kernel (see efgh_corr_planes); rp [B][h][rp_pitch][16]"""
     dev = cam.device

@@ -206,6 +206,11 @@ int efgh_depth_image(const float *pc, const float *cam_T_velo, int32_t B, int32_
 /* d(values)/d(img): gvals[b][i] = gimg[b][pix[b][i]] for every rasterised point */
 int efgh_raster_bwd(const int32_t *pix, const float *gimg, int32_t B, int32_t N, int64_t HW,
                     float *gvals, void *stream);
+/* gradient of the rasterised VALUES w.r.t. the pose that produced them, straight from the gradient image (no [B][N][4] pass):
+ * mode 0 = range image, g_pose [B][16] = d/d e_l (needs e_l); mode 1 = depth image, g_pose [B][12] = d/d cam_T_velo (row 2 only).
+ * partials: B * 64 * 16 doubles of scratch.  Replaces autograd through common/torch_utils.py:11-103 for the pose argument.  */
+int efgh_raster_pose_bwd(const int32_t *pix, const float *gimg, const float *pc, const float *e_l, int32_t B, int32_t N,
+                         int64_t HW, int32_t mode, double *partials, float *g_pose, void *stream);
 /* PIL.Image.rotate(angle) NEAREST on uint8 (common/torch_utils.py:235-254): img (B,3,H,W) float
  * holding 0..255, rot_deg [B] degrees (fp32, as torch_utils.py:245 computes it);
  * out_nchw (B,3,H,W) and/or out_nhwc4 [B][H][W][4] (4th channel 0).                           */
@@ -468,7 +473,7 @@ int efgh_sum_range_last(const float *pc, int64_t pc_cstride, int32_t N, const do
 int efgh_sum_paint(const void *jobs_dev, int32_t njobs, void *stream);
 int efgh_sum_colorize(const double *minmax, int64_t n, const uint8_t *lut, uint8_t *rgb, uint8_t *mask, void *stream);
 
-/* ---- pose heads, inference path (one launch each; the training path keeps them as tensor expressions for autograd) -----------
+/* ---- pose heads, forward (one launch each) -----------------------------------------------------------------------------------
  * efgh_pose_head_normal: softmax + L2 normalisation of the nd (2 or 3) "abs" logits, sign class = first argmax of the 2^nd sign
  *   logits decoded MSB-first, normal = abs * sign, rotation of the normal onto (dx,dy,dz) as a 4x4 (enet.py:161-176, hnet.py:59-77,
  *   torch_utils.py:105-146,170-200).  abs_out / normal: [B][nd], R44: [B][16].
@@ -479,6 +484,43 @@ int efgh_pose_head_normal(const float *abs_logits, int64_t lda, const float *sgn
 int efgh_pose_head_yaw(const float *score, int64_t lds, int32_t B, int32_t n, float *R44, void *stream);
 int efgh_pose_cam_T_velo(const float *c_T, int64_t ldc, const float *l_T, const float *calib, const float *A, int32_t B,
                          float *out34, void *stream);
+
+/* ---- pose heads, training path: hand-written backward (forward-mode duals inside the kernel, one seed per input) ------------
+ * efgh_pose_head_normal_bwd: d/d abs_logits [B][nd] of <g_abs, abs> + <g_normal, normal> + <g_R44, R>; any of the three incoming
+ *   gradients may be NULL.  As in the reference the skew matrix of the rotation is detached (torch_utils.py:184,194): only the
+ *   (1 - c)/s^2 factor carries a derivative; the sign logits get none (argmax).
+ * efgh_pose_rotation_between: rotation of unit vectors src3 [B][3] onto (dx,dy,dz) (torch_utils.py:170-200), R44 [B][16].
+ * efgh_pose_cam_T_velo_bwd: gradients of efgh_pose_cam_T_velo w.r.t. c_T ([B][9], may be NULL) and l_T ([B][16], may be NULL). */
+int efgh_pose_head_normal_bwd(const float *abs_logits, int64_t lda, const float *sgn_logits, int64_t lds, int32_t B, int32_t nd,
+                              float dx, float dy, float dz, const float *g_abs, const float *g_normal, const float *g_R44,
+                              float *g_abs_logits, void *stream);
+int efgh_pose_rotation_between(const float *src3, int32_t B, float dx, float dy, float dz, float *R44, void *stream);
+int efgh_pose_cam_T_velo_bwd(const float *c_T, int64_t ldc, const float *l_T, const float *calib, const float *A,
+                             const float *g_out34, int32_t B, float *g_cT33, float *g_lT44, void *stream);
+
+/* ---- pose terms of the loss: E / H cosine + sign cross-entropy, F hard-negative-mined BCE, G translation smooth-L1, and the
+ * ground truth they are measured against (losses/loss_utils.py:25-58, 77-144, 165-185, 227-262; losses/efghloss.py:19-38).
+ * Predictions: e_gn_abs [B][3], e_gn_sgn [B][>=8], h_hrzn_abs [B][2], h_hrzn_sgn [B][>=4], f_score [B][W] (probabilities),
+ * g_trs [B][3], e_l / f_l [B][16].  Ground truth: rand_init_l, rand_init_c ([B][3][3] or [B][4][4]), sensor2_T_sensor1 [B][16].
+ * fwd:  gt72 [B][72] floats = e_gn 0..2 | e_l 3..18 | h_hrzn 19..21 | h_c (3x3) 22..30 | f_l 31..46 | g_trs 47..49 | g_l 50..65 |
+ *       e_gn_abs 66..68 | h_hrzn_abs 69..70;  gt_cls2 [B][2] = sign classes (E, H);  gt_f_score / selected [B][W] (positives and
+ *       positives + mined negatives);  partials [B][7];  L11 = the eleven entries of the loss dictionary in `loss_name` order
+ *       (total first; g_depth / g_mask from the scalars l_depth / l_mask of efgh_gimg_loss_fwd);  n_selected [1].
+ * bwd:  gradients of <g_L11, L11> w.r.t. every prediction, and [2] w.r.t. (l_depth, l_mask).                                   */
+typedef struct {
+    const float *e_gn_abs, *e_gn_sgn, *h_hrzn_abs, *h_hrzn_sgn, *f_score, *g_trs, *e_l, *f_l;
+    int64_t ld_e_gn_sgn, ld_h_hrzn_sgn, ld_f_score;
+    const float *rand_init_l, *rand_init_c, *sensor2_T_sensor1;
+    int32_t rand_init_l_dim, rand_init_c_dim;       /* 3 or 4: the perturbations as [B][3][3] rotations or [B][4][4] transforms */
+    int32_t B, W, fov_pos_num;
+    float fov_neg_ratio;
+    float lambda_e_gn, lambda_h_hrzn, lambda_fov, lambda_g_trs, lambda_g_depth, lambda_g_mask;
+} efgh_pose_loss_desc;
+int efgh_pose_loss_fwd(const efgh_pose_loss_desc *d, const float *l_depth, const float *l_mask, float *gt72, int64_t *gt_cls2,
+                       float *gt_f_score, float *selected, float *partials, float *L11, float *n_selected, void *stream);
+int efgh_pose_loss_bwd(const efgh_pose_loss_desc *d, const float *g_L11, const float *selected, const float *n_selected,
+                       float *g_e_gn_abs, float *g_e_gn_sgn, float *g_h_hrzn_abs, float *g_h_hrzn_sgn, float *g_f_score,
+                       float *g_g_trs, float *g_e_l, float *g_ldepth_lmask, void *stream);
 
 #ifdef __cplusplus
 }
