@@ -153,13 +153,20 @@ __global__ void k_rotation_between(const float *__restrict__ src, int B, float d
     rotation_between<float>(v1, d, R + (long long)b * 16);
 }
 
-// fnet.py:87-91: peak of the correlation -> yaw -> (cos, sin, 0) -> rotation onto e1
-__global__ void k_head_yaw(const float *__restrict__ score, long long lds, int B, int n, float *__restrict__ R) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    int idx = 0;
-    float best = score[b * lds];
-    for (int i = 1; i < n; ++i) { const float v = score[b * lds + i]; if (v > best) { best = v; idx = i; } }
+// fnet.py:87-91: peak of the correlation (FIRST maximum) -> yaw -> (cos, sin, 0) -> rotation onto e1; one wave per sample
+__global__ void __launch_bounds__(64)
+k_head_yaw(const float *__restrict__ score, long long lds, int B, int n, float *__restrict__ R) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    int idx = n;
+    float best = -INFINITY;
+    for (int i = lane; i < n; i += 64) { const float v = score[b * lds + i]; if (v > best) { best = v; idx = i; } }
+    for (int o = 32; o; o >>= 1) {
+        const float ob = __shfl_xor(best, o);
+        const int oi = __shfl_xor(idx, o);
+        if (ob > best || (ob == best && oi < idx)) { best = ob; idx = oi; }
+    }
+    if (lane) return;
+    if (idx >= n) idx = 0;                               // all NaN: argmax convention of the scalar loop
     const float f_rad = -((float)idx / (float)(n - 1)) * 2.f * 3.14159274101257324f + 3.14159274101257324f;   // float32, as the tensor expression
     const double rad = (double)f_rad;
     const float v1[3] = {(float)cos(rad), (float)sin(rad), 0.f};
@@ -395,12 +402,25 @@ __device__ __forceinline__ float bce(float p, float t) {
 }
 
 // forward: gt buffers, the selection mask of the mined BCE, per-sample partial terms
-__global__ void __launch_bounds__(64)
+#define PL_TPB 256
+__device__ __forceinline__ float block_sum(float v, float *red) {      // PL_TPB threads; every thread gets the total
+    for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int w = 0; w < PL_TPB / 64; ++w) t += red[w];
+    return t;
+}
+
+__global__ void __launch_bounds__(PL_TPB)
 k_pose_loss_fwd(PoseLossArgs a, float *__restrict__ gtbuf, long long *__restrict__ gtcls, float *__restrict__ gt_fscore,
                 float *__restrict__ wsel, float *__restrict__ part) {
-    const int b = blockIdx.x, lane = threadIdx.x;
+    const int b = blockIdx.x, tid = threadIdx.x;
     __shared__ PoseGt gt;
-    if (lane == 0) {
+    __shared__ float red[PL_TPB / 64];
+    extern __shared__ float lc[];                      // [W] BCE of the non-positive columns against 0, positives as 0
+    if (tid == 0) {
         pose_gt(a, b, gt);
         float e_abs[3], e_sgn[8], h_abs[3], h_sgn[4], g_trs[3], e_l[16], out[5], gtrs[3];
         load_pred<float>(a, b, e_abs, e_sgn, h_abs, h_sgn, g_trs, e_l);
@@ -418,32 +438,30 @@ k_pose_loss_fwd(PoseLossArgs a, float *__restrict__ gtbuf, long long *__restrict
     // F: positives = pos_num columns from xmin (wrapping); negatives = the neg_ratio * #pos largest BCE values among the rest
     const int W = a.W, xmin = gt.xmin;
     const float *p = a.f_score + b * a.ld_fs;
-    int npos = 0;
-    for (int j = lane; j < W; j += 64) {
-        int r = (j - xmin) % W; if (r < 0) r += W;
-        const float t = r < a.pos_num ? 1.f : 0.f;
-        gt_fscore[(long long)b * W + j] = t;
-        npos += r < a.pos_num;
-    }
-    for (int o = 32; o; o >>= 1) npos += __shfl_xor(npos, o);
-    const float num_neg = fminf(a.neg_ratio * (float)npos, (float)(W - 1));
-    float lsum = 0.f, cnt = 0.f;
-    for (int j = lane; j < W; j += 64) {
+    float npos_f = 0.f;
+    for (int j = tid; j < W; j += PL_TPB) {
         int r = (j - xmin) % W; if (r < 0) r += W;
         const bool pos = r < a.pos_num;
-        const float lj = pos ? 0.f : bce(p[j], 0.f);
+        gt_fscore[(long long)b * W + j] = pos ? 1.f : 0.f;
+        lc[j] = pos ? 0.f : bce(p[j], 0.f);
+        npos_f += pos ? 1.f : 0.f;
+    }
+    npos_f = block_sum(npos_f, red);                   // (the barriers inside also publish lc)
+    const float num_neg = fminf(a.neg_ratio * npos_f, (float)(W - 1));
+    float lsum = 0.f, cnt = 0.f;
+    for (int j = tid; j < W; j += PL_TPB) {
+        int r = (j - xmin) % W; if (r < 0) r += W;
+        const bool pos = r < a.pos_num;
+        const float lj = lc[j];
         int rank = 0;                                   // position in the descending sort (ties: lower column first)
-        for (int q = 0; q < W; ++q) {
-            int rq = (q - xmin) % W; if (rq < 0) rq += W;
-            const float lq = rq < a.pos_num ? 0.f : bce(p[q], 0.f);
-            rank += (lq > lj) || (lq == lj && q < j);
-        }
+        for (int q = 0; q < W; ++q) { const float lq = lc[q]; rank += (lq > lj) || (lq == lj && q < j); }
         const bool sel = pos || (float)rank < num_neg;
         wsel[(long long)b * W + j] = sel ? 1.f : 0.f;
         if (sel) { lsum += bce(p[j], pos ? 1.f : 0.f); cnt += 1.f; }
     }
-    for (int o = 32; o; o >>= 1) { lsum += __shfl_xor(lsum, o); cnt += __shfl_xor(cnt, o); }
-    if (lane == 0) { part[b * PT_LD + PT_FOV_SUM] = lsum; part[b * PT_LD + PT_FOV_CNT] = cnt; }
+    lsum = block_sum(lsum, red);
+    cnt = block_sum(cnt, red);
+    if (tid == 0) { part[b * PT_LD + PT_FOV_SUM] = lsum; part[b * PT_LD + PT_FOV_CNT] = cnt; }
 }
 
 // L[11] in efghloss.py:13-17 order: total, e_gn, e_gn_sgn, e_gn_abs, h_hrzn, h_hrzn_abs, h_hrzn_sgn, fov, g_trs, g_depth, g_mask
@@ -529,7 +547,7 @@ extern "C" int efgh_pose_head_normal(const float *abs_logits, int64_t lda, const
 
 extern "C" int efgh_pose_head_yaw(const float *score, int64_t lds, int32_t B, int32_t n, float *R44, void *stream_) {
     EFGH_CHECK_ARG(score && R44 && B > 0 && n > 1);
-    k_head_yaw<<<cdiv(B, 64), 64, 0, (hipStream_t)stream_>>>(score, lds, B, n, R44);
+    k_head_yaw<<<B, 64, 0, (hipStream_t)stream_>>>(score, lds, B, n, R44);
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
 }
@@ -580,7 +598,7 @@ static PoseLossArgs pose_args(const efgh_pose_loss_desc *d) {
 
 static bool pose_desc_ok(const efgh_pose_loss_desc *d) {
     return d && d->e_gn_abs && d->e_gn_sgn && d->h_hrzn_abs && d->h_hrzn_sgn && d->f_score && d->g_trs && d->e_l && d->f_l &&
-           d->rand_init_l && d->rand_init_c && d->sensor2_T_sensor1 && (d->rand_init_l_dim == 3 || d->rand_init_l_dim == 4) &&
+           d->rand_init_l && d->rand_init_c && d->sensor2_T_sensor1 && d->W <= 8192 && (d->rand_init_l_dim == 3 || d->rand_init_l_dim == 4) &&
            (d->rand_init_c_dim == 3 || d->rand_init_c_dim == 4) && d->B > 0 && d->W > 1 && d->fov_pos_num > 0 &&
            d->ld_e_gn_sgn >= 8 && d->ld_h_hrzn_sgn >= 4 && d->ld_f_score >= d->W;
 }
@@ -590,7 +608,7 @@ extern "C" int efgh_pose_loss_fwd(const efgh_pose_loss_desc *d, const float *l_d
                                   float *n_selected, void *stream_) {
     EFGH_CHECK_ARG(pose_desc_ok(d) && l_depth && l_mask && gt72 && gt_cls2 && gt_f_score && selected && partials && L11 && n_selected);
     hipStream_t st = (hipStream_t)stream_;
-    k_pose_loss_fwd<<<d->B, 64, 0, st>>>(pose_args(d), gt72, (long long *)gt_cls2, gt_f_score, selected, partials);
+    k_pose_loss_fwd<<<d->B, PL_TPB, (size_t)d->W * sizeof(float), st>>>(pose_args(d), gt72, (long long *)gt_cls2, gt_f_score, selected, partials);
     const PoseLossLambda lam = {d->lambda_e_gn, d->lambda_h_hrzn, d->lambda_fov, d->lambda_g_trs, d->lambda_g_depth, d->lambda_g_mask};
     k_pose_loss_finish<<<1, 64, 0, st>>>(partials, d->B, lam, l_depth, l_mask, L11, n_selected);
     EFGH_CHECK_LAUNCH();
