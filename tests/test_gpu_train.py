@@ -335,3 +335,30 @@ def test_trainer_resume_and_frozen_set(manifest, tmp_path):
     next(iter(m2.parameters())).requires_grad = False
     with pytest.raises(_C.EfghError):
         tr2.step(*inp, gt)
+
+
+def test_training_step_is_not_torch_glue(manifest):
+    """the training step is the extension's kernels: at most a small, fixed number of aten ops on device tensors per step
+    (skip-connection gradient sums, a few clones / views-made-contiguous); the round-1 step issued ~2800 of them
+    (per-parameter AccumulateGrad copies and adds, per-layer BatchNorm counters, pose / loss tensor expressions)"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tools'))
+    from glue_census import census
+    from efgh_amd.losses import EFGHCriterion
+    from efgh_amd.nets import EFGHBackbone
+    from efgh_amd.train import Trainer
+    args = syn.default_args(RAW, 'cuda')
+    m = EFGHBackbone(args)
+    m.load_state_dict(syn.synthetic_state_dict(manifest['state_dict'], 1))
+    tr = Trainer(m.cuda(), EFGHCriterion(args), lr=1e-4)
+    b = syn.make_batch(RAW, NPTS, 2)
+    inp = [torch.from_numpy(b[k]).cuda().float() for k in ('pc', 'img', 'calib', 'A')]
+    gt = {k: torch.from_numpy(v).cuda() for k, v in b['gt'].items()}
+    for _ in range(2):
+        tr.step(*inp, gt)
+    count = census(lambda: tr.step(*inp, gt))
+    total = sum(count.values())
+    assert total <= 260, (total, count.most_common(12))
+    names = ' '.join(n for _, n in count)
+    assert 'bmm' not in names or count.most_common(1)[0][1] < 60
