@@ -173,6 +173,39 @@ class CamTVeloFn(torch.autograd.Function):
         return gc, gl, None, None
 
 
+def _mat44(a, b, ta=0, tb=0):
+    B = a.shape[0]
+    out = torch.empty((B, 4, 4), dtype=torch.float32, device=a.device)
+    _C.check(_C.lib().efgh_pose_mat44_mul(_C.ptr(a), _C.ptr(b), ctypes.c_int32(B), ctypes.c_int32(ta), ctypes.c_int32(tb),
+                                          _C.ptr(out), _C.stream_ptr()))
+    return out
+
+
+class ComposeFn(torch.autograd.Function):
+    """a @ b for (B,4,4) poses"""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        _C.require_cuda(a, b)
+        a, b = a.contiguous(), b.contiguous()
+        ctx.save_for_backward(a, b)
+        return _mat44(a, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        g = g.contiguous()
+        return (_mat44(g, b, 0, 1) if ctx.needs_input_grad[0] else None,
+                _mat44(a, g, 1, 0) if ctx.needs_input_grad[1] else None)
+
+
+def compose(a, b):
+    """torch.bmm(a, b) for (B,4,4) poses without a library GEMM launch"""
+    if not _fused():
+        return torch.bmm(a, b)
+    return ComposeFn.apply(a, b)
+
+
 def compute_cam_T_velo(c_T, l_T, calib, A):
     """torch_utils.py:256-269"""
     if _fused():

@@ -207,6 +207,21 @@ __global__ void k_cam_T_velo(const float *__restrict__ cT, long long ldc, const 
             out[(long long)b * 12 + i * 4 + j] = (inv[i][0] * m2[0][j] + inv[i][1] * m2[1][j]) + inv[i][2] * m2[2][j];
 }
 
+// out = op(a) op(b) for [B][4][4] matrices (pose accumulation sensor2_T_sensor1 <- f_l sensor2_T_sensor1, fnet.py:101, gnet.py:180)
+__global__ void k_mat44_mul(const float *__restrict__ a, const float *__restrict__ b, int B, int ta, int tb, float *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * 16) return;
+    const int s = i >> 4, r = (i >> 2) & 3, c = i & 3;
+    const float *A = a + s * 16, *Bm = b + s * 16;
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float x = ta ? A[k * 4 + r] : A[r * 4 + k], y = tb ? Bm[c * 4 + k] : Bm[k * 4 + c];
+        acc = k == 0 ? x * y : acc + x * y;
+    }
+    out[i] = acc;
+}
+
 // backward of k_cam_T_velo: out = A^-1 (c_T (P l_T)), P = A calib  ->  g_cT = (A^-T g) (P l_T)^T,  g_lT = P^T c_T^T (A^-T g)
 __global__ void k_cam_T_velo_bwd(const float *__restrict__ cT, long long ldc, const float *__restrict__ lT,
                                  const float *__restrict__ calib, const float *__restrict__ A, const float *__restrict__ g_out,
@@ -623,6 +638,14 @@ extern "C" int efgh_pose_loss_bwd(const efgh_pose_loss_desc *d, const float *g_L
     const PoseLossLambda lam = {d->lambda_e_gn, d->lambda_h_hrzn, d->lambda_fov, d->lambda_g_trs, d->lambda_g_depth, d->lambda_g_mask};
     k_pose_loss_bwd<<<d->B, 64, 0, (hipStream_t)stream_>>>(pose_args(d), lam, g_L11, selected, n_selected, g_e_gn_abs, g_e_gn_sgn,
                                                           g_h_hrzn_abs, g_h_hrzn_sgn, g_f_score, g_g_trs, g_e_l, g_ldepth_lmask);
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}
+
+extern "C" int efgh_pose_mat44_mul(const float *a, const float *b, int32_t B, int32_t transpose_a, int32_t transpose_b, float *out,
+                                   void *stream_) {
+    EFGH_CHECK_ARG(a && b && out && B > 0);
+    k_mat44_mul<<<cdiv((int64_t)B * 16, 64), 64, 0, (hipStream_t)stream_>>>(a, b, B, transpose_a, transpose_b, out);
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
 }

@@ -58,6 +58,6 @@ class Fnet(nn.Module):
         ret = dict(ret)
         ret['f_score'] = f_score
         ret['f_l'] = f_T
-        ret['sensor2_T_sensor1'] = torch.bmm(f_T, ret['sensor2_T_sensor1'])       # :101
+        ret['sensor2_T_sensor1'] = pose.compose(f_T, ret['sensor2_T_sensor1'])       # :101
         ret['network'] = ret['network'] + 'F'
         return ret

@@ -115,7 +115,7 @@ class Gnet(nn.Module):
             keep.update({'f_depth': f_depth})
         ret = dict(ret)
         ret.update({'g_depth': g_depth, 'g_mask': g_mask, 'g_trs': trs, 'g_l': g_T})
-        ret['sensor2_T_sensor1'] = torch.bmm(g_T, ret['sensor2_T_sensor1'])        # :180
+        ret['sensor2_T_sensor1'] = pose.compose(g_T, ret['sensor2_T_sensor1'])        # :180
         ret['network'] = ret['network'] + 'G'
         return ret
 

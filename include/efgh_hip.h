@@ -494,6 +494,8 @@ int efgh_pose_cam_T_velo(const float *c_T, int64_t ldc, const float *l_T, const 
 int efgh_pose_head_normal_bwd(const float *abs_logits, int64_t lda, const float *sgn_logits, int64_t lds, int32_t B, int32_t nd,
                               float dx, float dy, float dz, const float *g_abs, const float *g_normal, const float *g_R44,
                               float *g_abs_logits, void *stream);
+/* out = op(a) op(b), [B][4][4] each, op = transpose when the flag is set (fnet.py:101, gnet.py:180 and their gradients) */
+int efgh_pose_mat44_mul(const float *a, const float *b, int32_t B, int32_t transpose_a, int32_t transpose_b, float *out, void *stream);
 int efgh_pose_rotation_between(const float *src3, int32_t B, float dx, float dy, float dz, float *R44, void *stream);
 int efgh_pose_cam_T_velo_bwd(const float *c_T, int64_t ldc, const float *l_T, const float *calib, const float *A,
                              const float *g_out34, int32_t B, float *g_cT33, float *g_lT44, void *stream);
