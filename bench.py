@@ -31,8 +31,8 @@ PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, de
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=3)
-    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--mode', default='train', choices=['train', 'fwd'])
     ap.add_argument('--batch', type=int, default=None, help='frame-pairs per GPU per step (8 train / 4 fwd)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
