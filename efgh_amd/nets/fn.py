@@ -74,7 +74,7 @@ class GemmLayerFn(torch.autograd.Function):
     """y = act(BN(gemm(x, W) + bias) + residual)   with hand-written backward."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, gamma, beta, residual, spec):
+    def forward(ctx, x, weight, bias, gamma, beta, residual, spec, out_target=None):
         x = as_rows(x)
         dev = x.device
         N, Np = spec.N, ceil4(spec.N)
@@ -145,8 +145,16 @@ class GemmLayerFn(torch.autograd.Function):
                 assert res is None
                 y = ops.maxpool2_affine(raw, scale, shift, spec.act, spec.slope)
             else:
-                y = torch.empty_like(raw)
-                ops.scale_shift_act(raw, Np, scale, shift, y, Np, M, Np, spec.act, spec.slope, res=res,
+                # out_target = (buffer [..][Ct], channel offset): the activation is written straight into that channel slice (the
+                # training-path form of the decoder's torch.cat, see ConcatFn); the returned tensor is a view of the buffer
+                y = None
+                if out_target is not None and Np == N:
+                    tb, toff = out_target
+                    if tuple(tb.shape[:-1]) == tuple(raw.shape[:-1]) and toff % 4 == 0 and toff + N <= tb.shape[-1]:
+                        y = tb[..., toff:toff + N]
+                if y is None:
+                    y = torch.empty_like(raw)
+                ops.scale_shift_act(raw, Np, scale, shift, y, ld_of(y), M, Np, spec.act, spec.slope, res=res,
                                     ldr=0 if res is None else ld_of(res))
         ctx.spec = spec
         ctx.has = (bias is not None, gamma is not None, residual is not None)
@@ -206,7 +214,8 @@ class GemmLayerFn(torch.autograd.Function):
             train_bn = has_bn and spec.train
             m1 = torch.empty(Np, dtype=torch.float64, device=dev) if train_bn else None
             m2 = torch.empty(Np, dtype=torch.float64, device=dev) if train_bn else None
-            ops.act_bn_bwd_reduce(dy, ld_of(dy), ymask, Np, raw, Np, mean if has_bn else None,
+            ldy = Np if ymask is None else ld_of(ymask)
+            ops.act_bn_bwd_reduce(dy, ld_of(dy), ymask, ldy, raw, Np, mean if has_bn else None,
                                   invstd if has_bn else None, M, Np, spec.act, spec.slope, part, s1, s2, m1, m2,
                                   pscale=psc, pshift=psh)
             if has_bn and gs1 is None:
@@ -216,7 +225,7 @@ class GemmLayerFn(torch.autograd.Function):
             draw = torch.empty(tuple(spec.out_shape) + (Np,), dtype=torch.float32, device=dev)
             if has_res:
                 dres = torch.empty(tuple(spec.out_shape) + (Np,), dtype=torch.float32, device=dev)
-            ops.act_bn_bwd_apply(dy, ld_of(dy), ymask, Np, raw, Np, mean if train_bn else None,
+            ops.act_bn_bwd_apply(dy, ld_of(dy), ymask, ldy, raw, Np, mean if train_bn else None,
                                  invstd if train_bn else None, coef, m1, m2, M, Np, spec.act, spec.slope, draw, Np,
                                  dres, Np, pscale=psc, pshift=psh)
             if has_bias and has_bn:          # bias in front of BatchNorm: d/dbias = column sums of draw
@@ -248,10 +257,40 @@ class GemmLayerFn(torch.autograd.Function):
             dres = dres[..., :N]
         for done in delivered:               # after the writes are enqueued: the all-reduce bucket countdown
             done()
-        return dx, dW, dbias, dgamma, dbeta, dres, None
+        return dx, dW, dbias, dgamma, dbeta, dres, None, None
 
 
 # ---------------------------------------------------------------------------------------------
+class ConcatFn(torch.autograd.Function):
+    """torch.cat(parts, -1) of activations that their producers ALREADY wrote into adjacent channel slices of `buf`
+    (GemmLayerFn's out_target): no copy forward, channel-slice views of the gradient backward.  `concat()` falls back to
+    torch.cat when a part lives elsewhere (cropped decoder outputs of odd-height maps, layers without an out_target)."""
+
+    @staticmethod
+    def forward(ctx, buf, *parts):
+        ctx.widths = [p.shape[-1] for p in parts]
+        return buf.view_as(buf)
+
+    @staticmethod
+    def backward(ctx, g):
+        outs, off = [], 0
+        for w in ctx.widths:
+            outs.append(g[..., off:off + w])
+            off += w
+        return (None,) + tuple(outs)
+
+
+def concat(buf, parts):
+    off, ok = 0, buf is not None
+    for p in parts:
+        ok = ok and p.shape[:-1] == buf.shape[:-1] and p.stride() == buf.stride() and \
+            p.data_ptr() == buf.data_ptr() + 4 * off
+        off += p.shape[-1]
+    if ok and off == buf.shape[-1]:
+        return ConcatFn.apply(buf, *parts)
+    return torch.cat(parts, -1)
+
+
 class MaxPool2Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):

@@ -36,15 +36,15 @@ class Gnet(nn.Module):
         B, H, W, _ = x.shape
 
         def buf(h, w, c):
-            return None if ctx.grad else torch.empty((B, h, w, c), dtype=torch.float32, device=dev)
+            return torch.empty((B, h, w, c), dtype=torch.float32, device=dev)
 
         def tgt(b, off):
-            return None if ctx.grad else (b, off)
+            return (b, off)
 
         def cat(b, parts):
-            """torch.cat / concat_tensors of gnet.py:117-121: channel slices of one buffer (inference) or an
-            explicit concatenation (training, so that autograd sees it)"""
-            return torch.cat(parts, -1) if ctx.grad else b
+            """torch.cat / concat_tensors of gnet.py:117-121: channel slices of one buffer the producers wrote into; on the
+            training path an autograd node over the same buffer (FN.concat: no copy when every part already lives in its slice)"""
+            return FN.concat(b, parts) if ctx.grad else b
         # widths must halve exactly three times (the reference's torch.cat fails otherwise, SURVEY 8a-17); heights only need
         # H even: a stride-2 layer gives ceil(h/2) rows, the transposed convolution 2*ceil(h/2), and concat_tensors
         # (common/torch_utils.py:309-319) crops the surplus row: p1 = int((2*ceil(h/2) - h) / 2) = 0, i.e. the first h rows
@@ -65,8 +65,8 @@ class Gnet(nn.Module):
         c1 = L.run_conv_bn_relu(ctx, self.conv_i0, x)                              # gnet.py:103
         c2 = L.run_resnet_layer(ctx, self.conv_img2, c1, out=tgt(cat1, 64))
         if ctx.grad:
-            c3 = L.run_resnet_layer(ctx, self.conv_img3, c2)
-            c4 = L.run_resnet_layer(ctx, self.conv_img4, c3)
+            c3 = L.run_resnet_layer(ctx, self.conv_img3, c2, out=tgt(cat2, 0))
+            c4 = L.run_resnet_layer(ctx, self.conv_img4, c3, out=tgt(cat3, 0))
             c5 = L.run_resnet_layer(ctx, self.conv_img5, c4)
         else:
             c3 = _layer_from_slice(ctx, self.conv_img3, cat1, 64, 64, out=(cat2, 0))
@@ -91,9 +91,9 @@ class Gnet(nn.Module):
             f_depth, _ = ops.depth_image(pc, ret['efh_cam_T_velo'], rawH, rawW)
         cat0 = buf(H, W, 64)                  # [conv_i1 | conv_d1]
         if ctx.grad:
-            ci1 = L.run_conv_bn_relu(ctx, self.conv_i1, t2)
-            cd1 = L.run_conv_bn_relu(ctx, self.conv_d1, f_depth)
-            y = torch.cat([ci1, cd1], -1)
+            ci1 = L.run_conv_bn_relu(ctx, self.conv_i1, t2, out=tgt(cat0, 0))
+            cd1 = L.run_conv_bn_relu(ctx, self.conv_d1, f_depth, out=tgt(cat0, 32))
+            y = FN.concat(cat0, [ci1, cd1])
         else:
             L.run_conv_bn_relu(ctx, self.conv_i1, cat1, out=(cat0, 0), in_ch=(0, 64))
             L.run_conv_bn_relu(ctx, self.conv_d1, f_depth, out=(cat0, 32))

@@ -148,9 +148,9 @@ def conv2d(ctx, x, conv, bn=None, act=ACT_NONE, slope=0.0, residual=None, out=No
     geom = (B, H, W, Ho, Wo, sh, sw, dh, dw, Ho, Wo, 1, 1, 0, 0)
     M = B * Ho * Wo
     if ctx.grad:
-        assert out is None
         xs = x if in_ch is None else x[..., a_off:a_off + Cx]
-        return _conv2d_grad(ctx, xs, conv, bn, act, slope, residual, geom, (B, H, W, Ho, Wo), Cp, passthrough=skip_out, pool=pool)
+        return _conv2d_grad(ctx, xs, conv, bn, act, slope, residual, geom, (B, H, W, Ho, Wo), Cp, passthrough=skip_out, pool=pool,
+                            out=out)
     out_t, ldo, coff = _alloc_out(x, (B, Ho, Wo), O, out)
     res_ld = residual.shape[-1] if residual is not None else 0
     _run(ctx, x, ldx, Cp, T, Wp, O, M, 1, [(geom, Wp, M)], out_t, ldo, coff, conv.bias, bn, act, slope,
@@ -299,13 +299,13 @@ def run_vgg(ctx, features, x):
 
 def run_conv_bn_relu(ctx, seq, x, out=None, in_ch=None):
     """nets/net_utils.py:45-64: Conv2d(no bias) + BN + LeakyReLU(0.2)."""
-    return conv2d(ctx, x, seq[0], seq[1], ACT_LEAKY, 0.2, out=None if ctx.grad else out, in_ch=in_ch)
+    return conv2d(ctx, x, seq[0], seq[1], ACT_LEAKY, 0.2, out=out, in_ch=in_ch)
 
 
 def run_convt_bn_relu(ctx, seq, x, out=None):
     """nets/net_utils.py:66-98: ConvT+BN+LeakyReLU(0.2) then Conv3x3+BN+LeakyReLU(0.2)."""
     y = conv_transpose2d(ctx, x, seq[0], seq[1], ACT_LEAKY, 0.2)
-    return conv2d(ctx, y, seq[3], seq[4], ACT_LEAKY, 0.2, out=None if ctx.grad else out)
+    return conv2d(ctx, y, seq[3], seq[4], ACT_LEAKY, 0.2, out=out)
 
 
 def run_basic_block(ctx, blk, x, out=None):
@@ -317,7 +317,7 @@ def run_basic_block(ctx, blk, x, out=None):
     else:
         y = conv2d(ctx, x, blk.conv1, blk.bn1, ACT_RELU)
         idt = conv2d(ctx, x, blk.downsample[0], blk.downsample[1], ACT_NONE) if blk.downsample is not None else x
-    return conv2d(ctx, y, blk.conv2, blk.bn2, ACT_RELU, residual=idt, out=None if ctx.grad else out)
+    return conv2d(ctx, y, blk.conv2, blk.bn2, ACT_RELU, residual=idt, out=out)
 
 
 def run_resnet_layer(ctx, layer, x, out=None):
@@ -334,7 +334,7 @@ def _bn_args(bn):
     return (None, None) if bn is None else (bn.weight, bn.bias)
 
 
-def _conv2d_grad(ctx, x, conv, bn, act, slope, residual, geom, dims, Cp, passthrough=False, pool=False):
+def _conv2d_grad(ctx, x, conv, bn, act, slope, residual, geom, dims, Cp, passthrough=False, pool=False, out=None):
     B, H, W, Ho, Wo = dims
     Cw, O = conv.in_channels, conv.out_channels
     kh, kw = conv.kernel_size
@@ -391,7 +391,7 @@ def _conv2d_grad(ctx, x, conv, bn, act, slope, residual, geom, dims, Cp, passthr
                         bn=bn, train=ctx.train, act=act, slope=slope, c_real=Cw,
                         passthrough=passthrough and x.requires_grad and x.shape[-1] == Cp, pool=pool)
     g_, b_ = _bn_args(bn)
-    out = FN.GemmLayerFn.apply(x, conv.weight, conv.bias, g_, b_, residual, spec)
+    out = FN.GemmLayerFn.apply(x, conv.weight, conv.bias, g_, b_, residual, spec, out)
     if passthrough and not spec.passthrough:
         return out, x
     return out
