@@ -30,7 +30,8 @@ struct WArgs {
     const float *G; int64_t ldg;     // upstream gradient rows [orow][ldg], first N used
     int N;
     long long M; int mchunk;
-    float *dW;                       // [N][K], pre-zeroed
+    float *dW;                       // [N][K] (one row chunk only) or the partial planes [zs][nbatch][N][K] (zstride apart)
+    long long zstride;
     unsigned kt, nt;
     long long bsA, bsG, bsD;         // batched launch (gridDim.y): element strides of A, G, dW per batch entry
 };
@@ -58,6 +59,7 @@ k_gather_wgrad(const WArgs p0) {
     long long mend = mbeg + p.mchunk;
     if (mend > p.M) mend = p.M;
     if (mbeg >= mend) return;
+    p.dW += (long long)bz * p.zstride;           // this row chunk's partial plane (combined in a fixed order by k_fold_splits)
 
     // staging: thread -> rows (tid>>5) + 8q, columns (tid&31)*4 .. +3
     const int r0 = tid >> 5, c4 = (tid & 31) * 4;
@@ -170,9 +172,42 @@ k_gather_wgrad(const WArgs p0) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int n = n0 + (wn * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (n < p.N) atomicAdd(&p.dW[(long long)n * p.K + k], acc[i][j][r]);
+                if (n < p.N) p.dW[(long long)n * p.K + k] = acc[i][j][r];
             }
         }
+}
+
+// dst[i] = sum_z part[z][i]: the row-chunk partials of a weight gradient combined in a FIXED order (round 1 used fp32 atomics on a
+// zeroed buffer: run-to-run different sums).  The planes are small (N*K floats) and there can be hundreds of them, so the sum over
+// z is itself spread over 16 lanes per element: lane l adds planes l, l+16, ... in order, an LDS tree (fixed shape) adds the lanes.
+// dst may be plane 0 of `part` (every element is read and written by one workgroup only, reads before the barrier).
+__global__ void __launch_bounds__(256) k_fold_splits(const float4 *part, int zs, long long total4, float4 *dst) {
+    __shared__ float4 red[256];
+    const int e = threadIdx.x & 15, zl = threadIdx.x >> 4;
+    const long long i = (long long)blockIdx.x * 16 + e;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+    if (i < total4) {
+        int z = zl;
+        for (; z + 16 < zs; z += 32) {
+            const float4 u = part[(long long)z * total4 + i], v = part[(long long)(z + 16) * total4 + i];
+            a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+            b.x += v.x; b.y += v.y; b.z += v.z; b.w += v.w;
+        }
+        if (z < zs) { const float4 u = part[(long long)z * total4 + i]; a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w; }
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (int h = 8; h; h >>= 1) {
+        if (zl < h) {
+            const float4 o = red[threadIdx.x + h * 16];
+            float4 m = red[threadIdx.x];
+            m.x += o.x; m.y += o.y; m.z += o.z; m.w += o.w;
+            red[threadIdx.x] = m;
+        }
+        __syncthreads();
+    }
+    if (zl == 0 && i < total4) dst[i] = red[e];
 }
 
 // W.flat[n*sn + c*sc + tap[t]*st] = Wp[n][t][c]   (inverse of k_pack_weight; Wp may be padded to ldn/ldc)
@@ -214,29 +249,58 @@ k_table_scatter_add(const float *__restrict__ src, const int *__restrict__ table
 
 }  // namespace
 
-static int gather_wgrad_impl(const efgh_gemm_desc *d, const float *G, int64_t ldg, float *dWp, int nbatch, int64_t bsG,
-                             int64_t bsD, void *stream_);
+// (also used by efgh_wino_wgrad, wino.hip)
+void efgh_launch_fold_splits(const float *part, int zs, long long total, float *dst, hipStream_t st) {
+    const long long total4 = total / 4;
+    k_fold_splits<<<(unsigned)((total4 + 15) / 16), 256, 0, st>>>((const float4 *)part, zs, total4, (float4 *)dst);
+}
 
-extern "C" int efgh_gather_wgrad(const efgh_gemm_desc *d, const float *G, int64_t ldg, float *dWp, void *stream_) {
-    return gather_wgrad_impl(d, G, ldg, dWp, 1, 0, 0, stream_);
+static int gather_wgrad_impl(const efgh_gemm_desc *d, const float *G, int64_t ldg, float *dWp, float *workspace, int nbatch,
+                             int64_t bsG, int64_t bsD, void *stream_);
+
+// the rows m are cut into `zs` chunks so that the grid has ~2048+ workgroups; chunks are multiples of TM
+static long long wgrad_chunks(const efgh_gemm_desc *d, int nbatch, long long *chunk_out) {
+    const int K = d->T * d->C;
+    const int TN = d->N <= 64 ? 64 : 128;
+    const long long kt = (K + TK - 1) / TK, nt = (d->N + TN - 1) / TN;
+    long long want = 2048 / (kt * nt * nbatch);
+    if (want < 1) want = 1;
+    long long chunk = (d->M + want - 1) / want;
+    chunk = (chunk + TM - 1) / TM * TM;
+    if (chunk < 256) chunk = 256;
+    if (chunk_out) *chunk_out = chunk;
+    return (d->M + chunk - 1) / chunk;
+}
+
+/* floats of scratch efgh_gather_wgrad(_batched) needs for this problem (0: a single row chunk writes dWp directly) */
+extern "C" int64_t efgh_gather_wgrad_workspace(const efgh_gemm_desc *d) {
+    if (!d || d->C <= 0 || d->T < 1 || d->N < 1 || d->M < 1) return 0;
+    const int nbatch = d->nbatch > 1 ? d->nbatch : 1;
+    const long long zs = wgrad_chunks(d, nbatch, nullptr);
+    return zs > 1 ? zs * nbatch * (int64_t)d->N * d->T * d->C : 0;
+}
+
+extern "C" int efgh_gather_wgrad(const efgh_gemm_desc *d, const float *G, int64_t ldg, float *dWp, float *workspace,
+                                 void *stream_) {
+    return gather_wgrad_impl(d, G, ldg, dWp, workspace, 1, 0, 0, stream_);
 }
 
 /* the same contraction for d->nbatch independent problems in ONE launch (mode 0): problem b reads A + b*d->batch_stride_a and
  * G + b*batch_stride_g and writes dWp + b*batch_stride_dw  (the 36 alpha planes of the 2-D Winograd weight gradient) */
 extern "C" int efgh_gather_wgrad_batched(const efgh_gemm_desc *d, const float *G, int64_t ldg, int64_t batch_stride_g,
-                                         float *dWp, int64_t batch_stride_dw, void *stream_) {
+                                         float *dWp, int64_t batch_stride_dw, float *workspace, void *stream_) {
     EFGH_CHECK_ARG(d && d->mode == 0 && d->nbatch >= 1 && d->nbatch <= 65535);
     EFGH_CHECK_ARG(d->batch_stride_a % 4 == 0 && batch_stride_g % 4 == 0 && batch_stride_dw == (int64_t)d->N * d->C);
-    return gather_wgrad_impl(d, G, ldg, dWp, d->nbatch, batch_stride_g, batch_stride_dw, stream_);
+    return gather_wgrad_impl(d, G, ldg, dWp, workspace, d->nbatch, batch_stride_g, batch_stride_dw, stream_);
 }
 
-static int gather_wgrad_impl(const efgh_gemm_desc *d, const float *G, int64_t ldg, float *dWp, int nbatch, int64_t bsG,
-                             int64_t bsD, void *stream_) {
+static int gather_wgrad_impl(const efgh_gemm_desc *d, const float *G, int64_t ldg, float *dWp, float *workspace, int nbatch,
+                             int64_t bsG, int64_t bsD, void *stream_) {
     hipStream_t st = (hipStream_t)stream_;
     EFGH_CHECK_ARG(d && d->A && G && dWp);
     EFGH_CHECK_ARG(d->C > 0 && d->C % 4 == 0 && d->T >= 1 && d->T <= 16 && d->N >= 1 && d->M >= 1);
     EFGH_CHECK_ARG(d->lda % 4 == 0 && ldg % 4 == 0 && d->N % 4 == 0);
-    EFGH_CHECK_ARG((((uintptr_t)d->A) & 15) == 0 && (((uintptr_t)G) & 15) == 0);
+    EFGH_CHECK_ARG((((uintptr_t)d->A) & 15) == 0 && (((uintptr_t)G) & 15) == 0 && (((uintptr_t)dWp) & 15) == 0);
     EFGH_CHECK_ARG((int64_t)d->T * d->C < 65536 && d->mode >= 0 && d->mode <= 2);
     WArgs a;
     a.A = d->A; a.lda = d->lda; a.C = d->C; a.T = d->T; a.K = d->T * d->C;
@@ -249,26 +313,23 @@ static int gather_wgrad_impl(const efgh_gemm_desc *d, const float *G, int64_t ld
         a.dwpack |= (unsigned long long)((dw + 8) & 15) << (4 * t);
     }
     a.Ho = d->Ho; a.Wo = d->Wo; a.osh = d->osh; a.osw = d->osw; a.oh0 = d->oh0; a.ow0 = d->ow0;
-    a.table = d->table; a.G = G; a.ldg = ldg; a.N = d->N; a.M = d->M; a.dW = dWp;
+    a.table = d->table; a.G = G; a.ldg = ldg; a.N = d->N; a.M = d->M;
     a.bsA = nbatch > 1 ? d->batch_stride_a : 0; a.bsG = bsG; a.bsD = bsD;
     if (d->mode == 1) EFGH_CHECK_ARG(d->M == (int64_t)d->B * d->Hv * d->Wv && d->osh >= 1 && d->osw >= 1);
     if (d->mode == 2) EFGH_CHECK_ARG(d->table != nullptr);
     const int TN = a.N <= 64 ? 64 : 128;
     const int kt = (a.K + TK - 1) / TK, nt = (a.N + TN - 1) / TN;
-    // split m so that the grid has ~2048+ blocks, chunks are multiples of TM
-    long long want = 2048 / ((long long)kt * nt * nbatch);
-    if (want < 1) want = 1;
-    long long chunk = (d->M + want - 1) / want;
-    chunk = (chunk + TM - 1) / TM * TM;
-    if (chunk < 256) chunk = 256;
+    long long chunk = 0;
+    const long long zs = wgrad_chunks(d, nbatch, &chunk);
     a.mchunk = (int)chunk;
-    long long zs = (d->M + chunk - 1) / chunk;
     EFGH_CHECK_ARG(zs * kt * nt < 0x7fffffffLL);
     a.kt = (unsigned)kt; a.nt = (unsigned)nt;
-    if (hipMemsetAsync(dWp, 0, (size_t)a.N * a.K * 4 * nbatch, st) != hipSuccess) {
-        efgh_set_error("wgrad: memset failed");
-        return EFGH_E_LAUNCH;
-    }
+    // every row chunk writes its own [nbatch][N][K] plane with plain stores (each element of a plane is written by exactly one
+    // workgroup); k_fold_splits then adds the planes in chunk order: no memset, no atomics, bit-reproducible
+    const long long plane = (long long)nbatch * a.N * a.K;
+    EFGH_CHECK_ARG(zs == 1 || (workspace && (((uintptr_t)workspace) & 15) == 0));
+    a.dW = zs > 1 ? workspace : dWp;
+    a.zstride = zs > 1 ? plane : 0;
     const dim3 grid((unsigned)(zs * kt * nt), (unsigned)nbatch);
     if (TN == 128) {
         if (d->mode == 0) k_gather_wgrad<0, 128><<<grid, 256, 0, st>>>(a);
@@ -278,6 +339,10 @@ static int gather_wgrad_impl(const efgh_gemm_desc *d, const float *G, int64_t ld
         if (d->mode == 0) k_gather_wgrad<0, 64><<<grid, 256, 0, st>>>(a);
         else if (d->mode == 1) k_gather_wgrad<1, 64><<<grid, 256, 0, st>>>(a);
         else k_gather_wgrad<2, 64><<<grid, 256, 0, st>>>(a);
+    }
+    if (zs > 1) {
+        const long long total4 = plane / 4;           // N % 4 == 0
+        k_fold_splits<<<(unsigned)((total4 + 15) / 16), 256, 0, st>>>((const float4 *)workspace, (int)zs, total4, (float4 *)dWp);
     }
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;

@@ -19,6 +19,8 @@
 // activation, per-tile column statistics).
 #include "common.h"
 
+void efgh_launch_fold_splits(const float *part, int zs, long long total, float *dst, hipStream_t st);   // wgrad.hip
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -265,7 +267,7 @@ struct WinoWArgs {
     const float *G; long long ldg; int N;
     int B, H, W, TW;
     long long Mt; long long tchunk;
-    float *S;                      // [6][N][3C], pre-zeroed
+    float *S;                      // [zs][6][N][3C]: one partial per tile range (plain stores; folded by k_wino_wgrad_finish)
     unsigned kt, nt;               // column / row blocks of S
 };
 
@@ -398,23 +400,26 @@ __global__ void __launch_bounds__(256, 2) k_wino_wgrad(const WinoWArgs p) {
     const long long K3 = 3LL * p.C;
 #pragma unroll
     for (int a = 0; a < 6; ++a) {
-        float *sa = p.S + ((long long)a * p.N + n0 + wn * 32) * K3 + k0 + wc * 32 + l31;
+        float *sa = p.S + (((long long)bz * 6 + a) * p.N + n0 + wn * 32) * K3 + k0 + wc * 32 + l31;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int nl = (r & 3) + 8 * (r >> 2) + 4 * lh;
-            atomicAdd(sa + nl * K3, acc[a][r]);
+            sa[nl * K3] = acc[a][r];
         }
     }
 }
 
 // dWp[n][kh*3 + kw][c] = sum_alpha A3^T[kw][alpha] * S[alpha][n][kh*C + c]
-__global__ void k_wino_wgrad_finish(const float *__restrict__ S, float *__restrict__ dWp, int N, int C) {
+__global__ void k_wino_wgrad_finish(const float *__restrict__ S, int zs, float *__restrict__ dWp, int N, int C) {
     const long long K3 = 3LL * C, total = (long long)N * K3, plane = total;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int kc = (int)(i % K3); const long long n = i / K3;
         const int kh = kc / C, c = kc - kh * C;
-        const float s0 = S[i], s1 = S[plane + i], s2 = S[2 * plane + i], s3 = S[3 * plane + i], s4 = S[4 * plane + i],
-                    s5 = S[5 * plane + i];
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f;
+        for (int z = 0; z < zs; ++z) {                  // the tile ranges in order: a fixed summation order
+            const float *Sz = S + (long long)z * 6 * plane + i;
+            s0 += Sz[0]; s1 += Sz[plane]; s2 += Sz[2 * plane]; s3 += Sz[3 * plane]; s4 += Sz[4 * plane]; s5 += Sz[5 * plane];
+        }
         float *o = dWp + (n * 9 + kh * 3) * C + c;
         o[0] = s0 + s1 + s2 + s3 + s4;
         o[C] = (s1 - s2) + 2.f * (s3 - s4);
@@ -470,6 +475,24 @@ extern "C" int efgh_wino_wgrad_supported(const efgh_gemm_desc *d) {
     return (supported(d) && d->C % 64 == 0) ? 1 : 0;
 }
 
+static long long wino_wgrad_ranges(const efgh_gemm_desc *d, long long *chunk_out) {
+    const long long Mt = (long long)d->B * d->Hin * ((d->Win + 3) / 4);
+    const int kt = 3 * d->C / 64, nt = d->N / 64;
+    long long want = 1536 / (kt * nt);                 // ~3 workgroups per CU-slot pair
+    if (want < 1) want = 1;
+    long long chunk = (Mt + want - 1) / want;
+    chunk = (chunk + TT - 1) / TT * TT;
+    if (chunk < 8 * TT) chunk = 8 * TT;
+    if (chunk_out) *chunk_out = chunk;
+    return (Mt + chunk - 1) / chunk;
+}
+
+/* floats of scratch `S` efgh_wino_wgrad needs: one [6][N][3C] partial per tile range */
+extern "C" int64_t efgh_wino_wgrad_workspace(const efgh_gemm_desc *d) {
+    if (!supported(d) || d->C % 64 != 0 || d->B <= 0) return 0;
+    return wino_wgrad_ranges(d, nullptr) * 6 * (int64_t)d->N * 3 * d->C;
+}
+
 extern "C" int efgh_wino_wgrad(const efgh_gemm_desc *d, const float *G, int64_t ldg, float *S, float *dWp,
                                void *stream_) {
     hipStream_t st = (hipStream_t)stream_;
@@ -482,25 +505,17 @@ extern "C" int efgh_wino_wgrad(const efgh_gemm_desc *d, const float *G, int64_t 
     a.Mt = (long long)d->B * d->Hin * a.TW;
     a.S = S;
     const int kt = 3 * d->C / 64, nt = d->N / 64;
-    long long want = 1536 / (kt * nt);                 // ~3 workgroups per CU-slot pair
-    if (want < 1) want = 1;
-    long long chunk = (a.Mt + want - 1) / want;
-    chunk = (chunk + TT - 1) / TT * TT;
-    if (chunk < 8 * TT) chunk = 8 * TT;
+    long long chunk = 0;
+    const long long zs = wino_wgrad_ranges(d, &chunk);
     a.tchunk = chunk;
-    const long long zs = (a.Mt + chunk - 1) / chunk;
     EFGH_CHECK_ARG(zs * kt * nt < 0x7fffffffLL);
     a.kt = (unsigned)kt; a.nt = (unsigned)nt;
-    const size_t sbytes = (size_t)6 * d->N * 3 * d->C * 4;
-    if (hipMemsetAsync(S, 0, sbytes, st) != hipSuccess) {
-        efgh_set_error("wino wgrad: memset failed");
-        return EFGH_E_LAUNCH;
-    }
     k_wino_wgrad<<<(unsigned)(zs * kt * nt), 256, 0, st>>>(a);
     EFGH_CHECK_LAUNCH();
+    if (zs > 1) efgh_launch_fold_splits(S, (int)zs, 6LL * d->N * 3 * d->C, S, st);      // into the first partial, fixed order
     const long long total = (long long)d->N * 3 * d->C;
     long long g = (total + 255) / 256;
-    k_wino_wgrad_finish<<<(int)(g > 4096 ? 4096 : g), 256, 0, st>>>(S, dWp, d->N, d->C);
+    k_wino_wgrad_finish<<<(int)(g > 4096 ? 4096 : g), 256, 0, st>>>(S, 1, dWp, d->N, d->C);
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
 }

@@ -592,6 +592,23 @@ PROFILE_THIN = None
 USE_WINO_WGRAD = _os.environ.get('EFGH_WINO_WGRAD', '1') != '0'
 
 
+_SCRATCH = {}
+DETERMINISTIC = _os.environ.get('EFGH_DETERMINISTIC', '0') == '1'
+
+
+def _scratch(nfloats, device):
+    """transient fp32 workspace (row-chunk partials of a weight gradient), grown on demand and shared by all launches of a
+    stream: a partial plane set is written and folded by consecutive launches of ONE C-ABI call on the current stream"""
+    nfloats = int(nfloats)
+    if nfloats <= 0:
+        return None
+    key = (str(device), torch.cuda.current_stream().cuda_stream)
+    t = _SCRATCH.get(key)
+    if t is None or t.numel() < nfloats:
+        t = _SCRATCH[key] = torch.empty(max(nfloats, 1 << 22), dtype=torch.float32, device=device)
+    return t
+
+
 def gather_wgrad(A, lda, C, T, N, M, G, ldg, dWp, mode=0, geom=None, table=None):
     if PROFILE_WGRAD is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -605,11 +622,14 @@ def gather_wgrad(A, lda, C, T, N, M, G, ldg, dWp, mode=0, geom=None, table=None)
             d.dh[i], d.dw[i] = a, b
     d.table = 0 if table is None else table.data_ptr()
     d.N, d.M = N, M
-    thin = thin_eligible(mode, C, N, T) and (N == 4 or T in (1, 2, 4, 9))
+    # EFGH_DETERMINISTIC=1: the handful of layers whose weight gradient still combines partial sums with fp32 atomics (4-channel
+    # input convolutions, 1-/2-channel heads: 5 of 353 parameters) go through the generic kernel, whose row-chunk partials are
+    # added in a fixed order - every gradient of a training step is then bit-reproducible run to run
+    thin = thin_eligible(mode, C, N, T) and (N == 4 or T in (1, 2, 4, 9)) and not DETERMINISTIC
     wino = False
     if thin:
         _C.check(_L().efgh_thin_wgrad(ctypes.byref(d), ptr(G), c_int64(ldg), ptr(dWp), _st()))
-    elif c4_eligible(mode, C, N, geom, wgrad=True):
+    elif not DETERMINISTIC and c4_eligible(mode, C, N, geom, wgrad=True):
         thin = True             # (profile lists, as above)
         _C.check(_L().efgh_c4_wgrad(ctypes.byref(d), ptr(G), c_int64(ldg), ptr(dWp), _st()))
     elif USE_WINO_WGRAD and wino2d_eligible(mode, C, N, geom, wgrad=True):
@@ -619,7 +639,7 @@ def gather_wgrad(A, lda, C, T, N, M, G, ldg, dWp, mode=0, geom=None, table=None)
         dev = dWp.device
         kept = W2V_CACHE.pop((A.data_ptr(), lda, C, B, H, W), None)
         Gy = torch.empty((T2, 36, N), dtype=torch.float32, device=dev)
-        S = torch.empty((36, N, C), dtype=torch.float32, device=dev)               # zeroed by the C-ABI call
+        S = torch.empty((36, N, C), dtype=torch.float32, device=dev)
         if kept is not None and kept[1] == A._version and kept[0].shape == (T2, 36, C):
             V = kept[0]                                                            # B^T x B from the forward pass
         else:
@@ -633,17 +653,18 @@ def gather_wgrad(A, lda, C, T, N, M, G, ldg, dWp, mode=0, geom=None, table=None)
             f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             f0.record()
         _C.check(_L().efgh_gather_wgrad_batched(ctypes.byref(g), ptr(Gy), c_int64(36 * N), c_int64(N), ptr(S), c_int64(N * C),
-                                                _st()))
+                                                ptr(_scratch(_L().efgh_gather_wgrad_workspace(ctypes.byref(g)), dev)), _st()))
         if PROFILE_WINO2D_GEMM is not None:
             f1.record()
             PROFILE_WINO2D_GEMM.append((f0, f1, 2.0 * 36 * T2 * C * N, (0, T2, N, 36, C)))
         _C.check(_L().efgh_wino2d_wfinish(ptr(S), ptr(dWp), c_int32(N), c_int32(C), _st()))
     elif USE_WINO_WGRAD and C % 64 == 0 and wino_eligible(mode, C, N, geom):
         wino = True
-        S = torch.empty((6, N, 3 * C), dtype=torch.float32, device=dWp.device)       # zeroed by the C-ABI call
+        S = _scratch(_L().efgh_wino_wgrad_workspace(ctypes.byref(d)), dWp.device)    # per-tile-range partials
         _C.check(_L().efgh_wino_wgrad(ctypes.byref(d), ptr(G), c_int64(ldg), ptr(S), ptr(dWp), _st()))
     else:
-        _C.check(_L().efgh_gather_wgrad(ctypes.byref(d), ptr(G), c_int64(ldg), ptr(dWp), _st()))
+        _C.check(_L().efgh_gather_wgrad(ctypes.byref(d), ptr(G), c_int64(ldg), ptr(dWp),
+                                        ptr(_scratch(_L().efgh_gather_wgrad_workspace(ctypes.byref(d)), dWp.device)), _st()))
     if PROFILE_WGRAD is not None and thin:
         e1.record()
         if PROFILE_THIN is not None:

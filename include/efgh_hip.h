@@ -237,12 +237,17 @@ int efgh_corr1d(const float *rp, const float *cam, const float *cam_mm, int32_t 
 
 /* weight gradient in the packed layout: dWp[n][t*C+c] = sum_m G[orow(m)][n] * A[row(m,t)][c];
  * `d` describes the SAME gather as the forward launch (A, lda, C, T, mode, geometry/table, N, M);
- * G is the gradient w.r.t. the (pre-BatchNorm) GEMM output, rows addressed like `out`.         */
-int efgh_gather_wgrad(const efgh_gemm_desc *d, const float *G, int64_t ldg, float *dWp, void *stream);
+ * G is the gradient w.r.t. the (pre-BatchNorm) GEMM output, rows addressed like `out`.
+ * The rows m are cut into chunks (one workgroup row per chunk); every chunk writes its own partial [N][K] plane into
+ * `workspace` with plain stores and the planes are then added in chunk order: no atomics, no memset, the result is
+ * bit-reproducible run to run.  efgh_gather_wgrad_workspace(d) = floats of `workspace` needed (0: a single chunk writes dWp
+ * directly and `workspace` may be NULL); for the batched form set d->nbatch before asking.                               */
+int64_t efgh_gather_wgrad_workspace(const efgh_gemm_desc *d);
+int efgh_gather_wgrad(const efgh_gemm_desc *d, const float *G, int64_t ldg, float *dWp, float *workspace, void *stream);
 /* the same contraction for d->nbatch independent problems in ONE launch (mode 0 only): problem b reads A + b*d->batch_stride_a
  * and G + b*batch_stride_g and writes dWp + b*batch_stride_dw (= N*C) */
 int efgh_gather_wgrad_batched(const efgh_gemm_desc *d, const float *G, int64_t ldg, int64_t batch_stride_g, float *dWp,
-                              int64_t batch_stride_dw, void *stream);
+                              int64_t batch_stride_dw, float *workspace, void *stream);
 
 /* ------------------------------------------------------------------ Winograd F(4x4,3x3) --------
  * the 3x3 / stride 1 / pad 1 convolutions with >= 128 channels (nets/vgg.py:77, nets/resnet.py:22-30), their data and weight
@@ -399,9 +404,11 @@ int32_t efgh_wino_grid_m(int32_t B, int32_t H, int32_t W);
 int efgh_wino_pack(const float *Wp, float *U, int32_t N, int32_t C, void *stream);
 int efgh_wino_conv3x3(const efgh_gemm_desc *d, const float *U, void *stream);
 /* weight gradient of the same layers (replaces efgh_gather_wgrad for them; additionally C % 64 == 0): Winograd
- * F(3,4) over 4-pixel gradient tiles, six tile-contracted GEMMs accumulated into the scratch S [6][N][3C]
- * (zeroed here) with fp32 atomics, then folded into the packed dWp [N][9][C].                              */
+ * F(3,4) over 4-pixel gradient tiles, six tile-contracted GEMMs per tile range written as partials [6][N][3C] into the
+ * scratch S (efgh_wino_wgrad_workspace(d) floats; plain stores), then added in range order and folded into the packed
+ * dWp [N][9][C]: bit-reproducible.                                                                          */
 int efgh_wino_wgrad_supported(const efgh_gemm_desc *d);
+int64_t efgh_wino_wgrad_workspace(const efgh_gemm_desc *d);
 int efgh_wino_wgrad(const efgh_gemm_desc *d, const float *G, int64_t ldg, float *S, float *dWp, void *stream);
 
 /* ------------------------------------------------------------------ sample preparation --
