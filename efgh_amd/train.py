@@ -23,13 +23,12 @@ class FlatParams:
         ps = [p for p in model.parameters() if p.requires_grad]
         dev, n = ps[0].device, sum(p.numel() for p in ps)
         self.n = n
-        self.w = torch.empty(n, dtype=torch.float32, device=dev)
+        self.w = torch.cat([p.data.reshape(-1).float() for p in ps])          # (one launch, not one copy per parameter)
         self.g = torch.zeros(n, dtype=torch.float32, device=dev)
         self.offsets = []
         off = 0
         for p in ps:
             k = p.numel()
-            self.w[off:off + k].copy_(p.data.reshape(-1))
             p.data = self.w[off:off + k].view(p.shape)
             p.grad = self.g[off:off + k].view(p.shape)
             self.offsets.append((off, k))
