@@ -91,6 +91,7 @@ class GemmLayerFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, gamma, beta, residual, spec, out_target=None):
+        ctx.set_materialize_grads(False)      # an unused passthrough alias must arrive as None, not as a zero tensor to add
         x = as_rows(x)
         dev = x.device
         N, Np = spec.N, ceil4(spec.N)
@@ -186,6 +187,8 @@ class GemmLayerFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, dskip=None):
         spec = ctx.spec
+        if dy is None:                        # (only the alias was used downstream)
+            dy = torch.zeros(tuple(spec.out_shape) + (ceil4(spec.N),), dtype=torch.float32, device=ctx.saved_tensors[0].device)
         x, weight, y, raw, mean, invstd, coef, psc, psh = ctx.saved_tensors
         ymask = None if psc is not None else y
         has_bias, has_bn, has_res = ctx.has

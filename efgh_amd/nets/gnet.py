@@ -59,15 +59,23 @@ class Gnet(nn.Module):
             if not ctx.grad:
                 b[..., off:off + t.shape[-1]].copy_(t)
             return t
+        cat0_box = []
+
+        def cat0_early():
+            if not cat0_box:
+                cat0_box.append(buf(H, W, 64))
+            return cat0_box[0]
         cat3 = buf(h3, W // 4, 512)           # [conv_img4 | convt_img4]
         cat2 = buf(h2, W // 2, 256)           # [conv_img3 | convt_img3]
         cat1 = buf(H, W, 128)                 # [convt_img2 | conv_img2]
         c1 = L.run_conv_bn_relu(ctx, self.conv_i0, x)                              # gnet.py:103
         c2 = L.run_resnet_layer(ctx, self.conv_img2, c1, out=tgt(cat1, 64))
         if ctx.grad:
-            c3 = L.run_resnet_layer(ctx, self.conv_img3, c2, out=tgt(cat2, 0))
-            c4 = L.run_resnet_layer(ctx, self.conv_img4, c3, out=tgt(cat3, 0))
-            c5 = L.run_resnet_layer(ctx, self.conv_img5, c4)
+            # c2 / c3 / c4 each feed the next encoder layer AND a decoder concatenation: the concatenation takes the alias the
+            # encoder layer hands out, so the two gradients meet in a dgrad epilogue (L.run_basic_block)
+            c3, c2 = L.run_resnet_layer(ctx, self.conv_img3, c2, out=tgt(cat2, 0), alias_in=True)
+            c4, c3 = L.run_resnet_layer(ctx, self.conv_img4, c3, out=tgt(cat3, 0), alias_in=True)
+            c5, c4 = L.run_resnet_layer(ctx, self.conv_img5, c4, alias_in=True)
         else:
             c3 = _layer_from_slice(ctx, self.conv_img3, cat1, 64, 64, out=(cat2, 0))
             c4 = _layer_from_slice(ctx, self.conv_img4, cat2, 0, 128, out=(cat3, 0))
@@ -77,8 +85,11 @@ class Gnet(nn.Module):
         t3 = L.run_convt_bn_relu(ctx, self.convt_img3, cat(cat3, [c4, t4]), out=tgt(cat2, 128) if 2 * h3 == h2 else None)
         t3 = crop(t3, h2, cat2, 128)
         t2 = L.run_convt_bn_relu(ctx, self.convt_img2, cat(cat2, [c3, t3]), out=tgt(cat1, 0))
+        ci1 = None
+        if ctx.grad:                          # t2 feeds conv_i1 (below) and the concatenation: same chaining
+            ci1, t2 = L.run_conv_bn_relu(ctx, self.conv_i1, t2, out=tgt(cat0_early(), 0), skip_out=True)
         cv = cat(cat1, [t2, c2])
-        dimg = L.run_convt_bn_relu(ctx, self.convt_dimg, cv)                       # (B,2H,2W,4) ch0
+        dimg, cv = L.run_convt_bn_relu(ctx, self.convt_dimg, cv, skip_out=True)    # (B,2H,2W,4) ch0
         mask = L.run_convt_bn_relu(ctx, self.convt_mask, cv)                       # (B,2H,2W,4) ch0,1
         rawH, rawW = self.raw_cam_img_size
         if ctx.grad:
@@ -89,9 +100,8 @@ class Gnet(nn.Module):
             g_depth = ops.nhwc_to_nchw(dimg, 1)
             g_mask = ops.softmax2_to_nchw(mask)
             f_depth, _ = ops.depth_image(pc, ret['efh_cam_T_velo'], rawH, rawW)
-        cat0 = buf(H, W, 64)                  # [conv_i1 | conv_d1]
+        cat0 = cat0_early()                   # [conv_i1 | conv_d1]
         if ctx.grad:
-            ci1 = L.run_conv_bn_relu(ctx, self.conv_i1, t2, out=tgt(cat0, 0))
             cd1 = L.run_conv_bn_relu(ctx, self.conv_d1, f_depth, out=tgt(cat0, 32))
             y = FN.concat(cat0, [ci1, cd1])
         else:

@@ -183,7 +183,7 @@ def _convt_small_forward(x, convt, out_raw, scale=None, shift=None, act=ACT_NONE
     ops.convt_col2im(Y, B, H, W, Ho, Wo, O, convt.padding[0], scale, shift, act, slope, out_raw)
 
 
-def conv_transpose2d(ctx, x, convt, bn=None, act=ACT_NONE, slope=0.0, out=None):
+def conv_transpose2d(ctx, x, convt, bn=None, act=ACT_NONE, slope=0.0, out=None, skip_out=False):
     """nn.ConvTranspose2d(k=3, s=2) as four stride-1 sub-convolutions, one per output parity class
     (or, for <= 2 output channels, as ONE GEMM over the input pixels + a col2im fold)."""
     B, H, W, ldx = x.shape
@@ -224,7 +224,7 @@ def conv_transpose2d(ctx, x, convt, bn=None, act=ACT_NONE, slope=0.0, out=None):
             geoms.append((geom, Wp, B * Hv * Wv, tapidx, (cy, cx)))
     if ctx.grad:
         assert out is None
-        return _convt_grad(ctx, x, convt, bn, act, slope, geoms, (B, H, W, Ho, Wo))
+        return _convt_grad(ctx, x, convt, bn, act, slope, geoms, (B, H, W, Ho, Wo), passthrough=skip_out)
     _run(ctx, x, ldx, Cw, 0, None, O, B * Ho * Wo, 1, [g[:3] for g in geoms], out_t, ldo, coff, convt.bias, bn,
          act, slope)
     return out_t
@@ -297,34 +297,58 @@ def run_vgg(ctx, features, x):
     return x
 
 
-def run_conv_bn_relu(ctx, seq, x, out=None, in_ch=None):
-    """nets/net_utils.py:45-64: Conv2d(no bias) + BN + LeakyReLU(0.2)."""
-    return conv2d(ctx, x, seq[0], seq[1], ACT_LEAKY, 0.2, out=out, in_ch=in_ch)
+def run_conv_bn_relu(ctx, seq, x, out=None, in_ch=None, skip_out=False):
+    """nets/net_utils.py:45-64: Conv2d(no bias) + BN + LeakyReLU(0.2).  skip_out: see run_convt_bn_relu."""
+    if skip_out and not ctx.grad:
+        return conv2d(ctx, x, seq[0], seq[1], ACT_LEAKY, 0.2, out=out, in_ch=in_ch), x
+    return conv2d(ctx, x, seq[0], seq[1], ACT_LEAKY, 0.2, out=out, in_ch=in_ch, skip_out=skip_out)
 
 
-def run_convt_bn_relu(ctx, seq, x, out=None):
-    """nets/net_utils.py:66-98: ConvT+BN+LeakyReLU(0.2) then Conv3x3+BN+LeakyReLU(0.2)."""
+def run_convt_bn_relu(ctx, seq, x, out=None, skip_out=False):
+    """nets/net_utils.py:66-98: ConvT+BN+LeakyReLU(0.2) then Conv3x3+BN+LeakyReLU(0.2).
+    skip_out (training path): also returns an alias of x for x's NEXT consumer; the gradient that consumer sends back is added
+    in this layer's dgrad epilogue (see _conv2d_grad.dgrad)."""
+    if skip_out and ctx.grad:
+        y, alias = conv_transpose2d(ctx, x, seq[0], seq[1], ACT_LEAKY, 0.2, skip_out=True)
+        return conv2d(ctx, y, seq[3], seq[4], ACT_LEAKY, 0.2, out=out), alias
     y = conv_transpose2d(ctx, x, seq[0], seq[1], ACT_LEAKY, 0.2)
-    return conv2d(ctx, y, seq[3], seq[4], ACT_LEAKY, 0.2, out=out)
+    y = conv2d(ctx, y, seq[3], seq[4], ACT_LEAKY, 0.2, out=out)
+    return (y, x) if skip_out else y
 
 
-def run_basic_block(ctx, blk, x, out=None):
+def run_basic_block(ctx, blk, x, out=None, alias_in=False):
     """nets/resnet.py:55-71."""
     if ctx.grad and blk.downsample is None:
         # the identity branch takes an alias of x handed out by conv1's Function: its gradient is added in conv1's dgrad
         # epilogue instead of by autograd's elementwise accumulation (one read-read-write pass over the activation)
         y, idt = conv2d(ctx, x, blk.conv1, blk.bn1, ACT_RELU, skip_out=True)
+    elif ctx.grad:
+        # x has two consumers here (conv1, downsample) and possibly a third outside (a decoder concatenation, alias_in): they are
+        # chained through passthrough aliases, so the gradients of x are accumulated in dgrad epilogues, not by autograd
+        # (the 1x1 / stride-2 downsample is first in the chain: in backward it is the last to run and adds its one parity class
+        # IN PLACE to the gradient conv1 has already produced)
+        idt, a1 = conv2d(ctx, x, blk.downsample[0], blk.downsample[1], ACT_NONE, skip_out=True)
+        y, a2 = conv2d(ctx, a1, blk.conv1, blk.bn1, ACT_RELU, skip_out=True)
+        y = conv2d(ctx, y, blk.conv2, blk.bn2, ACT_RELU, residual=idt, out=out)
+        return (y, a2) if alias_in else y
     else:
         y = conv2d(ctx, x, blk.conv1, blk.bn1, ACT_RELU)
         idt = conv2d(ctx, x, blk.downsample[0], blk.downsample[1], ACT_NONE) if blk.downsample is not None else x
-    return conv2d(ctx, y, blk.conv2, blk.bn2, ACT_RELU, residual=idt, out=out)
+    y = conv2d(ctx, y, blk.conv2, blk.bn2, ACT_RELU, residual=idt, out=out)
+    return (y, x) if alias_in else y
 
 
-def run_resnet_layer(ctx, layer, x, out=None):
+def run_resnet_layer(ctx, layer, x, out=None, alias_in=False):
+    """alias_in: also return an alias of the layer's input for a further consumer of it (see run_basic_block)"""
     blocks = list(layer.children())
+    alias = x
     for i, blk in enumerate(blocks):
-        x = run_basic_block(ctx, blk, x, out=out if i == len(blocks) - 1 else None)
-    return x
+        last = i == len(blocks) - 1
+        if i == 0 and alias_in:
+            x, alias = run_basic_block(ctx, blk, x, out=out if last else None, alias_in=True)
+        else:
+            x = run_basic_block(ctx, blk, x, out=out if last else None)
+    return (x, alias) if alias_in else x
 
 
 # ==============================================================================================
@@ -349,9 +373,9 @@ def _conv2d_grad(ctx, x, conv, bn, act, slope, residual, geom, dims, Cp, passthr
         ops.unpack_weight(dWp, dW, O, T, Cw, Cp, Cw * T, T, 1, list(range(T)))
 
     def dgrad(spec, w, draw, xin, add=None):
+        """add: a gradient that reached x through ANOTHER consumer (handed over on this layer's passthrough alias); it is folded
+        into the result in the kernels' epilogues instead of by a separate elementwise pass of autograd"""
         dev = draw.device
-        if add is not None and not (sh == 1 and sw == 1):
-            return dgrad(spec, w, draw, xin) + add
         if sh == 1 and sw == 1:
             # taps in ascending (dh, dw) order = the canonical 3x3 order the Winograd kernel recognises
             order = sorted(range(T), key=lambda i: (ph - i // kw, pw - i % kw))
@@ -372,8 +396,17 @@ def _conv2d_grad(ctx, x, conv, bn, act, slope, residual, geom, dims, Cp, passthr
                 taps = [(a, b) for a in khs for b in kws]
                 Hv, Wv = (H - cy + 1) // 2, (W - cx + 1) // 2
                 classes.append((cy, cx, taps, Hv, Wv))
-        full = all(len(c[2]) > 0 for c in classes)
-        dx = (torch.empty if full else torch.zeros)((B, H, W, Cp), dtype=torch.float32, device=dev)
+        full = all(len(c[2]) > 0 and c[3] > 0 and c[4] > 0 for c in classes)
+        if add is not None and not full:
+            # e.g. the 1x1 / stride-2 downsample of a ResNet block: only one of the four input-parity classes receives anything.
+            # The other gradient IS the result there, so the launches accumulate into it in place (every element is read and
+            # written by one thread) - no zero fill, no addition pass
+            dx, ldx_ = add, FN.ld_of(add)
+            assert add.shape[-1] == Cp
+        elif full:
+            dx, ldx_ = torch.empty((B, H, W, Cp), dtype=torch.float32, device=dev), Cp
+        else:
+            dx, ldx_ = torch.zeros((B, H, W, Cp), dtype=torch.float32, device=dev), Cp
         for cy, cx, taps, Hv, Wv in classes:
             if not taps or Hv <= 0 or Wv <= 0:
                 continue
@@ -383,7 +416,8 @@ def _conv2d_grad(ctx, x, conv, bn, act, slope, residual, geom, dims, Cp, passthr
             Wd = ops.pack_weight(w, Cw, len(taps), O, T, Cw * T, 1, tapidx, Np=Cp, Cp=Np,
                                  key=('conv_d2', cy, cx, Np, Cp))
             g = (B, Ho, Wo, Hv, Wv, 1, 1, dhs, dws, H, W, 2, 2, cy, cx)
-            ops.gather_gemm(draw, Np, Np, len(taps), Wd, Cp, B * Hv * Wv, dx, Cp, mode=1, geom=g,
+            ops.gather_gemm(draw, Np, Np, len(taps), Wd, Cp, B * Hv * Wv, dx, ldx_, mode=1, geom=g,
+                            residual=add, ldr=0 if add is None else FN.ld_of(add),
                             flops=2.0 * B * Hv * Wv * Cw * len(taps) * O)
         return dx
 
@@ -397,7 +431,7 @@ def _conv2d_grad(ctx, x, conv, bn, act, slope, residual, geom, dims, Cp, passthr
     return out
 
 
-def _convt_grad(ctx, x, convt, bn, act, slope, geoms, dims):
+def _convt_grad(ctx, x, convt, bn, act, slope, geoms, dims, passthrough=False):
     B, H, W, Ho, Wo = dims
     Cw, O = convt.in_channels, convt.out_channels
     ph, pw = convt.padding
@@ -410,7 +444,7 @@ def _convt_grad(ctx, x, convt, bn, act, slope, geoms, dims):
         tapidx = geoms[i][3]
         ops.unpack_weight(dWp, dW, O, len(tapidx), Cw, Cw, 9, O * 9, 1, tapidx)
 
-    def dgrad(spec, w, draw, xin):
+    def dgrad(spec, w, draw, xin, add=None):
         # dX[ci][ih][iw] = sum_{co,kh,kw} dY[co][2ih-ph+kh][2iw-pw+kw] * W[ci][co][kh][kw]  (stride-2 conv)
         dhs = [k // 3 - ph for k in range(9)]
         dws = [k % 3 - pw for k in range(9)]
@@ -418,6 +452,7 @@ def _convt_grad(ctx, x, convt, bn, act, slope, geoms, dims):
         dx = torch.empty((B, H, W, Cw), dtype=torch.float32, device=draw.device)
         g = (B, Ho, Wo, H, W, 2, 2, dhs, dws, H, W, 1, 1, 0, 0)
         ops.gather_gemm(draw, Np, Np, 9, Wd, Cw, B * H * W, dx, Cw, mode=1, geom=g,
+                        residual=add, ldr=0 if add is None else FN.ld_of(add),
                         flops=2.0 * B * H * W * Cw * 9 * O / 4 * 4)
         return dx
 
@@ -437,9 +472,13 @@ def _convt_grad(ctx, x, convt, bn, act, slope, geoms, dims):
 
     spec = FN.LayerSpec(O, Cw, 0, 1, [(g[0], g[2]) for g in geoms], B * Ho * Wo, (B, Ho, Wo), pack_fwd, dgrad,
                         unpack, bn=bn, train=ctx.train, act=act, slope=slope, c_real=Cw,
-                        custom_forward=custom_fwd, custom_wgrad=custom_wgrad)
+                        custom_forward=custom_fwd, custom_wgrad=custom_wgrad,
+                        passthrough=passthrough and x.requires_grad)
     g_, b_ = _bn_args(bn)
-    return FN.GemmLayerFn.apply(x, convt.weight, convt.bias, g_, b_, None, spec)
+    out = FN.GemmLayerFn.apply(x, convt.weight, convt.bias, g_, b_, None, spec)
+    if passthrough and not spec.passthrough:
+        return out, x
+    return out
 
 
 def _linear_grad(ctx, x, M, C, weight, bias, bn, act, slope):

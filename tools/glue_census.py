@@ -19,6 +19,10 @@ NO_KERNEL = ('view', 'reshape', 'slice', 'select', 'expand', 'permute', 'transpo
              'record_stream', 'resize_', 'set_')
 
 
+SHAPES = collections.defaultdict(list)
+BIG = collections.Counter()      # (where, op) -> MB of the largest operand, summed over calls (ops on >= 16 M elements only)
+
+
 def census(step_fn):
     """run step_fn() under a TorchDispatchMode; Counter{(innermost efgh_amd frame, aten op): calls} of the ops on device tensors
     that are not pure views / allocations"""
@@ -37,6 +41,10 @@ def census(step_fn):
                         where = '%s:%d %s' % (os.path.relpath(fr.filename, ROOT), fr.lineno, fr.name)
                         break
                 count[(where, name)] += 1
+                big = max((t.numel() for t in flat), default=0)
+                if big >= (1 << 24):
+                    BIG[(where, name)] += big * 4 / 1e6
+                    SHAPES[(where, name)].append(tuple(max(flat, key=lambda t: t.numel()).shape))
             return out
 
     with Census():
@@ -73,6 +81,10 @@ def main():
     print('aten ops on device tensors in one training step (about one launch each): %d' % total)
     for (where, name), n in count.most_common(a.top):
         print('%5d  %-36s %s' % (n, name.replace('aten.', ''), where))
+    print('ops on large tensors (MB of the largest operand, summed):')
+    for (where, name), mb in BIG.most_common(30):
+        print('%9.0f MB  x%-3d %-30s %s' % (mb, count[(where, name)], name.replace('aten.', ''), where))
+        print('              shapes:', collections.Counter(SHAPES[(where, name)]).most_common(12))
 
 
 if __name__ == '__main__':
