@@ -428,26 +428,29 @@ __device__ __forceinline__ float block_sum(float v, float *red) {      // PL_TPB
     return t;
 }
 
+// grid (ceil(W / PL_TPB), B): every workgroup ranks PL_TPB columns of one sample's score row against the whole row (staged in LDS)
 __global__ void __launch_bounds__(PL_TPB)
 k_pose_loss_fwd(PoseLossArgs a, float *__restrict__ gtbuf, long long *__restrict__ gtcls, float *__restrict__ gt_fscore,
-                float *__restrict__ wsel, float *__restrict__ part) {
-    const int b = blockIdx.x, tid = threadIdx.x;
+                float *__restrict__ wsel, float *__restrict__ part, float *__restrict__ fpart) {
+    const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
     __shared__ PoseGt gt;
     __shared__ float red[PL_TPB / 64];
     extern __shared__ float lc[];                      // [W] BCE of the non-positive columns against 0, positives as 0
     if (tid == 0) {
         pose_gt(a, b, gt);
-        float e_abs[3], e_sgn[8], h_abs[3], h_sgn[4], g_trs[3], e_l[16], out[5], gtrs[3];
-        load_pred<float>(a, b, e_abs, e_sgn, h_abs, h_sgn, g_trs, e_l);
-        pose_terms<float>(a, b, gt, e_abs, e_sgn, h_abs, h_sgn, g_trs, e_l, out, gtrs);
-        float *g = gtbuf + (long long)b * GT_LD;
-        for (int i = 0; i < 3; ++i) { g[GT_E_GN + i] = gt.e_gn[i]; g[GT_H_HRZN + i] = gt.h_hrzn[i]; g[GT_G_TRS + i] = gtrs[i]; g[GT_E_ABS + i] = gt.e_absv[i]; }
-        g[GT_H_ABS] = gt.h_absv[0]; g[GT_H_ABS + 1] = gt.h_absv[1]; g[GT_H_ABS + 2] = 0.f;
-        for (int i = 0; i < 16; ++i) { g[GT_E_L + i] = gt.e_l[i]; g[GT_F_L + i] = gt.f_l[i]; g[GT_G_L + i] = gt.g_l[i]; }
-        for (int i = 0; i < 3; ++i)
-            for (int j = 0; j < 3; ++j) g[GT_H_C + i * 3 + j] = gt.h_c16[i * 4 + j];
-        gtcls[b * 2] = gt.cls_e; gtcls[b * 2 + 1] = gt.cls_h;
-        for (int i = 0; i < 5; ++i) part[b * PT_LD + i] = out[i];
+        if (chunk == 0) {
+            float e_abs[3], e_sgn[8], h_abs[3], h_sgn[4], g_trs[3], e_l[16], out[5], gtrs[3];
+            load_pred<float>(a, b, e_abs, e_sgn, h_abs, h_sgn, g_trs, e_l);
+            pose_terms<float>(a, b, gt, e_abs, e_sgn, h_abs, h_sgn, g_trs, e_l, out, gtrs);
+            float *g = gtbuf + (long long)b * GT_LD;
+            for (int i = 0; i < 3; ++i) { g[GT_E_GN + i] = gt.e_gn[i]; g[GT_H_HRZN + i] = gt.h_hrzn[i]; g[GT_G_TRS + i] = gtrs[i]; g[GT_E_ABS + i] = gt.e_absv[i]; }
+            g[GT_H_ABS] = gt.h_absv[0]; g[GT_H_ABS + 1] = gt.h_absv[1]; g[GT_H_ABS + 2] = 0.f;
+            for (int i = 0; i < 16; ++i) { g[GT_E_L + i] = gt.e_l[i]; g[GT_F_L + i] = gt.f_l[i]; g[GT_G_L + i] = gt.g_l[i]; }
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j) g[GT_H_C + i * 3 + j] = gt.h_c16[i * 4 + j];
+            gtcls[b * 2] = gt.cls_e; gtcls[b * 2 + 1] = gt.cls_h;
+            for (int i = 0; i < 5; ++i) part[b * PT_LD + i] = out[i];
+        }
     }
     __syncthreads();
     // F: positives = pos_num columns from xmin (wrapping); negatives = the neg_ratio * #pos largest BCE values among the rest
@@ -457,38 +460,45 @@ k_pose_loss_fwd(PoseLossArgs a, float *__restrict__ gtbuf, long long *__restrict
     for (int j = tid; j < W; j += PL_TPB) {
         int r = (j - xmin) % W; if (r < 0) r += W;
         const bool pos = r < a.pos_num;
-        gt_fscore[(long long)b * W + j] = pos ? 1.f : 0.f;
         lc[j] = pos ? 0.f : bce(p[j], 0.f);
         npos_f += pos ? 1.f : 0.f;
     }
     npos_f = block_sum(npos_f, red);                   // (the barriers inside also publish lc)
     const float num_neg = fminf(a.neg_ratio * npos_f, (float)(W - 1));
     float lsum = 0.f, cnt = 0.f;
-    for (int j = tid; j < W; j += PL_TPB) {
+    const int j = chunk * PL_TPB + tid;
+    if (j < W) {
         int r = (j - xmin) % W; if (r < 0) r += W;
         const bool pos = r < a.pos_num;
         const float lj = lc[j];
         int rank = 0;                                   // position in the descending sort (ties: lower column first)
         for (int q = 0; q < W; ++q) { const float lq = lc[q]; rank += (lq > lj) || (lq == lj && q < j); }
         const bool sel = pos || (float)rank < num_neg;
+        gt_fscore[(long long)b * W + j] = pos ? 1.f : 0.f;
         wsel[(long long)b * W + j] = sel ? 1.f : 0.f;
-        if (sel) { lsum += bce(p[j], pos ? 1.f : 0.f); cnt += 1.f; }
+        if (sel) { lsum = bce(p[j], pos ? 1.f : 0.f); cnt = 1.f; }
     }
     lsum = block_sum(lsum, red);
     cnt = block_sum(cnt, red);
-    if (tid == 0) { part[b * PT_LD + PT_FOV_SUM] = lsum; part[b * PT_LD + PT_FOV_CNT] = cnt; }
+    if (tid == 0) { fpart[((long long)b * gridDim.x + chunk) * 2] = lsum; fpart[((long long)b * gridDim.x + chunk) * 2 + 1] = cnt; }
 }
 
 // L[11] in efghloss.py:13-17 order: total, e_gn, e_gn_sgn, e_gn_abs, h_hrzn, h_hrzn_abs, h_hrzn_sgn, fov, g_trs, g_depth, g_mask
 struct PoseLossLambda { float e_gn, h_hrzn, fov, g_trs, g_depth, g_mask; };
 enum { L_TOTAL = 0, L_E_GN, L_E_SGN, L_E_ABS, L_H, L_H_ABS, L_H_SGN, L_FOV, L_G_TRS, L_G_DEPTH, L_G_MASK, L_N };
 
-__global__ void k_pose_loss_finish(const float *__restrict__ part, int B, PoseLossLambda lam, const float *__restrict__ l_dep,
-                                   const float *__restrict__ l_msk, float *__restrict__ L, float *__restrict__ nsel) {
+__global__ void k_pose_loss_finish(const float *__restrict__ part, const float *__restrict__ fpart, int nchunk, int B,
+                                   PoseLossLambda lam, const float *__restrict__ l_dep, const float *__restrict__ l_msk,
+                                   float *__restrict__ L, float *__restrict__ nsel) {
     if (threadIdx.x || blockIdx.x) return;
     float s[PT_LD] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int b = 0; b < B; ++b)
-        for (int i = 0; i < PT_LD; ++i) s[i] += part[b * PT_LD + i];
+    for (int b = 0; b < B; ++b) {
+        for (int i = 0; i < 5; ++i) s[i] += part[b * PT_LD + i];
+        for (int c = 0; c < nchunk; ++c) {              // fixed order
+            s[PT_FOV_SUM] += fpart[((long long)b * nchunk + c) * 2];
+            s[PT_FOV_CNT] += fpart[((long long)b * nchunk + c) * 2 + 1];
+        }
+    }
     const float la_e = s[PT_COS_E] / (float)B * 10.f, ls_e = s[PT_CE_E] / (float)B;
     const float la_h = s[PT_COS_H] / (float)B * 10.f, ls_h = s[PT_CE_H] / (float)B;
     L[L_E_GN] = (la_e + ls_e) * lam.e_gn; L[L_E_ABS] = la_e * lam.e_gn; L[L_E_SGN] = ls_e * lam.e_gn;
@@ -623,9 +633,12 @@ extern "C" int efgh_pose_loss_fwd(const efgh_pose_loss_desc *d, const float *l_d
                                   float *n_selected, void *stream_) {
     EFGH_CHECK_ARG(pose_desc_ok(d) && l_depth && l_mask && gt72 && gt_cls2 && gt_f_score && selected && partials && L11 && n_selected);
     hipStream_t st = (hipStream_t)stream_;
-    k_pose_loss_fwd<<<d->B, PL_TPB, (size_t)d->W * sizeof(float), st>>>(pose_args(d), gt72, (long long *)gt_cls2, gt_f_score, selected, partials);
+    const int nchunk = cdiv(d->W, PL_TPB);
+    float *fpart = partials + (size_t)d->B * PT_LD;   // [B][nchunk][2] behind the per-sample pose terms
+    k_pose_loss_fwd<<<dim3(nchunk, d->B), PL_TPB, (size_t)d->W * sizeof(float), st>>>(pose_args(d), gt72, (long long *)gt_cls2,
+                                                                                       gt_f_score, selected, partials, fpart);
     const PoseLossLambda lam = {d->lambda_e_gn, d->lambda_h_hrzn, d->lambda_fov, d->lambda_g_trs, d->lambda_g_depth, d->lambda_g_mask};
-    k_pose_loss_finish<<<1, 64, 0, st>>>(partials, d->B, lam, l_depth, l_mask, L11, n_selected);
+    k_pose_loss_finish<<<1, 64, 0, st>>>(partials, fpart, nchunk, d->B, lam, l_depth, l_mask, L11, n_selected);
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
 }

@@ -59,7 +59,8 @@ class PoseLossFn(torch.autograd.Function):
         assert t[8].shape[1:] in ((3, 3), (4, 4)) and t[9].shape[1:] in ((3, 3), (4, 4)) and t[10].shape[1:] == (4, 4)
         f32 = dict(dtype=torch.float32, device=dev)
         gtbuf, gtcls = torch.empty((B, 72), **f32), torch.empty((B, 2), dtype=torch.int64, device=dev)
-        gtfs, sel, part = torch.empty((B, W), **f32), torch.empty((B, W), **f32), torch.empty((B, 7), **f32)
+        gtfs, sel = torch.empty((B, W), **f32), torch.empty((B, W), **f32)
+        part = torch.empty(B * (7 + 2 * ((W + 255) // 256)), **f32)
         L, nsel = torch.empty(11, **f32), torch.empty(1, **f32)
         desc = _pose_desc(t, cfg)
         ops._C.check(ops._C.lib().efgh_pose_loss_fwd(ctypes.byref(desc), ops.ptr(l_dep.detach()), ops.ptr(l_msk.detach()),

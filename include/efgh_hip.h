@@ -513,7 +513,7 @@ int efgh_pose_cam_T_velo_bwd(const float *c_T, int64_t ldc, const float *l_T, co
  * g_trs [B][3], e_l / f_l [B][16].  Ground truth: rand_init_l, rand_init_c ([B][3][3] or [B][4][4]), sensor2_T_sensor1 [B][16].
  * fwd:  gt72 [B][72] floats = e_gn 0..2 | e_l 3..18 | h_hrzn 19..21 | h_c (3x3) 22..30 | f_l 31..46 | g_trs 47..49 | g_l 50..65 |
  *       e_gn_abs 66..68 | h_hrzn_abs 69..70;  gt_cls2 [B][2] = sign classes (E, H);  gt_f_score / selected [B][W] (positives and
- *       positives + mined negatives);  partials [B][7];  L11 = the eleven entries of the loss dictionary in `loss_name` order
+ *       positives + mined negatives);  partials: B * (7 + 2 * ceil(W / 256)) floats of scratch;  L11 = the eleven entries of the loss dictionary in `loss_name` order
  *       (total first; g_depth / g_mask from the scalars l_depth / l_mask of efgh_gimg_loss_fwd);  n_selected [1].
  * bwd:  gradients of <g_L11, L11> w.r.t. every prediction, and [2] w.r.t. (l_depth, l_mask).                                   */
 typedef struct {
