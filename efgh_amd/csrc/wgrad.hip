@@ -18,6 +18,9 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int TK = 128, TM = 32, LD = 128;
+#ifndef WGRAD_TARGET_BLOCKS
+#define WGRAD_TARGET_BLOCKS 1024      // workgroups a launch is cut into along the rows (each row chunk costs one partial plane)
+#endif
 
 struct WArgs {
     const float *A; int64_t lda;
@@ -263,7 +266,7 @@ static long long wgrad_chunks(const efgh_gemm_desc *d, int nbatch, long long *ch
     const int K = d->T * d->C;
     const int TN = d->N <= 64 ? 64 : 128;
     const long long kt = (K + TK - 1) / TK, nt = (d->N + TN - 1) / TN;
-    long long want = 2048 / (kt * nt * nbatch);
+    long long want = WGRAD_TARGET_BLOCKS / (kt * nt * nbatch);
     if (want < 1) want = 1;
     long long chunk = (d->M + want - 1) / want;
     chunk = (chunk + TM - 1) / TM * TM;

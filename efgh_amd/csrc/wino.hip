@@ -478,7 +478,7 @@ extern "C" int efgh_wino_wgrad_supported(const efgh_gemm_desc *d) {
 static long long wino_wgrad_ranges(const efgh_gemm_desc *d, long long *chunk_out) {
     const long long Mt = (long long)d->B * d->Hin * ((d->Win + 3) / 4);
     const int kt = 3 * d->C / 64, nt = d->N / 64;
-    long long want = 1536 / (kt * nt);                 // ~3 workgroups per CU-slot pair
+    long long want = 1024 / (kt * nt);                 // 2 rounds of 512 resident workgroups; each range costs one partial S
     if (want < 1) want = 1;
     long long chunk = (Mt + want - 1) / want;
     chunk = (chunk + TT - 1) / TT * TT;
