@@ -26,5 +26,5 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $SCR/sf -- python3 $ROOT
 cp $SCR/sf/*/*kernel_stats.csv $OUT/fwd_kernel_stats.csv
 cd $ROOT && python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 ls -la $OUT
-tail -2 $SCR/*.err | tail -30
+tail -n 2 $SCR/*.err | tail -n 30
 rm -rf $SCR
