@@ -359,7 +359,7 @@ def test_training_step_is_not_torch_glue(manifest):
         tr.step(*inp, gt)
     count = census(lambda: tr.step(*inp, gt))
     total = sum(count.values())
-    assert total <= 260, (total, count.most_common(12))
+    assert total <= 200, (total, count.most_common(12))
     names = ' '.join(n for _, n in count)
     assert 'bmm' not in names or count.most_common(1)[0][1] < 60
 
