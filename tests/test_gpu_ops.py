@@ -479,3 +479,17 @@ def test_neighbor_gather_adjoint_vs_atomic_scatter():
         for t in range(1, 15):
             ok = (nbr[:, t] >= 0) & ((nbr[:, 15] >> t) & 1 == 0)
             assert np.array_equal(nbr[nbr[ok, t], 15 - t], np.nonzero(ok)[0]), t
+
+
+def test_padded_pack_and_vector_pad():
+    """efgh_pack_weight_padded / efgh_pad_vec: the zero padding of layers whose width is not a multiple of 4, one launch each"""
+    from efgh_amd import ops
+    torch.manual_seed(0)
+    w = torch.randn(3, 10, 3, 3, device='cuda')                       # (O, C, kh, kw): O = 3 -> 4, C = 10 -> 12
+    Wp = ops.pack_weight(w, 3, 9, 10, 90, 9, 1, list(range(9)), Np=4, Cp=12)
+    want = torch.zeros(4, 9, 12, device='cuda')
+    want[:3, :, :10] = w.reshape(3, 10, 9).permute(0, 2, 1)
+    assert torch.equal(Wp, want)
+    v = torch.randn(5, device='cuda')
+    assert torch.equal(ops.pad_vec(v, 8, 1.5), torch.cat([v, torch.full((3,), 1.5, device='cuda')]))
+    assert ops.pad_vec(v, 5) is v
