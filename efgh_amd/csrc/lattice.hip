@@ -256,8 +256,8 @@ __device__ __forceinline__ unsigned long long load_slot(const unsigned long long
 }
 
 __device__ __forceinline__ int claim_slot(unsigned long long *__restrict__ hkeys, uint64_t hmask, unsigned long long ki,
-                                          uint64_t h, unsigned long long cur) {
-    for (;;) {
+                                          uint64_t h, unsigned long long cur, int *__restrict__ info) {
+    for (uint64_t probe = 0; probe <= hmask; ++probe) {
         if (cur == ki) return (int)h;
         if (cur == EMPTY) {
             const unsigned long long prev = atomicCAS(&hkeys[h], EMPTY, ki);
@@ -266,13 +266,17 @@ __device__ __forceinline__ int claim_slot(unsigned long long *__restrict__ hkeys
         h = (h + 1) & hmask;
         cur = load_slot(&hkeys[h]);
     }
+    // every slot holds another key: the caller sized the table from an estimate that was too small (hash_slots).  Flag it; the
+    // entry is counted on an arbitrary slot so that all sizes stay in bounds, and the host rebuilds with the default table.
+    atomicOr(&info[EFGH_LATTICE_INFO_ERR], 4);
+    return (int)h;
 }
 
 __global__ void __launch_bounds__(TPB)
 k_insert(const float *__restrict__ pts, int64_t cstride, const int *__restrict__ n_dev, int n_cap, float scale32,
          float std32, const int *__restrict__ mm, unsigned long long *__restrict__ hkeys, int *__restrict__ cnt,
          int64_t hmask, int4 *__restrict__ slot, int4 *__restrict__ rnk, const int *__restrict__ sid, int pps,
-         int nsamples) {
+         int nsamples, int *__restrict__ info) {
     const int n = n_of(n_dev, n_cap);
     const int p = blockIdx.x * TPB + threadIdx.x;
     if (p >= n) return;
@@ -296,7 +300,7 @@ k_insert(const float *__restrict__ pts, int64_t cstride, const int *__restrict__
     for (int rem = 0; rem < 4; ++rem) cur[rem] = hkeys[h[rem]];
 #pragma unroll
     for (int rem = 0; rem < 4; ++rem)
-        s[rem] = cur[rem] == ki[rem] ? (int)h[rem] : claim_slot(hkeys, (uint64_t)hmask, ki[rem], h[rem], load_slot(&hkeys[h[rem]]));
+        s[rem] = cur[rem] == ki[rem] ? (int)h[rem] : claim_slot(hkeys, (uint64_t)hmask, ki[rem], h[rem], load_slot(&hkeys[h[rem]]), info);
 #pragma unroll
     for (int rem = 0; rem < 4; ++rem) r[rem] = atomicAdd(&cnt[s[rem]], 1);
     slot[p] = make_int4(s[0], s[1], s[2], s[3]);
@@ -657,16 +661,25 @@ extern "C" int64_t efgh_lattice_workspace_bytes(int32_t n_cap, int32_t h_cap, in
     return ws_layout(n_cap, h_cap, nsamples, efgh_lattice_hash_capacity(n_cap)).total;
 }
 
+// hash_slots = 0: the default table (no overflow possible); else a power of two in [4096, default]
+static int64_t pick_hash_slots(int32_t n_cap, int64_t hash_slots) {
+    const int64_t dflt = efgh_lattice_hash_capacity(n_cap);
+    if (hash_slots <= 0 || hash_slots >= dflt) return dflt;
+    if (hash_slots < 4096 || (hash_slots & (hash_slots - 1))) return -1;
+    return hash_slots;
+}
+
 extern "C" int efgh_lattice_level_build(const float *pts, int64_t pts_cstride, const int32_t *n_dev, int32_t n_cap,
                                         const int32_t *sid, int32_t pts_per_sample, int32_t nsamples, float scale32,
                                         float div32, float *bary, float *emg, int32_t *off, int32_t *list, int32_t h_cap,
                                         int32_t *vseg, float *pts_next, int32_t *vsid, int32_t *info, void *workspace,
-                                        void *stream_) {
+                                        int64_t hash_slots, void *stream_) {
     hipStream_t st = (hipStream_t)stream_;
     EFGH_CHECK_ARG(n_cap > 0 && n_cap < (1 << 27) && h_cap > 0 && nsamples >= 1 && nsamples <= EFGH_LATTICE_MAX_SAMPLES);      // (LDS [nsamples][8] in k_minmax_finalize)
     EFGH_CHECK_ARG(sid || pts_per_sample > 0);
     EFGH_CHECK_ARG(pts && bary && emg && off && list && vseg && pts_next && vsid && info && workspace);
-    const int64_t hcap = efgh_lattice_hash_capacity(n_cap);
+    const int64_t hcap = pick_hash_slots(n_cap, hash_slots);
+    EFGH_CHECK_ARG(hcap > 0);
     const WsLayout w = ws_layout(n_cap, h_cap, nsamples, hcap);
     char *ws = (char *)workspace;
     int4 *slot = (int4 *)(ws + w.slot), *rnk = (int4 *)(ws + w.rnk);
@@ -689,7 +702,7 @@ extern "C" int efgh_lattice_level_build(const float *pts, int64_t pts_cstride, c
                                       pps);
     k_minmax_finalize<<<cdiv(nbp * (TPB / 64), TPB), TPB, 0, st>>>(part, nbp * (TPB / 64), mm);
     k_insert<<<nbp, TPB, 0, st>>>(pts, pts_cstride, n_dev, n_cap, scale32, std32, mm, hkeys, cnt, hcap - 1, slot, rnk, sid, pps,
-                                  nsamples);
+                                  nsamples, info);
     const int nb2 = (int)(hcap / (1024 * SEG_Q)) > 0 ? (int)(hcap / (1024 * SEG_Q)) : 1;      // hcap is a power of two >= 4096
     k_seg_count<<<nb2, TPB, 0, st>>>((const int4 *)cnt, bsum2);
     k_seg_scan<<<1, TPB, 0, st>>>(bsum2, nb2, info + EFGH_LATTICE_INFO_CURSOR);
@@ -711,10 +724,11 @@ extern "C" int efgh_lattice_level_build(const float *pts, int64_t pts_cstride, c
 
 extern "C" int efgh_lattice_level_neighbors(const void *workspace, int32_t n_cap, int32_t h_cap_build, int32_t nsamples,
                                             int32_t *info, const int32_t *vsid, int32_t h_cap, int32_t *nbr,
-                                            int32_t *alist, int32_t alias_cap, void *stream_) {
+                                            int32_t *alist, int32_t alias_cap, int64_t hash_slots, void *stream_) {
     hipStream_t st = (hipStream_t)stream_;
     EFGH_CHECK_ARG(workspace && info && vsid && nbr && alist && n_cap > 0 && h_cap > 0 && h_cap <= h_cap_build && alias_cap > 0);
-    const int64_t hcap = efgh_lattice_hash_capacity(n_cap);
+    const int64_t hcap = pick_hash_slots(n_cap, hash_slots);
+    EFGH_CHECK_ARG(hcap > 0);
     const WsLayout w = ws_layout(n_cap, h_cap_build, nsamples, hcap);
     const char *ws = (const char *)workspace;
     int grid = cdiv((int64_t)h_cap * 16, TPB);

@@ -9,6 +9,8 @@ the five counts come back in ONE read; a count that does not fit its capacity (f
 level-by-level path, which reads each count before sizing the next level."""
 import math
 
+import os
+
 import numpy as np
 import torch
 
@@ -30,7 +32,7 @@ class LatticeLevel:
     per vertex: nbr [H][16] (15 neighbours + alias mask), vseg [H][2] + list [4n] (vertex -> ascending flat positions
     4p + r), pts_next [3][H]; info = the level's device counters (INFO_*), alist = aliased neighbour records."""
     __slots__ = ('n_in', 'H', 'bary_pm', 'emg_pm', 'off_pm', 'nbr', 'vseg', 'list', 'pts_next_buf', 'info', 'alist',
-                 'seg_in', 'seg', 'vsid', '_ws', '_caps')
+                 'seg_in', 'seg', 'vsid', '_ws', '_caps', '_hash')
 
     # the reference's (4, n) / (3, H) arrays as views
     @property
@@ -80,6 +82,7 @@ def _level_arrays(L, dev, n_cap, h_cap, B):
     lv.alist = torch.empty((ALIAS_CAP, 2), dtype=torch.int32, device=dev)
     lv._ws = torch.empty(L.efgh_lattice_workspace_bytes(n_cap, h_cap, B), dtype=torch.uint8, device=dev)
     lv._caps = (n_cap, h_cap)
+    lv._hash = 0                       # hash_slots of the C-ABI calls: 0 = default table (8 * n_cap slots)
     return lv
 
 
@@ -89,7 +92,7 @@ def _launch_build(L, lv, pts, cstride, n_dev, sid, pps, B, s, st):
         _C.ptr(pts), _C.c_int64(cstride), _C.ptr(n_dev), _C.c_int32(n_cap), _C.ptr(sid), _C.c_int32(pps), _C.c_int32(B),
         _C.c_float(np.float32(s)), _C.c_float(np.float32(EXPECTED_STD * s)), _C.ptr(lv.bary_pm), _C.ptr(lv.emg_pm),
         _C.ptr(lv.off_pm), _C.ptr(lv.list), _C.c_int32(h_cap), _C.ptr(lv.vseg), _C.ptr(lv.pts_next_buf), _C.ptr(lv.vsid),
-        _C.ptr(lv.info), _C.ptr(lv._ws), st))
+        _C.ptr(lv.info), _C.ptr(lv._ws), _C.c_int64(lv._hash), st))
 
 
 def _launch_neighbors(L, lv, B, h_rows, st):
@@ -97,7 +100,7 @@ def _launch_neighbors(L, lv, B, h_rows, st):
     lv.nbr = torch.empty((h_rows, 16), dtype=torch.int32, device=lv.info.device)
     _C.check(L.efgh_lattice_level_neighbors(_C.ptr(lv._ws), _C.c_int32(n_cap), _C.c_int32(h_cap), _C.c_int32(B),
                                             _C.ptr(lv.info), _C.ptr(lv.vsid), _C.c_int32(h_rows), _C.ptr(lv.nbr),
-                                            _C.ptr(lv.alist), _C.c_int32(ALIAS_CAP), st))
+                                            _C.ptr(lv.alist), _C.c_int32(ALIAS_CAP), _C.c_int64(lv._hash), st))
 
 
 def _finish(lv, host, n_in, seg_in, B):
@@ -109,6 +112,9 @@ def _finish(lv, host, n_in, seg_in, B):
     lv._ws = None                      # scratch no longer needed (the stream orders its reuse)
     if lv.nbr.shape[0] != H:
         lv.nbr = lv.nbr[:H]
+
+
+SMALL_HASH = os.environ.get('EFGH_LATTICE_SMALL_HASH', '1') != '0'
 
 
 def build_pyramid_batched(pc, scales):
@@ -133,6 +139,9 @@ def build_pyramid_batched(pc, scales):
         for s, hp in zip(scales, prev):
             h_cap = min(4 * n_cap, hp + hp // 4 + 1024)
             lv = _level_arrays(L, dev, n_cap, h_cap, B)
+            # hash table sized for the expected vertex count (load <= 1/2) instead of the worst case 4 * n_cap keys: the build is
+            # bound by random probes into it; a table that was too small sets ERR bit 2 and the level-by-level path rebuilds
+            lv._hash = max(4096, 1 << (2 * h_cap - 1).bit_length()) if SMALL_HASH else 0
             _launch_build(L, lv, pts, cstride, n_dev, sid, N, B, s, st)
             _launch_neighbors(L, lv, B, h_cap, st)
             lvs.append(lv)
@@ -140,7 +149,7 @@ def build_pyramid_batched(pc, scales):
         if PROFILE is not None:
             e1.record()              # (before the read-back: the events bracket the launches only)
         host = torch.stack([lv.info for lv in lvs]).cpu().tolist()           # the one host sync of the pyramid
-        if not any(h[INFO_ERR] & 1 for h in host):
+        if not any(h[INFO_ERR] & 5 for h in host):
             n_in, seg_in = B * N, [b * N for b in range(B + 1)]
             for lv, h in zip(lvs, host):
                 _finish(lv, h, n_in, seg_in, B)

@@ -47,13 +47,17 @@ int efgh_version(void);
  * so the levels of a pyramid can be enqueued back to back (level l+1: pts = pts_next, pts_cstride = h_cap, n_dev =
  * info + EFGH_LATTICE_INFO_H, n_cap = h_cap, sid = vsid) with one host read-back at the end.                              */
 #define EFGH_LATTICE_INFO_H 0        /* number of vertices (pc1_hash_cnt summed over the samples) */
-#define EFGH_LATTICE_INFO_ERR 1      /* bit 0: H > h_cap; bit 1: more aliased neighbour hits than alias_cap */
+#define EFGH_LATTICE_INFO_ERR 1      /* bit 0: H > h_cap; bit 1: more aliased neighbour hits than alias_cap; bit 2: hash table full */
 #define EFGH_LATTICE_INFO_ALIAS 2    /* number of aliased neighbour hits (see efgh_lattice_level_neighbors) */
 #define EFGH_LATTICE_INFO_CURSOR 3   /* internal (number of occupied hash slots == H) */
 #define EFGH_LATTICE_INFO_SEG 4      /* info[SEG + b] = first vertex of sample b */
 #define EFGH_LATTICE_MAX_SAMPLES 1024
 
-/* entries of the level's hash table (power of two >= 8*n_cap) */
+/* entries of the level's default hash table (power of two >= 8*n_cap: 4*n_cap keys can never fill it).  `hash_slots` of the two
+ * calls below selects a SMALLER table (power of two >= 4096; 0 = default) when the caller knows roughly how many vertices to
+ * expect (e.g. from the previous batch): the build is bound by random probes into this table, and a table that fits the caches
+ * is ~2x faster.  If the estimate was too small the table fills up, bit 2 of info[EFGH_LATTICE_INFO_ERR] is set, nothing is
+ * written out of bounds, and the level has to be rebuilt with hash_slots = 0.  Both calls must get the same value.              */
 int64_t efgh_lattice_hash_capacity(int32_t n_cap);
 /* bytes of scratch for efgh_lattice_level_build; efgh_lattice_level_neighbors reads the same workspace afterwards */
 int64_t efgh_lattice_workspace_bytes(int32_t n_cap, int32_t h_cap, int32_t nsamples);
@@ -75,7 +79,7 @@ int efgh_lattice_level_build(const float *pts, int64_t pts_cstride, const int32_
                              const int32_t *sid, int32_t pts_per_sample, int32_t nsamples, float scale32,
                              float div32, float *bary, float *emg, int32_t *off, int32_t *list, int32_t h_cap,
                              int32_t *vseg, float *pts_next, int32_t *vsid, int32_t *info, void *workspace,
-                             void *stream);
+                             int64_t hash_slots, void *stream);
 
 /* blur neighbours (transforms.py:168-180): nbr[h*16 + t] = index of vertex key(h)+offset_t, or -1, t < 15.
  * key2int has no range check (transforms.py:173-180): a neighbour key outside the sample's key box aliases to the integer
@@ -85,7 +89,7 @@ int efgh_lattice_level_build(const float *pts, int64_t pts_cstride, const int32_
  * `workspace`, n_cap, h_cap_build, nsamples: as passed to efgh_lattice_level_build; h_cap (<= h_cap_build) rows of nbr.     */
 int efgh_lattice_level_neighbors(const void *workspace, int32_t n_cap, int32_t h_cap_build, int32_t nsamples,
                                  int32_t *info, const int32_t *vsid, int32_t h_cap, int32_t *nbr, int32_t *alist,
-                                 int32_t alias_cap, void *stream);
+                                 int32_t alias_cap, int64_t hash_slots, void *stream);
 
 /* ------------------------------------------------------------------ BCL splat (K3) ---------
  * replaces SparseSum + density normalisation, nets/bilateralNN.py:6-40, 179-211, as a gather over the vertex lists of the

@@ -125,3 +125,24 @@ def test_speculative_pyramid_equals_level_by_level():
             for h in (0, u.H // 3, u.H - 1):
                 su, sv = u.vseg[h].tolist(), v.vseg[h].tolist()
                 assert torch.equal(u.list[su[0]:su[0] + su[1]], v.list[sv[0]:sv[0] + sv[1]]), (l, h)
+
+
+def test_small_hash_table_overflow_is_flagged_not_fatal():
+    """hash_slots smaller than the number of distinct lattice keys: the build terminates, flags bit 2 of info[ERR], writes nothing
+    out of bounds; the same level with the default table is correct (this is what the speculative path falls back to)"""
+    from efgh_amd import _C, lattice
+    L = _C.lib()
+    pc = torch.from_numpy((np.random.RandomState(0).randn(3, 8192) * np.array([[30.], [30.], [3.]])).astype(np.float32)).cuda()
+    n = pc.shape[1]
+    st = _C.stream_ptr()
+    infos = []
+    for hs in (4096, 0):
+        lv = lattice._level_arrays(L, pc.device, n, 4 * n, 1)
+        lv._hash = hs
+        lattice._launch_build(L, lv, pc.contiguous(), n, None, None, n, 1, 1.0, st)
+        torch.cuda.synchronize()
+        infos.append(lv.info.cpu().tolist())
+    assert infos[0][lattice.INFO_ERR] & 4 and not infos[1][lattice.INFO_ERR]
+    assert infos[1][lattice.INFO_H] > 4096                       # (more vertices than the small table had slots)
+    from oracle import lattice as olat
+    assert infos[1][lattice.INFO_H] == olat.generate_data(pc.cpu().numpy())[0]['H']
