@@ -86,6 +86,7 @@ struct KArgs {
     unsigned nbx;              // n-tiles per m-tile (set by the launcher)
     unsigned nbatch;
     long long bsA, bsW, bsO;   // batched launch: per-problem element strides (blockIdx.y = problem)
+    int bsT;                   // ... and neighbour-table COLUMN offset per problem (mode 2: problem z takes taps z*bsT ..)
 };
 
 // MATH 0: exact fp32 MFMA (v_mfma_f32_32x32x2_f32).
@@ -111,6 +112,7 @@ k_gather_gemm(const KArgs p_in) {
     KArgs p = p_in;
     if (blockIdx.y) {              // batched launch: shift the operand pointers to problem blockIdx.y
         p.A += blockIdx.y * p.bsA; p.W += blockIdx.y * p.bsW; p.out += blockIdx.y * p.bsO;
+        if (MODE == 2) p.table += blockIdx.y * p.bsT;
         if (MATH != 0) { p.Wh += blockIdx.y * p.bsW; p.Wl += blockIdx.y * p.bsW; if (MATH == 2) p.Wm += blockIdx.y * p.bsW; }
     }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -451,6 +453,23 @@ __global__ void k_pack_weight(const float *__restrict__ W, float *__restrict__ W
     }
 }
 
+__global__ void k_fold_planes(const float4 *__restrict__ part, int S, long long M, int N4, const float4 *__restrict__ bias, int act,
+                              float slope, float *__restrict__ out, long long ldo) {
+    const long long total = M * N4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long m = i / N4; const int n4 = (int)(i - m * N4);
+        float4 a = part[i];
+        for (int z = 1; z < S; ++z) { const float4 b = part[(long long)z * total + i]; a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+        if (bias) { const float4 b = bias[n4]; a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+        if (act == 1) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
+        else if (act == 2) {
+            a.x = a.x > 0.f ? a.x : a.x * slope; a.y = a.y > 0.f ? a.y : a.y * slope;
+            a.z = a.z > 0.f ? a.z : a.z * slope; a.w = a.w > 0.f ? a.w : a.w * slope;
+        }
+        *reinterpret_cast<float4 *>(out + m * ldo + n4 * 4) = a;
+    }
+}
+
 __global__ void k_pad_vec(const float *__restrict__ v, int n, float *__restrict__ out, int np, float fill) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < np) out[i] = i < n ? v[i] : fill;
@@ -525,14 +544,14 @@ static int fill_args(const efgh_gemm_desc *d, KArgs &a) {
     a.act = d->act; a.slope = d->slope; a.out = d->out; a.ldo = d->ldo; a.stats = d->stats;
     a.Wh = a.Wm = a.Wl = nullptr;
     a.nbatch = d->nbatch > 1 ? (unsigned)d->nbatch : 1u;
-    a.bsA = d->batch_stride_a; a.bsW = d->batch_stride_w; a.bsO = d->batch_stride_out;
+    a.bsA = d->batch_stride_a; a.bsW = d->batch_stride_w; a.bsO = d->batch_stride_out; a.bsT = d->batch_stride_table;
     if (a.nbatch > 1) EFGH_CHECK_ARG(!d->stats && !d->residual && a.nbatch <= 65535 && a.bsA % 4 == 0 && a.bsW % 4 == 0);
     if (d->mode == 1) {
         EFGH_CHECK_ARG(d->B > 0 && d->Hin > 0 && d->Win > 0 && d->Hv > 0 && d->Wv > 0);
         EFGH_CHECK_ARG(d->M == (int64_t)d->B * d->Hv * d->Wv);
         EFGH_CHECK_ARG(d->osh >= 1 && d->osw >= 1 && d->Ho > 0 && d->Wo > 0);
     }
-    if (d->mode == 2) EFGH_CHECK_ARG(d->table != nullptr);
+    if (d->mode == 2) EFGH_CHECK_ARG(d->table != nullptr && d->batch_stride_table >= 0 && (int64_t)d->batch_stride_table * (a.nbatch - 1) + d->T <= 16);
     if (d->mode == 0) EFGH_CHECK_ARG(d->T == 1);
     if (d->mode == 3) EFGH_CHECK_ARG(d->B > 0 && d->Hin == d->T && d->Win > 0 && d->Wv > 0 && d->M == (int64_t)d->B * d->Wv);
     return EFGH_OK;
@@ -611,6 +630,18 @@ extern "C" int efgh_split_bf16(const float *w, void *hi, void *mid, void *lo, in
     long long g = (n + 255) / 256;
     k_split_bf16<<<(int)(g > 8192 ? 8192 : g), 256, 0, (hipStream_t)stream_>>>(w, (__bf16 *)hi, (__bf16 *)mid,
                                                                              (__bf16 *)lo, n);
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}
+
+extern "C" int efgh_fold_planes(const float *part, int32_t S, int64_t M, int32_t N, const float *bias, int32_t act, float slope,
+                                float *out, int64_t ldo, void *stream_) {
+    EFGH_CHECK_ARG(part && out && S >= 1 && M > 0 && N > 0 && N % 4 == 0 && ldo % 4 == 0 && ldo >= N);
+    EFGH_CHECK_ARG((((uintptr_t)part) & 15) == 0 && (((uintptr_t)out) & 15) == 0 && (!bias || (((uintptr_t)bias) & 15) == 0));
+    const long long total = M * (N / 4);
+    long long g = (total + 255) / 256;
+    k_fold_planes<<<(int)(g > 8192 ? 8192 : g), 256, 0, (hipStream_t)stream_>>>((const float4 *)part, S, M, N / 4, (const float4 *)bias,
+                                                                              act, slope, out, ldo);
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
 }

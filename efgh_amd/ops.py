@@ -202,10 +202,38 @@ PROFILE_WINO = None     # launches served by the Winograd kernel (else they are 
 PROFILE = None          # bench.py sets this to a list: (start_event, end_event, algorithmic_flops) per launch
 
 
+KSPLIT_MAX_ROWS = int(_os.environ.get('EFGH_BLUR_KSPLIT_ROWS', '16384'))     # 0 disables
+
+
+def _blur_gemm_ksplit(A, lda, C, Wp, N, M, out, ldo, table, bias, act, slope, a_off, out_off, flops):
+    """BCL blur on a level with few vertices (M <= 16 k rows: 9-75 workgroups each walking K = 15*C serially, 6-23 TFLOP/s): the
+    15 neighbour taps are split over 5 problems of ONE batched launch (3 taps each, their own columns of the neighbour table and
+    their own slice of the packed weight), the five partial planes are added - with bias and activation - by efgh_fold_planes."""
+    S, Ts = 5, 3
+    dev = out.device
+
+    def regroup():
+        return Wp.view(N, S, Ts * C).permute(1, 0, 2).contiguous()             # [S][N][Ts*C]
+    Wg = _cached(Wp, ('ksplit', S), (Wp._version,), regroup)
+    part = _scratch(S * M * N, dev)
+    gather_gemm(A, lda, C, Ts, Wg, N, M, part, N, mode=2, table=table, a_off=a_off, batch=(S, 0, N * Ts * C, M * N, Ts),
+                flops=flops if flops is not None else 2.0 * M * N * 15 * C)
+    b = None
+    if bias is not None:
+        b = bias if bias.numel() == N else None
+        assert b is not None
+    _C.check(_L().efgh_fold_planes(ptr(part), c_int32(S), c_int64(M), c_int32(N), ptr(b), c_int32(act), c_float(slope),
+                                   _C.c_void_p(out.data_ptr() + 4 * out_off), c_int64(ldo), _st()))
+
+
 def gather_gemm(A, lda, C, T, Wp, N, M, out, ldo, mode=0, geom=None, table=None, bias=None, scale=None,
                 shift=None, residual=None, ldr=0, act=ACT_NONE, slope=0.0, stats=None, a_off=0, out_off=0,
                 res_off=0, M_dev=None, flops=None, batch=None):
     """See efgh_gemm_desc.  A/out/residual may be addressed with an element offset (channel slices)."""
+    if (KSPLIT_MAX_ROWS and mode == 2 and M <= KSPLIT_MAX_ROWS and T == 15 and N % 4 == 0 and T * C >= 1024 and batch is None
+            and scale is None and shift is None and residual is None and stats is None and M_dev is None and MATH == 'f32'
+            and (bias is None or bias.numel() == N)):
+        return _blur_gemm_ksplit(A, lda, C, Wp, N, M, out, ldo, table, bias, act, slope, a_off, out_off, flops)
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -229,7 +257,8 @@ def gather_gemm(A, lda, C, T, Wp, N, M, out, ldo, mode=0, geom=None, table=None,
     d.ldo = ldo
     d.stats = 0 if stats is None else stats.data_ptr()
     if batch is not None:
-        d.nbatch, d.batch_stride_a, d.batch_stride_w, d.batch_stride_out = batch
+        d.nbatch, d.batch_stride_a, d.batch_stride_w, d.batch_stride_out = batch[:4]
+        d.batch_stride_table = batch[4] if len(batch) > 4 else 0
     thin = stats is None and M_dev is None and thin_eligible(mode, C, N, T)
     wino = False
     if thin:

@@ -152,6 +152,9 @@ typedef struct {
      * problem z uses A + z*batch_stride_a, W + z*batch_stride_w, out + z*batch_stride_out (elements) */
     int32_t nbatch;
     int64_t batch_stride_a, batch_stride_w, batch_stride_out;
+    /* mode 2 only: problem z reads table columns z*batch_stride_table .. + T (a split of the neighbour taps over the problems:
+     * split-K for levels with few vertices, the partial planes are added by efgh_fold_planes) */
+    int32_t batch_stride_table;
 } efgh_gemm_desc;
 
 int efgh_gather_gemm(const efgh_gemm_desc *d, void *stream);
@@ -163,6 +166,9 @@ int efgh_pack_weight(const float *W, float *Wp, int32_t N, int32_t T, int32_t C,
 /* same, Wp[Np][T][Cp] with zeros outside [N][.][C] (row / channel counts rounded up for the kernels' vector width) */
 int efgh_pack_weight_padded(const float *W, float *Wp, int32_t N, int32_t T, int32_t C, int32_t Np, int32_t Cp, int64_t sn,
                             int64_t sc, int64_t st, const int32_t *tapidx_host, void *stream);
+/* out[m][n] = act(sum_z part[z][m][n] + bias[n]), part [S][M][N] contiguous (N % 4 == 0): the planes of a split-K launch */
+int efgh_fold_planes(const float *part, int32_t S, int64_t M, int32_t N, const float *bias, int32_t act, float slope, float *out,
+                     int64_t ldo, void *stream);
 /* out[i] = i < n ? v[i] : fill, i < np   (bias / BatchNorm vectors of layers whose width is not a multiple of 4) */
 int efgh_pad_vec(const float *v, int32_t n, float *out, int32_t np, float fill, void *stream);
 
