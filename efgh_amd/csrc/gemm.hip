@@ -453,6 +453,23 @@ __global__ void k_pack_weight(const float *__restrict__ W, float *__restrict__ W
     }
 }
 
+// every packed layout of every weight in ONE launch (after an optimizer step all of them are stale): workgroup -> job by binary
+// search over the prefix sums of the jobs' output sizes
+__global__ void __launch_bounds__(256) k_pack_weight_batched(const efgh_pack_job *__restrict__ jobs, const long long *__restrict__ prefix,
+                                                             int njobs, long long total) {
+    for (long long i0 = (long long)blockIdx.x * 256; i0 < total; i0 += (long long)gridDim.x * 256) {
+        const long long i = i0 + threadIdx.x;
+        if (i >= total) continue;
+        int lo = 0, hi = njobs - 1;                      // largest j with prefix[j] <= i
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (prefix[mid] <= i) lo = mid; else hi = mid - 1; }
+        const efgh_pack_job &j = jobs[lo];
+        const long long e = i - prefix[lo];
+        const int c = (int)(e % j.Cp); const long long r = e / j.Cp;
+        const int t = (int)(r % j.T); const int n = (int)(r / j.T);
+        j.Wp[e] = (n < j.N && c < j.C) ? j.W[n * j.sn + c * j.sc + j.taps[t] * j.st] : 0.f;
+    }
+}
+
 __global__ void k_fold_planes(const float4 *__restrict__ part, int S, long long M, int N4, const float4 *__restrict__ bias, int act,
                               float slope, float *__restrict__ out, long long ldo) {
     const long long total = M * N4;
@@ -630,6 +647,16 @@ extern "C" int efgh_split_bf16(const float *w, void *hi, void *mid, void *lo, in
     long long g = (n + 255) / 256;
     k_split_bf16<<<(int)(g > 8192 ? 8192 : g), 256, 0, (hipStream_t)stream_>>>(w, (__bf16 *)hi, (__bf16 *)mid,
                                                                              (__bf16 *)lo, n);
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}
+
+extern "C" int efgh_pack_weight_batched(const efgh_pack_job *jobs_dev, const int64_t *prefix_dev, int32_t njobs, int64_t total,
+                                        void *stream_) {
+    EFGH_CHECK_ARG(jobs_dev && prefix_dev && njobs > 0 && total > 0);
+    long long g = (total + 255) / 256;
+    k_pack_weight_batched<<<(int)(g > 16384 ? 16384 : g), 256, 0, (hipStream_t)stream_>>>(jobs_dev, (const long long *)prefix_dev, njobs,
+                                                                                         total);
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
 }

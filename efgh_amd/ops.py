@@ -41,27 +41,105 @@ WEIGHT_EPOCH = 0        # bumped by optimizers that update parameters outside to
 
 
 def _ver(*tensors):
-    return (WEIGHT_EPOCH,) + tuple((t._version, t.data_ptr()) for t in tensors)
+    # _efgh_gen: content generation of a buffer this module rewrites in place through raw pointers (packed weights)
+    return (WEIGHT_EPOCH,) + tuple((t._version, t.data_ptr(), getattr(t, '_efgh_gen', 0)) for t in tensors)
+
+
+BATCH_PACK = _os.environ.get('EFGH_BATCH_PACK', '1') != '0'
+_PACK_JOBS = []          # [(weakref to the weight, key)]: every packed layout that has a persistent buffer
+_PACK_TABLE = {}         # device index -> (signature, jobs tensor, prefix tensor, total, [(weight, key)])
+
+
+class _PackJob(ctypes.Structure):
+    """mirror of efgh_pack_job (include/efgh_hip.h)"""
+    _fields_ = [('W', ctypes.c_void_p), ('Wp', ctypes.c_void_p), ('N', c_int32), ('T', c_int32), ('C', c_int32), ('Np', c_int32),
+                ('Cp', c_int32), ('pad', c_int32), ('sn', c_int64), ('sc', c_int64), ('st', c_int64), ('taps', c_int32 * 16)]
+
+
+def _pack_one(w, buf, prm):
+    N, T, C, Np, Cp, sn, sc, st, taps = prm
+    tp = (ctypes.c_int32 * 16)(*([int(t) for t in taps] + [0] * (16 - len(taps)))) if taps is not None else None
+    _C.check(_L().efgh_pack_weight_padded(ptr(w), ptr(buf), c_int32(N), c_int32(T), c_int32(C), c_int32(Np), c_int32(Cp),
+                                          c_int64(sn), c_int64(sc), c_int64(st), tp, _st()))
+    buf._efgh_gen = getattr(buf, '_efgh_gen', 0) + 1
+
+
+def _repack_all(device):
+    """ONE launch re-packs every registered layout of every live weight on `device` whose cache entry is stale only because the
+    optimizer stepped (train.FusedAdam bumps WEIGHT_EPOCH): 279 launches of 5 us per training step otherwise"""
+    import weakref  # noqa: F401
+    live, jobs = [], []
+    for ref, key in _PACK_JOBS:
+        w = ref()
+        if w is None:
+            continue
+        live.append((ref, key))
+        ent = w.__dict__.get('_efgh_cache', {}).get(key)
+        if ent is None or not w.is_cuda or w.device != device:
+            continue
+        cur = _ver(w)
+        if ent[0] != cur and ent[0][1:] == cur[1:]:
+            jobs.append((w, key, ent[1], cur))
+    _PACK_JOBS[:] = live
+    if not jobs:
+        return
+    sig = tuple((w.data_ptr(), buf.data_ptr(), key) for w, key, buf, _ in jobs)
+    tab = _PACK_TABLE.get(device.index)
+    if tab is None or tab[0] != sig:
+        arr = (_PackJob * len(jobs))()
+        prefix, total = [], 0
+        for i, (w, key, buf, _) in enumerate(jobs):
+            N, T, C, Np, Cp, sn, sc, st, taps = buf._efgh_pack
+            j = arr[i]
+            j.W, j.Wp, j.N, j.T, j.C, j.Np, j.Cp, j.sn, j.sc, j.st = w.data_ptr(), buf.data_ptr(), N, T, C, Np, Cp, sn, sc, st
+            for q in range(16):
+                j.taps[q] = int(taps[q]) if (taps is not None and q < len(taps)) else (q if q < T else 0)
+            prefix.append(total)
+            total += Np * T * Cp
+        prefix.append(total)
+        raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
+        pre = torch.tensor(prefix, dtype=torch.int64).to(device)
+        tab = _PACK_TABLE[device.index] = (sig, raw, pre, total)
+    _C.check(_L().efgh_pack_weight_batched(ptr(tab[1]), ptr(tab[2]), c_int32(len(jobs)), c_int64(tab[3]), _st()))
+    for w, key, buf, cur in jobs:
+        buf._efgh_gen = getattr(buf, '_efgh_gen', 0) + 1
+        w.__dict__['_efgh_cache'][key] = (cur, buf)
 
 
 def pack_weight(w, N, T, C, sn, sc, st, taps=None, Np=None, Cp=None, key=None):
-    """Wp[n][t][c] = w.flat[n*sn + c*sc + taps[t]*st]; optionally zero-padded to (Np, T, Cp)."""
+    """Wp[n][t][c] = w.flat[n*sn + c*sc + taps[t]*st]; optionally zero-padded to (Np, T, Cp).  With a `key` the layout gets a
+    persistent buffer on the weight that is re-packed IN PLACE when the weight changes (derived caches see `_efgh_gen` move)."""
+    import weakref
     Np = Np or N
     Cp = Cp or C
-
-    def make():
-        wd = w.detach()
-        _C.require_cuda(wd)
-        wd = wd.contiguous()
+    prm = (N, T, C, Np, Cp, sn, sc, st, None if taps is None else tuple(int(t) for t in taps))
+    wd = w.detach()
+    _C.require_cuda(wd)
+    if key is None or not wd.is_contiguous():
         out = torch.empty((Np, T, Cp), dtype=torch.float32, device=wd.device)
-        tp = (ctypes.c_int32 * 16)(*([int(t) for t in taps] + [0] * (16 - len(taps)))) if taps is not None else None
-        _C.check(_L().efgh_pack_weight_padded(ptr(wd), ptr(out), c_int32(N), c_int32(T), c_int32(C), c_int32(Np), c_int32(Cp),
-                                              c_int64(sn), c_int64(sc), c_int64(st), tp, _st()))
+        _pack_one(wd.contiguous(), out, prm)
         return out
-
-    if key is None:
-        return make()
-    return _cached(w, tuple(key), _ver(w), make)
+    key = tuple(key)
+    store = w.__dict__.setdefault('_efgh_cache', {})
+    ent = store.get(key)
+    cur = _ver(w)
+    if ent is not None and ent[0] == cur:
+        return ent[1]
+    if ent is None or getattr(ent[1], '_efgh_pack', None) != prm:
+        buf = torch.empty((Np, T, Cp), dtype=torch.float32, device=wd.device)
+        buf._efgh_pack = prm
+        _pack_one(wd, buf, prm)
+        store[key] = (cur, buf)
+        _PACK_JOBS.append((weakref.ref(w), key))
+        return buf
+    if BATCH_PACK and ent[0][1:] == cur[1:]:          # only the optimizer epoch moved: everything else is stale the same way
+        _repack_all(wd.device)
+        ent = store[key]
+        if ent[0] == cur:
+            return ent[1]
+    _pack_one(wd, ent[1], prm)
+    store[key] = (cur, ent[1])
+    return ent[1]
 
 
 def pad_vec(v, Np, fill=0.0):
@@ -214,7 +292,7 @@ def _blur_gemm_ksplit(A, lda, C, Wp, N, M, out, ldo, table, bias, act, slope, a_
 
     def regroup():
         return Wp.view(N, S, Ts * C).permute(1, 0, 2).contiguous()             # [S][N][Ts*C]
-    Wg = _cached(Wp, ('ksplit', S), (Wp._version,), regroup)
+    Wg = _cached(Wp, ('ksplit', S), _ver(Wp), regroup)
     part = _scratch(S * M * N, dev)
     gather_gemm(A, lda, C, Ts, Wg, N, M, part, N, mode=2, table=table, a_off=a_off, batch=(S, 0, N * Ts * C, M * N, Ts),
                 flops=flops if flops is not None else 2.0 * M * N * 15 * C)

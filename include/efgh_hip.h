@@ -166,6 +166,15 @@ int efgh_pack_weight(const float *W, float *Wp, int32_t N, int32_t T, int32_t C,
 /* same, Wp[Np][T][Cp] with zeros outside [N][.][C] (row / channel counts rounded up for the kernels' vector width) */
 int efgh_pack_weight_padded(const float *W, float *Wp, int32_t N, int32_t T, int32_t C, int32_t Np, int32_t Cp, int64_t sn,
                             int64_t sc, int64_t st, const int32_t *tapidx_host, void *stream);
+/* the same for MANY weights in one launch (all packed layouts of a model after an optimizer step): jobs_dev = device array of
+ * njobs records, prefix_dev [njobs + 1] = exclusive prefix sums of Np*T*Cp (int64), total = prefix_dev[njobs] */
+typedef struct {
+    const float *W; float *Wp;
+    int32_t N, T, C, Np, Cp, pad_;
+    int64_t sn, sc, st;
+    int32_t taps[16];
+} efgh_pack_job;
+int efgh_pack_weight_batched(const efgh_pack_job *jobs_dev, const int64_t *prefix_dev, int32_t njobs, int64_t total, void *stream);
 /* out[m][n] = act(sum_z part[z][m][n] + bias[n]), part [S][M][N] contiguous (N % 4 == 0): the planes of a split-K launch */
 int efgh_fold_planes(const float *part, int32_t S, int64_t M, int32_t N, const float *bias, int32_t act, float slope, float *out,
                      int64_t ldo, void *stream);
