@@ -1,5 +1,8 @@
 """EFGHBackbone with the reference's module API (nets/efghbackbone.py:11-43): same constructor,
 same forward(pc, img, calib, A, check) -> dict with the reference's 22 keys, same state_dict."""
+import os
+
+import torch
 import torch.nn as nn
 
 from .. import ops
@@ -10,6 +13,16 @@ from .gnet import Gnet
 from .hnet import Hnet
 
 __all__ = ['EFGHBackbone']
+
+SIDE_STREAM = os.environ.get('EFGH_SIDE_STREAM', '1') != '0'
+_SIDE = {}
+
+
+def _side_stream(device):
+    s = _SIDE.get(device.index)
+    if s is None:
+        s = _SIDE[device.index] = torch.cuda.Stream(device=device)
+    return s
 
 
 def _stamp_pose(state, key, calib, A):
@@ -34,8 +47,25 @@ class EFGHBackbone(nn.Module):
         ops._C.require_cuda(pc, img, calib, A)
         ops._C.require_f32(pc, img, calib, A)
         shared_img = ops.nchw_to_nhwc(img, 4)                # channels-last copy used by both H and G
-        point_part = self.E(pc, check, keep=keep)
-        image_part = self.H(img, check, img_nhwc=shared_img, keep=keep)
+        if SIDE_STREAM and pc.is_cuda:
+            # E (point branch: ~450 small launches, many of them grids of a few workgroups) and H (image branch: full-chip MFMA
+            # kernels) are independent: H is enqueued first on the current stream, E runs on a side stream underneath it - the
+            # host-side read-back of the lattice sizes then waits for the side stream only.  Autograd runs each node's backward on
+            # the stream of its forward, so the two branches overlap in backward as well.
+            main = torch.cuda.current_stream()
+            side = _side_stream(pc.device)
+            side.wait_stream(main)
+            pc.record_stream(side)
+            image_part = self.H(img, check, img_nhwc=shared_img, keep=keep)
+            with torch.cuda.stream(side):
+                point_part = self.E(pc, check, keep=keep)
+            main.wait_stream(side)
+            for v in point_part.values():
+                if torch.is_tensor(v):
+                    v.record_stream(main)
+        else:
+            point_part = self.E(pc, check, keep=keep)
+            image_part = self.H(img, check, img_nhwc=shared_img, keep=keep)
         state = {**point_part, **image_part, 'network': point_part['network'] + image_part['network']}
         _stamp_pose(state, 'eh', calib, A)
         state = _stamp_pose(self.F(pc, state, check, keep=keep), 'efh', calib, A)

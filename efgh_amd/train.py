@@ -243,6 +243,11 @@ class Trainer:
         self.flat.zero_grad()
         self.comm.start_step()
         losses['total'].backward()            # bucket all-reduces start from the parameter hooks during this call
+        # the point branch runs on a side stream (nets/efghbackbone.py) and so does its backward; autograd joins the streams of the
+        # AccumulateGrad nodes it ran, but gradients written directly into the flat buffer have no such node: join explicitly
+        from .nets import efghbackbone as _bb
+        for s in _bb._SIDE.values():
+            torch.cuda.current_stream().wait_stream(s)
         self.comm.finish()
         self.opt.step(grad_scale=1.0 / self.world)
         self.it += 1

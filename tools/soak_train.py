@@ -39,6 +39,8 @@ for it in range(a.steps):
     assert tot == tot and abs(tot) < 1e9, (it, tot)
     if it == 3:
         mem0 = torch.cuda.memory_allocated()
+    if os.environ.get('EFGH_SOAK_EXACT'):
+        print('exact %d %r' % (it, tot))
     if it % 5 == 0 or it == a.steps - 1:
         print('step %3d  npts %6d  total %.2f  %.1f ms  alloc %.1f GB  peak %.1f GB  lattice sizes %s' % (
             it, npts, tot, times[-1], torch.cuda.memory_allocated() / 1e9, torch.cuda.max_memory_allocated() / 1e9,
