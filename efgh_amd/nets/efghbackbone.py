@@ -18,10 +18,14 @@ SIDE_STREAM = os.environ.get('EFGH_SIDE_STREAM', '1') != '0'
 _SIDE = {}
 
 
-def _side_stream(device):
-    s = _SIDE.get(device.index)
+G_SIDE = os.environ.get('EFGH_G_SIDE', '1') != '0'          # G's image part next to H / F (needs SIDE_STREAM)
+F_SIDE = os.environ.get('EFGH_F_SIDE', '1') != '0'          # F's camera trunk next to its range trunk (nets/fnet.py)
+
+
+def _side_stream(device, i=0):
+    s = _SIDE.get((device.index, i))
     if s is None:
-        s = _SIDE[device.index] = torch.cuda.Stream(device=device)
+        s = _SIDE[(device.index, i)] = torch.cuda.Stream(device=device)
     return s
 
 
@@ -47,19 +51,29 @@ class EFGHBackbone(nn.Module):
         ops._C.require_cuda(pc, img, calib, A)
         ops._C.require_f32(pc, img, calib, A)
         shared_img = ops.nchw_to_nhwc(img, 4)                # channels-last copy used by both H and G
+        g_pre = None
         if SIDE_STREAM and pc.is_cuda:
-            # E (point branch: ~450 small launches, many of them grids of a few workgroups) and H (image branch: full-chip MFMA
-            # kernels) are independent: H is enqueued first on the current stream, E runs on a side stream underneath it - the
-            # host-side read-back of the lattice sizes then waits for the side stream only.  Autograd runs each node's backward on
-            # the stream of its forward, so the two branches overlap in backward as well.
+            # Three independent pieces of work start here: H (image branch, full-chip MFMA kernels), E (point branch: ~450 small
+            # launches, many of them grids of a few workgroups) and the part of G that only needs the camera image (encoder, decoder,
+            # depth / mask heads).  H is enqueued on the current stream, G's image part and E on side streams underneath it: kernels
+            # of one branch fill the tails and the small grids of the others, and the host-side read-back of the lattice sizes
+            # (inside E, enqueued last) waits for E's stream only.  Autograd runs each node's backward on the stream of its forward,
+            # so the branches overlap in backward as well.
             main = torch.cuda.current_stream()
-            side = _side_stream(pc.device)
-            side.wait_stream(main)
-            pc.record_stream(side)
+            s_e = _side_stream(pc.device, 0)
+            s_e.wait_stream(main)
+            pc.record_stream(s_e)
             image_part = self.H(img, check, img_nhwc=shared_img, keep=keep)
-            with torch.cuda.stream(side):
+            if G_SIDE:
+                s_g = _side_stream(pc.device, 1)
+                s_g.wait_stream(main)            # (shared_img; H's kernels enqueued above do not have to finish first ...
+                shared_img.record_stream(s_g)
+                img.record_stream(s_g)
+                with torch.cuda.stream(s_g):     # ... but stream order makes them: acceptable, H starts first anyway)
+                    g_pre = self.G.image_part(img, shared_img)
+            with torch.cuda.stream(s_e):
                 point_part = self.E(pc, check, keep=keep)
-            main.wait_stream(side)
+            main.wait_stream(s_e)
             for v in point_part.values():
                 if torch.is_tensor(v):
                     v.record_stream(main)
@@ -69,7 +83,12 @@ class EFGHBackbone(nn.Module):
         state = {**point_part, **image_part, 'network': point_part['network'] + image_part['network']}
         _stamp_pose(state, 'eh', calib, A)
         state = _stamp_pose(self.F(pc, state, check, keep=keep), 'efh', calib, A)
-        state = _stamp_pose(self.G(pc, img, state, check, img_nhwc=shared_img, keep=keep), 'efgh', calib, A)
+        if g_pre is not None:
+            torch.cuda.current_stream().wait_stream(_side_stream(pc.device, 1))
+            for v in g_pre.values():
+                if torch.is_tensor(v):
+                    v.record_stream(torch.cuda.current_stream())
+        state = _stamp_pose(self.G(pc, img, state, check, img_nhwc=shared_img, keep=keep, pre=g_pre), 'efgh', calib, A)
         state['cam_T_velo'] = state['efgh_cam_T_velo']
         state.pop('_h_img_nhwc', None)
         return state

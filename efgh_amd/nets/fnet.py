@@ -1,5 +1,6 @@
 """F-net: yaw by cross-modal correlation (reference nets/fnet.py) on the HIP path."""
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -45,9 +46,20 @@ class Fnet(nn.Module):
         h_img = ret.get('_h_img_nhwc')
         if h_img is None:
             h_img = ops.nchw_to_nhwc(ret['h_img'], 4)
-        cam = self._trunk(ctx, h_img, 'camera')                                   # (B,h,wc,16)
-        r0 = L.run_conv_bn_relu(ctx, self.conv_range, e_range)                    # (B,H,W-1,4)
-        rng = self._trunk(ctx, r0, 'range')                                       # (B,h,wr,16)
+        from . import efghbackbone as bb
+        if bb.SIDE_STREAM and bb.F_SIDE and pc.is_cuda:
+            main, side = torch.cuda.current_stream(), bb._side_stream(pc.device)
+            side.wait_stream(main)
+            r0 = L.run_conv_bn_relu(ctx, self.conv_range, e_range)                # (B,H,W-1,4)
+            rng = self._trunk(ctx, r0, 'range')                                   # (B,h,wr,16)
+            with torch.cuda.stream(side):
+                cam = self._trunk(ctx, h_img, 'camera')                           # (B,h,wc,16)
+            main.wait_stream(side)
+            cam.record_stream(main)
+        else:
+            cam = self._trunk(ctx, h_img, 'camera')                               # (B,h,wc,16)
+            r0 = L.run_conv_bn_relu(ctx, self.conv_range, e_range)                # (B,H,W-1,4)
+            rng = self._trunk(ctx, r0, 'range')                                   # (B,h,wr,16)
         if ctx.grad:
             f_score, logit = FN.CorrHeadFn.apply(cam, rng), None                  # fnet.py:57-81
         else:

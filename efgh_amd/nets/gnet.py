@@ -29,7 +29,9 @@ class Gnet(nn.Module):
         self.conv_trs_3 = conv_bn_relu(512, 512, 1)
         self.conv_trs_4 = nn.Conv1d(512, 3, 1)
 
-    def forward(self, pc, img, ret, check=False, img_nhwc=None, keep=None):
+    def image_part(self, img, img_nhwc=None):
+        """everything of G that depends on the camera image only (encoder, decoder, the depth / mask heads, conv_i1): the backbone
+        runs it on a side stream next to F, which it does not depend on (gnet.py:103-134)"""
         ctx = L.Ctx(self.training)
         dev = img.device
         x = img_nhwc if img_nhwc is not None else ops.nchw_to_nhwc(img, 4)
@@ -91,21 +93,35 @@ class Gnet(nn.Module):
         cv = cat(cat1, [t2, c2])
         dimg, cv = L.run_convt_bn_relu(ctx, self.convt_dimg, cv, skip_out=True)    # (B,2H,2W,4) ch0
         mask = L.run_convt_bn_relu(ctx, self.convt_mask, cv)                       # (B,2H,2W,4) ch0,1
-        rawH, rawW = self.raw_cam_img_size
+        cat0 = cat0_early()                   # [conv_i1 | conv_d1]
         if ctx.grad:
             g_depth = FN.NhwcToNchwFn.apply(dimg, 1)
             g_mask = FN.Softmax2ToNchwFn.apply(mask)
-            f_depth = FN.DepthImageFn.apply(pc, ret['efh_cam_T_velo'], rawH, rawW)  # :136
         else:
             g_depth = ops.nhwc_to_nchw(dimg, 1)
             g_mask = ops.softmax2_to_nchw(mask)
+            L.run_conv_bn_relu(ctx, self.conv_i1, cat1, out=(cat0, 0), in_ch=(0, 64))
+        return {'g_depth': g_depth, 'g_mask': g_mask, 'ci1': ci1, 'cat0': cat0}
+
+    def forward(self, pc, img, ret, check=False, img_nhwc=None, keep=None, pre=None):
+        """pre: the result of image_part() when the caller has already run it (EFGHBackbone overlaps it with F)"""
+        ctx = L.Ctx(self.training)
+        if pre is None:
+            pre = self.image_part(img, img_nhwc)
+        g_depth, g_mask, ci1, cat0 = pre['g_depth'], pre['g_mask'], pre['ci1'], pre['cat0']
+        B = cat0.shape[0]
+
+        def tgt(b, off):
+            return (b, off)
+        rawH, rawW = self.raw_cam_img_size
+        if ctx.grad:
+            f_depth = FN.DepthImageFn.apply(pc, ret['efh_cam_T_velo'], rawH, rawW)  # :136
+        else:
             f_depth, _ = ops.depth_image(pc, ret['efh_cam_T_velo'], rawH, rawW)
-        cat0 = cat0_early()                   # [conv_i1 | conv_d1]
         if ctx.grad:
             cd1 = L.run_conv_bn_relu(ctx, self.conv_d1, f_depth, out=tgt(cat0, 32))
             y = FN.concat(cat0, [ci1, cd1])
         else:
-            L.run_conv_bn_relu(ctx, self.conv_i1, cat1, out=(cat0, 0), in_ch=(0, 64))
             L.run_conv_bn_relu(ctx, self.conv_d1, f_depth, out=(cat0, 32))
             y = cat0
         y = L.run_resnet_layer(ctx, self.conv2, y)
