@@ -249,6 +249,34 @@ class GemmLayerFn(torch.autograd.Function):
                                  dres, Np, pscale=psc, pshift=psh)
             if has_bias and has_bn:          # bias in front of BatchNorm: d/dbias = column sums of draw
                 dbias = _bias_grad_behind_bn(ctx, p_bias, draw, M, Np, N, train_bn, delivered)
+        # ---- wgrad (first when it can go to the weight-gradient stream: it only needs draw and x, and nothing in this backward pass
+        # waits for it, so it runs underneath the HBM-bound BatchNorm passes and the dgrads of the layers that follow)
+        dW = None
+        if ctx.needs_input_grad[1] and spec.custom_wgrad is not None:
+            dW = spec.custom_wgrad(x, weight, draw)
+        elif ctx.needs_input_grad[1]:
+            gW, dw_done = claim_grad(p_w)
+            dW = gW if gW is not None else torch.empty_like(weight)
+            side = ops.wgrad_stream(dev) if (gW is not None and ops.WGRAD_SIDE) else None
+
+            def run_wgrad():
+                for li, (geom, m) in enumerate(spec.launches):
+                    T = spec.T if geom is None else len(geom[7])
+                    dWp = torch.empty((Np, T, spec.C), dtype=torch.float32, device=dev)
+                    ops.gather_wgrad(x, ld_of(x), spec.C, T, Np, m, draw, Np, dWp, mode=spec.mode, geom=geom,
+                                     table=spec.table)
+                    spec.wgrad_unpack(dWp, li, dW)
+            if side is None:
+                run_wgrad()
+            else:
+                side.wait_stream(torch.cuda.current_stream())       # draw is complete
+                x.record_stream(side)
+                draw.record_stream(side)
+                with torch.cuda.stream(side):
+                    run_wgrad()
+            if gW is not None:
+                dW = None
+                delivered.append(dw_done)
         # ---- dgrad
         dx = None
         if ctx.needs_input_grad[0]:
@@ -256,22 +284,6 @@ class GemmLayerFn(torch.autograd.Function):
                 dx = spec.dgrad(spec, weight, draw, x, add=as_rows(dskip))
             else:
                 dx = spec.dgrad(spec, weight, draw, x)
-        # ---- wgrad
-        dW = None
-        if ctx.needs_input_grad[1] and spec.custom_wgrad is not None:
-            dW = spec.custom_wgrad(x, weight, draw)
-        elif ctx.needs_input_grad[1]:
-            gW, dw_done = claim_grad(p_w)
-            dW = gW if gW is not None else torch.empty_like(weight)
-            for li, (geom, m) in enumerate(spec.launches):
-                T = spec.T if geom is None else len(geom[7])
-                dWp = torch.empty((Np, T, spec.C), dtype=torch.float32, device=dev)
-                ops.gather_wgrad(x, ld_of(x), spec.C, T, Np, m, draw, Np, dWp, mode=spec.mode, geom=geom,
-                                 table=spec.table)
-                spec.wgrad_unpack(dWp, li, dW)
-            if gW is not None:
-                dW = None
-                delivered.append(dw_done)
         if dres is not None and Np != N:
             dres = dres[..., :N]
         for done in delivered:               # after the writes are enqueued: the all-reduce bucket countdown

@@ -700,6 +700,23 @@ USE_WINO_WGRAD = _os.environ.get('EFGH_WINO_WGRAD', '1') != '0'
 
 
 _SCRATCH = {}
+WGRAD_SIDE = _os.environ.get('EFGH_WGRAD_STREAM', '1') != '0'
+_WGRAD_STREAMS = {}
+
+
+def wgrad_stream(device):
+    """the stream weight gradients are launched on when they are written straight into a flat gradient buffer (nets/fn.py):
+    train.Trainer joins it before the optimizer"""
+    s = _WGRAD_STREAMS.get(device.index)
+    if s is None:
+        s = _WGRAD_STREAMS[device.index] = torch.cuda.Stream(device=device)
+    return s
+
+
+def side_streams():
+    """every side stream this package has created (branch streams of the backbone + the weight-gradient stream)"""
+    from .nets import efghbackbone as bb
+    return list(bb._SIDE.values()) + list(_WGRAD_STREAMS.values())
 DETERMINISTIC = _os.environ.get('EFGH_DETERMINISTIC', '0') == '1'
 
 
@@ -745,6 +762,8 @@ def gather_wgrad(A, lda, C, T, N, M, G, ldg, dWp, mode=0, geom=None, table=None)
         T2 = _L().efgh_wino2d_tiles(c_int32(B), c_int32(H), c_int32(W))
         dev = dWp.device
         kept = W2V_CACHE.pop((A.data_ptr(), lda, C, B, H, W), None)
+        if kept is not None:
+            kept[0].record_stream(torch.cuda.current_stream())          # (made on the forward's stream, maybe read on another)
         Gy = torch.empty((T2, 36, N), dtype=torch.float32, device=dev)
         S = torch.empty((36, N, C), dtype=torch.float32, device=dev)
         if kept is not None and kept[1] == A._version and kept[0].shape == (T2, 36, C):

@@ -152,6 +152,8 @@ class OverlappedAllReduce:
         if self.launched[b]:
             return
         self.launched[b] = True
+        for st in ops.side_streams():         # gradients of this bucket may have been written on a side stream
+            torch.cuda.current_stream().wait_stream(st)
         s, e = self.buckets[b]
         self.order.append(b)
         self.works.append(dist.all_reduce(self.flat.g[s:e], op=dist.ReduceOp.SUM, async_op=True))
@@ -245,8 +247,7 @@ class Trainer:
         losses['total'].backward()            # bucket all-reduces start from the parameter hooks during this call
         # the point branch runs on a side stream (nets/efghbackbone.py) and so does its backward; autograd joins the streams of the
         # AccumulateGrad nodes it ran, but gradients written directly into the flat buffer have no such node: join explicitly
-        from .nets import efghbackbone as _bb
-        for s in _bb._SIDE.values():
+        for s in ops.side_streams():
             torch.cuda.current_stream().wait_stream(s)
         self.comm.finish()
         self.opt.step(grad_scale=1.0 / self.world)
