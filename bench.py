@@ -297,18 +297,19 @@ def main():
         return dt, prof
 
     def attach_serialized(dst, step_fn, workload):
-        """the point branch runs on a side stream underneath the image branch (nets/efghbackbone.py), so inside the timed region the
-        event interval of a launch of either branch includes time it shares the GPU with the other one (`roofline*` above: as the
-        contract asks, from the timed region).  Two extra, untimed steps with the branches on ONE stream give every family's
-        isolated launch durations: `serialized` = {achieved, frac, kernel_ms_per_step} next to the timed-region figures."""
+        """independent branches of the network run on several streams (nets/efghbackbone.py, nets/fnet.py; weight gradients on their
+        own stream, nets/fn.py), so inside the timed region the event interval of a launch includes time it shares the GPU with
+        launches of other branches (`roofline*` above: as the contract asks, from the timed region).  Two extra, untimed steps
+        with everything on ONE stream give every family's isolated launch durations: `serialized` = {achieved, frac,
+        kernel_ms_per_step} next to the timed-region figures."""
         from efgh_amd.nets import efghbackbone as bb
         if not bb.SIDE_STREAM:
             return
-        bb.SIDE_STREAM = False
+        bb.SIDE_STREAM, wg, ops.WGRAD_SIDE = False, ops.WGRAD_SIDE, False
         try:
             _, prof2 = timed(step_fn, 2, 1)
         finally:
-            bb.SIDE_STREAM = True
+            bb.SIDE_STREAM, ops.WGRAD_SIDE = True, wg
         if dst is None:
             return
         mine = {v['kernel']: v for k, v in dst.items() if k.startswith('roofline') and isinstance(v, dict)}
