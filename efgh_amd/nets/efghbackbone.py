@@ -20,6 +20,8 @@ _SIDE = {}
 
 G_SIDE = os.environ.get('EFGH_G_SIDE', '1') != '0'          # G's image part next to H / F (needs SIDE_STREAM)
 F_SIDE = os.environ.get('EFGH_F_SIDE', '1') != '0'          # F's camera trunk next to its range trunk (nets/fnet.py)
+H_SIDE = os.environ.get('EFGH_H_SIDE', '1') != '0'          # inference only: H on its own stream, F's camera trunk follows it
+#   (measured: -0.7 ms per batch-4 forward; with autograd on, a fourth concurrent MFMA stream costs 13 ms per training step)
 
 
 def _side_stream(device, i=0):
@@ -63,13 +65,23 @@ class EFGHBackbone(nn.Module):
             s_e = _side_stream(pc.device, 0)
             s_e.wait_stream(main)
             pc.record_stream(s_e)
-            image_part = self.H(img, check, img_nhwc=shared_img, keep=keep)
+            # H_SIDE: H gets a stream of its own and F's camera trunk follows it there, so that F's range trunk - which only needs
+            # E's rotation - starts on the current stream as soon as E is done instead of after H
+            s_h = _side_stream(pc.device, 2) if (H_SIDE and F_SIDE and not torch.is_grad_enabled()) else None
+            if s_h is not None:
+                s_h.wait_stream(main)
+                shared_img.record_stream(s_h)
+                img.record_stream(s_h)
+                with torch.cuda.stream(s_h):
+                    image_part = self.H(img, check, img_nhwc=shared_img, keep=keep)
+            else:
+                image_part = self.H(img, check, img_nhwc=shared_img, keep=keep)
             if G_SIDE:
                 s_g = _side_stream(pc.device, 1)
-                s_g.wait_stream(main)            # (shared_img; H's kernels enqueued above do not have to finish first ...
+                s_g.wait_stream(main)
                 shared_img.record_stream(s_g)
                 img.record_stream(s_g)
-                with torch.cuda.stream(s_g):     # ... but stream order makes them: acceptable, H starts first anyway)
+                with torch.cuda.stream(s_g):
                     g_pre = self.G.image_part(img, shared_img)
             with torch.cuda.stream(s_e):
                 point_part = self.E(pc, check, keep=keep)
@@ -78,11 +90,22 @@ class EFGHBackbone(nn.Module):
                 if torch.is_tensor(v):
                     v.record_stream(main)
         else:
+            s_h = None
             point_part = self.E(pc, check, keep=keep)
             image_part = self.H(img, check, img_nhwc=shared_img, keep=keep)
         state = {**point_part, **image_part, 'network': point_part['network'] + image_part['network']}
-        _stamp_pose(state, 'eh', calib, A)
-        state = _stamp_pose(self.F(pc, state, check, keep=keep), 'efh', calib, A)
+        if s_h is None:
+            _stamp_pose(state, 'eh', calib, A)
+            state = self.F(pc, state, check, keep=keep)
+        else:
+            state['eh_cam_T_velo'] = None                     # (keeps the reference's key order; filled in after the join below)
+            pre_f = state
+            state = self.F(pc, state, check, keep=keep, cam_stream=s_h)      # joins s_h before the correlation head
+            for v in image_part.values():
+                if torch.is_tensor(v):
+                    v.record_stream(torch.cuda.current_stream())
+            state['eh_cam_T_velo'] = _stamp_pose(dict(pre_f), 'eh', calib, A)['eh_cam_T_velo']
+        state = _stamp_pose(state, 'efh', calib, A)
         if g_pre is not None:
             torch.cuda.current_stream().wait_stream(_side_stream(pc.device, 1))
             for v in g_pre.values():

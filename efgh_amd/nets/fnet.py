@@ -35,7 +35,9 @@ class Fnet(nn.Module):
         x = L.run_convt_bn_relu(ctx, getattr(self, 'vgg_5_2_' + side), x)
         return L.run_convt_bn_relu(ctx, getattr(self, 'vgg_5_3_' + side), x)
 
-    def forward(self, pc, ret, check=False, keep=None):
+    def forward(self, pc, ret, check=False, keep=None, cam_stream=None):
+        """cam_stream: the stream H ran on (EFGHBackbone): the camera trunk is enqueued there, behind H, while the range trunk -
+        which needs E's rotation only - runs on the current stream; joined before the correlation head"""
         ctx = L.Ctx(self.training)
         H, W = self.range_img_size
         fov = (self.lidar_fov_rad[0] * math.pi, self.lidar_fov_rad[1] * math.pi)
@@ -43,23 +45,35 @@ class Fnet(nn.Module):
             e_range = FN.RangeImageFn.apply(pc, ret['e_l'], H, W, fov[0], fov[1])  # fnet.py:43-45
         else:
             e_range, _ = ops.range_image(pc, ret['e_l'], H, W, fov[0], fov[1])
-        h_img = ret.get('_h_img_nhwc')
-        if h_img is None:
-            h_img = ops.nchw_to_nhwc(ret['h_img'], 4)
         from . import efghbackbone as bb
-        if bb.SIDE_STREAM and bb.F_SIDE and pc.is_cuda:
-            main, side = torch.cuda.current_stream(), bb._side_stream(pc.device)
-            side.wait_stream(main)
+        main = torch.cuda.current_stream() if pc.is_cuda else None
+
+        def camera():
+            h_img = ret.get('_h_img_nhwc')
+            if h_img is None:
+                h_img = ops.nchw_to_nhwc(ret['h_img'], 4)
+            return self._trunk(ctx, h_img, 'camera')                              # (B,h,wc,16)
+
+        def rng_branch():
             r0 = L.run_conv_bn_relu(ctx, self.conv_range, e_range)                # (B,H,W-1,4)
-            rng = self._trunk(ctx, r0, 'range')                                   # (B,h,wr,16)
+            return self._trunk(ctx, r0, 'range')                                  # (B,h,wr,16)
+        if cam_stream is not None:
+            rng = rng_branch()
+            with torch.cuda.stream(cam_stream):
+                cam = camera()
+            main.wait_stream(cam_stream)
+            cam.record_stream(main)
+        elif bb.SIDE_STREAM and bb.F_SIDE and pc.is_cuda:
+            side = bb._side_stream(pc.device)
+            side.wait_stream(main)
+            rng = rng_branch()
             with torch.cuda.stream(side):
-                cam = self._trunk(ctx, h_img, 'camera')                           # (B,h,wc,16)
+                cam = camera()
             main.wait_stream(side)
             cam.record_stream(main)
         else:
-            cam = self._trunk(ctx, h_img, 'camera')                               # (B,h,wc,16)
-            r0 = L.run_conv_bn_relu(ctx, self.conv_range, e_range)                # (B,H,W-1,4)
-            rng = self._trunk(ctx, r0, 'range')                                   # (B,h,wr,16)
+            cam = camera()
+            rng = rng_branch()
         if ctx.grad:
             f_score, logit = FN.CorrHeadFn.apply(cam, rng), None                  # fnet.py:57-81
         else:

@@ -706,17 +706,17 @@ _WGRAD_STREAMS = {}
 
 def wgrad_stream(device):
     """the stream weight gradients are launched on when they are written straight into a flat gradient buffer (nets/fn.py):
-    train.Trainer joins it before the optimizer"""
-    s = _WGRAD_STREAMS.get(device.index)
-    if s is None:
-        s = _WGRAD_STREAMS[device.index] = torch.cuda.Stream(device=device)
-    return s
+    train.Trainer joins it before the optimizer.  It is the backbone's third side stream (which inference uses for H): HIP
+    multiplexes streams onto 4 hardware queues, and a fifth stream in the process makes two of them share a queue - measured:
+    +12 ms per training step from merely having created it."""
+    from .nets import efghbackbone as bb
+    return bb._side_stream(device, 2)
 
 
 def side_streams():
     """every side stream this package has created (branch streams of the backbone + the weight-gradient stream)"""
     from .nets import efghbackbone as bb
-    return list(bb._SIDE.values()) + list(_WGRAD_STREAMS.values())
+    return list(bb._SIDE.values())
 DETERMINISTIC = _os.environ.get('EFGH_DETERMINISTIC', '0') == '1'
 
 
