@@ -23,6 +23,9 @@ python3 $ROOT/tools/collect_mfma_busy.py $SCR/mb $OUT/mfma_busy_train.json "$CMD
 # 30 timed steps: the one-off launches of model construction (637 parameter uploads) stop weighing on the per-step launch census
 rocprofv3 --kernel-trace --stats --output-format csv -d $SCR/st -- python3 $ROOT/bench.py --no-cpu-baseline --no-forward-section --steps 30 --warmup 2 > $OUT/bench_train_under_rocprof.json 2> $SCR/st.err
 cp $SCR/st/*/*kernel_stats.csv $OUT/train_kernel_stats.csv
+# the same on ONE stream: the per-kernel durations the roofline objects of bench.py are computed from
+EFGH_SIDE_STREAM=0 EFGH_WGRAD_STREAM=0 rocprofv3 --kernel-trace --stats --output-format csv -d $SCR/s1 -- python3 $ROOT/bench.py --no-cpu-baseline --no-forward-section --steps 10 --warmup 2 > $OUT/bench_train_single_stream_under_rocprof.json 2> $SCR/s1.err
+cp $SCR/s1/*/*kernel_stats.csv $OUT/train_kernel_stats_single_stream.csv
 rocprofv3 --kernel-trace --stats --output-format csv -d $SCR/sf -- python3 $ROOT/bench.py --mode fwd --no-cpu-baseline > $OUT/bench_fwd_under_rocprof.json 2> $SCR/sf.err
 cp $SCR/sf/*/*kernel_stats.csv $OUT/fwd_kernel_stats.csv
 cd $ROOT && python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
