@@ -19,9 +19,7 @@ _SIDE = {}
 
 
 G_SIDE = os.environ.get('EFGH_G_SIDE', '1') != '0'          # G's image part next to H / F (needs SIDE_STREAM)
-F_SIDE = os.environ.get('EFGH_F_SIDE', '1') != '0'          # F's camera trunk next to its range trunk (nets/fnet.py)
-H_SIDE = os.environ.get('EFGH_H_SIDE', '1') != '0'          # inference only: H on its own stream, F's camera trunk follows it
-#   (measured: -0.7 ms per batch-4 forward; with autograd on, a fourth concurrent MFMA stream costs 13 ms per training step)
+F_SIDE = os.environ.get('EFGH_F_SIDE', '1') != '0'          # H and F's camera trunk on a side stream, E and F's range trunk on the current one
 
 
 def _side_stream(device, i=0):
@@ -54,21 +52,17 @@ class EFGHBackbone(nn.Module):
         ops._C.require_f32(pc, img, calib, A)
         shared_img = ops.nchw_to_nhwc(img, 4)                # channels-last copy used by both H and G
         g_pre = None
+        s_h = None
         if SIDE_STREAM and pc.is_cuda:
-            # Three independent pieces of work start here: H (image branch, full-chip MFMA kernels), E (point branch: ~450 small
-            # launches, many of them grids of a few workgroups) and the part of G that only needs the camera image (encoder, decoder,
-            # depth / mask heads).  H is enqueued on the current stream, G's image part and E on side streams underneath it: kernels
-            # of one branch fill the tails and the small grids of the others, and the host-side read-back of the lattice sizes
-            # (inside E, enqueued last) waits for E's stream only.  Autograd runs each node's backward on the stream of its forward,
-            # so the branches overlap in backward as well.
+            # Three independent pieces of work start here: H (image branch), E (point branch: ~450 small launches) and the part of G
+            # that only needs the camera image (encoder, decoder, depth / mask heads).  H and G's image part are enqueued on side
+            # streams first; E runs on the current stream (its host-side read-back of the lattice sizes then only waits for E), and
+            # F's range trunk - which needs nothing but E's rotation - follows it there, while F's camera trunk follows H on H's
+            # stream.  Kernels of one branch fill the tails and the HBM-bound phases of the others; autograd runs each node's
+            # backward on the stream of its forward, so the branches overlap in backward as well.
             main = torch.cuda.current_stream()
-            s_e = _side_stream(pc.device, 0)
-            s_e.wait_stream(main)
-            pc.record_stream(s_e)
-            # H_SIDE: H gets a stream of its own and F's camera trunk follows it there, so that F's range trunk - which only needs
-            # E's rotation - starts on the current stream as soon as E is done instead of after H
-            s_h = _side_stream(pc.device, 2) if (H_SIDE and F_SIDE and not torch.is_grad_enabled()) else None
-            if s_h is not None:
+            if F_SIDE:
+                s_h = _side_stream(pc.device, 0)
                 s_h.wait_stream(main)
                 shared_img.record_stream(s_h)
                 img.record_stream(s_h)
@@ -83,14 +77,8 @@ class EFGHBackbone(nn.Module):
                 img.record_stream(s_g)
                 with torch.cuda.stream(s_g):
                     g_pre = self.G.image_part(img, shared_img)
-            with torch.cuda.stream(s_e):
-                point_part = self.E(pc, check, keep=keep)
-            main.wait_stream(s_e)
-            for v in point_part.values():
-                if torch.is_tensor(v):
-                    v.record_stream(main)
+            point_part = self.E(pc, check, keep=keep)
         else:
-            s_h = None
             point_part = self.E(pc, check, keep=keep)
             image_part = self.H(img, check, img_nhwc=shared_img, keep=keep)
         state = {**point_part, **image_part, 'network': point_part['network'] + image_part['network']}

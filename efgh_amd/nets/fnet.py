@@ -63,14 +63,6 @@ class Fnet(nn.Module):
                 cam = camera()
             main.wait_stream(cam_stream)
             cam.record_stream(main)
-        elif bb.SIDE_STREAM and bb.F_SIDE and pc.is_cuda:
-            side = bb._side_stream(pc.device)
-            side.wait_stream(main)
-            rng = rng_branch()
-            with torch.cuda.stream(side):
-                cam = camera()
-            main.wait_stream(side)
-            cam.record_stream(main)
         else:
             cam = camera()
             rng = rng_branch()

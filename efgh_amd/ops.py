@@ -706,9 +706,9 @@ _WGRAD_STREAMS = {}
 
 def wgrad_stream(device):
     """the stream weight gradients are launched on when they are written straight into a flat gradient buffer (nets/fn.py):
-    train.Trainer joins it before the optimizer.  It is the backbone's third side stream (which inference uses for H): HIP
-    multiplexes streams onto 4 hardware queues, and a fifth stream in the process makes two of them share a queue - measured:
-    +12 ms per training step from merely having created it."""
+    train.Trainer joins it before the optimizer.  Together with the backbone's two side streams and the current stream that makes
+    four: HIP multiplexes streams onto 4 hardware queues, and a fifth stream in the process makes two of them share a queue -
+    measured: +12 ms per training step from merely having created it."""
     from .nets import efghbackbone as bb
     return bb._side_stream(device, 2)
 
