@@ -95,11 +95,16 @@ class EFGHBackbone(nn.Module):
             state['eh_cam_T_velo'] = _stamp_pose(dict(pre_f), 'eh', calib, A)['eh_cam_T_velo']
         state = _stamp_pose(state, 'efh', calib, A)
         if g_pre is not None:
-            torch.cuda.current_stream().wait_stream(_side_stream(pc.device, 1))
-            for v in g_pre.values():
-                if torch.is_tensor(v):
-                    v.record_stream(torch.cuda.current_stream())
+            # the rest of G needs conv_i1's output only; the depth / mask heads keep running on their stream next to it
+            torch.cuda.current_stream().wait_event(g_pre['ready'])
+            for k in ('ci1', 'cat0'):
+                if torch.is_tensor(g_pre[k]):
+                    g_pre[k].record_stream(torch.cuda.current_stream())
         state = _stamp_pose(self.G(pc, img, state, check, img_nhwc=shared_img, keep=keep, pre=g_pre), 'efgh', calib, A)
+        if g_pre is not None:
+            torch.cuda.current_stream().wait_stream(_side_stream(pc.device, 1))
+            for k in ('g_depth', 'g_mask'):
+                g_pre[k].record_stream(torch.cuda.current_stream())
         state['cam_T_velo'] = state['efgh_cam_T_velo']
         state.pop('_h_img_nhwc', None)
         return state

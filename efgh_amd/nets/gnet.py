@@ -90,6 +90,13 @@ class Gnet(nn.Module):
         ci1 = None
         if ctx.grad:                          # t2 feeds conv_i1 (below) and the concatenation: same chaining
             ci1, t2 = L.run_conv_bn_relu(ctx, self.conv_i1, t2, out=tgt(cat0_early(), 0), skip_out=True)
+        else:
+            L.run_conv_bn_relu(ctx, self.conv_i1, cat1, out=(cat0_early(), 0), in_ch=(0, 64))
+        # everything the rest of G needs from this part exists now; the two heads below can run next to it
+        ready = None
+        if x.is_cuda:
+            ready = torch.cuda.Event()
+            ready.record()
         cv = cat(cat1, [t2, c2])
         dimg, cv = L.run_convt_bn_relu(ctx, self.convt_dimg, cv, skip_out=True)    # (B,2H,2W,4) ch0
         mask = L.run_convt_bn_relu(ctx, self.convt_mask, cv)                       # (B,2H,2W,4) ch0,1
@@ -100,8 +107,7 @@ class Gnet(nn.Module):
         else:
             g_depth = ops.nhwc_to_nchw(dimg, 1)
             g_mask = ops.softmax2_to_nchw(mask)
-            L.run_conv_bn_relu(ctx, self.conv_i1, cat1, out=(cat0, 0), in_ch=(0, 64))
-        return {'g_depth': g_depth, 'g_mask': g_mask, 'ci1': ci1, 'cat0': cat0}
+        return {'g_depth': g_depth, 'g_mask': g_mask, 'ci1': ci1, 'cat0': cat0, 'ready': ready}
 
     def forward(self, pc, img, ret, check=False, img_nhwc=None, keep=None, pre=None):
         """pre: the result of image_part() when the caller has already run it (EFGHBackbone overlaps it with F)"""
