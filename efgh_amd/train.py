@@ -133,6 +133,7 @@ class OverlappedAllReduce:
             self.sizes[b] += 1
         self.pending, self.works, self.launched = list(self.sizes), [], [False] * len(self.buckets)
         self.next_b, self.order = len(self.buckets) - 1, []
+        self.main_stream = None           # the stream backward() is called on (set by start_step)
         if world > 1:
             flat.listeners.append(self._arrived)
 
@@ -152,13 +153,17 @@ class OverlappedAllReduce:
         if self.launched[b]:
             return
         self.launched[b] = True
-        for st in ops.side_streams():         # gradients of this bucket may have been written on a side stream
-            torch.cuda.current_stream().wait_stream(st)
+        if self.flat.g.is_cuda:
+            cur = torch.cuda.current_stream()     # (a hook may run with a side stream current: the bucket's gradients were written
+            for st in ops.side_streams() + ([self.main_stream] if self.main_stream is not None else []):      # on any of them)
+                if st != cur:
+                    cur.wait_stream(st)
         s, e = self.buckets[b]
         self.order.append(b)
         self.works.append(dist.all_reduce(self.flat.g[s:e], op=dist.ReduceOp.SUM, async_op=True))
 
     def start_step(self):
+        self.main_stream = torch.cuda.current_stream() if self.flat.g.is_cuda else None
         self.pending, self.works, self.launched = list(self.sizes), [], [False] * len(self.buckets)
         self.next_b, self.order = len(self.buckets) - 1, []
 
