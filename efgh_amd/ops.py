@@ -701,7 +701,6 @@ USE_WINO_WGRAD = _os.environ.get('EFGH_WINO_WGRAD', '1') != '0'
 
 _SCRATCH = {}
 WGRAD_SIDE = _os.environ.get('EFGH_WGRAD_STREAM', '1') != '0'
-_WGRAD_STREAMS = {}
 
 
 def wgrad_stream(device):
