@@ -116,11 +116,30 @@ def committed_traffic(family, workload='train'):
     as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE; tools/collect_traffic.py), collected offline on the same bench
     command, see profiles/README.md.  PMC collection cannot run inside the timed region."""
     try:
-        f = 'r02_hbm_traffic_train.json' if workload == 'train' else 'r02_hbm_traffic_fwd.json'
-        d = json.load(open(os.path.join(ROOT, 'profiles', f)))['per_launch']
+        d = json.load(open(os.path.join(ROOT, 'profiles', TRAFFIC_FILE[workload])))['per_launch']
         return d[family]['traffic_bytes']
     except Exception:
         return None
+
+
+# the PMC passes the `traffic` fields are read from (tools/collect_round_evidence.sh writes them, profiles/README.md)
+TRAFFIC_FILE = {'train': 'r03_hbm_traffic_train.json', 'fwd': 'r03_hbm_traffic_fwd.json'}
+
+
+def mfma_step_utilisation(prof, steps, ms_per_step):
+    """the roofline of the TIMED schedule as a whole: MFMA FLOP executed per step by every contraction family (Winograd kernels
+    counted at the products they execute, half / a quarter of the direct form) / wall time of a step / dense fp32 MFMA peak"""
+    fl = 0.0
+    for name, lst in prof.items():
+        if name in ('bcl', 'wino2d') or not lst:        # 'wino2d' = whole layers in direct-form FLOP: its GEMM launches are 'wino2d_gemm'
+            continue
+        f = sum(p[2] for p in lst)
+        fl += f / 2 if name in ('wino', 'wino_wgrad') else f
+    per_step = fl / max(1, steps)
+    tf = per_step / (ms_per_step * 1e-3) / 1e12 if ms_per_step > 0 else 0.0
+    return {'executed_mfma_tflop_per_step': per_step / 1e12, 'achieved': tf, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': tf / PEAK_F32_MFMA_TFLOPS,
+            'note': 'timed region (multi-stream schedule): sum of executed MFMA FLOP of all contraction kernels / ms_per_step'}
 
 
 def gemm_roofline(prof, steps, kernel):
@@ -132,7 +151,7 @@ def gemm_roofline(prof, steps, kernel):
     ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     return {'bound': 'mfma', 'kernel': kernel, 'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
             'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
-            'traffic_unit': 'HBM-side bytes per launch (committed rocprofv3 PMC passes of this bench command, profiles/r02_hbm_traffic_*.json)',
+            'traffic_unit': 'HBM-side bytes per launch (committed rocprofv3 PMC passes of this bench command, profiles/r03_hbm_traffic_*.json)',
             'launches_per_step': n / max(1, steps),
             'avg_launch_ms': ms / max(1, n), 'algorithmic_gflop_per_launch': fl / max(1, n) / 1e9,
             'kernel_ms_per_step': ms / max(1, steps)}
@@ -184,7 +203,7 @@ def rooflines(prof, steps, workload='train'):
                                + (' + splat / neighbour-gather adjoints' if any(k.endswith('bwd') for k in parts) else ''),
                                'achieved': ach, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': ach / PEAK_HBM_GBS,
                                'traffic': committed_traffic('bcl', workload),
-                               'traffic_unit': 'HBM-side bytes per STEP, all lattice.hip + bcl.hip launches (profiles/r02_hbm_traffic_*.json)',
+                               'traffic_unit': 'HBM-side bytes per STEP, all lattice.hip + bcl.hip launches (profiles/r03_hbm_traffic_*.json)',
                                'launches_per_step': len(bcl) / max(1, steps), 'kernel_ms_per_step': ms / max(1, steps),
                                'algorithmic_mb_per_step': by / max(1, steps) / 1e6,
                                'parts': {k: {'ms_per_step': v[0] / max(1, steps), 'algorithmic_mb_per_step': v[1] / max(1, steps) / 1e6,
@@ -348,6 +367,7 @@ def main():
                'workload': 'BASELINE.json configs[1]: EFGHNet forward only (eval), batch=%d per GPU' % Bf,
                }
         fwd.update(rooflines(prof, a.steps, 'fwd'))
+        fwd['mfma_step_utilisation'] = mfma_step_utilisation(prof, a.steps, fwd['ms_per_step'])
         attach_serialized(fwd, fstep, 'fwd')
         # opt-in fast math (NOT the default; `value` above is exact fp32 MFMA): split MFMA with fp32 accumulation.
         #   f16x3 : x = hi + lo*2^-11 in fp16, 3 fp16 MFMAs per fp32 product, ~2^-22 per product (fp32-equivalent,
@@ -386,6 +406,7 @@ def main():
                 'forward_only': fwd,
             }
             out.update(rooflines(prof, a.steps))
+            out['mfma_step_utilisation'] = mfma_step_utilisation(prof, a.steps, out['ms_per_step'])
             out['peak_hbm_gb_per_gpu'] = torch.cuda.max_memory_allocated() / 1e9      # of 288 GB
         attach_serialized(out, tstep, 'train')
     elif rank == 0:
@@ -397,7 +418,7 @@ def main():
                           'global_batch': world * (a.batch or 4), 'points': npts, 'parallelism': 'dp%d' % world},
                'rccl_ranks': rccl_ranks, 'dist_backend': backend, 'visible_gpus': ndev,
                }
-        out.update({k: v for k, v in fwd.items() if k.startswith('roofline')})
+        out.update({k: v for k, v in fwd.items() if k.startswith('roofline') or k == 'mfma_step_utilisation'})
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(raw, npts, a.mode)

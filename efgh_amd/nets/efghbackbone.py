@@ -50,6 +50,11 @@ class EFGHBackbone(nn.Module):
     def forward(self, pc, img, calib, A, check=False, keep=None):
         ops._C.require_cuda(pc, img, calib, A)
         ops._C.require_f32(pc, img, calib, A)
+        # packed weights that went stale with the last optimizer step are rewritten in place by ONE launch; every branch below
+        # reads them, so that launch goes out here, on the current stream, before the streams fork
+        ops.repack_stale(pc.device)
+        if self.training:
+            ops.w2v_clear()
         shared_img = ops.nchw_to_nhwc(img, 4)                # channels-last copy used by both H and G
         g_pre = None
         s_h = None

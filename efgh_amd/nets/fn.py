@@ -70,6 +70,14 @@ def claim_grad(p):
     return g, (lambda: flat.deliver(i))
 
 
+def note_use(*params):
+    """forward-side count of a FlatParams parameter's consumers in this step (train.FlatParams.uses)"""
+    for p in params:
+        slot = getattr(p, '_efgh_flat', None) if p is not None else None
+        if slot is not None:
+            slot[0].uses[slot[1]] += 1
+
+
 def _bias_grad_behind_bn(ctx, p_bias, draw, M, Np, N, train_bn, delivered):
     """gradient of a conv / conv1d bias that feeds a BatchNorm.  Train mode: the batch mean absorbs the bias, so
     d/dbias = sum_m draw = coef * (sum dpre - M * mean(dpre) - mean(dpre * xhat) * sum xhat) = 0 exactly (sum xhat = 0); a column-sum
@@ -176,6 +184,8 @@ class GemmLayerFn(torch.autograd.Function):
         ctx.spec = spec
         ctx.has = (bias is not None, gamma is not None, residual is not None)
         ctx.params = (weight, bias, gamma, beta)      # the Parameter objects themselves (claim_grad), not saved copies
+        if any(ctx.needs_input_grad[1:5]):
+            note_use(weight, bias, gamma, beta)
         # layers without a residual re-derive the activation mask from raw*scale+shift in backward
         psc, psh = (scale, shift) if (bn is not None and residual is None) else (None, None)
         # coef = gamma * invstd of the BatchNorm backward is the forward's `scale`

@@ -106,6 +106,23 @@ def _repack_all(device):
         w.__dict__['_efgh_cache'][key] = (cur, buf)
 
 
+_REPACKED_AT = {}        # device index -> WEIGHT_EPOCH of the last batched repack enqueued by repack_stale
+
+
+def repack_stale(device):
+    """Enqueue the batched in-place repack of every packed weight that went stale with the last optimizer step on the CURRENT
+    stream.  Callers that fork work onto several streams (nets.EFGHBackbone.forward) call this BEFORE the fork: the repack
+    rewrites persistent buffers that layers on every branch read, so it has to be ordered before all of them - left to the
+    first pack_weight() of the step it would run on whichever branch stream happens to be enqueued first, unordered with the
+    others."""
+    if not BATCH_PACK or device is None or device.type != 'cuda':
+        return
+    if _REPACKED_AT.get(device.index) == WEIGHT_EPOCH:
+        return
+    _REPACKED_AT[device.index] = WEIGHT_EPOCH
+    _repack_all(device)
+
+
 def pack_weight(w, N, T, C, sn, sc, st, taps=None, Np=None, Cp=None, key=None):
     """Wp[n][t][c] = w.flat[n*sn + c*sc + taps[t]*st]; optionally zero-padded to (Np, T, Cp).  With a `key` the layout gets a
     persistent buffer on the weight that is re-packed IN PLACE when the weight changes (derived caches see `_efgh_gen` move)."""
@@ -401,7 +418,8 @@ W2V_WANTED = False      # set by GemmLayerFn.forward around its launches when th
 
 
 def w2v_clear():
-    """drop transformed inputs that no backward came for (train.Trainer calls this at the start of every step)"""
+    """drop transformed inputs that no backward came for (nets.EFGHBackbone.forward calls this at the start of every train-mode
+    forward, train.Trainer at the start of every step: an entry never outlives the step that made it, whatever loop drives it)"""
     W2V_CACHE.clear()
 
 

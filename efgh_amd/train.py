@@ -45,10 +45,16 @@ class FlatParams:
                and m.num_batches_tracked is not None]
         self.nbt = torch.stack([m.num_batches_tracked.to(dev) for m in bns]).clone() if bns else None
         self.ticks, self.collect_ticks = [0] * len(bns), False
+        self._bns = bns
         for j, m in enumerate(bns):
             m.num_batches_tracked = self.nbt[j]
             m._efgh_nbt = (self, j)
         self.arrived = [False] * len(ps)
+        # uses[i]: how many layers of the current forward consume parameter i (nets/fn.py note_use).  A parameter with more than
+        # one consumer is never claimed: all of its contributions go through autograd, which sums them and fires the
+        # post-accumulate hook once - a direct write by the first consumer (on the weight-gradient stream) would be unordered
+        # with the accumulation of the second, and would count the all-reduce bucket down before the second has arrived.
+        self.uses = [0] * len(ps)
         self.listeners = []               # callables(index), e.g. the overlapped all-reduce's bucket countdown
         for i, p in enumerate(ps):
             p._efgh_flat = (self, i)
@@ -68,7 +74,7 @@ class FlatParams:
 
     def claim(self, p, i):
         """the flat gradient view of parameter i if a backward may overwrite it now (zeroed, nothing delivered yet), else None"""
-        if not self.direct or self.arrived[i]:
+        if not self.direct or self.arrived[i] or self.uses[i] > 1:
             return None
         off, k = self.offsets[i]
         if p.grad is None or p.grad.data_ptr() != self.g.data_ptr() + 4 * off:
@@ -81,6 +87,17 @@ class FlatParams:
     def flush_ticks(self):
         self.collect_ticks = False
         if any(self.ticks):
+            # a model.to() / .double() / rebinding after the Trainer was built breaks the aliasing of num_batches_tracked with
+            # self.nbt silently: count on the module's own buffer then
+            base, item = self.nbt.data_ptr(), self.nbt.element_size()
+            for j, m in enumerate(self._bns):
+                if m.num_batches_tracked.data_ptr() != base + j * item:
+                    if self.ticks[j]:
+                        m.num_batches_tracked += self.ticks[j]
+                    m._efgh_nbt = None
+                    self.ticks[j] = 0
+            if not any(self.ticks):
+                return
             k = self.ticks[0]
             if all(t == k for t in self.ticks):
                 self.nbt += k
@@ -240,6 +257,7 @@ class Trainer:
                                'requires_grad): freeze parameters first, then construct the Trainer')
         self.opt.lr = adjust_learning_rate(self.base_lr, self.it)
         ops.w2v_clear()
+        self.flat.uses = [0] * len(self.flat.params)
         self.model.train()
         self.flat.collect_ticks = True
         try:

@@ -113,6 +113,30 @@ def test_lr_schedule_and_flat_params_cpu():
     assert float(f.g.abs().sum()) > 0 and all(p.grad.data_ptr() >= f.g.data_ptr() for p in f.params)
 
 
+def test_flat_params_shared_parameter_and_rebound_counter_cpu():
+    """a parameter consumed by two layers of one forward is never claimed for a direct gradient write (all contributions go
+    through autograd, one post-accumulate hook); a BatchNorm counter that no longer aliases the flat vector is counted on
+    the module's own buffer"""
+    from efgh_amd.nets import fn
+    from efgh_amd.train import FlatParams
+    m = torch.nn.Sequential(torch.nn.Linear(4, 4), torch.nn.BatchNorm1d(4), torch.nn.BatchNorm1d(4))
+    f = FlatParams(m)
+    w = m[0].weight
+    assert f.claim(w, 0) is w.grad
+    fn.note_use(w)
+    assert f.uses[0] == 1 and f.claim(w, 0) is w.grad
+    fn.note_use(w, None, m[0].bias)
+    assert f.uses[0] == 2 and f.uses[1] == 1 and f.claim(w, 0) is None
+    # counters: both alias f.nbt; rebind the second (what model.to()/.double() does)
+    f.tick(0); f.tick(1)
+    m[2].num_batches_tracked = m[2].num_batches_tracked.clone()
+    f.flush_ticks()
+    assert int(m[1].num_batches_tracked) == 1 and int(m[2].num_batches_tracked) == 1
+    f.tick(0)
+    f.flush_ticks()
+    assert int(m[1].num_batches_tracked) == 2 and int(f.nbt[0]) == 2 and int(m[2].num_batches_tracked) == 1
+
+
 def test_header_is_plain_c():
     """the boundary is a C ABI: include/efgh_hip.h must compile as C99 (no C++ or torch types in the signatures)"""
     import os

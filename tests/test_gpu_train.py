@@ -397,3 +397,44 @@ def test_gradients_are_reproducible_run_to_run(manifest):
             assert len(a) == 353 and len(differ) <= allowed, (flag, differ)
     finally:
         ops.DETERMINISTIC = old
+
+
+def test_repack_is_ordered_before_the_stream_fork(manifest):
+    """after FusedAdam every packed weight is re-packed in place by ONE launch; H, G's image part and E / F start on three streams
+    and all read those buffers, so the launch has to sit on the current stream BEFORE the fork (ops.repack_stale).  No host sync
+    between steps, the H stream stalled at the start of every step (where the repack used to be enqueued): the losses of step 3
+    must be bit-identical to a single-stream run."""
+    from efgh_amd import ops
+    from efgh_amd.losses import EFGHCriterion
+    from efgh_amd.nets import EFGHBackbone, efghbackbone as bb
+    from efgh_amd.train import Trainer
+    args = syn.default_args(RAW, 'cuda')
+    sd = syn.synthetic_state_dict(manifest['state_dict'], 1)
+    b = syn.make_batch(RAW, NPTS, 2)
+    inp = [torch.from_numpy(b[k]).cuda() for k in ('pc', 'img', 'calib', 'A')]
+    gt = {k: torch.from_numpy(v) for k, v in b['gt'].items()}
+
+    def run(side):
+        m = EFGHBackbone(args)
+        m.load_state_dict(sd)
+        tr = Trainer(m.cuda(), EFGHCriterion(args), lr=1e-3)
+        out = []
+        for _ in range(3):
+            if side:
+                with torch.cuda.stream(bb._side_stream(inp[0].device, 0)):
+                    torch.cuda._sleep(40_000_000)             # ~20 ms
+            losses, _ = tr.step(*inp, gt)
+            out.append(losses['total'].detach())
+        torch.cuda.synchronize()
+        return [float(x) for x in out], tr.flat.w.detach().clone()
+    old = (ops.DETERMINISTIC, bb.SIDE_STREAM)
+    try:
+        ops.DETERMINISTIC = True
+        bb.SIDE_STREAM = True
+        la, wa = run(True)
+        bb.SIDE_STREAM = False
+        lb, wb = run(False)
+    finally:
+        ops.DETERMINISTIC, bb.SIDE_STREAM = old
+    assert la == lb, (la, lb)
+    assert torch.equal(wa, wb)

@@ -13,10 +13,10 @@ TRAIN="$ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-forward-sectio
 FWD="$ROOT/bench.py --mode fwd --steps 1 --warmup 1 --no-cpu-baseline"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $SCR/tf -- python3 $TRAIN > /dev/null 2> $SCR/tf.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $SCR/tw -- python3 $TRAIN > /dev/null 2> $SCR/tw.err
-python3 $ROOT/tools/collect_traffic.py $SCR/tf $SCR/tw $OUT/hbm_traffic_train.json "bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-forward-section (training step, batch 8)" 2
+python3 $ROOT/tools/collect_traffic.py $SCR/tf $SCR/tw $OUT/hbm_traffic_train.json "bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-forward-section (training step, batch 8)"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $SCR/ff -- python3 $FWD > /dev/null 2> $SCR/ff.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $SCR/fw -- python3 $FWD > /dev/null 2> $SCR/fw.err
-python3 $ROOT/tools/collect_traffic.py $SCR/ff $SCR/fw $OUT/hbm_traffic_fwd.json "bench.py --mode fwd --steps 1 --warmup 1 --no-cpu-baseline (eval forward, batch 4; exact + two fast-math passes)" 6
+python3 $ROOT/tools/collect_traffic.py $SCR/ff $SCR/fw $OUT/hbm_traffic_fwd.json "bench.py --mode fwd --steps 1 --warmup 1 --no-cpu-baseline (eval forward, batch 4; exact + two fast-math passes)"
 CMD="rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-forward-section"
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $SCR/mb -- python3 $TRAIN > /dev/null 2> $SCR/mb.err
 python3 $ROOT/tools/collect_mfma_busy.py $SCR/mb $OUT/mfma_busy_train.json "$CMD"
