@@ -51,6 +51,10 @@ def lib():
         _lib.efgh_lattice_hash_capacity.argtypes = [c_int32]
         _lib.efgh_lattice_workspace_bytes.restype = c_int64
         _lib.efgh_lattice_workspace_bytes.argtypes = [c_int32, c_int32, c_int32]
+        _lib.efgh_lattice_part_max_entries.argtypes = [c_int32]
+        _lib.efgh_lattice_part_buckets.argtypes = [c_int32]
+        _lib.efgh_lattice_part_workspace_bytes.restype = c_int64
+        _lib.efgh_lattice_part_workspace_bytes.argtypes = [c_int32, c_int32, c_int32, c_int32, c_int32]
     return _lib
 
 

@@ -622,6 +622,468 @@ k_neighbors(const int4 *__restrict__ vkeys, const int *__restrict__ mm, const un
     }
 }
 
+// =====================================================================================================================
+// Partitioned build (round 3): the same lattice, built WITHOUT a global hash insert and without scattered global stores.
+//
+// The hash build above is bound by memory-side atomics (~2 per (point, corner) entry at ~26 G/s chip-wide).  Measured on this
+// part while rebuilding it: 4.2 M random 4-byte STORES cost 80-100 us, 4.2 M random 4-byte LOADS 14 us - so every permutation
+// below is a gather.
+//   k_lat_scatter  a tile of points computes its 4 entries per point, counts them per bucket in LDS (bucket = top bits of
+//                  mix64(key integer): mix64 is a bijection, so equal keys meet in one bucket and the buckets are balanced whatever
+//                  the key distribution), and writes them bucket-sorted into the TILE's own window of `ent` (a local scatter that
+//                  the L2 merges into full lines) + the tile's row of bucket offsets + where[f] = (bucket, rank in the tile's run).
+//   k_lat_bucket   one workgroup per bucket gathers its runs from all tiles (<= maxe entries) and groups them by key entirely in
+//                  LDS (open-addressing table + counts + segment scan + place + rank-sort of every vertex's entries, LDS atomics
+//                  only), which leaves the vertex lists (`list`, ascending flat position per vertex: the splat's fixed summation
+//                  order), one bit per flat position marking the first-seen entry of every vertex, a read-only image of the
+//                  bucket's table for the neighbour probes, and the bucket-local vertex of every arrival position.
+//   k_lat_rank     first-seen numbering = prefix count over those bits.
+//   k_lat_number   vertex records (segment, key, sample, next level's point).
+//   k_lat_nbr      15 neighbour probes per vertex; the same launch gathers lattice_offset per point through where[].
+// A bucket that overflows maxe entries or its table sets bit 2 of info[ERR]: the caller rebuilds with the hash build.
+constexpr int SMAX = 2048;          // slots of a bucket's table
+constexpr int NBMAX = 8192;         // buckets (LDS counters of k_lat_scatter)
+constexpr int NTMAX = 1024;         // tiles (LDS run table of k_lat_bucket)
+constexpr int STP = 512;            // threads of k_lat_scatter
+
+struct LatPart {                    // workspace of the partitioned build
+    unsigned long long *ent;        // [ntiles][tile entries]  key integer << fb | flat position, bucket-sorted inside a tile
+    int *toff;                      // [ntiles][nb + 1]  exclusive prefix of the tile's bucket counts
+    int *cumul;                     // [nb][ntiles]      entries of bucket b in the tiles before t
+    unsigned *where;                // [4 n_cap]         bucket << 14 | rank inside the (tile, bucket) run
+    unsigned short *larr;           // [nb][maxe]        bucket-local vertex of arrival position i
+    int *cursor;                    // [nb]              entries of bucket b
+    int *gcount;                    // [nb]              vertices of bucket b
+    int4 *grec;                     // [nb][S]           (slot, start, length, first-seen flat position) of bucket-local vertex g
+    int *gvix;                      // [nb][S]           vertex number of bucket-local vertex g
+    int4 *table;                    // [nb][S]           (key lo, key hi, vertex number, -) : the neighbour lookup
+    unsigned *fbits;                // [W]               bit f = flat position f is the first-seen entry of its vertex
+    int *wprefix;                   // [W]               set bits in front of word w inside its block of 256 words
+    int *bsum;                      // [W/256]           set bits per block -> exclusive prefix
+    int *ticket;                    // last-block election of k_lat_rank
+    int nb, bb, S, sb, maxe;        // buckets = 1 << bb, slots per bucket = 1 << sb, entries per bucket
+    int ntiles, tp;                 // tiles (capacity), points per tile
+    int fb;                         // bits of a flat position (4 n_cap <= 1 << fb); a key integer must fit the other 64 - fb
+};
+
+__device__ __forceinline__ int part_bucket(uint64_t mixed, int bb) { return (int)(mixed >> (64 - bb)); }
+__device__ __forceinline__ int part_slot(uint64_t mixed, int bb, int sb) { return (int)((mixed >> (64 - bb - sb)) & ((1u << sb) - 1u)); }
+
+__global__ void __launch_bounds__(TPB)
+k_lat_init(LatPart P, int W, int *__restrict__ mm, int nsamples, int *__restrict__ info, int ninfo) {
+    const int i0 = blockIdx.x * TPB + threadIdx.x, stride = gridDim.x * TPB;
+    for (int i = i0; i < W; i += stride) P.fbits[i] = 0u;
+    if (i0 < nsamples * 8) mm[i0] = (i0 & 7) < 4 ? INT32_MAX : INT32_MIN;
+    if (i0 < ninfo) info[i0] = 0;
+    if (i0 == 0) *P.ticket = 0;
+}
+
+// exclusive prefix over the NT threads of a block (NT = 256 or 512), one value each; *total = block sum
+template <int NT>
+__device__ __forceinline__ int block_exclusive_scan_n(int v, int *total) {
+    __shared__ int wsum_n[NT / 64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o); if (lane >= o) x += y; }
+    if (lane == 63) wsum_n[w] = x;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < NT / 64; ++i) { if (i < w) base += wsum_n[i]; tot += wsum_n[i]; }
+    __syncthreads();
+    *total = tot;
+    return base + x - v;
+}
+
+// ---- tile-local bucket sort of the entries.  A tile = STP * PPT points.
+template <int PPT>
+__global__ void __launch_bounds__(STP)
+k_lat_scatter(const float *__restrict__ pts, int64_t cstride, const int *__restrict__ n_dev, int n_cap, float scale32,
+              float std32, const int *__restrict__ mm, const int *__restrict__ sid, int pps, int nsamples, LatPart P,
+              int *__restrict__ info) {
+    __shared__ int cnt[NBMAX];
+    const int n = n_of(n_dev, n_cap);
+    const int p0 = blockIdx.x * (STP * PPT);
+    if (p0 >= n) return;
+    for (int b = threadIdx.x; b < P.nb; b += STP) cnt[b] = 0;
+    __syncthreads();
+    unsigned long long ki[PPT][4];
+    unsigned br[PPT][4];                         // bucket << 14 | rank inside the (tile, bucket) run
+    bool wide = false;
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        const int p = p0 + j * STP + threadIdx.x;
+        if (p < n) {
+            PointKeys pk;
+            point_keys(pts[p], pts[cstride + p], pts[2 * cstride + p], scale32, std32, pk);
+            const int b = sample_of(sid, pps, p);
+#pragma unroll
+            for (int rem = 0; rem < 4; ++rem) {
+                int k[4];
+                entry_key(pk, rem, k);
+                ki[j][rem] = (unsigned long long)(key2int(k, mm + 8 * b) * nsamples + b);
+                wide |= (ki[j][rem] >> (64 - P.fb)) != 0ULL;
+                const int bk = part_bucket(mix64(ki[j][rem]), P.bb);
+                br[j][rem] = ((unsigned)bk << 14) | (unsigned)atomicAdd(&cnt[bk], 1);
+            }
+        }
+    }
+    if (wide) atomicOr(&info[EFGH_LATTICE_INFO_ERR], 4);        // key range x positions do not fit 64 bits: the hash build serves the level
+    __syncthreads();
+    // exclusive prefix of the bucket counts: the tile's row of offsets, and the start of every run inside the tile's window
+    {
+        const int per = (P.nb + STP - 1) / STP;
+        const int b0 = threadIdx.x * per;
+        int mine = 0;
+        for (int q = 0; q < per; ++q) if (b0 + q < P.nb) mine += cnt[b0 + q];
+        int tot;
+        int ex = block_exclusive_scan_n<STP>(mine, &tot);
+        int *row = P.toff + (int64_t)blockIdx.x * (P.nb + 1);
+        for (int q = 0; q < per; ++q) if (b0 + q < P.nb) {
+            const int c = cnt[b0 + q];
+            cnt[b0 + q] = ex;
+            row[b0 + q] = ex;
+            ex += c;
+        }
+        if (threadIdx.x == 0) row[P.nb] = tot;
+    }
+    __syncthreads();
+    unsigned long long *win = P.ent + (int64_t)blockIdx.x * (4 * STP * PPT);
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        const int p = p0 + j * STP + threadIdx.x;
+        if (p < n) {
+            uint4 w4;
+            unsigned *wv = reinterpret_cast<unsigned *>(&w4);
+#pragma unroll
+            for (int rem = 0; rem < 4; ++rem) {
+                const int bk = (int)(br[j][rem] >> 14);
+                win[cnt[bk] + (int)(br[j][rem] & 0x3FFFu)] = (ki[j][rem] << P.fb) | (unsigned long long)(4u * (unsigned)p + rem);
+                wv[rem] = br[j][rem];
+            }
+            reinterpret_cast<uint4 *>(P.where)[p] = w4;
+        }
+    }
+}
+
+// ---- one workgroup per bucket: gather its runs into LDS, group the entries by key there.  Nothing is carried in registers
+// across the phases (the kernel is a chain of dependent LDS / memory round trips: what hides them is workgroups per CU).
+template <int MAXE>
+__global__ void __launch_bounds__(TPB)
+k_lat_bucket(LatPart P, const int *__restrict__ n_dev, int n_cap, int *__restrict__ list, int *__restrict__ info) {
+    extern __shared__ unsigned char smem_[];
+    const int S = P.S;
+    unsigned long long *tkey = reinterpret_cast<unsigned long long *>(smem_);     // [S]
+    unsigned long long *stage = tkey + S;                                         // [MAXE] entry words in arrival order; after the insert:
+                                                                                  //        (slot << 16 | rank in slot) << 32 | flat position
+    int *tcnt = reinterpret_cast<int *>(stage + MAXE);                            // [S]
+    int *tstart = tcnt + S;                                                       // [S]
+    int *tgid = tstart + S;                                                       // [S]
+    int *lst = tgid + S;                                                          // [MAXE] flat positions, grouped by slot
+    unsigned short *lslot = reinterpret_cast<unsigned short *>(lst + MAXE);       // [MAXE] slot of list position q
+    // while the runs are gathered the list area holds the run table instead (NTMAX * 10 bytes <= MAXE * 6)
+    int *runsrc = lst;                                                            // [NTMAX] source of tile t's run
+    int *runpre = lst + NTMAX;                                                    // [NTMAX] arrival position of its head
+    unsigned short *rid = reinterpret_cast<unsigned short *>(lst + 2 * NTMAX);    // [MAXE]  run of arrival position i
+    static_assert(NTMAX * 8 + MAXE * 2 <= MAXE * 6, "run table must fit the list area");
+    const int b = blockIdx.x;
+    const int n = n_of(n_dev, n_cap);
+    const int ntl = (n + P.tp - 1) / P.tp;                                        // tiles that hold points
+    for (int s = threadIdx.x; s < S; s += TPB) { tkey[s] = EMPTY; tcnt[s] = 0; }
+    for (int i = threadIdx.x; i < MAXE; i += TPB) rid[i] = 0;
+    __syncthreads();
+    int m;
+    {
+        const int te = 4 * P.tp;
+        constexpr int PER = NTMAX / TPB;
+        int c[PER], mine = 0;
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int t = threadIdx.x * PER + q;
+            c[q] = 0;
+            if (t < ntl) {
+                const int *row = P.toff + (int64_t)t * (P.nb + 1) + b;
+                const int a0 = row[0];
+                c[q] = row[1] - a0;
+                runsrc[t] = t * te + a0;
+            }
+            mine += c[q];
+        }
+        int tot;
+        int ex = block_exclusive_scan(mine, &tot);
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int t = threadIdx.x * PER + q;
+            if (t < ntl) {
+                runpre[t] = ex;
+                P.cumul[(int64_t)b * P.ntiles + t] = ex;
+                if (c[q] > 0 && ex < MAXE) rid[ex] = (unsigned short)t;           // head of a non-empty run
+            }
+            ex += c[q];
+        }
+        if (threadIdx.x == 0) {
+            if (tot > MAXE) atomicOr(&info[EFGH_LATTICE_INFO_ERR], 4);
+            P.cursor[b] = min(tot, MAXE);
+        }
+        m = min(tot, MAXE);
+    }
+    __syncthreads();
+    // run of every arrival position: running maximum of the head marks (runs are laid out in tile order)
+    {
+        constexpr int PT = MAXE / TPB;
+        const int i0 = threadIdx.x * PT;
+        int v[PT], mx = 0;
+#pragma unroll
+        for (int k = 0; k < PT; ++k) { mx = max(mx, (int)rid[i0 + k]); v[k] = mx; }
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        int x = mx;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o); if (lane >= o) x = max(x, y); }
+        __shared__ int wmax[TPB / 64];
+        if (lane == 63) wmax[w] = x;
+        __syncthreads();
+        int before = __shfl_up(x, 1);
+        if (lane == 0) before = 0;
+#pragma unroll
+        for (int q = 0; q < TPB / 64; ++q) if (q < w) before = max(before, wmax[q]);
+#pragma unroll
+        for (int k = 0; k < PT; ++k) rid[i0 + k] = (unsigned short)max(v[k], before);
+    }
+    __syncthreads();
+    for (int i0 = 0; i0 < m; i0 += 4 * TPB) {
+        unsigned long long wd[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * TPB + threadIdx.x;
+            wd[u] = 0ULL;
+            if (i < m) { const int t = rid[i]; wd[u] = P.ent[runsrc[t] + (i - runpre[t])]; }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * TPB + threadIdx.x;
+            if (i < m) stage[i] = wd[u];
+        }
+    }
+    __syncthreads();
+    bool full = false;
+    const unsigned long long fmask = (1ULL << P.fb) - 1ULL;
+    for (int i = threadIdx.x; i < m; i += TPB) {
+        const unsigned long long wd = stage[i];
+        const unsigned long long key = wd >> P.fb;
+        int s = part_slot(mix64(key), P.bb, P.sb);
+        int probe = 0;
+        for (; probe < S; ++probe) {
+            const unsigned long long prev = atomicCAS(&tkey[s], EMPTY, key);
+            if (prev == EMPTY || prev == key) break;
+            s = (s + 1) & (S - 1);
+        }
+        if (probe >= S) { full = true; s = 0; }
+        const unsigned sr = ((unsigned)s << 16) | (unsigned)atomicAdd(&tcnt[s], 1);
+        stage[i] = ((unsigned long long)sr << 32) | (wd & fmask);
+    }
+    if (full) atomicOr(&info[EFGH_LATTICE_INFO_ERR], 4);
+    __syncthreads();
+    // segments: exclusive scan of the slot counts (and of the occupied flags: the bucket-local vertex numbers)
+    {
+        const int per = (S + TPB - 1) / TPB;
+        const int s0 = threadIdx.x * per;
+        int2 mine = make_int2(0, 0);
+        for (int q = 0; q < per; ++q) if (s0 + q < S) { const int c = tcnt[s0 + q]; mine.x += c; mine.y += c > 0; }
+        int2 tot;
+        int2 ex = block_exclusive_scan2(mine, &tot);
+        for (int q = 0; q < per; ++q) if (s0 + q < S) {
+            const int c = tcnt[s0 + q];
+            tstart[s0 + q] = ex.x; tgid[s0 + q] = ex.y;
+            ex.x += c; ex.y += c > 0;
+        }
+        if (threadIdx.x == 0) P.gcount[b] = tot.y;
+    }
+    __syncthreads();
+    unsigned short *larr = P.larr + (int64_t)b * MAXE;
+    for (int i = threadIdx.x; i < m; i += TPB) {
+        const unsigned long long v = stage[i];
+        const unsigned sr = (unsigned)(v >> 32);
+        const int s = (int)(sr >> 16);
+        const int pos = tstart[s] + (int)(sr & 0xFFFFu);
+        lst[pos] = (int)(unsigned)v;
+        lslot[pos] = (unsigned short)s;
+        larr[i] = (unsigned short)tgid[s];
+    }
+    __syncthreads();
+    // place of every entry inside its vertex's list = number of smaller flat positions there (positions are distinct); the head of
+    // the list is the vertex's first-seen entry.  Neighbouring threads hold neighbouring list positions, i.e. mostly the same
+    // vertex: the LDS reads of the count loop are broadcasts.
+    int *glist = list + (int64_t)b * MAXE;
+    for (int q = threadIdx.x; q < m; q += TPB) {
+        const int s = lslot[q];
+        const int st = tstart[s], c = tcnt[s];
+        const int me = lst[q];
+        int r = 0;
+        for (int k = 0; k < c; ++k) r += lst[st + k] < me ? 1 : 0;
+        glist[st + r] = me;
+        if (r == 0) {
+            atomicOr(&P.fbits[(unsigned)me >> 5], 1u << ((unsigned)me & 31u));
+            P.grec[(int64_t)b * S + tgid[s]] = make_int4(s, st, c, me);
+        }
+    }
+    int4 *tab = P.table + (int64_t)b * S;
+    for (int s = threadIdx.x; s < S; s += TPB) {
+        const unsigned long long k = tkey[s];
+        tab[s] = make_int4((int)(unsigned)k, (int)(unsigned)(k >> 32), -1, 0);
+    }
+}
+
+// ---- first-seen numbering: vertex number = number of first-seen bits in front of the vertex's own.  Per 32-bit word its
+// prefix inside a block of 256 words; the last block to finish turns the block sums into their exclusive prefix and writes H.
+__global__ void __launch_bounds__(TPB)
+k_lat_rank(LatPart P, int W, int *__restrict__ info, int h_cap) {
+    const int w = blockIdx.x * TPB + threadIdx.x;
+    int tot;
+    const int ex = block_exclusive_scan(w < W ? __popc(P.fbits[w]) : 0, &tot);
+    if (w < W) P.wprefix[w] = ex;
+    __shared__ int last_s;
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&P.bsum[blockIdx.x], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        last_s = atomicAdd(P.ticket, 1) == (int)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last_s) return;
+    __threadfence();
+    const int nb = gridDim.x;
+    __shared__ int carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int s = 0; s < nb; s += TPB) {
+        const int i = s + threadIdx.x;
+        const int v = i < nb ? __hip_atomic_load(&P.bsum[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+        int t2;
+        const int e2 = block_exclusive_scan(v, &t2);
+        const int carry = carry_s;
+        if (i < nb) P.bsum[i] = carry + e2;
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s = carry + t2;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        info[EFGH_LATTICE_INFO_H] = carry_s;
+        if (carry_s > h_cap) atomicOr(&info[EFGH_LATTICE_INFO_ERR], 1);
+    }
+}
+
+// ---- number the vertices and emit their records: one thread per (bucket, bucket-local vertex) slot of the grid nb x S
+__global__ void __launch_bounds__(TPB)
+k_lat_number(LatPart P, const float *__restrict__ pts, int64_t cstride, float scale32, float std32, float div32,
+             const int *__restrict__ sid, int pps, int4 *__restrict__ vkeys, int2 *__restrict__ vseg,
+             float *__restrict__ pts_next, int *__restrict__ vsid, int h_cap, int *__restrict__ info) {
+    const int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    const int b = (int)(i >> P.sb), g = (int)(i & (P.S - 1));
+    if (b >= P.nb || g >= P.gcount[b]) return;
+    const int4 rec = P.grec[(int64_t)b * P.S + g];
+    const unsigned hf = (unsigned)rec.w;
+    const unsigned w = hf >> 5;
+    const int idx = P.bsum[w >> 8] + P.wprefix[w] + __popc(P.fbits[w] & ((1u << (hf & 31u)) - 1u));
+    P.gvix[i] = idx;                              // (k_lat_nbr hands it to the vertex's entries)
+    if (idx >= h_cap) return;
+    P.table[(int64_t)b * P.S + rec.x].z = idx;
+    vseg[idx] = make_int2(b * P.maxe + rec.y, rec.z);
+    const int p = (int)(hf >> 2), rem = (int)(hf & 3u);
+    PointKeys pk;
+    point_keys(pts[p], pts[cstride + p], pts[2 * cstride + p], scale32, std32, pk);
+    int k[4];
+    entry_key(pk, rem, k);
+    const int smp = sample_of(sid, pps, p);
+    vkeys[idx] = make_int4(k[0], k[1], k[2], k[3]);
+    vsid[idx] = smp;
+    // vertices are numbered sample-major, and the very first key of a sample is always new: its number is the sample's first
+    if (rem == 0 && (p == 0 || sample_of(sid, pps, p - 1) != smp)) info[EFGH_LATTICE_INFO_SEG + smp] = idx;
+    // generate_data.py:176-178: key (as fp32) / float32(std*scale), then E^T . (4-term fma chain)
+    float kf[4] = {__fdiv_rn((float)k[0], div32), __fdiv_rn((float)k[1], div32),
+                   __fdiv_rn((float)k[2], div32), __fdiv_rn((float)k[3], div32)};
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        float acc = __fmul_rn(elev(0, q), kf[0]);
+        acc = __fmaf_rn(elev(1, q), kf[1], acc);
+        acc = __fmaf_rn(elev(2, q), kf[2], acc);
+        acc = __fmaf_rn(elev(3, q), kf[3], acc);
+        pts_next[(int64_t)q * h_cap + idx] = acc;
+    }
+}
+
+// ---- 15 blur neighbours per vertex through the buckets' table images (see k_neighbors for the aliasing semantics).
+// The same launch gathers lattice_offset: blocks >= nbr_blocks take 256 points each and follow where[] -> arrival position ->
+// bucket-local vertex -> vertex number (three loads, two of them into L2-resident tables) to a coalesced 16-byte store.
+__global__ void __launch_bounds__(TPB)
+k_lat_nbr(LatPart P, const int4 *__restrict__ vkeys, const int *__restrict__ mm, int *__restrict__ info, int h_cap,
+          int *__restrict__ nbr, const int *__restrict__ vsid, int nsamples, int2 *__restrict__ alist, int alias_cap,
+          int nbr_blocks, const int *__restrict__ n_dev, int n_cap, int4 *__restrict__ off) {
+    if ((int)blockIdx.x >= nbr_blocks) {
+        const int n = n_of(n_dev, n_cap);
+        const int p = (blockIdx.x - nbr_blocks) * TPB + threadIdx.x;
+        if (p >= n) return;
+        const uint4 w4 = reinterpret_cast<const uint4 *>(P.where)[p];
+        const unsigned wv[4] = {w4.x, w4.y, w4.z, w4.w};
+        const int t = p / P.tp;
+        int o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int bk = (int)(wv[r] >> 14);
+            const int pos = P.cumul[(int64_t)bk * P.ntiles + t] + (int)(wv[r] & 0x3FFFu);
+            o[r] = pos < P.maxe ? P.gvix[(int64_t)bk * P.S + P.larr[(int64_t)bk * P.maxe + pos]] : 0;       // (else: flagged by k_lat_bucket)
+        }
+        off[p] = make_int4(o[0], o[1], o[2], o[3]);
+        return;
+    }
+    int H = info[EFGH_LATTICE_INFO_H];
+    if (H > h_cap) H = h_cap;
+    const int lane = threadIdx.x & 63;
+    const int S = P.S;
+    for (int64_t g0 = (int64_t)blockIdx.x * TPB; g0 < (int64_t)H * 16; g0 += (int64_t)nbr_blocks * TPB) {
+        const int64_t g = g0 + threadIdx.x;
+        const int h = (int)(g >> 4), t = (int)(g & 15);
+        int res = -1;
+        bool aliased = false;
+        if (h < H && t == 0) res = h;              // offset 0: the vertex itself
+        if (h < H && t > 0 && t < 15) {
+            int4 kk = vkeys[h];
+            int k[4] = {kk.x + c_nbr[t][0], kk.y + c_nbr[t][1], kk.z + c_nbr[t][2], kk.w + c_nbr[t][3]};
+            const int b = vsid[h];
+            const int *m8 = mm + 8 * b;
+            int64_t ki = key2int(k, m8);
+            if (ki >= 0) {   // every inserted key integer is >= 0
+                ki = ki * nsamples + b;
+                const uint64_t mixed = mix64((uint64_t)ki);
+                const int4 *tab = P.table + (int64_t)part_bucket(mixed, P.bb) * S;
+                int s = part_slot(mixed, P.bb, P.sb);
+                const int klo = (int)(unsigned)(uint64_t)ki, khi = (int)(unsigned)((uint64_t)ki >> 32);
+                for (int probe = 0; probe < S; ++probe) {
+                    const int4 cur = tab[s];
+                    if (cur.x == -1 && cur.y == -1) break;           // EMPTY
+                    if (cur.x == klo && cur.y == khi) { res = cur.z; break; }
+                    s = (s + 1) & (S - 1);
+                }
+            }
+            aliased = res >= 0 && (k[1] < m8[1] || k[1] > m8[5] || k[2] < m8[2] || k[2] > m8[6] || k[3] < m8[3] || k[3] > m8[7]);
+        }
+        const unsigned long long am = __ballot(aliased);
+        if (h < H) {
+            if (t < 15) nbr[g] = res;
+            else nbr[g] = (int)((am >> (lane & 48)) & 0x7FFFu);
+        }
+        if (am) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&info[EFGH_LATTICE_INFO_ALIAS], __popcll(am));
+            base = __shfl(base, 0);
+            if (aliased) {
+                const int k_ = base + __popcll(am & ((1ULL << lane) - 1ULL));
+                if (k_ < alias_cap) alist[k_] = make_int2((int)g, res);
+                else atomicOr(&info[EFGH_LATTICE_INFO_ERR], 2);
+            }
+        }
+    }
+}
+
 int64_t align256(int64_t x) { return (x + 255) / 256 * 256; }
 
 struct WsLayout {
@@ -736,6 +1198,158 @@ extern "C" int efgh_lattice_level_neighbors(const void *workspace, int32_t n_cap
     k_neighbors<<<grid, TPB, 0, st>>>((const int4 *)(ws + w.vkeys), (const int *)(ws + w.mm),
                                       (const unsigned long long *)(ws + w.hkeys), (const int *)(ws + w.hvals), hcap - 1, info,
                                       h_cap, nbr, vsid, nsamples, (int2 *)alist, alias_cap);
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// partitioned build: host side
+namespace {
+
+struct PartLayout {
+    int64_t ent, toff, cumul, where, larr, cursor, gcount, grec, gvix, table, fbits, wprefix, bsum, ticket, mm, vkeys, part, total;
+    int W, nblk, ntiles, tp, ppt;
+};
+
+int ilog2(int64_t v) { int b = 0; while ((1LL << b) < v) ++b; return b; }
+
+// tile of the scatter kernel: 8 points per thread when that still leaves >= 192 tiles, else 2
+int part_ppt(int32_t n_cap) { return (int64_t)n_cap >= 192LL * STP * 8 ? 8 : 2; }
+
+// entries per bucket: 2048 (five workgroups of k_lat_bucket per CU) unless the level needs more than NBMAX buckets of ~1000
+int part_maxe(int32_t n_cap) { return (int64_t)n_cap * 4 > (int64_t)NBMAX * 1024 ? 4096 : 2048; }
+
+PartLayout part_layout(int32_t n_cap, int32_t h_cap, int32_t nsamples, int nb, int S) {
+    PartLayout w;
+    int64_t o = 0;
+    const int maxe = part_maxe(n_cap);
+    w.ppt = part_ppt(n_cap);
+    w.tp = STP * w.ppt;
+    w.ntiles = cdiv(n_cap, w.tp);
+    w.W = cdiv((int64_t)n_cap * 4, 32);
+    w.nblk = cdiv(w.W, TPB);
+    w.ent = o;     o += align256((int64_t)w.ntiles * w.tp * 4 * 8);
+    w.toff = o;    o += align256((int64_t)w.ntiles * (nb + 1) * 4);
+    w.cumul = o;   o += align256((int64_t)nb * w.ntiles * 4);
+    w.where = o;   o += align256((int64_t)n_cap * 16);
+    w.larr = o;    o += align256((int64_t)nb * maxe * 2);
+    w.cursor = o;  o += align256((int64_t)nb * 4);
+    w.gcount = o;  o += align256((int64_t)nb * 4);
+    w.grec = o;    o += align256((int64_t)nb * S * 16);
+    w.gvix = o;    o += align256((int64_t)nb * S * 4);
+    w.table = o;   o += align256((int64_t)nb * S * 16);
+    w.fbits = o;   o += align256((int64_t)w.W * 4);
+    w.wprefix = o; o += align256((int64_t)w.W * 4);
+    w.bsum = o;    o += align256((int64_t)w.nblk * 4);
+    w.ticket = o;  o += 256;
+    w.mm = o;      o += align256((int64_t)nsamples * 32);
+    w.vkeys = o;   o += align256((int64_t)h_cap * 16);
+    w.part = o;    o += align256(((int64_t)cdiv(n_cap, 64) + 4) * 48);
+    w.total = o;
+    return w;
+}
+
+bool part_args_ok(int32_t n_cap, int32_t nb, int32_t S) {
+    return nb >= 2 && nb <= NBMAX && !(nb & (nb - 1)) && S >= 16 && S <= SMAX && !(S & (S - 1)) &&
+           cdiv(n_cap, STP * part_ppt(n_cap)) <= NTMAX;
+}
+
+LatPart part_ptrs(char *ws, const PartLayout &w, int32_t n_cap, int nb, int S) {
+    LatPart P;
+    P.ent = (unsigned long long *)(ws + w.ent);
+    P.toff = (int *)(ws + w.toff);
+    P.cumul = (int *)(ws + w.cumul);
+    P.where = (unsigned *)(ws + w.where);
+    P.larr = (unsigned short *)(ws + w.larr);
+    P.cursor = (int *)(ws + w.cursor);
+    P.gcount = (int *)(ws + w.gcount);
+    P.grec = (int4 *)(ws + w.grec);
+    P.gvix = (int *)(ws + w.gvix);
+    P.table = (int4 *)(ws + w.table);
+    P.fbits = (unsigned *)(ws + w.fbits);
+    P.wprefix = (int *)(ws + w.wprefix);
+    P.bsum = (int *)(ws + w.bsum);
+    P.ticket = (int *)(ws + w.ticket);
+    P.nb = nb; P.bb = ilog2(nb); P.S = S; P.sb = ilog2(S); P.maxe = part_maxe(n_cap);
+    P.ntiles = w.ntiles; P.tp = w.tp; P.fb = ilog2((int64_t)n_cap * 4);
+    return P;
+}
+
+}  // namespace
+
+extern "C" int32_t efgh_lattice_part_max_entries(int32_t n_cap) { return part_maxe(n_cap); }
+
+extern "C" int32_t efgh_lattice_part_buckets(int32_t n_cap) {
+    // ~1000 entries per bucket on average (half of the 2048 a bucket holds: room for the spread of the bucket sizes), ~2000 of
+    // 4096 when that would take more than NBMAX buckets; 0 = too many points even so (the hash build serves those)
+    const int64_t per = part_maxe(n_cap) == 2048 ? 1024 : 2048;
+    int64_t nb = 8;
+    while (nb * per < (int64_t)n_cap * 4) nb <<= 1;
+    return (nb > NBMAX || cdiv(n_cap, STP * part_ppt(n_cap)) > NTMAX) ? 0 : (int32_t)nb;
+}
+
+extern "C" int64_t efgh_lattice_part_workspace_bytes(int32_t n_cap, int32_t h_cap, int32_t nsamples, int32_t nbuckets,
+                                                     int32_t slots) {
+    if (!part_args_ok(n_cap, nbuckets, slots)) return -1;
+    return part_layout(n_cap, h_cap, nsamples, nbuckets, slots).total;
+}
+
+extern "C" int efgh_lattice_part_build(const float *pts, int64_t pts_cstride, const int32_t *n_dev, int32_t n_cap,
+                                       const int32_t *sid, int32_t pts_per_sample, int32_t nsamples, float scale32,
+                                       float div32, float *bary, float *emg, int32_t *list, int32_t h_cap,
+                                       int32_t *vseg, float *pts_next, int32_t *vsid, int32_t *info, void *workspace,
+                                       int32_t nbuckets, int32_t slots, void *stream_) {
+    hipStream_t st = (hipStream_t)stream_;
+    EFGH_CHECK_ARG(n_cap > 0 && n_cap < (1 << 27) && h_cap > 0 && nsamples >= 1 && nsamples <= EFGH_LATTICE_MAX_SAMPLES);
+    EFGH_CHECK_ARG(sid || pts_per_sample > 0);
+    EFGH_CHECK_ARG(pts && bary && emg && list && vseg && pts_next && vsid && info && workspace);
+    EFGH_CHECK_ARG(part_args_ok(n_cap, nbuckets, slots));
+    const PartLayout w = part_layout(n_cap, h_cap, nsamples, nbuckets, slots);
+    char *ws = (char *)workspace;
+    const LatPart P = part_ptrs(ws, w, n_cap, nbuckets, slots);
+    int *mm = (int *)(ws + w.mm), *part = (int *)(ws + w.part);
+    int4 *vkeys = (int4 *)(ws + w.vkeys);
+    const uint32_t std_bits = 0x405105ECu;         // float32(4*sqrt(2/3)), generate_data.py:19
+    float std32;
+    memcpy(&std32, &std_bits, 4);
+    const int nbp = cdiv(n_cap, TPB);
+    const int pps = sid ? 1 : pts_per_sample;
+    int ginit = cdiv(w.W, TPB);
+    if (ginit > 2048) ginit = 2048;
+    if (ginit < 64) ginit = 64;                   // covers mm (8 * nsamples <= 8192) and info
+    k_lat_init<<<ginit, TPB, 0, st>>>(P, w.W, mm, nsamples, info, EFGH_LATTICE_INFO_SEG + nsamples);
+    k_point_keys<<<nbp, TPB, 0, st>>>(pts, pts_cstride, n_dev, n_cap, scale32, std32, (float4 *)bary, (float4 *)emg, mm, part, sid,
+                                      pps);
+    k_minmax_finalize<<<cdiv(nbp * (TPB / 64), TPB), TPB, 0, st>>>(part, nbp * (TPB / 64), mm);
+    if (w.ppt == 8)
+        k_lat_scatter<8><<<w.ntiles, STP, 0, st>>>(pts, pts_cstride, n_dev, n_cap, scale32, std32, mm, sid, pps, nsamples, P, info);
+    else
+        k_lat_scatter<2><<<w.ntiles, STP, 0, st>>>(pts, pts_cstride, n_dev, n_cap, scale32, std32, mm, sid, pps, nsamples, P, info);
+    if (P.maxe == 2048)
+        k_lat_bucket<2048><<<nbuckets, TPB, (size_t)slots * 20 + (size_t)2048 * 14, st>>>(P, n_dev, n_cap, list, info);
+    else
+        k_lat_bucket<4096><<<nbuckets, TPB, (size_t)slots * 20 + (size_t)4096 * 14, st>>>(P, n_dev, n_cap, list, info);
+    k_lat_rank<<<w.nblk, TPB, 0, st>>>(P, w.W, info, h_cap);
+    k_lat_number<<<cdiv((int64_t)nbuckets * slots, TPB), TPB, 0, st>>>(P, pts, pts_cstride, scale32, std32, div32, sid, pps, vkeys,
+                                                                       (int2 *)vseg, pts_next, vsid, h_cap, info);
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}
+
+extern "C" int efgh_lattice_part_neighbors(const void *workspace, const int32_t *n_dev, int32_t n_cap, int32_t h_cap_build,
+                                           int32_t nsamples, int32_t *info, const int32_t *vsid, int32_t h_cap, int32_t *nbr,
+                                           int32_t *alist, int32_t alias_cap, int32_t nbuckets, int32_t slots, int32_t *off,
+                                           void *stream_) {
+    hipStream_t st = (hipStream_t)stream_;
+    EFGH_CHECK_ARG(workspace && info && vsid && nbr && alist && off && n_cap > 0 && h_cap > 0 && h_cap <= h_cap_build && alias_cap > 0);
+    EFGH_CHECK_ARG(part_args_ok(n_cap, nbuckets, slots));
+    const PartLayout w = part_layout(n_cap, h_cap_build, nsamples, nbuckets, slots);
+    char *ws = (char *)workspace;
+    const LatPart P = part_ptrs(ws, w, n_cap, nbuckets, slots);
+    int grid = cdiv((int64_t)h_cap * 16, TPB);
+    if (grid > 8192) grid = 8192;
+    k_lat_nbr<<<grid + cdiv(n_cap, TPB), TPB, 0, st>>>(P, (const int4 *)(ws + w.vkeys), (const int *)(ws + w.mm), info, h_cap, nbr, vsid,
+                                                       nsamples, (int2 *)alist, alias_cap, grid, n_dev, n_cap, (int4 *)off);
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
 }

@@ -32,7 +32,7 @@ class LatticeLevel:
     per vertex: nbr [H][16] (15 neighbours + alias mask), vseg [H][2] + list [4n] (vertex -> ascending flat positions
     4p + r), pts_next [3][H]; info = the level's device counters (INFO_*), alist = aliased neighbour records."""
     __slots__ = ('n_in', 'H', 'bary_pm', 'emg_pm', 'off_pm', 'nbr', 'vseg', 'list', 'pts_next_buf', 'info', 'alist',
-                 'seg_in', 'seg', 'vsid', '_ws', '_caps', '_hash')
+                 'seg_in', 'seg', 'vsid', '_ws', '_caps', '_mode', '_n_dev')
 
     # the reference's (4, n) / (3, H) arrays as views
     @property
@@ -69,38 +69,75 @@ class _SampleView:
     __slots__ = ('n_in', 'H', 'bary', 'emg', 'off', 'nbr', 'pts_next')
 
 
-def _level_arrays(L, dev, n_cap, h_cap, B):
+PART = os.environ.get('EFGH_LATTICE_PART', '1') != '0'      # partitioned build (lattice.hip, round 3); 0 = global-hash build only
+SMALL_HASH = os.environ.get('EFGH_LATTICE_SMALL_HASH', '1') != '0'
+
+
+def _pow2ceil(v):
+    return 1 << max(0, int(v) - 1).bit_length()
+
+
+def _plan(L, n_cap, h_est):
+    """how to build a level of n_cap points expecting ~h_est vertices (None: unknown):
+    ('part', buckets, slots per bucket) - entries dealt into buckets, every bucket grouped in LDS - or, for more points than the
+    partitioned build's bucket limit (~2.8 M), ('hash', slots) - the global hash insert (0 = its default table)"""
+    nb = L.efgh_lattice_part_buckets(_C.c_int32(n_cap)) if PART else 0
+    if nb:
+        if h_est is None:
+            return ('part', nb, 2048)
+        return ('part', nb, min(2048, max(64, _pow2ceil(2.5 * h_est / nb + 64))))
+    if h_est is None or not SMALL_HASH:
+        return ('hash', 0)
+    # hash table sized for the expected vertex count (load <= 1/2) instead of the worst case 4 * n_cap keys
+    return ('hash', max(4096, 1 << (2 * h_est - 1).bit_length()))
+
+
+def _level_arrays(L, dev, n_cap, h_cap, B, mode=('hash', 0)):
     lv = LatticeLevel()
+    lv._mode = mode
     lv.bary_pm = torch.empty((n_cap, 4), dtype=torch.float32, device=dev)
     lv.emg_pm = torch.empty((n_cap, 4), dtype=torch.float32, device=dev)
     lv.off_pm = torch.empty((n_cap, 4), dtype=torch.int32, device=dev)
-    lv.list = torch.empty(4 * n_cap, dtype=torch.int32, device=dev)
+    if mode[0] == 'part':       # every bucket owns a fixed window of the list array
+        lv.list = torch.empty(mode[1] * L.efgh_lattice_part_max_entries(_C.c_int32(n_cap)), dtype=torch.int32, device=dev)
+        ws_bytes = L.efgh_lattice_part_workspace_bytes(n_cap, h_cap, B, mode[1], mode[2])
+    else:
+        lv.list = torch.empty(4 * n_cap, dtype=torch.int32, device=dev)
+        ws_bytes = L.efgh_lattice_workspace_bytes(n_cap, h_cap, B)
     lv.vseg = torch.empty((h_cap, 2), dtype=torch.int32, device=dev)
     lv.pts_next_buf = torch.empty((3, h_cap), dtype=torch.float32, device=dev)
     lv.vsid = torch.empty(h_cap, dtype=torch.int32, device=dev)
     lv.info = torch.empty(INFO_SEG + B, dtype=torch.int32, device=dev)
     lv.alist = torch.empty((ALIAS_CAP, 2), dtype=torch.int32, device=dev)
-    lv._ws = torch.empty(L.efgh_lattice_workspace_bytes(n_cap, h_cap, B), dtype=torch.uint8, device=dev)
+    lv._ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     lv._caps = (n_cap, h_cap)
-    lv._hash = 0                       # hash_slots of the C-ABI calls: 0 = default table (8 * n_cap slots)
     return lv
 
 
 def _launch_build(L, lv, pts, cstride, n_dev, sid, pps, B, s, st):
     n_cap, h_cap = lv._caps
-    _C.check(L.efgh_lattice_level_build(
-        _C.ptr(pts), _C.c_int64(cstride), _C.ptr(n_dev), _C.c_int32(n_cap), _C.ptr(sid), _C.c_int32(pps), _C.c_int32(B),
-        _C.c_float(np.float32(s)), _C.c_float(np.float32(EXPECTED_STD * s)), _C.ptr(lv.bary_pm), _C.ptr(lv.emg_pm),
-        _C.ptr(lv.off_pm), _C.ptr(lv.list), _C.c_int32(h_cap), _C.ptr(lv.vseg), _C.ptr(lv.pts_next_buf), _C.ptr(lv.vsid),
-        _C.ptr(lv.info), _C.ptr(lv._ws), _C.c_int64(lv._hash), st))
+    head = (_C.ptr(pts), _C.c_int64(cstride), _C.ptr(n_dev), _C.c_int32(n_cap), _C.ptr(sid), _C.c_int32(pps), _C.c_int32(B),
+            _C.c_float(np.float32(s)), _C.c_float(np.float32(EXPECTED_STD * s)), _C.ptr(lv.bary_pm), _C.ptr(lv.emg_pm))
+    tail = (_C.ptr(lv.list), _C.c_int32(h_cap), _C.ptr(lv.vseg), _C.ptr(lv.pts_next_buf), _C.ptr(lv.vsid), _C.ptr(lv.info),
+            _C.ptr(lv._ws))
+    lv._n_dev = n_dev                  # (kept alive for the neighbours call)
+    if lv._mode[0] == 'part':
+        _C.check(L.efgh_lattice_part_build(*head, *tail, _C.c_int32(lv._mode[1]), _C.c_int32(lv._mode[2]), st))
+    else:
+        _C.check(L.efgh_lattice_level_build(*head, _C.ptr(lv.off_pm), *tail, _C.c_int64(lv._mode[1]), st))
 
 
 def _launch_neighbors(L, lv, B, h_rows, st):
     n_cap, h_cap = lv._caps
     lv.nbr = torch.empty((h_rows, 16), dtype=torch.int32, device=lv.info.device)
-    _C.check(L.efgh_lattice_level_neighbors(_C.ptr(lv._ws), _C.c_int32(n_cap), _C.c_int32(h_cap), _C.c_int32(B),
-                                            _C.ptr(lv.info), _C.ptr(lv.vsid), _C.c_int32(h_rows), _C.ptr(lv.nbr),
-                                            _C.ptr(lv.alist), _C.c_int32(ALIAS_CAP), _C.c_int64(lv._hash), st))
+    common = (_C.c_int32(n_cap), _C.c_int32(h_cap), _C.c_int32(B), _C.ptr(lv.info), _C.ptr(lv.vsid),
+              _C.c_int32(h_rows), _C.ptr(lv.nbr), _C.ptr(lv.alist), _C.c_int32(ALIAS_CAP))
+    if lv._mode[0] == 'part':
+        _C.check(L.efgh_lattice_part_neighbors(_C.ptr(lv._ws), _C.ptr(lv._n_dev), *common, _C.c_int32(lv._mode[1]),
+                                               _C.c_int32(lv._mode[2]), _C.ptr(lv.off_pm), st))
+    else:
+        _C.check(L.efgh_lattice_level_neighbors(_C.ptr(lv._ws), *common, _C.c_int64(lv._mode[1]), st))
+    lv._n_dev = None
 
 
 def _finish(lv, host, n_in, seg_in, B):
@@ -112,9 +149,6 @@ def _finish(lv, host, n_in, seg_in, B):
     lv._ws = None                      # scratch no longer needed (the stream orders its reuse)
     if lv.nbr.shape[0] != H:
         lv.nbr = lv.nbr[:H]
-
-
-SMALL_HASH = os.environ.get('EFGH_LATTICE_SMALL_HASH', '1') != '0'
 
 
 def build_pyramid_batched(pc, scales):
@@ -138,10 +172,9 @@ def build_pyramid_batched(pc, scales):
         lvs, pts, cstride, n_dev, sid, n_cap = [], pts0, B * N, None, None, B * N
         for s, hp in zip(scales, prev):
             h_cap = min(4 * n_cap, hp + hp // 4 + 1024)
-            lv = _level_arrays(L, dev, n_cap, h_cap, B)
-            # hash table sized for the expected vertex count (load <= 1/2) instead of the worst case 4 * n_cap keys: the build is
-            # bound by random probes into it; a table that was too small sets ERR bit 2 and the level-by-level path rebuilds
-            lv._hash = max(4096, 1 << (2 * h_cap - 1).bit_length()) if SMALL_HASH else 0
+            # tables sized for the expected vertex count; one that turns out too small sets ERR bit 2 and the level-by-level path
+            # below rebuilds the pyramid
+            lv = _level_arrays(L, dev, n_cap, h_cap, B, _plan(L, n_cap, h_cap))
             _launch_build(L, lv, pts, cstride, n_dev, sid, N, B, s, st)
             _launch_neighbors(L, lv, B, h_cap, st)
             lvs.append(lv)
@@ -160,9 +193,13 @@ def build_pyramid_batched(pc, scales):
         out, pts, cstride, sid, n = [], pts0, B * N, None, B * N
         seg_in = [b * N for b in range(B + 1)]
         for s in scales:
-            lv = _level_arrays(L, dev, n, 4 * n, B)
-            _launch_build(L, lv, pts, cstride, None, sid, N, B, s, st)
-            H = int(lv.info[INFO_H].item())          # host sync (sizes the next level)
+            for mode in (_plan(L, n, None), ('hash', 0)):
+                lv = _level_arrays(L, dev, n, 4 * n, B, mode)
+                _launch_build(L, lv, pts, cstride, None, sid, N, B, s, st)
+                head = lv.info[:2].tolist()           # host sync (sizes the next level)
+                if not head[INFO_ERR] & 4 or mode == ('hash', 0):
+                    break                             # (a bucket of the partitioned build overflowed: the hash build serves the level)
+            H = head[INFO_H]
             _launch_neighbors(L, lv, B, H, st)
             host = lv.info.cpu().tolist()
             _finish(lv, host, n, seg_in, B)

@@ -47,7 +47,7 @@ int efgh_version(void);
  * so the levels of a pyramid can be enqueued back to back (level l+1: pts = pts_next, pts_cstride = h_cap, n_dev =
  * info + EFGH_LATTICE_INFO_H, n_cap = h_cap, sid = vsid) with one host read-back at the end.                              */
 #define EFGH_LATTICE_INFO_H 0        /* number of vertices (pc1_hash_cnt summed over the samples) */
-#define EFGH_LATTICE_INFO_ERR 1      /* bit 0: H > h_cap; bit 1: more aliased neighbour hits than alias_cap; bit 2: hash table full */
+#define EFGH_LATTICE_INFO_ERR 1      /* bit 0: H > h_cap; bit 1: more aliased neighbour hits than alias_cap; bit 2: hash table / bucket full */
 #define EFGH_LATTICE_INFO_ALIAS 2    /* number of aliased neighbour hits (see efgh_lattice_level_neighbors) */
 #define EFGH_LATTICE_INFO_CURSOR 3   /* internal (number of occupied hash slots == H) */
 #define EFGH_LATTICE_INFO_SEG 4      /* info[SEG + b] = first vertex of sample b */
@@ -90,6 +90,30 @@ int efgh_lattice_level_build(const float *pts, int64_t pts_cstride, const int32_
 int efgh_lattice_level_neighbors(const void *workspace, int32_t n_cap, int32_t h_cap_build, int32_t nsamples,
                                  int32_t *info, const int32_t *vsid, int32_t h_cap, int32_t *nbr, int32_t *alist,
                                  int32_t alias_cap, int64_t hash_slots, void *stream);
+
+/* The same level WITHOUT a global hash insert (round 3; the default of efgh_amd/lattice.py): every (point, corner) entry is
+ * bucket-sorted inside its tile of points (bucket = top bits of a bijective mix of its key integer), one workgroup per bucket
+ * gathers its runs and groups them in LDS, the first-seen numbering is a prefix count over one bit per entry, the neighbour
+ * lookup probes a read-only image of the buckets' tables and lattice_offset is gathered per point - no global atomics per entry,
+ * no scattered global stores.  Results are identical to efgh_lattice_level_build / _neighbors (same arrays, same meaning) except:
+ *      list has efgh_lattice_part_max_entries(n_cap) * nbuckets elements (vseg starts point into per-bucket windows);
+ *      off is written by the NEIGHBOURS call (the same launch), not by the build.
+ * nbuckets: power of two in [2, 8192], normally efgh_lattice_part_buckets(n_cap) (0: more points than the bucket limit - use the
+ * hash build); slots: table slots per bucket, power of two in [16, 2048], >= ~2.5x the expected vertices per bucket.
+ * A bucket with more than efgh_lattice_part_max_entries(n_cap) entries, or more vertices than slots, sets bit 2 of
+ * info[EFGH_LATTICE_INFO_ERR] (nothing is written out of bounds): rebuild with more slots or with the hash build.          */
+int32_t efgh_lattice_part_max_entries(int32_t n_cap);
+int32_t efgh_lattice_part_buckets(int32_t n_cap);
+int64_t efgh_lattice_part_workspace_bytes(int32_t n_cap, int32_t h_cap, int32_t nsamples, int32_t nbuckets, int32_t slots);
+int efgh_lattice_part_build(const float *pts, int64_t pts_cstride, const int32_t *n_dev, int32_t n_cap,
+                            const int32_t *sid, int32_t pts_per_sample, int32_t nsamples, float scale32,
+                            float div32, float *bary, float *emg, int32_t *list, int32_t h_cap,
+                            int32_t *vseg, float *pts_next, int32_t *vsid, int32_t *info, void *workspace,
+                            int32_t nbuckets, int32_t slots, void *stream);
+int efgh_lattice_part_neighbors(const void *workspace, const int32_t *n_dev, int32_t n_cap, int32_t h_cap_build,
+                                int32_t nsamples, int32_t *info, const int32_t *vsid, int32_t h_cap, int32_t *nbr,
+                                int32_t *alist, int32_t alias_cap, int32_t nbuckets, int32_t slots, int32_t *off,
+                                void *stream);
 
 /* ------------------------------------------------------------------ BCL splat (K3) ---------
  * replaces SparseSum + density normalisation, nets/bilateralNN.py:6-40, 179-211, as a gather over the vertex lists of the

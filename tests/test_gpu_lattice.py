@@ -137,8 +137,7 @@ def test_small_hash_table_overflow_is_flagged_not_fatal():
     st = _C.stream_ptr()
     infos = []
     for hs in (4096, 0):
-        lv = lattice._level_arrays(L, pc.device, n, 4 * n, 1)
-        lv._hash = hs
+        lv = lattice._level_arrays(L, pc.device, n, 4 * n, 1, ('hash', hs))
         lattice._launch_build(L, lv, pc.contiguous(), n, None, None, n, 1, 1.0, st)
         torch.cuda.synchronize()
         infos.append(lv.info.cpu().tolist())
@@ -146,3 +145,74 @@ def test_small_hash_table_overflow_is_flagged_not_fatal():
     assert infos[1][lattice.INFO_H] > 4096                       # (more vertices than the small table had slots)
     from oracle import lattice as olat
     assert infos[1][lattice.INFO_H] == olat.generate_data(pc.cpu().numpy())[0]['H']
+
+
+def _build_level(pc, mode, scale=1.0):
+    """one level of one or more samples through the C-ABI with an explicit build plan; returns (LatticeLevel, host info)"""
+    from efgh_amd import _C, lattice
+    L = _C.lib()
+    B, _, N = pc.shape
+    n = B * N
+    pts = pc.permute(1, 0, 2).reshape(3, n).contiguous()
+    st = _C.stream_ptr()
+    lv = lattice._level_arrays(L, pc.device, n, 4 * n, B, mode)
+    lattice._launch_build(L, lv, pts, n, None, None, N, B, scale, st)
+    H = int(lv.info[lattice.INFO_H].item())
+    lattice._launch_neighbors(L, lv, B, max(H, 1), st)
+    torch.cuda.synchronize()
+    return lv, lv.info.cpu().tolist()
+
+
+@pytest.mark.parametrize('B,n,scale', [(1, 1, 1.0), (1, 777, 1.0), (3, 4096, 0.5), (2, 40000, 1.0), (8, 16384, 0.125)])
+def test_partitioned_build_equals_hash_build(B, n, scale):
+    """the two builds of lattice.hip (buckets grouped in LDS vs global hash insert) give the same level: vertex numbering, offsets,
+    neighbours + alias marks, next-level points, and the same ascending list per vertex"""
+    from efgh_amd import _C, lattice
+    rs = np.random.RandomState(B * 1000 + n)
+    pc = torch.from_numpy((rs.randn(B, 3, n) * np.array([[25.], [25.], [2.5]])).astype(np.float32)).cuda()
+    L = _C.lib()
+    nb = L.efgh_lattice_part_buckets(_C.c_int32(B * n))
+    assert nb >= 8
+    a, ia = _build_level(pc, ('hash', 0), scale)
+    for mode in (('part', nb, 2048), ('part', max(2, nb // 4), 1024)):
+        b, ib = _build_level(pc, mode, scale)
+        if ib[lattice.INFO_ERR] & 4:
+            # only the deliberately coarse plan may overflow - or a scale at which single vertices hold thousands of entries
+            # (what build_pyramid then does is covered by test_partitioned_build_overflow_is_flagged_not_fatal)
+            assert mode[1] < nb or scale < 0.25
+            continue
+        H = ia[lattice.INFO_H]
+        assert ib[:3] == ia[:3] and ib[lattice.INFO_SEG:] == ia[lattice.INFO_SEG:]
+        for name in ('bary_pm', 'emg_pm', 'off_pm'):
+            assert torch.equal(getattr(a, name), getattr(b, name)), name
+        assert torch.equal(a.nbr[:H], b.nbr[:H])
+        assert torch.equal(a.pts_next_buf[:, :H], b.pts_next_buf[:, :H]) and torch.equal(a.vsid[:H], b.vsid[:H])
+        assert torch.equal(a.vseg[:H, 1], b.vseg[:H, 1])
+        # the lists, vertex by vertex (segments sit at different places): gather both into vertex-major order and compare
+        la, lb = a.list.cpu().numpy(), b.list.cpu().numpy()
+        sa, sb_ = a.vseg[:H].cpu().numpy(), b.vseg[:H].cpu().numpy()
+        idx = np.repeat(np.arange(H), sa[:, 1])
+        within = np.arange(idx.size) - np.repeat(np.cumsum(sa[:, 1]) - sa[:, 1], sa[:, 1])
+        assert np.array_equal(la[sa[idx, 0] + within], lb[sb_[idx, 0] + within])
+        assert idx.size == 4 * B * n
+
+
+def test_partitioned_build_overflow_is_flagged_not_fatal():
+    """too few table slots for a bucket's vertices, and more entries than a bucket holds (every point in one lattice cell): bit 2 of
+    info[ERR], nothing out of bounds; build_pyramid falls back to the hash build and stays exact"""
+    from efgh_amd import lattice
+    from oracle import lattice as olat
+    rs = np.random.RandomState(0)
+    pc = torch.from_numpy((rs.randn(1, 3, 8192) * np.array([[30.], [30.], [3.]])).astype(np.float32)).cuda()
+    _, info = _build_level(pc, ('part', 8, 16))
+    assert info[lattice.INFO_ERR] & 4
+    same = torch.zeros(1, 3, 5000).cuda() + torch.tensor([1.0, 2.0, 0.5]).view(1, 3, 1).cuda()       # 5000 entries per vertex
+    _, info = _build_level(same, ('part', 8, 64))
+    assert info[lattice.INFO_ERR] & 4
+    lattice._SIZES.clear()
+    for _ in range(2):                 # level by level, then speculative
+        lv = lattice.build_pyramid(same[0], SCALES)
+        ref = olat.generate_data(same[0].cpu().numpy())
+        for d, r in zip(lv, ref):
+            assert d.H == r['H'] and np.array_equal(d.off.cpu().numpy().astype(np.int64), r['off'])
+            assert np.array_equal(d.nbr.cpu().numpy()[:, :15].T.astype(np.int64), r['nbr'])
