@@ -628,6 +628,7 @@ k_neighbors(const int4 *__restrict__ vkeys, const int *__restrict__ mm, const un
 // The hash build above is bound by memory-side atomics (~2 per (point, corner) entry at ~26 G/s chip-wide).  Measured on this
 // part while rebuilding it: 4.2 M random 4-byte STORES cost 80-100 us, 4.2 M random 4-byte LOADS 14 us - so every permutation
 // below is a gather.
+//   k_lat_keys     barycentric weights + one key-extrema record per block; k_lat_minmax folds the records (one workgroup).
 //   k_lat_scatter  a tile of points computes its 4 entries per point, counts them per bucket in LDS (bucket = top bits of
 //                  mix64(key integer): mix64 is a bijection, so equal keys meet in one bucket and the buckets are balanced whatever
 //                  the key distribution), and writes them bucket-sorted into the TILE's own window of `ent` (a local scatter that
@@ -638,8 +639,9 @@ k_neighbors(const int4 *__restrict__ vkeys, const int *__restrict__ mm, const un
 //                  order), one bit per flat position marking the first-seen entry of every vertex, a read-only image of the
 //                  bucket's table for the neighbour probes, and the bucket-local vertex of every arrival position.
 //   k_lat_rank     first-seen numbering = prefix count over those bits.
-//   k_lat_number   vertex records (segment, key, sample, next level's point).
-//   k_lat_nbr      15 neighbour probes per vertex; the same launch gathers lattice_offset per point through where[].
+//   k_lat_number   vertex numbers (to the tables) and their inverse.
+//   k_lat_nbr      15 neighbour probes per vertex; the same launch gathers lattice_offset per point through where[] and emits
+//                  the vertex records (list segment, sample, next level's point) in number order.
 // A bucket that overflows maxe entries or its table sets bit 2 of info[ERR]: the caller rebuilds with the hash build.
 constexpr int SMAX = 2048;          // slots of a bucket's table
 constexpr int NBMAX = 8192;         // buckets (LDS counters of k_lat_scatter)
@@ -656,10 +658,11 @@ struct LatPart {                    // workspace of the partitioned build
     int *gcount;                    // [nb]              vertices of bucket b
     int4 *grec;                     // [nb][S]           (slot, start, length, first-seen flat position) of bucket-local vertex g
     int *gvix;                      // [nb][S]           vertex number of bucket-local vertex g
+    int *vrec;                      // [h_cap]           b * S + g of vertex number h (the inverse of gvix)
     int4 *table;                    // [nb][S]           (key lo, key hi, vertex number, -) : the neighbour lookup
     unsigned *fbits;                // [W]               bit f = flat position f is the first-seen entry of its vertex
-    int *wprefix;                   // [W]               set bits in front of word w inside its block of 256 words
-    int *bsum;                      // [W/256]           set bits per block -> exclusive prefix
+    int *wprefix;                   // [W]               set bits in front of word w inside its block of 2048 words
+    int *bsum;                      // [W/2048]          set bits per block -> exclusive prefix
     int *ticket;                    // last-block election of k_lat_rank
     int nb, bb, S, sb, maxe;        // buckets = 1 << bb, slots per bucket = 1 << sb, entries per bucket
     int ntiles, tp;                 // tiles (capacity), points per tile
@@ -669,13 +672,137 @@ struct LatPart {                    // workspace of the partitioned build
 __device__ __forceinline__ int part_bucket(uint64_t mixed, int bb) { return (int)(mixed >> (64 - bb)); }
 __device__ __forceinline__ int part_slot(uint64_t mixed, int bb, int sb) { return (int)((mixed >> (64 - bb - sb)) & ((1u << sb) - 1u)); }
 
+// ---- keys + barycentric weights of the partitioned build: k_point_keys with one extrema record per BLOCK of 256 points
+// (sample, mins, maxs; sample -1: no points, -2: the block straddles a sample boundary)
 __global__ void __launch_bounds__(TPB)
-k_lat_init(LatPart P, int W, int *__restrict__ mm, int nsamples, int *__restrict__ info, int ninfo) {
-    const int i0 = blockIdx.x * TPB + threadIdx.x, stride = gridDim.x * TPB;
-    for (int i = i0; i < W; i += stride) P.fbits[i] = 0u;
-    if (i0 < nsamples * 8) mm[i0] = (i0 & 7) < 4 ? INT32_MAX : INT32_MIN;
-    if (i0 < ninfo) info[i0] = 0;
-    if (i0 == 0) *P.ticket = 0;
+k_lat_keys(const float *__restrict__ pts, int64_t cstride, const int *__restrict__ n_dev, int n_cap, float scale32,
+           float std32, float4 *__restrict__ bary, float4 *__restrict__ emg, int *__restrict__ part,
+           const int *__restrict__ sid, int pps) {
+    const int n = n_of(n_dev, n_cap);
+    const int p = blockIdx.x * TPB + threadIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int kmin[4] = {INT32_MAX, INT32_MAX, INT32_MAX, INT32_MAX};
+    int kmax[4] = {INT32_MIN, INT32_MIN, INT32_MIN, INT32_MIN};
+    int blo = INT32_MAX, bhi = -1;
+    if (p < n) {
+        PointKeys pk;
+        point_keys(pts[p], pts[cstride + p], pts[2 * cstride + p], scale32, std32, pk);
+        bary[p] = make_float4(pk.bary[0], pk.bary[1], pk.bary[2], pk.bary[3]);
+        emg[p] = make_float4(pk.emg[0], pk.emg[1], pk.emg[2], pk.emg[3]);
+#pragma unroll
+        for (int rem = 0; rem < 4; ++rem) {
+            int k[4];
+            entry_key(pk, rem, k);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { kmin[c] = min(kmin[c], k[c]); kmax[c] = max(kmax[c], k[c]); }
+        }
+        blo = bhi = sample_of(sid, pps, p);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        blo = min(blo, __shfl_xor(blo, o)); bhi = max(bhi, __shfl_xor(bhi, o));
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { kmin[c] = min(kmin[c], __shfl_xor(kmin[c], o)); kmax[c] = max(kmax[c], __shfl_xor(kmax[c], o)); }
+    }
+    __shared__ int wrec[TPB / 64][10];
+    if (lane == 0) {
+        wrec[wv][0] = blo; wrec[wv][1] = bhi;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { wrec[wv][2 + c] = kmin[c]; wrec[wv][6 + c] = kmax[c]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 12) {
+        // word 0: the sample (or -1 / -2); words 1..4 mins, 5..8 maxs
+        int lo = INT32_MAX, hi = -1;
+#pragma unroll
+        for (int w = 0; w < TPB / 64; ++w) { lo = min(lo, wrec[w][0]); hi = max(hi, wrec[w][1]); }
+        int v = 0;
+        const int t = threadIdx.x;
+        if (t == 0) v = hi < 0 ? -1 : (lo == hi ? lo : -2);
+        else if (t <= 4) { v = INT32_MAX; for (int w = 0; w < TPB / 64; ++w) v = min(v, wrec[w][1 + t]); }
+        else if (t <= 8) { v = INT32_MIN; for (int w = 0; w < TPB / 64; ++w) v = max(v, wrec[w][1 + t]); }
+        part[12 * blockIdx.x + t] = v;
+    }
+}
+
+// ---- per-sample key extrema from the per-block records of k_lat_keys: ONE workgroup, register folding + shuffle reductions +
+// LDS atomics, plain stores of the result (no global atomics, nothing to initialise).  Blocks that straddle a sample boundary (at
+// most one per boundary; record -2) are revisited point by point.
+constexpr int MMT = 1024;
+__global__ void __launch_bounds__(MMT)
+k_lat_minmax(const int *__restrict__ part, const float *__restrict__ pts, int64_t cstride,
+             const int *__restrict__ n_dev, int n_cap, float scale32, float std32, const int *__restrict__ sid, int pps,
+             int nsamples, int *__restrict__ mm) {
+    __shared__ int lmm[EFGH_LATTICE_MAX_SAMPLES * 8];
+    __shared__ int strad[EFGH_LATTICE_MAX_SAMPLES];
+    __shared__ int nstr;
+    for (int i = threadIdx.x; i < nsamples * 8; i += MMT) lmm[i] = (i & 7) < 4 ? INT32_MAX : INT32_MIN;
+    if (threadIdx.x == 0) nstr = 0;
+    __syncthreads();
+    const int n = n_of(n_dev, n_cap);
+    const int nrec = (n + TPB - 1) / TPB;
+    {
+        // every thread folds a contiguous run of records (almost always one sample) in registers, four loads in flight; a change of
+        // sample inside the run goes to the LDS table directly, the last one through a shuffle reduction per wave
+        const int per = (nrec + MMT - 1) / MMT;
+        int b = -1;
+        int kmin[4] = {INT32_MAX, INT32_MAX, INT32_MAX, INT32_MAX};
+        int kmax[4] = {INT32_MIN, INT32_MIN, INT32_MIN, INT32_MIN};
+        for (int r0 = 0; r0 < per; r0 += 4) {
+            int4 q0[4], q1[4], q2[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int w = threadIdx.x * per + r0 + u;
+                q0[u] = make_int4(-1, 0, 0, 0); q1[u] = q2[u] = q0[u];
+                if (r0 + u < per && w < nrec) {
+                    const int4 *q = reinterpret_cast<const int4 *>(part + 12 * w);
+                    q0[u] = q[0]; q1[u] = q[1]; q2[u] = q[2];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (q0[u].x == -2) {
+                    const int k = atomicAdd(&nstr, 1);
+                    if (k < EFGH_LATTICE_MAX_SAMPLES) strad[k] = threadIdx.x * per + r0 + u;
+                    continue;
+                }
+                if (q0[u].x < 0) continue;
+                if (b >= 0 && q0[u].x != b) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) { atomicMin(&lmm[8 * b + c], kmin[c]); atomicMax(&lmm[8 * b + 4 + c], kmax[c]); }
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) { kmin[c] = INT32_MAX; kmax[c] = INT32_MIN; }
+                }
+                b = q0[u].x;
+                kmin[0] = min(kmin[0], q0[u].y); kmin[1] = min(kmin[1], q0[u].z); kmin[2] = min(kmin[2], q0[u].w); kmin[3] = min(kmin[3], q1[u].x);
+                kmax[0] = max(kmax[0], q1[u].y); kmax[1] = max(kmax[1], q1[u].z); kmax[2] = max(kmax[2], q1[u].w); kmax[3] = max(kmax[3], q2[u].x);
+            }
+        }
+        wave_minmax_by_sample(b, kmin, kmax, lmm);
+    }
+    __syncthreads();
+    const int ns = min(nstr, EFGH_LATTICE_MAX_SAMPLES);
+    for (int k = threadIdx.x >> 6; k < ns * (TPB / 64); k += MMT / 64) {
+        const int p = TPB * strad[k / (TPB / 64)] + 64 * (k % (TPB / 64)) + (threadIdx.x & 63);
+        int b = -1;
+        int kmin[4] = {INT32_MAX, INT32_MAX, INT32_MAX, INT32_MAX};
+        int kmax[4] = {INT32_MIN, INT32_MIN, INT32_MIN, INT32_MIN};
+        if (p < n) {
+            PointKeys pk;
+            point_keys(pts[p], pts[cstride + p], pts[2 * cstride + p], scale32, std32, pk);
+#pragma unroll
+            for (int rem = 0; rem < 4; ++rem) {
+                int kk[4];
+                entry_key(pk, rem, kk);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { kmin[c] = min(kmin[c], kk[c]); kmax[c] = max(kmax[c], kk[c]); }
+            }
+            b = sample_of(sid, pps, p);
+        }
+        wave_minmax_by_sample(b, kmin, kmax, lmm);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nsamples * 8; i += MMT) mm[i] = lmm[i];
 }
 
 // exclusive prefix over the NT threads of a block (NT = 256 or 512), one value each; *total = block sum
@@ -935,13 +1062,19 @@ k_lat_bucket(LatPart P, const int *__restrict__ n_dev, int n_cap, int *__restric
 }
 
 // ---- first-seen numbering: vertex number = number of first-seen bits in front of the vertex's own.  Per 32-bit word its
-// prefix inside a block of 256 words; the last block to finish turns the block sums into their exclusive prefix and writes H.
+// prefix inside a block of 2048 words (8 per thread: few blocks, so the last-block election costs few same-address atomics);
+// the last block to finish turns the block sums into their exclusive prefix and writes H.
+constexpr int RWT = 8;
 __global__ void __launch_bounds__(TPB)
 k_lat_rank(LatPart P, int W, int *__restrict__ info, int h_cap) {
-    const int w = blockIdx.x * TPB + threadIdx.x;
+    const int w0 = (blockIdx.x * TPB + threadIdx.x) * RWT;
+    int c[RWT], mine = 0;
+#pragma unroll
+    for (int k = 0; k < RWT; ++k) { c[k] = w0 + k < W ? __popc(P.fbits[w0 + k]) : 0; mine += c[k]; }
     int tot;
-    const int ex = block_exclusive_scan(w < W ? __popc(P.fbits[w]) : 0, &tot);
-    if (w < W) P.wprefix[w] = ex;
+    int ex = block_exclusive_scan(mine, &tot);
+#pragma unroll
+    for (int k = 0; k < RWT; ++k) { if (w0 + k < W) P.wprefix[w0 + k] = ex; ex += c[k]; }
     __shared__ int last_s;
     if (threadIdx.x == 0) {
         __hip_atomic_store(&P.bsum[blockIdx.x], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -972,52 +1105,74 @@ k_lat_rank(LatPart P, int W, int *__restrict__ info, int h_cap) {
     }
 }
 
-// ---- number the vertices and emit their records: one thread per (bucket, bucket-local vertex) slot of the grid nb x S
+// ---- number the vertices: one thread per (bucket, bucket-local vertex) slot of the grid nb x S.  Only the number leaves this
+// kernel (to the bucket's tables and, as the inverse vrec[number] = (bucket, vertex), to k_lat_nbr, which emits the vertex
+// records in number order with coalesced stores).
 __global__ void __launch_bounds__(TPB)
-k_lat_number(LatPart P, const float *__restrict__ pts, int64_t cstride, float scale32, float std32, float div32,
-             const int *__restrict__ sid, int pps, int4 *__restrict__ vkeys, int2 *__restrict__ vseg,
-             float *__restrict__ pts_next, int *__restrict__ vsid, int h_cap, int *__restrict__ info) {
+k_lat_number(LatPart P, int h_cap) {
     const int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
     const int b = (int)(i >> P.sb), g = (int)(i & (P.S - 1));
     if (b >= P.nb || g >= P.gcount[b]) return;
-    const int4 rec = P.grec[(int64_t)b * P.S + g];
+    const int4 rec = P.grec[i];
     const unsigned hf = (unsigned)rec.w;
     const unsigned w = hf >> 5;
-    const int idx = P.bsum[w >> 8] + P.wprefix[w] + __popc(P.fbits[w] & ((1u << (hf & 31u)) - 1u));
-    P.gvix[i] = idx;                              // (k_lat_nbr hands it to the vertex's entries)
+    const int idx = P.bsum[w >> 11] + P.wprefix[w] + __popc(P.fbits[w] & ((1u << (hf & 31u)) - 1u));
+    P.gvix[i] = idx;
     if (idx >= h_cap) return;
     P.table[(int64_t)b * P.S + rec.x].z = idx;
-    vseg[idx] = make_int2(b * P.maxe + rec.y, rec.z);
-    const int p = (int)(hf >> 2), rem = (int)(hf & 3u);
-    PointKeys pk;
-    point_keys(pts[p], pts[cstride + p], pts[2 * cstride + p], scale32, std32, pk);
-    int k[4];
-    entry_key(pk, rem, k);
-    const int smp = sample_of(sid, pps, p);
-    vkeys[idx] = make_int4(k[0], k[1], k[2], k[3]);
-    vsid[idx] = smp;
-    // vertices are numbered sample-major, and the very first key of a sample is always new: its number is the sample's first
-    if (rem == 0 && (p == 0 || sample_of(sid, pps, p - 1) != smp)) info[EFGH_LATTICE_INFO_SEG + smp] = idx;
-    // generate_data.py:176-178: key (as fp32) / float32(std*scale), then E^T . (4-term fma chain)
-    float kf[4] = {__fdiv_rn((float)k[0], div32), __fdiv_rn((float)k[1], div32),
-                   __fdiv_rn((float)k[2], div32), __fdiv_rn((float)k[3], div32)};
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-        float acc = __fmul_rn(elev(0, q), kf[0]);
-        acc = __fmaf_rn(elev(1, q), kf[1], acc);
-        acc = __fmaf_rn(elev(2, q), kf[2], acc);
-        acc = __fmaf_rn(elev(3, q), kf[3], acc);
-        pts_next[(int64_t)q * h_cap + idx] = acc;
-    }
+    P.vrec[idx] = (int)i;
 }
 
-// ---- 15 blur neighbours per vertex through the buckets' table images (see k_neighbors for the aliasing semantics).
-// The same launch gathers lattice_offset: blocks >= nbr_blocks take 256 points each and follow where[] -> arrival position ->
-// bucket-local vertex -> vertex number (three loads, two of them into L2-resident tables) to a coalesced 16-byte store.
+struct LatGeom {                    // what the point -> key recipe needs
+    const float *pts; int64_t cstride; float scale32, std32, div32; const int *sid; int pps;
+};
+
+// key, sample of vertex h from its first-seen entry
+__device__ __forceinline__ void vertex_key(const LatPart &P, const LatGeom &G, int h, int k[4], int &smp, int4 &rec, int &p, int &rem) {
+    rec = P.grec[P.vrec[h]];
+    p = (int)((unsigned)rec.w >> 2); rem = rec.w & 3;
+    PointKeys pk;
+    point_keys(G.pts[p], G.pts[G.cstride + p], G.pts[2 * G.cstride + p], G.scale32, G.std32, pk);
+    entry_key(pk, rem, k);
+    smp = sample_of(G.sid, G.pps, p);
+}
+
+// ---- one launch, three independent jobs selected by the block index:
+//   blocks [0, nbr_blocks)      15 blur neighbours per vertex through the buckets' table images (see k_neighbors for the aliasing
+//                               semantics); the vertex's key is recomputed from its first-seen point by lane t = 0 of its 16 lanes
+//   the next off_blocks         lattice_offset per point, gathered through where[] -> arrival position -> bucket-local vertex ->
+//                               vertex number (three loads, two of them into L2-resident tables) to a coalesced 16-byte store
+//   the rest                    vertex records in number order: list segment, sample, the next level's point
 __global__ void __launch_bounds__(TPB)
-k_lat_nbr(LatPart P, const int4 *__restrict__ vkeys, const int *__restrict__ mm, int *__restrict__ info, int h_cap,
-          int *__restrict__ nbr, const int *__restrict__ vsid, int nsamples, int2 *__restrict__ alist, int alias_cap,
-          int nbr_blocks, const int *__restrict__ n_dev, int n_cap, int4 *__restrict__ off) {
+k_lat_nbr(LatPart P, LatGeom G, const int *__restrict__ mm, int *__restrict__ info, int h_cap, int *__restrict__ nbr,
+          int nsamples, int2 *__restrict__ alist, int alias_cap, int nbr_blocks, int off_blocks, const int *__restrict__ n_dev,
+          int n_cap, int4 *__restrict__ off, int2 *__restrict__ vseg, float *__restrict__ pts_next, int h_cap_build,
+          int *__restrict__ vsid) {
+    int H = info[EFGH_LATTICE_INFO_H];
+    if (H > h_cap) H = h_cap;
+    if ((int)blockIdx.x >= nbr_blocks + off_blocks) {
+        for (int h = (blockIdx.x - nbr_blocks - off_blocks) * TPB + threadIdx.x; h < H; h += (gridDim.x - nbr_blocks - off_blocks) * TPB) {
+            int k[4], smp, p, rem;
+            int4 rec;
+            vertex_key(P, G, h, k, smp, rec, p, rem);
+            vseg[h] = make_int2((P.vrec[h] >> P.sb) * P.maxe + rec.y, rec.z);
+            vsid[h] = smp;
+            // vertices are numbered sample-major, and the very first key of a sample is always new: its number is the sample's first
+            if (rem == 0 && (p == 0 || sample_of(G.sid, G.pps, p - 1) != smp)) info[EFGH_LATTICE_INFO_SEG + smp] = h;
+            // generate_data.py:176-178: key (as fp32) / float32(std*scale), then E^T . (4-term fma chain)
+            float kf[4] = {__fdiv_rn((float)k[0], G.div32), __fdiv_rn((float)k[1], G.div32),
+                           __fdiv_rn((float)k[2], G.div32), __fdiv_rn((float)k[3], G.div32)};
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                float acc = __fmul_rn(elev(0, q), kf[0]);
+                acc = __fmaf_rn(elev(1, q), kf[1], acc);
+                acc = __fmaf_rn(elev(2, q), kf[2], acc);
+                acc = __fmaf_rn(elev(3, q), kf[3], acc);
+                pts_next[(int64_t)q * h_cap_build + h] = acc;
+            }
+        }
+        return;
+    }
     if ((int)blockIdx.x >= nbr_blocks) {
         const int n = n_of(n_dev, n_cap);
         const int p = (blockIdx.x - nbr_blocks) * TPB + threadIdx.x;
@@ -1035,20 +1190,26 @@ k_lat_nbr(LatPart P, const int4 *__restrict__ vkeys, const int *__restrict__ mm,
         off[p] = make_int4(o[0], o[1], o[2], o[3]);
         return;
     }
-    int H = info[EFGH_LATTICE_INFO_H];
-    if (H > h_cap) H = h_cap;
     const int lane = threadIdx.x & 63;
     const int S = P.S;
     for (int64_t g0 = (int64_t)blockIdx.x * TPB; g0 < (int64_t)H * 16; g0 += (int64_t)nbr_blocks * TPB) {
         const int64_t g = g0 + threadIdx.x;
         const int h = (int)(g >> 4), t = (int)(g & 15);
+        int k0[4] = {0, 0, 0, 0}, b = 0;
+        if (h < H && t == 0) {
+            int p_, rem_;
+            int4 rec_;
+            vertex_key(P, G, h, k0, b, rec_, p_, rem_);
+        }
+        const int src = lane & 48;               // lane t = 0 of this vertex's 16 lanes
+        b = __shfl(b, src);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) k0[c] = __shfl(k0[c], src);
         int res = -1;
         bool aliased = false;
         if (h < H && t == 0) res = h;              // offset 0: the vertex itself
         if (h < H && t > 0 && t < 15) {
-            int4 kk = vkeys[h];
-            int k[4] = {kk.x + c_nbr[t][0], kk.y + c_nbr[t][1], kk.z + c_nbr[t][2], kk.w + c_nbr[t][3]};
-            const int b = vsid[h];
+            int k[4] = {k0[0] + c_nbr[t][0], k0[1] + c_nbr[t][1], k0[2] + c_nbr[t][2], k0[3] + c_nbr[t][3]};
             const int *m8 = mm + 8 * b;
             int64_t ki = key2int(k, m8);
             if (ki >= 0) {   // every inserted key integer is >= 0
@@ -1207,7 +1368,7 @@ extern "C" int efgh_lattice_level_neighbors(const void *workspace, int32_t n_cap
 namespace {
 
 struct PartLayout {
-    int64_t ent, toff, cumul, where, larr, cursor, gcount, grec, gvix, table, fbits, wprefix, bsum, ticket, mm, vkeys, part, total;
+    int64_t ent, toff, cumul, where, larr, cursor, gcount, grec, gvix, vrec, table, wprefix, bsum, mm, part, total;
     int W, nblk, ntiles, tp, ppt;
 };
 
@@ -1216,7 +1377,7 @@ int ilog2(int64_t v) { int b = 0; while ((1LL << b) < v) ++b; return b; }
 // tile of the scatter kernel: 8 points per thread when that still leaves >= 192 tiles, else 2
 int part_ppt(int32_t n_cap) { return (int64_t)n_cap >= 192LL * STP * 8 ? 8 : 2; }
 
-// entries per bucket: 2048 (five workgroups of k_lat_bucket per CU) unless the level needs more than NBMAX buckets of ~1000
+// entries per bucket: 2048 (four workgroups of k_lat_bucket per CU) unless the level needs more than NBMAX buckets of ~1000
 int part_maxe(int32_t n_cap) { return (int64_t)n_cap * 4 > (int64_t)NBMAX * 1024 ? 4096 : 2048; }
 
 PartLayout part_layout(int32_t n_cap, int32_t h_cap, int32_t nsamples, int nb, int S) {
@@ -1227,7 +1388,7 @@ PartLayout part_layout(int32_t n_cap, int32_t h_cap, int32_t nsamples, int nb, i
     w.tp = STP * w.ppt;
     w.ntiles = cdiv(n_cap, w.tp);
     w.W = cdiv((int64_t)n_cap * 4, 32);
-    w.nblk = cdiv(w.W, TPB);
+    w.nblk = cdiv(w.W, TPB * RWT);
     w.ent = o;     o += align256((int64_t)w.ntiles * w.tp * 4 * 8);
     w.toff = o;    o += align256((int64_t)w.ntiles * (nb + 1) * 4);
     w.cumul = o;   o += align256((int64_t)nb * w.ntiles * 4);
@@ -1237,13 +1398,11 @@ PartLayout part_layout(int32_t n_cap, int32_t h_cap, int32_t nsamples, int nb, i
     w.gcount = o;  o += align256((int64_t)nb * 4);
     w.grec = o;    o += align256((int64_t)nb * S * 16);
     w.gvix = o;    o += align256((int64_t)nb * S * 4);
+    w.vrec = o;    o += align256((int64_t)h_cap * 4);
     w.table = o;   o += align256((int64_t)nb * S * 16);
-    w.fbits = o;   o += align256((int64_t)w.W * 4);
     w.wprefix = o; o += align256((int64_t)w.W * 4);
     w.bsum = o;    o += align256((int64_t)w.nblk * 4);
-    w.ticket = o;  o += 256;
     w.mm = o;      o += align256((int64_t)nsamples * 32);
-    w.vkeys = o;   o += align256((int64_t)h_cap * 16);
     w.part = o;    o += align256(((int64_t)cdiv(n_cap, 64) + 4) * 48);
     w.total = o;
     return w;
@@ -1254,7 +1413,7 @@ bool part_args_ok(int32_t n_cap, int32_t nb, int32_t S) {
            cdiv(n_cap, STP * part_ppt(n_cap)) <= NTMAX;
 }
 
-LatPart part_ptrs(char *ws, const PartLayout &w, int32_t n_cap, int nb, int S) {
+LatPart part_ptrs(char *ws, char *zeroed, const PartLayout &w, int32_t n_cap, int nb, int S) {
     LatPart P;
     P.ent = (unsigned long long *)(ws + w.ent);
     P.toff = (int *)(ws + w.toff);
@@ -1265,14 +1424,22 @@ LatPart part_ptrs(char *ws, const PartLayout &w, int32_t n_cap, int nb, int S) {
     P.gcount = (int *)(ws + w.gcount);
     P.grec = (int4 *)(ws + w.grec);
     P.gvix = (int *)(ws + w.gvix);
+    P.vrec = (int *)(ws + w.vrec);
     P.table = (int4 *)(ws + w.table);
-    P.fbits = (unsigned *)(ws + w.fbits);
+    P.ticket = (int *)zeroed;
+    P.fbits = (unsigned *)(zeroed + 256);
     P.wprefix = (int *)(ws + w.wprefix);
     P.bsum = (int *)(ws + w.bsum);
-    P.ticket = (int *)(ws + w.ticket);
     P.nb = nb; P.bb = ilog2(nb); P.S = S; P.sb = ilog2(S); P.maxe = part_maxe(n_cap);
     P.ntiles = w.ntiles; P.tp = w.tp; P.fb = ilog2((int64_t)n_cap * 4);
     return P;
+}
+
+float part_std32() {
+    const uint32_t std_bits = 0x405105ECu;         // float32(4*sqrt(2/3)), generate_data.py:19
+    float std32;
+    memcpy(&std32, &std_bits, 4);
+    return std32;
 }
 
 }  // namespace
@@ -1294,33 +1461,28 @@ extern "C" int64_t efgh_lattice_part_workspace_bytes(int32_t n_cap, int32_t h_ca
     return part_layout(n_cap, h_cap, nsamples, nbuckets, slots).total;
 }
 
+extern "C" int64_t efgh_lattice_part_zeroed_bytes(int32_t n_cap) {
+    return 256 + align256((int64_t)cdiv((int64_t)n_cap * 4, 32) * 4);
+}
+
 extern "C" int efgh_lattice_part_build(const float *pts, int64_t pts_cstride, const int32_t *n_dev, int32_t n_cap,
                                        const int32_t *sid, int32_t pts_per_sample, int32_t nsamples, float scale32,
-                                       float div32, float *bary, float *emg, int32_t *list, int32_t h_cap,
-                                       int32_t *vseg, float *pts_next, int32_t *vsid, int32_t *info, void *workspace,
-                                       int32_t nbuckets, int32_t slots, void *stream_) {
+                                       float *bary, float *emg, int32_t *list, int32_t h_cap, int32_t *info, void *workspace,
+                                       void *zeroed, int32_t nbuckets, int32_t slots, void *stream_) {
     hipStream_t st = (hipStream_t)stream_;
     EFGH_CHECK_ARG(n_cap > 0 && n_cap < (1 << 27) && h_cap > 0 && nsamples >= 1 && nsamples <= EFGH_LATTICE_MAX_SAMPLES);
     EFGH_CHECK_ARG(sid || pts_per_sample > 0);
-    EFGH_CHECK_ARG(pts && bary && emg && list && vseg && pts_next && vsid && info && workspace);
+    EFGH_CHECK_ARG(pts && bary && emg && list && info && workspace && zeroed);
     EFGH_CHECK_ARG(part_args_ok(n_cap, nbuckets, slots));
     const PartLayout w = part_layout(n_cap, h_cap, nsamples, nbuckets, slots);
     char *ws = (char *)workspace;
-    const LatPart P = part_ptrs(ws, w, n_cap, nbuckets, slots);
+    const LatPart P = part_ptrs(ws, (char *)zeroed, w, n_cap, nbuckets, slots);
     int *mm = (int *)(ws + w.mm), *part = (int *)(ws + w.part);
-    int4 *vkeys = (int4 *)(ws + w.vkeys);
-    const uint32_t std_bits = 0x405105ECu;         // float32(4*sqrt(2/3)), generate_data.py:19
-    float std32;
-    memcpy(&std32, &std_bits, 4);
+    const float std32 = part_std32();
     const int nbp = cdiv(n_cap, TPB);
     const int pps = sid ? 1 : pts_per_sample;
-    int ginit = cdiv(w.W, TPB);
-    if (ginit > 2048) ginit = 2048;
-    if (ginit < 64) ginit = 64;                   // covers mm (8 * nsamples <= 8192) and info
-    k_lat_init<<<ginit, TPB, 0, st>>>(P, w.W, mm, nsamples, info, EFGH_LATTICE_INFO_SEG + nsamples);
-    k_point_keys<<<nbp, TPB, 0, st>>>(pts, pts_cstride, n_dev, n_cap, scale32, std32, (float4 *)bary, (float4 *)emg, mm, part, sid,
-                                      pps);
-    k_minmax_finalize<<<cdiv(nbp * (TPB / 64), TPB), TPB, 0, st>>>(part, nbp * (TPB / 64), mm);
+    k_lat_keys<<<nbp, TPB, 0, st>>>(pts, pts_cstride, n_dev, n_cap, scale32, std32, (float4 *)bary, (float4 *)emg, part, sid, pps);
+    k_lat_minmax<<<1, MMT, 0, st>>>(part, pts, pts_cstride, n_dev, n_cap, scale32, std32, sid, pps, nsamples, mm);
     if (w.ppt == 8)
         k_lat_scatter<8><<<w.ntiles, STP, 0, st>>>(pts, pts_cstride, n_dev, n_cap, scale32, std32, mm, sid, pps, nsamples, P, info);
     else
@@ -1330,26 +1492,33 @@ extern "C" int efgh_lattice_part_build(const float *pts, int64_t pts_cstride, co
     else
         k_lat_bucket<4096><<<nbuckets, TPB, (size_t)slots * 20 + (size_t)4096 * 14, st>>>(P, n_dev, n_cap, list, info);
     k_lat_rank<<<w.nblk, TPB, 0, st>>>(P, w.W, info, h_cap);
-    k_lat_number<<<cdiv((int64_t)nbuckets * slots, TPB), TPB, 0, st>>>(P, pts, pts_cstride, scale32, std32, div32, sid, pps, vkeys,
-                                                                       (int2 *)vseg, pts_next, vsid, h_cap, info);
+    k_lat_number<<<cdiv((int64_t)nbuckets * slots, TPB), TPB, 0, st>>>(P, h_cap);
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
 }
 
-extern "C" int efgh_lattice_part_neighbors(const void *workspace, const int32_t *n_dev, int32_t n_cap, int32_t h_cap_build,
-                                           int32_t nsamples, int32_t *info, const int32_t *vsid, int32_t h_cap, int32_t *nbr,
-                                           int32_t *alist, int32_t alias_cap, int32_t nbuckets, int32_t slots, int32_t *off,
-                                           void *stream_) {
+extern "C" int efgh_lattice_part_neighbors(const void *workspace, const float *pts, int64_t pts_cstride, const int32_t *n_dev,
+                                           int32_t n_cap, const int32_t *sid, int32_t pts_per_sample, int32_t nsamples,
+                                           float scale32, float div32, int32_t h_cap_build, int32_t *info, int32_t h_cap,
+                                           int32_t *nbr, int32_t *alist, int32_t alias_cap, int32_t *off, int32_t *vseg,
+                                           float *pts_next, int32_t *vsid, int32_t nbuckets, int32_t slots, void *stream_) {
     hipStream_t st = (hipStream_t)stream_;
-    EFGH_CHECK_ARG(workspace && info && vsid && nbr && alist && off && n_cap > 0 && h_cap > 0 && h_cap <= h_cap_build && alias_cap > 0);
+    EFGH_CHECK_ARG(workspace && pts && info && vsid && nbr && alist && off && vseg && pts_next && n_cap > 0 && h_cap > 0 &&
+                   h_cap <= h_cap_build && alias_cap > 0 && (sid || pts_per_sample > 0));
     EFGH_CHECK_ARG(part_args_ok(n_cap, nbuckets, slots));
     const PartLayout w = part_layout(n_cap, h_cap_build, nsamples, nbuckets, slots);
     char *ws = (char *)workspace;
-    const LatPart P = part_ptrs(ws, w, n_cap, nbuckets, slots);
-    int grid = cdiv((int64_t)h_cap * 16, TPB);
-    if (grid > 8192) grid = 8192;
-    k_lat_nbr<<<grid + cdiv(n_cap, TPB), TPB, 0, st>>>(P, (const int4 *)(ws + w.vkeys), (const int *)(ws + w.mm), info, h_cap, nbr, vsid,
-                                                       nsamples, (int2 *)alist, alias_cap, grid, n_dev, n_cap, (int4 *)off);
+    const LatPart P = part_ptrs(ws, ws, w, n_cap, nbuckets, slots);        // (the zeroed area is not used any more)
+    LatGeom G;
+    G.pts = pts; G.cstride = pts_cstride; G.scale32 = scale32; G.std32 = part_std32(); G.div32 = div32; G.sid = sid;
+    G.pps = sid ? 1 : pts_per_sample;
+    int gn = cdiv((int64_t)h_cap * 16, TPB);
+    if (gn > 8192) gn = 8192;
+    const int go = cdiv(n_cap, TPB);
+    int gv = cdiv(h_cap, TPB);
+    if (gv > 2048) gv = 2048;
+    k_lat_nbr<<<gn + go + gv, TPB, 0, st>>>(P, G, (const int *)(ws + w.mm), info, h_cap, nbr, nsamples, (int2 *)alist, alias_cap, gn, go,
+                                            n_dev, n_cap, (int4 *)off, (int2 *)vseg, pts_next, h_cap_build, vsid);
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
 }

@@ -32,7 +32,7 @@ class LatticeLevel:
     per vertex: nbr [H][16] (15 neighbours + alias mask), vseg [H][2] + list [4n] (vertex -> ascending flat positions
     4p + r), pts_next [3][H]; info = the level's device counters (INFO_*), alist = aliased neighbour records."""
     __slots__ = ('n_in', 'H', 'bary_pm', 'emg_pm', 'off_pm', 'nbr', 'vseg', 'list', 'pts_next_buf', 'info', 'alist',
-                 'seg_in', 'seg', 'vsid', '_ws', '_caps', '_mode', '_n_dev')
+                 'seg_in', 'seg', 'vsid', '_ws', '_caps', '_mode', '_geom', '_zeroed')
 
     # the reference's (4, n) / (3, H) arrays as views
     @property
@@ -92,7 +92,15 @@ def _plan(L, n_cap, h_est):
     return ('hash', max(4096, 1 << (2 * h_est - 1).bit_length()))
 
 
-def _level_arrays(L, dev, n_cap, h_cap, B, mode=('hash', 0)):
+def _ctrl_bytes(L, n_cap, B, mode):
+    """bytes of the zero-initialised control block of a level: info, and for the partitioned build its `zeroed` area"""
+    info_b = (4 * (INFO_SEG + B) + 255) // 256 * 256
+    return info_b, (L.efgh_lattice_part_zeroed_bytes(_C.c_int32(n_cap)) if mode[0] == 'part' else 0)
+
+
+def _level_arrays(L, dev, n_cap, h_cap, B, mode=('hash', 0), ctrl=None):
+    """arrays of one level.  ctrl: a ZEROED uint8 tensor of sum(_ctrl_bytes) bytes (one fill serves all levels of a pyramid);
+    None = allocate and zero one here"""
     lv = LatticeLevel()
     lv._mode = mode
     lv.bary_pm = torch.empty((n_cap, 4), dtype=torch.float32, device=dev)
@@ -107,7 +115,11 @@ def _level_arrays(L, dev, n_cap, h_cap, B, mode=('hash', 0)):
     lv.vseg = torch.empty((h_cap, 2), dtype=torch.int32, device=dev)
     lv.pts_next_buf = torch.empty((3, h_cap), dtype=torch.float32, device=dev)
     lv.vsid = torch.empty(h_cap, dtype=torch.int32, device=dev)
-    lv.info = torch.empty(INFO_SEG + B, dtype=torch.int32, device=dev)
+    info_b, zero_b = _ctrl_bytes(L, n_cap, B, mode)
+    if ctrl is None:
+        ctrl = torch.zeros(info_b + zero_b, dtype=torch.uint8, device=dev)
+    lv.info = ctrl[:4 * (INFO_SEG + B)].view(torch.int32)
+    lv._zeroed = ctrl[info_b:info_b + zero_b] if zero_b else None
     lv.alist = torch.empty((ALIAS_CAP, 2), dtype=torch.int32, device=dev)
     lv._ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     lv._caps = (n_cap, h_cap)
@@ -117,27 +129,34 @@ def _level_arrays(L, dev, n_cap, h_cap, B, mode=('hash', 0)):
 def _launch_build(L, lv, pts, cstride, n_dev, sid, pps, B, s, st):
     n_cap, h_cap = lv._caps
     head = (_C.ptr(pts), _C.c_int64(cstride), _C.ptr(n_dev), _C.c_int32(n_cap), _C.ptr(sid), _C.c_int32(pps), _C.c_int32(B),
-            _C.c_float(np.float32(s)), _C.c_float(np.float32(EXPECTED_STD * s)), _C.ptr(lv.bary_pm), _C.ptr(lv.emg_pm))
-    tail = (_C.ptr(lv.list), _C.c_int32(h_cap), _C.ptr(lv.vseg), _C.ptr(lv.pts_next_buf), _C.ptr(lv.vsid), _C.ptr(lv.info),
-            _C.ptr(lv._ws))
-    lv._n_dev = n_dev                  # (kept alive for the neighbours call)
+            _C.c_float(np.float32(s)))
+    lv._geom = (pts, cstride, n_dev, sid, pps, s)          # (kept alive for the neighbours call)
     if lv._mode[0] == 'part':
-        _C.check(L.efgh_lattice_part_build(*head, *tail, _C.c_int32(lv._mode[1]), _C.c_int32(lv._mode[2]), st))
+        _C.check(L.efgh_lattice_part_build(*head, _C.ptr(lv.bary_pm), _C.ptr(lv.emg_pm), _C.ptr(lv.list), _C.c_int32(h_cap),
+                                           _C.ptr(lv.info), _C.ptr(lv._ws), _C.ptr(lv._zeroed), _C.c_int32(lv._mode[1]),
+                                           _C.c_int32(lv._mode[2]), st))
     else:
-        _C.check(L.efgh_lattice_level_build(*head, _C.ptr(lv.off_pm), *tail, _C.c_int64(lv._mode[1]), st))
+        _C.check(L.efgh_lattice_level_build(*head, _C.c_float(np.float32(EXPECTED_STD * s)), _C.ptr(lv.bary_pm), _C.ptr(lv.emg_pm),
+                                            _C.ptr(lv.off_pm), _C.ptr(lv.list), _C.c_int32(h_cap), _C.ptr(lv.vseg),
+                                            _C.ptr(lv.pts_next_buf), _C.ptr(lv.vsid), _C.ptr(lv.info), _C.ptr(lv._ws),
+                                            _C.c_int64(lv._mode[1]), st))
 
 
 def _launch_neighbors(L, lv, B, h_rows, st):
     n_cap, h_cap = lv._caps
     lv.nbr = torch.empty((h_rows, 16), dtype=torch.int32, device=lv.info.device)
-    common = (_C.c_int32(n_cap), _C.c_int32(h_cap), _C.c_int32(B), _C.ptr(lv.info), _C.ptr(lv.vsid),
-              _C.c_int32(h_rows), _C.ptr(lv.nbr), _C.ptr(lv.alist), _C.c_int32(ALIAS_CAP))
     if lv._mode[0] == 'part':
-        _C.check(L.efgh_lattice_part_neighbors(_C.ptr(lv._ws), _C.ptr(lv._n_dev), *common, _C.c_int32(lv._mode[1]),
-                                               _C.c_int32(lv._mode[2]), _C.ptr(lv.off_pm), st))
+        pts, cstride, n_dev, sid, pps, s = lv._geom
+        _C.check(L.efgh_lattice_part_neighbors(
+            _C.ptr(lv._ws), _C.ptr(pts), _C.c_int64(cstride), _C.ptr(n_dev), _C.c_int32(n_cap), _C.ptr(sid), _C.c_int32(pps),
+            _C.c_int32(B), _C.c_float(np.float32(s)), _C.c_float(np.float32(EXPECTED_STD * s)), _C.c_int32(h_cap), _C.ptr(lv.info),
+            _C.c_int32(h_rows), _C.ptr(lv.nbr), _C.ptr(lv.alist), _C.c_int32(ALIAS_CAP), _C.ptr(lv.off_pm), _C.ptr(lv.vseg),
+            _C.ptr(lv.pts_next_buf), _C.ptr(lv.vsid), _C.c_int32(lv._mode[1]), _C.c_int32(lv._mode[2]), st))
     else:
-        _C.check(L.efgh_lattice_level_neighbors(_C.ptr(lv._ws), *common, _C.c_int64(lv._mode[1]), st))
-    lv._n_dev = None
+        _C.check(L.efgh_lattice_level_neighbors(_C.ptr(lv._ws), _C.c_int32(n_cap), _C.c_int32(h_cap), _C.c_int32(B), _C.ptr(lv.info),
+                                                _C.ptr(lv.vsid), _C.c_int32(h_rows), _C.ptr(lv.nbr), _C.ptr(lv.alist),
+                                                _C.c_int32(ALIAS_CAP), _C.c_int64(lv._mode[1]), st))
+    lv._geom = lv._zeroed = None
 
 
 def _finish(lv, host, n_in, seg_in, B):
@@ -170,11 +189,20 @@ def build_pyramid_batched(pc, scales):
     if prev is not None:
         # speculative path: capacities from the previous build of this signature, no read-back between levels
         lvs, pts, cstride, n_dev, sid, n_cap = [], pts0, B * N, None, None, B * N
-        for s, hp in zip(scales, prev):
-            h_cap = min(4 * n_cap, hp + hp // 4 + 1024)
-            # tables sized for the expected vertex count; one that turns out too small sets ERR bit 2 and the level-by-level path
-            # below rebuilds the pyramid
-            lv = _level_arrays(L, dev, n_cap, h_cap, B, _plan(L, n_cap, h_cap))
+        # capacities and plans of all levels first: their control blocks (device counters, first-seen bitmaps) are zeroed by ONE fill.
+        # Tables are sized for the expected vertex count; one that turns out too small sets ERR bit 2 and the level-by-level
+        # path below rebuilds the pyramid
+        caps, nc = [], n_cap
+        for hp in prev:
+            hc = min(4 * nc, hp + hp // 4 + 1024)
+            caps.append((nc, hc, _plan(L, nc, hc)))
+            nc = hc
+        sizes = [_ctrl_bytes(L, nc_, B, md) for nc_, _, md in caps]
+        ctrl = torch.zeros(sum(a + b for a, b in sizes), dtype=torch.uint8, device=dev)
+        coff = 0
+        for s, (n_cap, h_cap, mode), (ib, zb) in zip(scales, caps, sizes):
+            lv = _level_arrays(L, dev, n_cap, h_cap, B, mode, ctrl[coff:coff + ib + zb])
+            coff += ib + zb
             _launch_build(L, lv, pts, cstride, n_dev, sid, N, B, s, st)
             _launch_neighbors(L, lv, B, h_cap, st)
             lvs.append(lv)

@@ -97,7 +97,7 @@ int efgh_lattice_level_neighbors(const void *workspace, int32_t n_cap, int32_t h
  * lookup probes a read-only image of the buckets' tables and lattice_offset is gathered per point - no global atomics per entry,
  * no scattered global stores.  Results are identical to efgh_lattice_level_build / _neighbors (same arrays, same meaning) except:
  *      list has efgh_lattice_part_max_entries(n_cap) * nbuckets elements (vseg starts point into per-bucket windows);
- *      off is written by the NEIGHBOURS call (the same launch), not by the build.
+ *      off, vseg, pts_next, vsid and info[SEG..] are written by the NEIGHBOURS call, not by the build.
  * nbuckets: power of two in [2, 8192], normally efgh_lattice_part_buckets(n_cap) (0: more points than the bucket limit - use the
  * hash build); slots: table slots per bucket, power of two in [16, 2048], >= ~2.5x the expected vertices per bucket.
  * A bucket with more than efgh_lattice_part_max_entries(n_cap) entries, or more vertices than slots, sets bit 2 of
@@ -105,15 +105,21 @@ int efgh_lattice_level_neighbors(const void *workspace, int32_t n_cap, int32_t h
 int32_t efgh_lattice_part_max_entries(int32_t n_cap);
 int32_t efgh_lattice_part_buckets(int32_t n_cap);
 int64_t efgh_lattice_part_workspace_bytes(int32_t n_cap, int32_t h_cap, int32_t nsamples, int32_t nbuckets, int32_t slots);
+/* bytes of `zeroed` (first-seen bitmap + an election counter): must be ALL ZERO when efgh_lattice_part_build is enqueued, and so
+ * must info - so that one fill can serve every level of a pyramid */
+int64_t efgh_lattice_part_zeroed_bytes(int32_t n_cap);
+/* six launches: keys + barycentric weights, key extrema, tile-local bucket sort, per-bucket grouping, first-seen numbering */
 int efgh_lattice_part_build(const float *pts, int64_t pts_cstride, const int32_t *n_dev, int32_t n_cap,
                             const int32_t *sid, int32_t pts_per_sample, int32_t nsamples, float scale32,
-                            float div32, float *bary, float *emg, int32_t *list, int32_t h_cap,
-                            int32_t *vseg, float *pts_next, int32_t *vsid, int32_t *info, void *workspace,
-                            int32_t nbuckets, int32_t slots, void *stream);
-int efgh_lattice_part_neighbors(const void *workspace, const int32_t *n_dev, int32_t n_cap, int32_t h_cap_build,
-                                int32_t nsamples, int32_t *info, const int32_t *vsid, int32_t h_cap, int32_t *nbr,
-                                int32_t *alist, int32_t alias_cap, int32_t nbuckets, int32_t slots, int32_t *off,
-                                void *stream);
+                            float *bary, float *emg, int32_t *list, int32_t h_cap, int32_t *info, void *workspace,
+                            void *zeroed, int32_t nbuckets, int32_t slots, void *stream);
+/* one launch: nbr + alist (as efgh_lattice_level_neighbors), off, and the vertex records vseg / pts_next / vsid / info[SEG..]
+ * (pts ... div32 as passed to the build; pts_next has h_cap_build columns) */
+int efgh_lattice_part_neighbors(const void *workspace, const float *pts, int64_t pts_cstride, const int32_t *n_dev,
+                                int32_t n_cap, const int32_t *sid, int32_t pts_per_sample, int32_t nsamples,
+                                float scale32, float div32, int32_t h_cap_build, int32_t *info, int32_t h_cap,
+                                int32_t *nbr, int32_t *alist, int32_t alias_cap, int32_t *off, int32_t *vseg,
+                                float *pts_next, int32_t *vsid, int32_t nbuckets, int32_t slots, void *stream);
 
 /* ------------------------------------------------------------------ BCL splat (K3) ---------
  * replaces SparseSum + density normalisation, nets/bilateralNN.py:6-40, 179-211, as a gather over the vertex lists of the
