@@ -1,0 +1,106 @@
+"""The two workloads bench.py times, at their stated batch sizes (BASELINE.json configs[1] and configs[2]): 384x1280 RGB +
+131 072 points, eval forward at batch 4 and one training step at batch 8.  The oracle covers these sizes per sample
+(test_gpu_fullsize.py); here the BATCHED programs themselves are held to the per-sample ones and to themselves."""
+import numpy as np
+import pytest
+import torch
+
+from efgh_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+RAW, NPTS = (768, 2560), 131072
+
+
+def _model(manifest):
+    from efgh_amd.nets import EFGHBackbone
+    m = EFGHBackbone(syn.default_args(RAW, 'cuda'))
+    m.load_state_dict(syn.synthetic_state_dict(manifest['state_dict'], 1), strict=True)
+    return m.cuda()
+
+
+def test_config1_batch4_forward_equals_four_single_forwards(manifest):
+    """configs[1]: the batch-4 eval forward is the four batch-1 forwards - eval-mode BatchNorm is an affine map, every sample has
+    its own lattice, no kernel reduces across samples, and no launch splits its sums differently at another batch size: every one
+    of the 21 output tensors is BIT-EQUAL."""
+    m = _model(manifest).eval()
+    b = syn.make_batch(RAW, NPTS, 4)
+    inp = [torch.from_numpy(b[k]).cuda() for k in ('pc', 'img', 'calib', 'A')]
+    with torch.no_grad():
+        out4 = m(*inp)
+        singles = [m(*[t[i:i + 1] for t in inp]) for i in range(4)]
+    assert len([k for k, v in out4.items() if torch.is_tensor(v)]) == 21
+    for k, v in out4.items():
+        if torch.is_tensor(v):
+            ref = torch.cat([s[k] for s in singles])
+            assert v.shape == ref.shape and torch.equal(v, ref), k          # bit-equal, all 21 tensors
+
+
+def test_config2_batch8_training_step_full_size(manifest):
+    """configs[2]: one (and a second) full-size batch-8 training step.
+    * the 11 loss terms of the batch equal the per-sample terms (the criterion on each sample's slice of the same predictions - the
+      program the oracle checks at B = 1) combined as the reference's reductions combine them: plain batch means, g_depth
+      weighted by the samples' valid-pixel counts (mse over the masked pixels of the whole batch, loss_utils / efghloss.py);
+    * all 353 gradients finite and non-degenerate;
+    * with EFGH_DETERMINISTIC=1 the step is bit-identical on one stream and on four (losses of both steps, the whole gradient
+      buffer, the updated weights): nothing races, nothing depends on the schedule."""
+    from efgh_amd import ops
+    from efgh_amd.losses import EFGHCriterion
+    from efgh_amd.nets import efghbackbone as bb
+    from efgh_amd.train import Trainer
+    args = syn.default_args(RAW, 'cuda')
+    b = syn.make_batch(RAW, NPTS, 8)
+    inp = [torch.from_numpy(b[k]).cuda() for k in ('pc', 'img', 'calib', 'A')]
+    gt = {k: torch.from_numpy(v).cuda() for k, v in b['gt'].items()}
+    crit = EFGHCriterion(args)
+
+    def run(streams):
+        bb.SIDE_STREAM = ops.WGRAD_SIDE = streams
+        tr = Trainer(_model(manifest), EFGHCriterion(args), lr=1e-4)
+        l1, pred = tr.step(*inp, dict(gt))
+        g1 = tr.flat.g.detach().clone()
+        l2, _ = tr.step(*inp, dict(gt))
+        torch.cuda.synchronize()
+        res = ({k: float(v.detach()) for k, v in l1.items()}, {k: float(v.detach()) for k, v in l2.items()}, g1, tr.flat.w.detach().clone(),
+               {k: (v.detach() if torch.is_tensor(v) else v) for k, v in pred.items()}, [p.shape for p in tr.flat.params],
+               list(tr.flat.offsets))
+        del tr
+        return res
+    old = (ops.DETERMINISTIC, bb.SIDE_STREAM, ops.WGRAD_SIDE)
+    try:
+        ops.DETERMINISTIC = True
+        l1a, l2a, ga, wa, pred, shapes, offsets = run(True)
+        torch.cuda.empty_cache()
+        l1b, l2b, gb, wb, _, _, _ = run(False)
+    finally:
+        ops.DETERMINISTIC, bb.SIDE_STREAM, ops.WGRAD_SIDE = old
+    assert len(shapes) == 353
+    assert l1a.keys() == l1b.keys() and len(l1a) == 11
+    assert l1a == l1b and l2a == l2b, (l1a, l1b, l2a, l2b)
+    assert torch.equal(ga, gb) and torch.equal(wa, wb)
+    assert all(np.isfinite(v) for v in l1a.values()) and l2a['total'] != l1a['total']
+    assert bool(torch.isfinite(ga).all())
+    dead = [i for i, (off, k) in enumerate(offsets) if float(ga[off:off + k].abs().max()) == 0.0]
+    # exactly-zero gradients are legitimate only where the reference has them too: conv biases in front of a train-mode BatchNorm
+    #  and F at saturated scores (test_gpu_fullsize); E, H and G must all be alive
+    assert len(dead) < 120, len(dead)
+    # ---- batch terms vs per-sample terms on the same predictions
+    per = []
+    for i in range(8):
+        pi = {k: (v[i:i + 1] if torch.is_tensor(v) else v) for k, v in pred.items()}
+        Li, gti = crit.compute_loss(*[t[i:i + 1] for t in inp], {k: v[i:i + 1] for k, v in gt.items()}, pi)
+        valid = float(((gti['g_depth'] > 0) & (gti['img_mask'].to(gti['g_depth'].device) > 0)).sum())
+        per.append(({k: float(v) for k, v in Li.items()}, valid))
+    L8, _ = crit.compute_loss(*inp, dict(gt), pred)
+    L8 = {k: float(v) for k, v in L8.items()}
+    for k in L8:
+        assert abs(L8[k] - l1a[k]) <= 1e-6 * abs(l1a[k]) + 1e-9, k            # the criterion is a function of its inputs
+    wsum = sum(v for _, v in per)
+    comb = {}
+    for k in L8:
+        if k == 'g_depth':
+            comb[k] = sum(p[k] * v for p, v in per) / wsum
+        elif k != 'total':
+            comb[k] = sum(p[k] for p, _ in per) / 8
+    comb['total'] = sum(comb.values())           # efghloss.py:33-36 adds up EVERY entry, the abs / sgn parts a second time
+    for k in L8:
+        assert abs(L8[k] - comb[k]) <= 2e-5 * abs(comb[k]) + 1e-7, (k, L8[k], comb[k])
