@@ -31,7 +31,7 @@ class GemmDesc(ctypes.Structure):
         ('act', c_int32), ('slope', c_float), ('out', c_void_p), ('ldo', c_int64),
         ('stats', c_void_p),
         ('nbatch', c_int32), ('batch_stride_a', c_int64), ('batch_stride_w', c_int64), ('batch_stride_out', c_int64),
-        ('batch_stride_table', c_int32),
+        ('batch_stride_table', c_int32), ('table_alias_mask', c_int32),
     ]
 
 

@@ -165,15 +165,61 @@ k_table_gather_t(const float *__restrict__ src, int C, const int *__restrict__ t
     if (g + G < c4n) d[g + G] = a1;
 }
 
-// the aliased neighbour hits (a handful per level): dst[target] += src[m][t*C ..]
+// ---- the aliased neighbour hits (a handful per level; k_neighbors / k_lat_nbr list them in arrival order, which varies from run
+// to run).  Both kernels below apply them in a FIXED order without atomics: every block loads the records, ranks them by their
+// (entry, target) key in LDS, and owns the targets with target % gridDim.x == blockIdx.x - it walks the sorted records and adds the
+// ones that land on its own targets, one after the other.
+constexpr int ALIAS_LDS = 4096;
+
+__device__ __forceinline__ int load_sorted_alias(const int2 *__restrict__ alist, const int *__restrict__ n_alias, int alias_cap,
+                                                 int2 *sorted) {
+    const int na = min(min(*n_alias, alias_cap), ALIAS_LDS);
+    for (int i = threadIdx.x; i < na; i += TPB) {
+        const int2 a = alist[i];
+        int r = 0;
+        for (int j = 0; j < na; ++j) {              // (records are distinct: an entry is listed once)
+            const int2 o = alist[j];
+            r += (o.x < a.x || (o.x == a.x && o.y < a.y)) ? 1 : 0;
+        }
+        sorted[r] = a;
+    }
+    __syncthreads();
+    return na;
+}
+
+// dst[target][c] += src[m][t*C + c]   (adjoint of the neighbour gather on an explicit [H][15 C] intermediate)
 __global__ void __launch_bounds__(TPB)
 k_table_alias_add(const float *__restrict__ src, int C, const int2 *__restrict__ alist, const int *__restrict__ n_alias,
                   int alias_cap, float *__restrict__ dst) {
-    const int na = min(*n_alias, alias_cap);
-    for (int k = blockIdx.x; k < na; k += gridDim.x) {
-        const int2 a = alist[k];
+    __shared__ int2 sorted[ALIAS_LDS];
+    const int na = load_sorted_alias(alist, n_alias, alias_cap, sorted);
+    for (int k = 0; k < na; ++k) {
+        const int2 a = sorted[k];
+        if (a.y % (int)gridDim.x != (int)blockIdx.x) continue;
         const int m = a.x >> 4, t = a.x & 15;
-        for (int c = threadIdx.x; c < C; c += TPB) atomicAdd(&dst[(int64_t)a.y * C + c], src[((int64_t)m * 15 + t) * C + c]);
+        for (int c = threadIdx.x; c < C; c += TPB) dst[(int64_t)a.y * C + c] += src[((int64_t)m * 15 + t) * C + c];
+        __syncthreads();                            // (the next record may hit the same target)
+    }
+}
+
+// dx[target][c] += sum_n dy[m][n] * w[(n*C + c)*15 + t]   (the same adjoint when the gather and the convolution are one GEMM)
+__global__ void __launch_bounds__(TPB)
+k_blur_dgrad_alias(const float *__restrict__ dy, int64_t ldy, int N, const float *__restrict__ w, int C,
+                   const int2 *__restrict__ alist, const int *__restrict__ n_alias, int alias_cap, float *__restrict__ dx,
+                   int64_t ldx) {
+    __shared__ int2 sorted[ALIAS_LDS];
+    const int na = load_sorted_alias(alist, n_alias, alias_cap, sorted);
+    for (int k = 0; k < na; ++k) {
+        const int2 a = sorted[k];
+        if (a.y % (int)gridDim.x != (int)blockIdx.x) continue;
+        const int m = a.x >> 4, t = a.x & 15;
+        const float *row = dy + (int64_t)m * ldy;
+        for (int c = threadIdx.x; c < C; c += TPB) {
+            float acc = 0.f;
+            for (int n = 0; n < N; ++n) acc += row[n] * w[((int64_t)n * C + c) * 15 + t];
+            dx[(int64_t)a.y * ldx + c] += acc;
+        }
+        __syncthreads();
     }
 }
 
@@ -223,7 +269,7 @@ extern "C" int efgh_splat_bwd(const float *gsplat, int32_t C, int32_t coff, cons
 extern "C" int efgh_table_gather_transposed(const float *src, const int32_t *table, int32_t H, int32_t C, const int32_t *alist,
                                             const int32_t *n_alias, int32_t alias_cap, float *dst, void *stream_) {
     hipStream_t st = (hipStream_t)stream_;
-    EFGH_CHECK_ARG(src && table && dst && alist && n_alias && H > 0 && C > 0 && C % 4 == 0 && C <= 512 && alias_cap > 0);
+    EFGH_CHECK_ARG(src && table && dst && alist && n_alias && H > 0 && C > 0 && C % 4 == 0 && C <= 512 && alias_cap > 0 && alias_cap <= ALIAS_LDS);
     const int64_t nblocks = ((int64_t)H + TPB / 64 - 1) / (TPB / 64);
     const unsigned grid = (unsigned)((nblocks + 7) / 8 * 8);
     const int c4n = C / 4;
@@ -231,6 +277,15 @@ extern "C" int efgh_table_gather_transposed(const float *src, const int32_t *tab
     else if (c4n <= 32) k_table_gather_t<32><<<grid, TPB, 0, st>>>(src, C, table, H, dst);
     else k_table_gather_t<64><<<grid, TPB, 0, st>>>(src, C, table, H, dst);
     k_table_alias_add<<<64, TPB, 0, st>>>(src, C, (const int2 *)alist, n_alias, alias_cap, dst);
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}
+
+extern "C" int efgh_blur_dgrad_alias(const float *dy, int64_t ldy, int32_t N, const float *w, int32_t C, const int32_t *alist,
+                                     const int32_t *n_alias, int32_t alias_cap, float *dx, int64_t ldx, void *stream_) {
+    hipStream_t st = (hipStream_t)stream_;
+    EFGH_CHECK_ARG(dy && w && alist && n_alias && dx && N > 0 && C > 0 && alias_cap > 0 && alias_cap <= ALIAS_LDS);
+    k_blur_dgrad_alias<<<64, TPB, 0, st>>>(dy, ldy, N, w, C, (const int2 *)alist, n_alias, alias_cap, dx, ldx);
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
 }

@@ -87,6 +87,7 @@ struct KArgs {
     unsigned nbatch;
     long long bsA, bsW, bsO;   // batched launch: per-problem element strides (blockIdx.y = problem)
     int bsT;                   // ... and neighbour-table COLUMN offset per problem (mode 2: problem z takes taps z*bsT ..)
+    int tam;                   // mode 2: taps marked in column 15 of the table row read zeros
 };
 
 // MATH 0: exact fp32 MFMA (v_mfma_f32_32x32x2_f32).
@@ -146,7 +147,11 @@ k_gather_gemm(const KArgs p_in) {
         amask[q] = 0;
         if (ok) {
             if (MODE == 0) { abase[q] = m * p.lda; amask[q] = 1; }
-            else if (MODE == 2) { abase[q] = m * 16; amask[q] = 0xFFFFu; }
+            else if (MODE == 2) {
+                abase[q] = m * 16;
+                amask[q] = 0xFFFFu;
+                if (p.tam) amask[q] = (0x7FFFu & ~(unsigned)p_in.table[m * 16 + 15]) >> (blockIdx.y * p.bsT);
+            }
             else if (MODE == 3) {            // row stack: tap t = image row t, window of C floats starting at pixel j
                 long long b = m / p.Wv; int j = (int)(m - b * p.Wv);
                 abase[q] = b * p.Hin * p.Win + j; amask[q] = 1;
@@ -213,7 +218,7 @@ k_gather_gemm(const KArgs p_in) {
 #pragma unroll
             for (int q = 0; q < NA; ++q) {
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (amask[q] && kin) {
+                if (kin && (MODE == 2 ? ((amask[q] >> t) & 1u) : amask[q])) {
                     if (MODE == 0) {
                         v = *reinterpret_cast<const float4 *>(p.A + abase[q] + kk);
                     } else {
@@ -562,6 +567,7 @@ static int fill_args(const efgh_gemm_desc *d, KArgs &a) {
     a.Wh = a.Wm = a.Wl = nullptr;
     a.nbatch = d->nbatch > 1 ? (unsigned)d->nbatch : 1u;
     a.bsA = d->batch_stride_a; a.bsW = d->batch_stride_w; a.bsO = d->batch_stride_out; a.bsT = d->batch_stride_table;
+    a.tam = d->mode == 2 ? d->table_alias_mask : 0;
     if (a.nbatch > 1) EFGH_CHECK_ARG(!d->stats && !d->residual && a.nbatch <= 65535 && a.bsA % 4 == 0 && a.bsW % 4 == 0);
     if (d->mode == 1) {
         EFGH_CHECK_ARG(d->B > 0 && d->Hin > 0 && d->Win > 0 && d->Hv > 0 && d->Wv > 0);

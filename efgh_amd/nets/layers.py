@@ -513,6 +513,8 @@ def _blur_grad(ctx, splat, H, C, table, conv0, lv=None):
         ops.unpack_weight(dWp, dW, C0, 15, C, C, C * 15, 15, 1, list(range(15)))
 
     def dgrad(spec, w, draw, xin):
+        if lv is not None and ops.BLUR_DGRAD_FUSED and C % 4 == 0 and C0 % 4 == 0:
+            return ops.blur_dgrad(lv, draw, C0, w, C)        # one gather-GEMM through the lattice's symmetric table
         # tmp[m][t*C+c] = sum_n draw[m][n] * W0[n][c][t], then scattered through the neighbour table
         Wd = w.detach().squeeze(-1).permute(2, 1, 0).contiguous().view(15 * C, C0)
         tmp = torch.empty((H, 15 * C), dtype=torch.float32, device=draw.device)

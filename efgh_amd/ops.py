@@ -300,7 +300,7 @@ PROFILE = None          # bench.py sets this to a list: (start_event, end_event,
 KSPLIT_MAX_ROWS = int(_os.environ.get('EFGH_BLUR_KSPLIT_ROWS', '16384'))     # 0 disables
 
 
-def _blur_gemm_ksplit(A, lda, C, Wp, N, M, out, ldo, table, bias, act, slope, a_off, out_off, flops):
+def _blur_gemm_ksplit(A, lda, C, Wp, N, M, out, ldo, table, bias, act, slope, a_off, out_off, flops, alias_mask=False):
     """BCL blur on a level with few vertices (M <= 16 k rows: 9-75 workgroups each walking K = 15*C serially, 6-23 TFLOP/s): the
     15 neighbour taps are split over 5 problems of ONE batched launch (3 taps each, their own columns of the neighbour table and
     their own slice of the packed weight), the five partial planes are added - with bias and activation - by efgh_fold_planes."""
@@ -312,7 +312,7 @@ def _blur_gemm_ksplit(A, lda, C, Wp, N, M, out, ldo, table, bias, act, slope, a_
     Wg = _cached(Wp, ('ksplit', S), _ver(Wp), regroup)
     part = _scratch(S * M * N, dev)
     gather_gemm(A, lda, C, Ts, Wg, N, M, part, N, mode=2, table=table, a_off=a_off, batch=(S, 0, N * Ts * C, M * N, Ts),
-                flops=flops if flops is not None else 2.0 * M * N * 15 * C)
+                flops=flops if flops is not None else 2.0 * M * N * 15 * C, alias_mask=alias_mask)
     b = None
     if bias is not None:
         b = bias if bias.numel() == N else None
@@ -323,12 +323,12 @@ def _blur_gemm_ksplit(A, lda, C, Wp, N, M, out, ldo, table, bias, act, slope, a_
 
 def gather_gemm(A, lda, C, T, Wp, N, M, out, ldo, mode=0, geom=None, table=None, bias=None, scale=None,
                 shift=None, residual=None, ldr=0, act=ACT_NONE, slope=0.0, stats=None, a_off=0, out_off=0,
-                res_off=0, M_dev=None, flops=None, batch=None):
+                res_off=0, M_dev=None, flops=None, batch=None, alias_mask=False):
     """See efgh_gemm_desc.  A/out/residual may be addressed with an element offset (channel slices)."""
     if (KSPLIT_MAX_ROWS and mode == 2 and M <= KSPLIT_MAX_ROWS and T == 15 and N % 4 == 0 and T * C >= 1024 and batch is None
             and scale is None and shift is None and residual is None and stats is None and M_dev is None and MATH == 'f32'
             and (bias is None or bias.numel() == N)):
-        return _blur_gemm_ksplit(A, lda, C, Wp, N, M, out, ldo, table, bias, act, slope, a_off, out_off, flops)
+        return _blur_gemm_ksplit(A, lda, C, Wp, N, M, out, ldo, table, bias, act, slope, a_off, out_off, flops, alias_mask)
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -354,6 +354,7 @@ def gather_gemm(A, lda, C, T, Wp, N, M, out, ldo, mode=0, geom=None, table=None,
     if batch is not None:
         d.nbatch, d.batch_stride_a, d.batch_stride_w, d.batch_stride_out = batch[:4]
         d.batch_stride_table = batch[4] if len(batch) > 4 else 0
+    d.table_alias_mask = 1 if (alias_mask and mode == 2) else 0
     thin = stats is None and M_dev is None and thin_eligible(mode, C, N, T)
     wino = False
     if thin:
@@ -600,6 +601,30 @@ def neighbor_gather_adjoint(lv, src, C):
                                                    _C.c_void_p(lv.info.data_ptr() + 4 * INFO_ALIAS), c_int32(ALIAS_CAP), ptr(dst),
                                                    _st()))
     return dst
+
+
+BLUR_DGRAD_FUSED = _os.environ.get('EFGH_BLUR_DGRAD_FUSED', '1') != '0'
+
+
+def blur_dgrad(lv, draw, C0, w, C):
+    """data gradient of the BCL blur (15-neighbour gather + Conv2d(C, C0, (15,1)), bilateralNN.py:240-246) w.r.t. the splatted rows:
+    draw [H][C0] -> [H][C].  The neighbour relation of the lattice is symmetric except for the aliased hits the build marks, so
+    the adjoint of gather + convolution is the SAME gather-GEMM on the gradient with tap-mirrored weights
+    (dx[h] = sum_t W_{inv t}^T draw[nbr[h][t]], inv t = 15 - t): no [H][15 C] intermediate is written and read back
+    (538 MB at level 0 of a batch of 8).  The handful of aliased hits is added by efgh_blur_dgrad_alias in a fixed order."""
+    from .lattice import ALIAS_CAP, INFO_ALIAS
+    H = lv.H
+    inv = [0] + [15 - t for t in range(1, 15)]
+    Wd = pack_weight(w, C, 15, C0, 15, C * 15, 1, inv, key=('blur0_d',))
+    dx = torch.empty((H, C), dtype=torch.float32, device=draw.device)
+    gather_gemm(draw, draw.stride(0), C0, 15, Wd, C, H, dx, C, mode=2, table=lv.nbr, alias_mask=True,
+                flops=2.0 * H * 15 * C * C0)
+    wd = w.detach()
+    assert wd.is_contiguous() and wd.numel() == C0 * C * 15
+    _C.check(_L().efgh_blur_dgrad_alias(ptr(draw), c_int64(draw.stride(0)), c_int32(C0), ptr(wd), c_int32(C), ptr(lv.alist),
+                                        _C.c_void_p(lv.info.data_ptr() + 4 * INFO_ALIAS), c_int32(ALIAS_CAP), ptr(dx), c_int64(C),
+                                        _st()))
+    return dx
 
 
 # ----------------------------------------------------------------------------------------------

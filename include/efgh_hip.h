@@ -141,6 +141,11 @@ int efgh_splat_bwd(const float *gsplat, int32_t C, int32_t coff, const float *ws
  * n_alias = info + EFGH_LATTICE_INFO_ALIAS (device).                                                                */
 int efgh_table_gather_transposed(const float *src, const int32_t *nbr, int32_t H, int32_t C, const int32_t *alist,
                                  const int32_t *n_alias, int32_t alias_cap, float *dst, void *stream);
+/* the aliased part of the blur's data gradient (see efgh_gemm_desc.table_alias_mask): for every record (m*16 + t, target) of
+ * alist  dx[target][c] += sum_n dy[m][n] * w[(n*C + c)*15 + t], c < C  - w = the blur weight in the reference layout
+ * [N][C][15] (bilateralNN.py:107).  Records are applied in a fixed order (sorted, one owner block per target): no atomics. */
+int efgh_blur_dgrad_alias(const float *dy, int64_t ldy, int32_t N, const float *w, int32_t C, const int32_t *alist,
+                          const int32_t *n_alias, int32_t alias_cap, float *dx, int64_t ldx, void *stream);
 
 /* ------------------------------------------------------------------ gather-GEMM (K4,K6,K8) -
  * One implicit-GEMM kernel family on fp32 MFMA (v_mfma_f32_32x32x2_f32):
@@ -185,6 +190,11 @@ typedef struct {
     /* mode 2 only: problem z reads table columns z*batch_stride_table .. + T (a split of the neighbour taps over the problems:
      * split-K for levels with few vertices, the partial planes are added by efgh_fold_planes) */
     int32_t batch_stride_table;
+    /* mode 2 only: != 0 = taps whose bit is set in column 15 of the table row (the aliased neighbour hits marked by the lattice
+     * build) read zeros.  What is left of the table is a symmetric relation, so the data gradient of the blur's neighbour gather
+     * + convolution is this same gather-GEMM on the gradient with tap-mirrored weights (no [H][15 C] intermediate); the aliased
+     * hits are added by efgh_blur_dgrad_alias. */
+    int32_t table_alias_mask;
 } efgh_gemm_desc;
 
 int efgh_gather_gemm(const efgh_gemm_desc *d, void *stream);

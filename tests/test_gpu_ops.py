@@ -481,6 +481,64 @@ def test_neighbor_gather_adjoint_vs_atomic_scatter():
             assert np.array_equal(nbr[nbr[ok, t], 15 - t], np.nonzero(ok)[0]), t
 
 
+def _inject_aliased_hits(lv, count, seed):
+    """key2int's aliased neighbour hits need key boxes that real sweeps do not produce (a lattice point and its alias differ in
+    their residue mod 4 unless a key range degenerates), so the tests plant them: `count` absent table entries (h, t) are pointed at
+    arbitrary vertices and marked exactly as the build marks a real one - bit t of column 15 and a record in alist."""
+    from efgh_amd import lattice
+    rs = np.random.RandomState(seed)
+    nbr = lv.nbr.cpu().numpy().copy()
+    hh, tt = np.nonzero(nbr[:, 1:15] < 0)
+    pick = rs.choice(len(hh), size=min(count, len(hh)), replace=False)
+    recs = []
+    for k in pick:
+        h, t = int(hh[k]), int(tt[k]) + 1
+        target = int(rs.randint(0, lv.H))
+        nbr[h, t] = target
+        nbr[h, 15] |= 1 << t
+        recs.append((h * 16 + t, target))
+    rs.shuffle(recs)                              # (arrival order of the records is arbitrary on the device too)
+    lv.nbr = torch.from_numpy(nbr).cuda()
+    alist = np.zeros((lattice.ALIAS_CAP, 2), np.int32)
+    alist[:len(recs)] = np.asarray(recs, np.int32).reshape(-1, 2)
+    lv.alist = torch.from_numpy(alist).cuda()
+    lv.info = lv.info.clone()
+    lv.info[lattice.INFO_ALIAS] = len(recs)
+    return len(recs)
+
+
+@pytest.mark.parametrize('C,C0,npts', [(36, 32, 6000), (68, 64, 6000), (260, 256, 900)])
+def test_fused_blur_dgrad_equals_gemm_plus_scatter(C, C0, npts):
+    """data gradient of the blur's neighbour gather + (15,1) convolution as ONE gather-GEMM through the lattice's symmetric table
+    (+ the aliased hits in a fixed order) == GEMM into the [H][15 C] intermediate + float64 scatter-add over the table; with
+    planted aliased hits (several on one target), at a level large enough for the plain launch and one small enough for the
+    split-K launch; two runs are bit-identical"""
+    from efgh_amd import lattice, ops
+    rs = np.random.RandomState(11)
+    pc = (rs.randn(3, npts) * np.array([[3.], [3.], [0.4]])).astype(np.float32)
+    torch.manual_seed(1)
+    for lv in lattice.build_pyramid(torch.from_numpy(pc).cuda(), (1.0, 0.5)):
+        H = lv.H
+        assert _inject_aliased_hits(lv, 40, 3) == 40
+        w = torch.randn(C0, C, 15, 1, device='cuda') * 0.1
+        draw = torch.randn(H, C0, device='cuda')
+        got = ops.blur_dgrad(lv, draw, C0, w, C)
+        again = ops.blur_dgrad(lv, draw, C0, w, C)
+        assert torch.equal(got, again)
+        nbr = lv.nbr[:, :15].cpu().numpy()
+        tmp = torch.einsum('mn,nct->mtc', draw.cpu().double(), w[..., 0].cpu().double())        # [H][15][C]
+        ref = torch.zeros((H, C), dtype=torch.float64)
+        for t in range(15):
+            ok = np.nonzero(nbr[:, t] >= 0)[0]
+            ref.index_add_(0, torch.from_numpy(nbr[ok, t]).long(), tmp[ok, t])
+        assert _rel(got.cpu().double(), ref) < 1e-5, H
+        # and the two-step form (explicit intermediate, gather through the table + the same alias records)
+        src = tmp.reshape(H, 15 * C).float().cuda()
+        two = ops.neighbor_gather_adjoint(lv, src, C)
+        assert torch.equal(two, ops.neighbor_gather_adjoint(lv, src, C))
+        assert _rel(two.cpu().double(), ref) < 1e-5
+
+
 def test_padded_pack_and_vector_pad():
     """efgh_pack_weight_padded / efgh_pad_vec: the zero padding of layers whose width is not a multiple of 4, one launch each"""
     from efgh_amd import ops
