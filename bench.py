@@ -408,6 +408,17 @@ def main():
             out.update(rooflines(prof, a.steps))
             out['mfma_step_utilisation'] = mfma_step_utilisation(prof, a.steps, out['ms_per_step'])
             out['peak_hbm_gb_per_gpu'] = torch.cuda.max_memory_allocated() / 1e9      # of 288 GB
+        if world > 1:
+            # data parallelism keeps the replicas identical: same start (broadcast), same all-reduced gradients, same Adam.  Two
+            # position-weighted checksums of the flat weight buffer, max == min over the ranks
+            w = trainer.flat.w.double()
+            ck = torch.stack([w.sum(), (w * torch.arange(1, w.numel() + 1, device=dev, dtype=torch.float64).remainder(977.0)).sum()])
+            hi, lo = ck.clone(), ck.clone()
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            if rank == 0:
+                out['replicas_identical'] = bool(torch.equal(hi, lo))
+                out['compute_streams'] = 1 + len(ops.side_streams())
         attach_serialized(out, tstep, 'train')
     elif rank == 0:
         out = {'metric': fwd['metric'], 'value': fwd['value'], 'unit': 'frame-pairs/s', 'n_gpus': world,

@@ -67,7 +67,7 @@ def claim_grad(p):
     g = flat.claim(p, i)
     if g is None:
         return None, None
-    return g, (lambda: flat.deliver(i))
+    return g, (lambda stream=None: flat.deliver(i, stream))
 
 
 def note_use(*params):
@@ -298,7 +298,7 @@ class GemmLayerFn(torch.autograd.Function):
                     run_wgrad()
             if gW is not None:
                 dW = None
-                delivered.append(dw_done)
+                delivered.append(dw_done if side is None else (lambda: dw_done(side)))
         if dres is not None and Np != N:
             dres = dres[..., :N]
         for done in delivered:               # after the writes are enqueued: the all-reduce bucket countdown

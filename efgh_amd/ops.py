@@ -755,6 +755,17 @@ def wgrad_stream(device):
     return bb._side_stream(device, 2)
 
 
+def reserve_comm_queue():
+    """data-parallel training (train.Trainer with world > 1): the collective library brings its own stream, and HIP multiplexes
+    streams onto four hardware queues - a fifth stream makes two of them share a queue (measured: +12 ms per step from merely
+    having created it).  The weight gradients therefore go back onto the stream of their layer's backward, which leaves the
+    current stream + two branch streams + the communication stream.  EFGH_WGRAD_STREAM=1 in the environment keeps the fourth
+    compute stream regardless."""
+    global WGRAD_SIDE
+    if _os.environ.get('EFGH_WGRAD_STREAM') is None:
+        WGRAD_SIDE = False
+
+
 def side_streams():
     """every side stream this package has created (branch streams of the backbone + the weight-gradient stream)"""
     from .nets import efghbackbone as bb

@@ -65,12 +65,13 @@ class FlatParams:
             self.deliver(i)
         return hook
 
-    def deliver(self, i):
-        """parameter i's gradient for this backward pass is (enqueued to be) in the flat buffer"""
+    def deliver(self, i, stream=None):
+        """parameter i's gradient for this backward pass is (enqueued to be) in the flat buffer; `stream`: the stream the write was
+        enqueued on when that is not the current one (weight gradients on the weight-gradient stream, nets/fn.py)"""
         first, self.arrived[i] = not self.arrived[i], True
         if first:
             for fn in self.listeners:
-                fn(i)
+                fn(i, stream)
 
     def claim(self, p, i):
         """the flat gradient view of parameter i if a backward may overwrite it now (zeroed, nothing delivered yet), else None"""
@@ -151,11 +152,19 @@ class OverlappedAllReduce:
         self.pending, self.works, self.launched = list(self.sizes), [], [False] * len(self.buckets)
         self.next_b, self.order = len(self.buckets) - 1, []
         self.main_stream = None           # the stream backward() is called on (set by start_step)
+        self.written = [[] for _ in self.buckets]         # per bucket: events recorded behind the gradient writes into it
         if world > 1:
             flat.listeners.append(self._arrived)
 
-    def _arrived(self, i):
-        self.pending[self.bucket_of[i]] -= 1
+    def _arrived(self, i, stream=None):
+        b = self.bucket_of[i]
+        if self.flat.g.is_cuda:
+            # an event right behind the write, on the stream that carries it: the bucket's all-reduce waits for exactly the work
+            # that produced its gradients, not for everything else that happens to be enqueued on the branch streams
+            ev = torch.cuda.Event()
+            ev.record(stream if stream is not None else torch.cuda.current_stream())
+            self.written[b].append(ev)
+        self.pending[b] -= 1
         self._launch_ready()
 
     def _launch_ready(self):
@@ -171,10 +180,14 @@ class OverlappedAllReduce:
             return
         self.launched[b] = True
         if self.flat.g.is_cuda:
-            cur = torch.cuda.current_stream()     # (a hook may run with a side stream current: the bucket's gradients were written
-            for st in ops.side_streams() + ([self.main_stream] if self.main_stream is not None else []):      # on any of them)
-                if st != cur:
-                    cur.wait_stream(st)
+            cur = torch.cuda.current_stream()     # (a hook may run with any branch stream current)
+            if self.pending[b] <= 0:
+                for ev in self.written[b]:        # every parameter of the bucket was delivered: wait for those writes only
+                    cur.wait_event(ev)
+            else:                                 # finish(): parameters without a gradient this step - join everything
+                for st in ops.side_streams() + ([self.main_stream] if self.main_stream is not None else []):
+                    if st != cur:
+                        cur.wait_stream(st)
         s, e = self.buckets[b]
         self.order.append(b)
         self.works.append(dist.all_reduce(self.flat.g[s:e], op=dist.ReduceOp.SUM, async_op=True))
@@ -183,6 +196,7 @@ class OverlappedAllReduce:
         self.main_stream = torch.cuda.current_stream() if self.flat.g.is_cuda else None
         self.pending, self.works, self.launched = list(self.sizes), [], [False] * len(self.buckets)
         self.next_b, self.order = len(self.buckets) - 1, []
+        self.written = [[] for _ in self.buckets]
 
     def finish(self):
         if self.world <= 1:
@@ -233,6 +247,8 @@ class Trainer:
                     dist.broadcast(t.data, 0)
         self.opt = FusedAdam(self.flat, lr=lr, weight_decay=weight_decay)
         self.comm = OverlappedAllReduce(self.flat, self.world)
+        if self.world > 1:
+            ops.reserve_comm_queue()
         self.base_lr, self.it = lr, 0
 
     def load_checkpoint(self, ckpt):

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_bench_spawns_its_own_ranks():
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
-    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--small', '--steps', '2', '--warmup', '1',
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--small', '--steps', '3', '--warmup', '1',
                         '--no-cpu-baseline'], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
@@ -25,6 +25,9 @@ def test_bench_spawns_its_own_ranks():
         assert out['dist_backend'] == 'nccl' and out['rccl_ranks'] == 2
     else:
         assert out['dist_backend'] == 'gloo' and out['rccl_ranks'] is None
+    # after the timed steps every rank holds bit-identical weights (same start, same all-reduced gradients, same Adam), and the
+    # communication stream has its hardware queue: three compute streams under world > 1
+    assert out['replicas_identical'] is True and out['compute_streams'] == 3
     for k in ('roofline', 'forward_only'):
         assert k in out
     assert out['roofline']['frac'] <= 1.0
