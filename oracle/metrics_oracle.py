@@ -1,6 +1,7 @@
 """TEST INFRASTRUCTURE ONLY — numpy restatement of the reference's pose-error metrics (common/helper.py:163-207).
-`odom` is pinned against tests/golden/metrics_cases.npz (outputs of the unmodified `Err`); `raw` needs pyquaternion, which is
-absent from the build container: parity unpinned against the reference for that mode, checked against scipy instead."""
+Both modes are pinned against tests/golden/metrics_cases.npz, outputs of the unmodified `Err`: `odom` directly; `raw` (which needs
+pyquaternion, absent from the build container) through the reference's own calc_error_raw_np / quaternion_distance run over a
+quaternion-algebra stand-in in the fixture harness (tests/golden/ref_harness.py) - this restatement agrees with it to 1e-14."""
 import numpy as np
 
 

@@ -1,4 +1,4 @@
-"""tests/golden/metrics_cases.npz: `Err.update` / `calc_error_odom_np` of the unmodified reference (common/helper.py:128-207)
+"""tests/golden/metrics_cases.npz: `Err.update` / `calc_error_odom_np` / `calc_error_raw_np` of the unmodified reference (common/helper.py:128-207)
 on random pose pairs (float32 tensors, as the training loop hands them over).  Run in the build container only."""
 import importlib
 import os
@@ -38,10 +38,17 @@ def main():
         err.update(gt, pr)
         gts.append(gt['sensor2_T_sensor1'].numpy()[0]); preds.append(pr['sensor2_T_sensor1'].numpy()[0])
         rots.append(err.error_dict['rot'][-1]); trss.append(err.error_dict['trs'][-1])
+    # raw mode (camera-LiDAR extrinsic calibration, helper.py:147-148,166-196): the reference's own calc_error_raw_np /
+    # quaternion_distance on the same pairs, over the quaternion stand-in of ref_harness (pyquaternion is absent here)
+    raw = helper.Err('KITTI_RAW')
+    for g, p in zip(gts, preds):
+        raw.update({'sensor2_T_sensor1': torch.from_numpy(g[None])}, {'sensor2_T_sensor1': torch.from_numpy(p[None])})
     path = os.path.join(HERE, 'metrics_cases.npz')
     np.savez_compressed(path, gt=np.stack(gts), pred=np.stack(preds), rot=np.array(rots, np.float64),
                         trs=np.array(trss, np.float64),
-                        final=np.array([err.dict['rot_mean'], err.dict['rot_std'], err.dict['trs_mean'], err.dict['trs_std']]))
+                        final=np.array([err.dict['rot_mean'], err.dict['rot_std'], err.dict['trs_mean'], err.dict['trs_std']]),
+                        raw_rot=np.array(raw.error_dict['rot'], np.float64), raw_trs=np.array(raw.error_dict['trs'], np.float64),
+                        raw_final=np.array([raw.dict['rot_mean'], raw.dict['rot_std'], raw.dict['trs_mean'], raw.dict['trs_std']]))
     print('wrote', path)
 
 

@@ -83,8 +83,31 @@ def _install_stubs():
         if name not in sys.modules:
             sys.modules[name] = types.ModuleType(name)
     sys.modules['tensorboardX'].SummaryWriter = object
+    # pyquaternion is absent from the build container.  The reference uses four things of it (common/helper.py:185-190):
+    # Quaternion(w, x, y, z), the Hamilton product `*`, `.inverse` and indexing [0..3] = (w, x, y, z) - plain quaternion
+    # algebra, stood in for here so that the reference's OWN raw-mode error routine (calc_error_raw_np / quaternion_distance)
+    # can produce the fixtures of make_golden_metrics.py.  Fixture generation only; nothing under tests/ or the product uses it.
+    class Quaternion:
+        def __init__(self, w, x, y, z):
+            self.q = np.array([w, x, y, z], dtype=np.float64)
+
+        def __mul__(self, o):
+            w1, x1, y1, z1 = self.q
+            w2, x2, y2, z2 = o.q
+            return Quaternion(w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2, w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2,
+                              w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2, w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2)
+
+        @property
+        def inverse(self):
+            w, x, y, z = self.q
+            n = float(np.dot(self.q, self.q))
+            return Quaternion(w / n, -x / n, -y / n, -z / n)
+
+        def __getitem__(self, i):
+            return self.q[i]
+
     pq = types.ModuleType('pyquaternion')
-    pq.Quaternion = object
+    pq.Quaternion = Quaternion
     sys.modules.setdefault('pyquaternion', pq)
     sys.modules['nuscenes.nuscenes'].NuScenes = object
     sys.modules['nuscenes.utils.data_classes'].LidarPointCloud = object

@@ -24,6 +24,17 @@ def test_oracle_odom_equals_reference(golden_dir):
         assert abs(ro - r) <= _tol(np.array(r)) and abs(to - t) <= 1e-6 * max(1.0, t)
 
 
+def test_oracle_raw_equals_reference(golden_dir):
+    """raw mode (KITTI_RAW): fixtures from the reference's own calc_error_raw_np / quaternion_distance (helper.py:166-196; run over
+    a quaternion-algebra stand-in for the absent pyquaternion, tests/golden/ref_harness.py)"""
+    from oracle import metrics_oracle as MO
+    G = _G(golden_dir)
+    assert len(G['raw_rot']) == 64
+    for g, p, r, t in zip(G['gt'], G['pred'], G['raw_rot'], G['raw_trs']):
+        ro, to = MO.calc_error_raw(g, p)
+        assert abs(ro - r) <= 1e-9 * max(1.0, r) and abs(to - t) <= 1e-7 * max(1.0, t)
+
+
 @pytest.mark.gpu
 def test_hip_pose_errors_vs_reference_and_oracle(golden_dir):
     from efgh_amd.common.metrics import Err
@@ -40,9 +51,15 @@ def test_hip_pose_errors_vs_reference_and_oracle(golden_dir):
     assert abs(d['trs_mean'] - G['final'][2]) < 1e-5 and abs(d['trs_std'] - G['final'][3]) < 1e-5
     assert abs(d['rot_mean'] - G['final'][0]) < 0.05 and abs(d['rot_std'] - G['final'][1]) < 0.05 and big.sum() > 10
     raw = Err('KITTI_RAW')
-    for g, p in zip(G['gt'][:32], G['pred'][:32]):
+    for g, p in zip(G['gt'], G['pred']):
         raw.update({'sensor2_T_sensor1': torch.from_numpy(g[None]).cuda()}, {'sensor2_T_sensor1': torch.from_numpy(p[None]).cuda()})
     hr = raw.error_dict
-    for i, (g, p) in enumerate(zip(G['gt'][:32], G['pred'][:32])):
+    for i, (g, p) in enumerate(zip(G['gt'], G['pred'])):
         ro, to = MO.calc_error_raw(g, p)
         assert abs(hr['rot'][i] - ro) < 2e-3 + 1e-5 * ro and abs(hr['trs'][i] - to) < 1e-6 * max(1.0, to)
+        # ... and the reference's own raw-mode outputs
+        assert abs(hr['rot'][i] - G['raw_rot'][i]) < 2e-3 + 1e-5 * G['raw_rot'][i]
+        assert abs(hr['trs'][i] - G['raw_trs'][i]) < 1e-6 * max(1.0, G['raw_trs'][i])
+    dr = raw.dict
+    assert abs(dr['rot_mean'] - G['raw_final'][0]) < 2e-3 and abs(dr['rot_std'] - G['raw_final'][1]) < 2e-3
+    assert abs(dr['trs_mean'] - G['raw_final'][2]) < 1e-5 and abs(dr['trs_std'] - G['raw_final'][3]) < 1e-5
