@@ -32,6 +32,9 @@ class GemmDesc(ctypes.Structure):
         ('stats', c_void_p),
         ('nbatch', c_int32), ('batch_stride_a', c_int64), ('batch_stride_w', c_int64), ('batch_stride_out', c_int64),
         ('batch_stride_table', c_int32), ('table_alias_mask', c_int32),
+        ('stats_mode', c_int32), ('bn_raw', c_void_p), ('bn_ldraw', c_int64), ('bn_y', c_void_p), ('bn_ldy', c_int64),
+        ('bn_pscale', c_void_p), ('bn_pshift', c_void_p), ('bn_mean', c_void_p), ('bn_invstd', c_void_p),
+        ('bn_act', c_int32), ('bn_slope', c_float),
     ]
 
 

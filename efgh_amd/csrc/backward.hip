@@ -473,6 +473,43 @@ extern "C" int efgh_act_bn_bwd_reduce(const float *dy, int64_t lddy, const float
     return EFGH_OK;
 }
 
+// the same fold over float rows [G][2][C] (the BatchNorm-backward sums an MFMA kernel left per row block, efgh_gemm_desc.stats_mode)
+__global__ void __launch_bounds__(1024)
+k_bwd_finalize_f32(const float *__restrict__ part, int G, int C, double count, float *__restrict__ sum_dpre,
+                   float *__restrict__ sum_dpre_xhat, double *__restrict__ mean_dpre, double *__restrict__ mean_dpre_xhat) {
+    __shared__ double sa[32][33], sb[32][33];
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int c = blockIdx.x * 32 + tx;
+    double a = 0.0, b = 0.0;
+    if (c < C) {
+        double a1 = 0.0, b1 = 0.0, a2 = 0.0, b2 = 0.0, a3 = 0.0, b3 = 0.0;
+        int g = ty;
+        for (; g + 96 < G; g += 128) {
+            a += (double)part[((long long)g * 2) * C + c]; b += (double)part[((long long)g * 2 + 1) * C + c];
+            a1 += (double)part[((long long)(g + 32) * 2) * C + c]; b1 += (double)part[((long long)(g + 32) * 2 + 1) * C + c];
+            a2 += (double)part[((long long)(g + 64) * 2) * C + c]; b2 += (double)part[((long long)(g + 64) * 2 + 1) * C + c];
+            a3 += (double)part[((long long)(g + 96) * 2) * C + c]; b3 += (double)part[((long long)(g + 96) * 2 + 1) * C + c];
+        }
+        for (; g < G; g += 32) { a += (double)part[((long long)g * 2) * C + c]; b += (double)part[((long long)g * 2 + 1) * C + c]; }
+        a += (a1 + a2) + a3; b += (b1 + b2) + b3;
+    }
+    sa[ty][tx] = a; sb[ty][tx] = b;
+    __syncthreads();
+    if (ty != 0 || c >= C) return;
+    for (int i = 1; i < 32; ++i) { a += sa[i][tx]; b += sb[i][tx]; }
+    sum_dpre[c] = (float)a; sum_dpre_xhat[c] = (float)b;
+    mean_dpre[c] = a / count; mean_dpre_xhat[c] = b / count;
+}
+
+extern "C" int efgh_bwd_finalize_f32(const float *stats, int32_t rows, int32_t C, double count, float *sum_dpre,
+                                     float *sum_dpre_xhat, double *mean_dpre, double *mean_dpre_xhat, void *stream_) {
+    EFGH_CHECK_ARG(stats && rows > 0 && C > 0 && count > 0 && sum_dpre && sum_dpre_xhat && mean_dpre && mean_dpre_xhat);
+    k_bwd_finalize_f32<<<cdiv(C, 32), dim3(32, 32), 0, (hipStream_t)stream_>>>(stats, rows, C, count, sum_dpre, sum_dpre_xhat,
+                                                                               mean_dpre, mean_dpre_xhat);
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}
+
 extern "C" int efgh_act_bn_bwd_apply(const float *dy, int64_t lddy, const float *y, int64_t ldy, const float *raw,
                                      int64_t ldraw, const float *mean, const float *invstd, const float *coef,
                                      const double *m1, const double *m2, const float *pscale, const float *pshift,

@@ -40,6 +40,12 @@ struct WinoArgs {
     float *out; long long ldo;
     float *stats;
     unsigned nbx;
+    // stats_mode 1: BatchNorm-backward column sums of the written value (see efgh_gemm_desc)
+    int smode;
+    const float *bn_raw; long long bn_ldraw;
+    const float *bn_y; long long bn_ldy;
+    const float *bn_psc, *bn_psh, *bn_mean, *bn_invstd;
+    int bn_act; float bn_slope;
 };
 
 __global__ void __launch_bounds__(256, 2) k_wino43(const WinoArgs p) {
@@ -204,6 +210,12 @@ __global__ void __launch_bounds__(256, 2) k_wino43(const WinoArgs p) {
     const float sc = p.scale ? p.scale[col] : 1.f;
     const float sf = p.shift ? p.shift[col] : 0.f;
     float s1 = 0.f, s2 = 0.f;
+    const bool bnm = p.smode == 1;
+    float b_psc = 0.f, b_psh = 0.f, b_mu = 0.f, b_is = 0.f;
+    if (bnm) {
+        if (!p.bn_y) { b_psc = p.bn_psc[col]; b_psh = p.bn_psh[col]; }
+        b_mu = p.bn_mean[col]; b_is = p.bn_invstd[col];
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int rl = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -217,12 +229,18 @@ __global__ void __launch_bounds__(256, 2) k_wino43(const WinoArgs p) {
         for (int i = 0; i < 4; ++i) {
             if (i >= cnt) continue;
             float v = (i == 0 ? y0 : i == 1 ? y1 : i == 2 ? y2 : y3) + bi;
-            s1 += v; s2 += v * v;
+            if (!bnm) { s1 += v; s2 += v * v; }
             v = v * sc + sf;
             if (p.residual) v += p.residual[(opix + i) * p.ldr + col];
             if (p.act == 1) v = v > 0.f ? v : 0.f;
             else if (p.act == 2) v = v > 0.f ? v : v * p.slope;
             p.out[(opix + i) * p.ldo + col] = v;
+            if (bnm) {
+                const float rw = p.bn_raw[(opix + i) * p.bn_ldraw + col];
+                const float yy = p.bn_y ? p.bn_y[(opix + i) * p.bn_ldy + col] : rw * b_psc + b_psh;
+                const float g = p.bn_act == 1 ? (yy > 0.f ? v : 0.f) : p.bn_act == 2 ? (yy > 0.f ? v : v * p.bn_slope) : v;
+                s1 += g; s2 += g * ((rw - b_mu) * b_is);
+            }
         }
     }
     if (p.stats) {
@@ -463,6 +481,11 @@ extern "C" int efgh_wino_conv3x3(const efgh_gemm_desc *d, const float *U, void *
     a.U = U; a.N = d->N; a.Mt = (long long)d->B * d->Hin * a.TW;
     a.bias = d->bias; a.scale = d->scale; a.shift = d->shift; a.residual = d->residual; a.ldr = d->ldr;
     a.act = d->act; a.slope = d->slope; a.out = d->out; a.ldo = d->ldo; a.stats = d->stats;
+    a.smode = d->stats ? d->stats_mode : 0;
+    if (a.smode == 1) EFGH_CHECK_ARG(d->bn_raw && d->bn_mean && d->bn_invstd && (d->bn_y || (d->bn_pscale && d->bn_pshift)));
+    a.bn_raw = d->bn_raw; a.bn_ldraw = d->bn_ldraw; a.bn_y = d->bn_y; a.bn_ldy = d->bn_ldy;
+    a.bn_psc = d->bn_pscale; a.bn_psh = d->bn_pshift; a.bn_mean = d->bn_mean; a.bn_invstd = d->bn_invstd;
+    a.bn_act = d->bn_act; a.bn_slope = d->bn_slope;
     a.nbx = (unsigned)(d->N / TN);
     const long long nby = (a.Mt + TM - 1) / TM;
     EFGH_CHECK_ARG(a.nbx * nby < 0x7fffffffLL);

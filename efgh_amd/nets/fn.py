@@ -94,12 +94,32 @@ def _bias_grad_behind_bn(ctx, p_bias, draw, M, Np, N, train_bn, delivered):
     return torch.zeros(N, dtype=torch.float32, device=draw.device)
 
 
+class BnSrc:
+    """what the BatchNorm backward of a layer needs besides dy, attached (`_efgh_bnsrc`) to the activation the layer returns: the
+    consumer of that activation hands it to its data-gradient kernel, which then takes the layer's two column sums in its epilogue
+    (ops.gather_gemm bn_bwd) and tags the gradient it returns (`_efgh_bnsums`); the layer's own backward finds the tag on its dy
+    and skips the reduction pass over dy and raw.  Any detour of the gradient through autograd (several consumers summed by the
+    engine, a view, a clone) arrives as another tensor object without the tag: the layer then reduces as before."""
+    __slots__ = ('raw', 'y', 'psc', 'psh', 'mean', 'invstd', 'act', 'slope', 'M', 'N')
+
+    def __init__(self, raw, y, psc, psh, mean, invstd, act, slope, M, N):
+        self.raw, self.y, self.psc, self.psh, self.mean, self.invstd = raw, y, psc, psh, mean, invstd
+        self.act, self.slope, self.M, self.N = act, slope, M, N
+
+    def fits(self, M, N):
+        return self.M == M and self.N == N
+
+
+TRACE = None          # debug aid (tools/layer_census.py): list of per-layer records appended by GemmLayerFn.backward
+
+
 class GemmLayerFn(torch.autograd.Function):
     """y = act(BN(gemm(x, W) + bias) + residual)   with hand-written backward."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, gamma, beta, residual, spec, out_target=None):
         ctx.set_materialize_grads(False)      # an unused passthrough alias must arrive as None, not as a zero tensor to add
+        ctx.xsrc = getattr(x, '_efgh_bnsrc', None)           # the BatchNorm layer that produced x (BnSrc), if any
         x = as_rows(x)
         dev = x.device
         N, Np = spec.N, ceil4(spec.N)
@@ -181,6 +201,15 @@ class GemmLayerFn(torch.autograd.Function):
                     y = torch.empty_like(raw)
                 ops.scale_shift_act(raw, Np, scale, shift, y, ld_of(y), M, Np, spec.act, spec.slope, res=res,
                                     ldr=0 if res is None else ld_of(res))
+        if TRACE is not None:
+            y._efgh_src = ('bn' if bn is not None else 'plain', spec.N, spec.pool, residual is not None)
+        ctx.bnsrc = None
+        if need_stats and not spec.pool and Np == N and any(ctx.needs_input_grad):
+            # (mask from y for residual layers, re-derived from raw * scale + shift otherwise - as the layer's own backward does)
+            # (y.detach(): an alias object - y itself carrying a reference to something that refers to y would be a cycle, and a step's
+            # activations would wait for the garbage collector instead of being freed by reference count)
+            ctx.bnsrc = y._efgh_bnsrc = BnSrc(raw, y.detach() if residual is not None else None, scale, shift, mean, invstd,
+                                              spec.act, spec.slope, M, Np)
         ctx.spec = spec
         ctx.has = (bias is not None, gamma is not None, residual is not None)
         ctx.params = (weight, bias, gamma, beta)      # the Parameter objects themselves (claim_grad), not saved copies
@@ -197,6 +226,9 @@ class GemmLayerFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, dskip=None):
         spec = ctx.spec
+        sums = getattr(dy, '_efgh_bnsums', None) if dy is not None else None
+        if sums is not None and (sums[1] is not ctx.bnsrc or sums[2] != dy._version):
+            sums = None
         if dy is None:                        # (only the alias was used downstream)
             dy = torch.zeros(tuple(spec.out_shape) + (ceil4(spec.N),), dtype=torch.float32, device=ctx.saved_tensors[0].device)
         x, weight, y, raw, mean, invstd, coef, psc, psh = ctx.saved_tensors
@@ -205,6 +237,14 @@ class GemmLayerFn(torch.autograd.Function):
         N, Np, M = spec.N, ceil4(spec.N), spec.M
         dev = x.device
         fused_pool = spec.pool and has_bn and spec.train and not has_res and Np == N
+        if TRACE is not None:
+            g0 = spec.launches[0][0] if spec.launches else None
+            TRACE.append(dict(M=M, N=N, C=spec.C, T=spec.T, mode=spec.mode, bn=has_bn, res=has_res, pool=spec.pool, act=spec.act,
+                              nl=len(spec.launches), wino=bool(g0 is not None and ops.wino_eligible(spec.mode, spec.C, Np, g0)),
+                              wino2d=bool(g0 is not None and ops.wino2d_eligible(spec.mode, spec.C, Np, g0)),
+                              c4=bool(g0 is not None and ops.c4_eligible(spec.mode, spec.C, Np, g0)),
+                              x_from=getattr(x, '_efgh_src', None), dx=bool(ctx.needs_input_grad[0]),
+                              in_elems=int(x.numel()), custom=spec.custom_forward is not None))
         if spec.pool and not fused_pool:    # pooled gradient -> full resolution (window recomputed from raw*scale+shift)
             dy = ops.maxpool2_bwd_affine(raw, psc, psh, spec.act, spec.slope, dy.contiguous())
         dy = as_rows(dy)
@@ -244,9 +284,17 @@ class GemmLayerFn(torch.autograd.Function):
             m1 = torch.empty(Np, dtype=torch.float64, device=dev) if train_bn else None
             m2 = torch.empty(Np, dtype=torch.float64, device=dev) if train_bn else None
             ldy = Np if ymask is None else ld_of(ymask)
-            ops.act_bn_bwd_reduce(dy, ld_of(dy), ymask, ldy, raw, Np, mean if has_bn else None,
-                                  invstd if has_bn else None, M, Np, spec.act, spec.slope, part, s1, s2, m1, m2,
-                                  pscale=psc, pshift=psh)
+            if sums is not None and train_bn:
+                # the kernel that produced dy took the two column sums in its epilogue: fold its per-block partials
+                f1, f2, m1, m2 = ops.bwd_finalize_f32(sums[0], Np, float(M))
+                if gs1 is not None:
+                    gs1.copy_(f1)
+                    gs2.copy_(f2)
+                s1, s2 = (gs1, gs2) if gs1 is not None else (f1, f2)
+            else:
+                ops.act_bn_bwd_reduce(dy, ld_of(dy), ymask, ldy, raw, Np, mean if has_bn else None,
+                                      invstd if has_bn else None, M, Np, spec.act, spec.slope, part, s1, s2, m1, m2,
+                                      pscale=psc, pshift=psh)
             if has_bn and gs1 is None:
                 dbeta, dgamma = s1[:N].clone(), s2[:N].clone()
             if has_bias and not has_bn and gs1 is None:
@@ -270,10 +318,12 @@ class GemmLayerFn(torch.autograd.Function):
             side = ops.wgrad_stream(dev) if (gW is not None and ops.WGRAD_SIDE) else None
         dx = None
         if ctx.needs_input_grad[0]:
+            kw = {}
             if dskip is not None:
-                dx = spec.dgrad(spec, weight, draw, x, add=as_rows(dskip))
-            else:
-                dx = spec.dgrad(spec, weight, draw, x)
+                kw['add'] = as_rows(dskip)
+            if ctx.xsrc is not None and getattr(spec.dgrad, 'takes_bnsrc', False):
+                kw['bnsrc'] = ctx.xsrc
+            dx = spec.dgrad(spec, weight, draw, x, **kw)
         # ---- wgrad
         dW = None
         if ctx.needs_input_grad[1] and spec.custom_wgrad is not None:

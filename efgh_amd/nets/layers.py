@@ -372,9 +372,11 @@ def _conv2d_grad(ctx, x, conv, bn, act, slope, residual, geom, dims, Cp, passthr
     def unpack(dWp, i, dW):
         ops.unpack_weight(dWp, dW, O, T, Cw, Cp, Cw * T, T, 1, list(range(T)))
 
-    def dgrad(spec, w, draw, xin, add=None):
+    def dgrad(spec, w, draw, xin, add=None, bnsrc=None):
         """add: a gradient that reached x through ANOTHER consumer (handed over on this layer's passthrough alias); it is folded
-        into the result in the kernels' epilogues instead of by a separate elementwise pass of autograd"""
+        into the result in the kernels' epilogues instead of by a separate elementwise pass of autograd.
+        bnsrc: the BatchNorm layer that produced x (fn.BnSrc): its backward column sums are taken in this launch's epilogue when
+        the kernel supports it, and the returned gradient is tagged with them"""
         dev = draw.device
         if sh == 1 and sw == 1:
             # taps in ascending (dh, dw) order = the canonical 3x3 order the Winograd kernel recognises
@@ -384,8 +386,11 @@ def _conv2d_grad(ctx, x, conv, bn, act, slope, residual, geom, dims, Cp, passthr
             Wd = ops.pack_weight(w, Cw, T, O, T, Cw * T, 1, order, Np=Cp, Cp=Np, key=('conv_d', Np, Cp))
             dx = torch.empty((B, H, W, Cp), dtype=torch.float32, device=dev)
             g = (B, Ho, Wo, H, W, 1, 1, dhs, dws, H, W, 1, 1, 0, 0)
-            ops.gather_gemm(draw, Np, Np, T, Wd, Cp, B * H * W, dx, Cp, mode=1, geom=g,
-                            residual=add, ldr=0 if add is None else FN.ld_of(add), flops=2.0 * B * H * W * Cw * T * O)
+            st = ops.gather_gemm(draw, Np, Np, T, Wd, Cp, B * H * W, dx, Cp, mode=1, geom=g,
+                                 residual=add, ldr=0 if add is None else FN.ld_of(add), flops=2.0 * B * H * W * Cw * T * O,
+                                 bn_bwd=bnsrc)
+            if st is not None:
+                dx._efgh_bnsums = (st, bnsrc, dx._version)      # (an in-place accumulation by autograd moves the version on)
             return dx
         assert sh == 2 and sw == 2
         classes = []
@@ -421,6 +426,7 @@ def _conv2d_grad(ctx, x, conv, bn, act, slope, residual, geom, dims, Cp, passthr
                             flops=2.0 * B * Hv * Wv * Cw * len(taps) * O)
         return dx
 
+    dgrad.takes_bnsrc = True
     spec = FN.LayerSpec(O, Cp, T, 1, [(geom, B * Ho * Wo)], B * Ho * Wo, (B, Ho, Wo), pack_fwd, dgrad, unpack,
                         bn=bn, train=ctx.train, act=act, slope=slope, c_real=Cw,
                         passthrough=passthrough and x.requires_grad and x.shape[-1] == Cp, pool=pool)

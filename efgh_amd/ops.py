@@ -323,8 +323,11 @@ def _blur_gemm_ksplit(A, lda, C, Wp, N, M, out, ldo, table, bias, act, slope, a_
 
 def gather_gemm(A, lda, C, T, Wp, N, M, out, ldo, mode=0, geom=None, table=None, bias=None, scale=None,
                 shift=None, residual=None, ldr=0, act=ACT_NONE, slope=0.0, stats=None, a_off=0, out_off=0,
-                res_off=0, M_dev=None, flops=None, batch=None, alias_mask=False):
-    """See efgh_gemm_desc.  A/out/residual may be addressed with an element offset (channel slices)."""
+                res_off=0, M_dev=None, flops=None, batch=None, alias_mask=False, bn_bwd=None):
+    """See efgh_gemm_desc.  A/out/residual may be addressed with an element offset (channel slices).
+    bn_bwd: a BnSrc (nets/fn.py) - the BatchNorm layer that produced the tensor whose GRADIENT this launch writes; when the
+    kernel serving the launch supports it (Winograd F(4,3)) the column sums of that layer's BatchNorm backward are taken in the
+    epilogue and the [rows][2][N] partials are RETURNED (else None: the layer runs its own reduction pass)."""
     if (KSPLIT_MAX_ROWS and mode == 2 and M <= KSPLIT_MAX_ROWS and T == 15 and N % 4 == 0 and T * C >= 1024 and batch is None
             and scale is None and shift is None and residual is None and stats is None and M_dev is None and MATH == 'f32'
             and (bias is None or bias.numel() == N)):
@@ -332,6 +335,7 @@ def gather_gemm(A, lda, C, T, Wp, N, M, out, ldo, mode=0, geom=None, table=None,
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
+    bn_stats = None
     d = _C.GemmDesc()
     es = 4
     d.A = A.data_ptr() + a_off * es
@@ -368,6 +372,17 @@ def gather_gemm(A, lda, C, T, Wp, N, M, out, ldo, mode=0, geom=None, table=None,
         _wino2d_forward(d, A, a_off, lda, C, N, geom, Wp)
     elif M_dev is None and batch is None and wino_eligible(mode, C, N, geom):
         wino = True
+        if bn_bwd is not None and stats is None and BN_BWD_FUSED and out_off == 0 and bn_bwd.fits(M, N):
+            rows = _L().efgh_wino_grid_m(c_int32(geom[0]), c_int32(geom[1]), c_int32(geom[2]))
+            bn_stats = torch.empty((rows, 2, N), dtype=torch.float32, device=out.device)
+            d.stats, d.stats_mode = bn_stats.data_ptr(), 1
+            d.bn_raw, d.bn_ldraw = bn_bwd.raw.data_ptr(), bn_bwd.raw.stride(-2)
+            if bn_bwd.y is not None:
+                d.bn_y, d.bn_ldy = bn_bwd.y.data_ptr(), bn_bwd.y.stride(-2)
+            else:
+                d.bn_pscale, d.bn_pshift = bn_bwd.psc.data_ptr(), bn_bwd.psh.data_ptr()
+            d.bn_mean, d.bn_invstd = bn_bwd.mean.data_ptr(), bn_bwd.invstd.data_ptr()
+            d.bn_act, d.bn_slope = bn_bwd.act, bn_bwd.slope
         _C.check(_L().efgh_wino_conv3x3(ctypes.byref(d), ptr(wino_weight(Wp, N, C)), _st()))
     elif MATH == 'bf16x3':
         hi, _, lo = split_weight(Wp, 2)
@@ -391,6 +406,7 @@ def gather_gemm(A, lda, C, T, Wp, N, M, out, ldo, mode=0, geom=None, table=None,
             PROFILE_WINO2D.append(rec)
         else:
             (PROFILE_WINO if (wino and PROFILE_WINO is not None) else PROFILE).append(rec)
+    return bn_stats
 
 
 PROFILE_WINO2D = None           # bench.py: whole 2-D Winograd layers (three launches), direct-form FLOPs
@@ -601,6 +617,25 @@ def neighbor_gather_adjoint(lv, src, C):
                                                    _C.c_void_p(lv.info.data_ptr() + 4 * INFO_ALIAS), c_int32(ALIAS_CAP), ptr(dst),
                                                    _st()))
     return dst
+
+
+# BatchNorm-backward column sums in the epilogue of the Winograd dgrad that produces dy (saves the reduction pass's read of dy).
+# OPT-IN: measured on a batch-8 training step it LOSES 3 ms (317.0 vs 313.7 ms on four streams, 348.0 vs 345.2 on one): the
+# epilogue's 64 extra 4-byte loads per thread of the producer's raw output sit at the end of the kernel, behind the MFMA loop, and
+# cost k_wino43 more than the 1-GB read the reduction pass no longer does.
+BN_BWD_FUSED = _os.environ.get('EFGH_BN_BWD_FUSED', '0') == '1'
+
+
+def bwd_finalize_f32(stats, C, count):
+    """fold of the [rows][2][C] partials of a stats_mode-1 launch -> (sum_dpre, sum_dpre_xhat) float, (mean, mean) double"""
+    dev = stats.device
+    s1 = torch.empty(C, dtype=torch.float32, device=dev)
+    s2 = torch.empty(C, dtype=torch.float32, device=dev)
+    m1 = torch.empty(C, dtype=torch.float64, device=dev)
+    m2 = torch.empty(C, dtype=torch.float64, device=dev)
+    _C.check(_L().efgh_bwd_finalize_f32(ptr(stats), c_int32(stats.shape[0]), c_int32(C), ctypes.c_double(count), ptr(s1), ptr(s2),
+                                        ptr(m1), ptr(m2), _st()))
+    return s1, s2, m1, m2
 
 
 BLUR_DGRAD_FUSED = _os.environ.get('EFGH_BLUR_DGRAD_FUSED', '1') != '0'

@@ -195,9 +195,24 @@ typedef struct {
      * + convolution is this same gather-GEMM on the gradient with tap-mirrored weights (no [H][15 C] intermediate); the aliased
      * hits are added by efgh_blur_dgrad_alias. */
     int32_t table_alias_mask;
+    /* stats_mode 1 (honoured by efgh_wino_conv3x3): `stats` [rows][2][N] receives, instead of the forward statistics, the two
+     * column sums the BatchNorm backward of the PRODUCER of A's gradient needs of the value this launch writes (a data gradient,
+     * after the residual add):   sum g   and   sum g * (bn_raw - bn_mean) * bn_invstd,
+     *     g = out * act'(bn_y ? bn_y : bn_raw * bn_pscale + bn_pshift)
+     * where bn_raw / bn_y are the producer layer's raw convolution output / activation at the rows and columns of `out`.
+     * efgh_bwd_finalize_f32 folds the rows (in float64); the layer's own reduction pass over dy and raw is then not needed. */
+    int32_t stats_mode;
+    const float *bn_raw; int64_t bn_ldraw;
+    const float *bn_y; int64_t bn_ldy;
+    const float *bn_pscale, *bn_pshift, *bn_mean, *bn_invstd;
+    int32_t bn_act; float bn_slope;
 } efgh_gemm_desc;
 
 int efgh_gather_gemm(const efgh_gemm_desc *d, void *stream);
+/* fold of the stats_mode-1 rows: sum_dpre [C], sum_dpre_xhat [C] (float) and their means over `count` rows (double) - what
+ * efgh_act_bn_bwd_reduce returns */
+int efgh_bwd_finalize_f32(const float *stats, int32_t rows, int32_t C, double count, float *sum_dpre, float *sum_dpre_xhat,
+                          double *mean_dpre, double *mean_dpre_xhat, void *stream);
 int32_t efgh_gather_gemm_grid_m(int64_t M, int32_t N);      /* rows of `stats` */
 
 /* Wp[n][t][c] = W[n*sn + c*sc + tapidx[t]*st]   (weight re-layout for the kernel above) */

@@ -438,3 +438,45 @@ def test_repack_is_ordered_before_the_stream_fork(manifest):
         ops.DETERMINISTIC, bb.SIDE_STREAM = old
     assert la == lb, (la, lb)
     assert torch.equal(wa, wb)
+
+
+def test_bn_backward_sums_in_the_dgrad_epilogue_match_the_reduction_pass(manifest):
+    """opt-in EFGH_BN_BWD_FUSED: the Winograd dgrad that produces a BatchNorm layer's dy also takes that layer's two backward
+    column sums (per row block in fp32, folded in float64) and the layer skips its reduction pass - same gradients as the default
+    path to rounding, and the tag really is consumed (fewer reduction launches)"""
+    from efgh_amd import ops
+    from efgh_amd.losses import EFGHCriterion
+    from efgh_amd.nets import EFGHBackbone
+    args = syn.default_args(RAW, 'cuda')
+    m = EFGHBackbone(args)
+    m.load_state_dict(syn.synthetic_state_dict(manifest['state_dict'], 1))
+    m = m.cuda().train()
+    crit = EFGHCriterion(args)
+    b = syn.make_batch(RAW, NPTS, 2)
+    inp = [torch.from_numpy(b[k]).cuda().float() for k in ('pc', 'img', 'calib', 'A')]
+    gt = {k: torch.from_numpy(v).cuda() for k, v in b['gt'].items()}
+    calls = []
+    real = ops.act_bn_bwd_reduce
+
+    def counting(*a, **k):
+        calls.append(1)
+        return real(*a, **k)
+
+    def grads(flag):
+        old = ops.BN_BWD_FUSED
+        ops.BN_BWD_FUSED = flag
+        ops.act_bn_bwd_reduce = counting
+        del calls[:]
+        try:
+            m.zero_grad(set_to_none=True)
+            L, _ = crit.compute_loss(*inp, dict(gt), m(*inp))
+            L['total'].backward()
+        finally:
+            ops.BN_BWD_FUSED, ops.act_bn_bwd_reduce = old, real
+        return {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}, len(calls)
+    ga, na = grads(False)
+    gb, nb = grads(True)
+    assert nb < na - 4, (na, nb)
+    num = sum(float((ga[k] - gb[k]).double().pow(2).sum()) for k in ga if k.startswith(('G.', 'H.')))
+    den = sum(float(ga[k].double().pow(2).sum()) for k in ga if k.startswith(('G.', 'H.')))
+    assert (num / den) ** 0.5 < 1e-4, (num / den) ** 0.5
