@@ -667,6 +667,7 @@ struct LatPart {                    // workspace of the partitioned build
     int nb, bb, S, sb, maxe;        // buckets = 1 << bb, slots per bucket = 1 << sb, entries per bucket
     int ntiles, tp;                 // tiles (capacity), points per tile
     int fb;                         // bits of a flat position (4 n_cap <= 1 << fb); a key integer must fit the other 64 - fb
+    int want_off;                   // 0: lattice_offset is not needed (inference: the splat walks the vertex lists) - where / larr / cumul stay unwritten
 };
 
 __device__ __forceinline__ int part_bucket(uint64_t mixed, int bb) { return (int)(mixed >> (64 - bb)); }
@@ -889,15 +890,38 @@ k_lat_scatter(const float *__restrict__ pts, int64_t cstride, const int *__restr
                 win[cnt[bk] + (int)(br[j][rem] & 0x3FFFu)] = (ki[j][rem] << P.fb) | (unsigned long long)(4u * (unsigned)p + rem);
                 wv[rem] = br[j][rem];
             }
-            reinterpret_cast<uint4 *>(P.where)[p] = w4;
+            if (P.want_off) reinterpret_cast<uint4 *>(P.where)[p] = w4;
         }
     }
 }
 
 // ---- one workgroup per bucket: gather its runs into LDS, group the entries by key there.  Nothing is carried in registers
 // across the phases (the kernel is a chain of dependent LDS / memory round trips: what hides them is workgroups per CU).
-template <int MAXE>
-__global__ void __launch_bounds__(TPB)
+template <int NT>
+__device__ __forceinline__ int2 block_exclusive_scan2_n(int2 v, int2 *total) {
+    __shared__ int2 wsum2_n[NT / 64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int2 x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int y0 = __shfl_up(x.x, o), y1 = __shfl_up(x.y, o);
+        if (lane >= o) { x.x += y0; x.y += y1; }
+    }
+    if (lane == 63) wsum2_n[w] = x;
+    __syncthreads();
+    int2 base = make_int2(0, 0), tot = make_int2(0, 0);
+#pragma unroll
+    for (int i = 0; i < NT / 64; ++i) {
+        if (i < w) { base.x += wsum2_n[i].x; base.y += wsum2_n[i].y; }
+        tot.x += wsum2_n[i].x; tot.y += wsum2_n[i].y;
+    }
+    __syncthreads();
+    *total = tot;
+    return make_int2(base.x + x.x - v.x, base.y + x.y - v.y);
+}
+
+template <int MAXE, int BT>
+__global__ void __launch_bounds__(BT)
 k_lat_bucket(LatPart P, const int *__restrict__ n_dev, int n_cap, int *__restrict__ list, int *__restrict__ info) {
     extern __shared__ unsigned char smem_[];
     const int S = P.S;
@@ -917,13 +941,13 @@ k_lat_bucket(LatPart P, const int *__restrict__ n_dev, int n_cap, int *__restric
     const int b = blockIdx.x;
     const int n = n_of(n_dev, n_cap);
     const int ntl = (n + P.tp - 1) / P.tp;                                        // tiles that hold points
-    for (int s = threadIdx.x; s < S; s += TPB) { tkey[s] = EMPTY; tcnt[s] = 0; }
-    for (int i = threadIdx.x; i < MAXE; i += TPB) rid[i] = 0;
+    for (int s = threadIdx.x; s < S; s += BT) { tkey[s] = EMPTY; tcnt[s] = 0; }
+    for (int i = threadIdx.x; i < MAXE; i += BT) rid[i] = 0;
     __syncthreads();
     int m;
     {
         const int te = 4 * P.tp;
-        constexpr int PER = NTMAX / TPB;
+        constexpr int PER = NTMAX / BT;
         int c[PER], mine = 0;
 #pragma unroll
         for (int q = 0; q < PER; ++q) {
@@ -938,13 +962,13 @@ k_lat_bucket(LatPart P, const int *__restrict__ n_dev, int n_cap, int *__restric
             mine += c[q];
         }
         int tot;
-        int ex = block_exclusive_scan(mine, &tot);
+        int ex = block_exclusive_scan_n<BT>(mine, &tot);
 #pragma unroll
         for (int q = 0; q < PER; ++q) {
             const int t = threadIdx.x * PER + q;
             if (t < ntl) {
                 runpre[t] = ex;
-                P.cumul[(int64_t)b * P.ntiles + t] = ex;
+                if (P.want_off) P.cumul[(int64_t)b * P.ntiles + t] = ex;
                 if (c[q] > 0 && ex < MAXE) rid[ex] = (unsigned short)t;           // head of a non-empty run
             }
             ex += c[q];
@@ -958,7 +982,7 @@ k_lat_bucket(LatPart P, const int *__restrict__ n_dev, int n_cap, int *__restric
     __syncthreads();
     // run of every arrival position: running maximum of the head marks (runs are laid out in tile order)
     {
-        constexpr int PT = MAXE / TPB;
+        constexpr int PT = MAXE / BT;
         const int i0 = threadIdx.x * PT;
         int v[PT], mx = 0;
 #pragma unroll
@@ -967,35 +991,35 @@ k_lat_bucket(LatPart P, const int *__restrict__ n_dev, int n_cap, int *__restric
         int x = mx;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o); if (lane >= o) x = max(x, y); }
-        __shared__ int wmax[TPB / 64];
+        __shared__ int wmax[BT / 64];
         if (lane == 63) wmax[w] = x;
         __syncthreads();
         int before = __shfl_up(x, 1);
         if (lane == 0) before = 0;
 #pragma unroll
-        for (int q = 0; q < TPB / 64; ++q) if (q < w) before = max(before, wmax[q]);
+        for (int q = 0; q < BT / 64; ++q) if (q < w) before = max(before, wmax[q]);
 #pragma unroll
         for (int k = 0; k < PT; ++k) rid[i0 + k] = (unsigned short)max(v[k], before);
     }
     __syncthreads();
-    for (int i0 = 0; i0 < m; i0 += 4 * TPB) {
+    for (int i0 = 0; i0 < m; i0 += 4 * BT) {
         unsigned long long wd[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int i = i0 + u * TPB + threadIdx.x;
+            const int i = i0 + u * BT + threadIdx.x;
             wd[u] = 0ULL;
             if (i < m) { const int t = rid[i]; wd[u] = P.ent[runsrc[t] + (i - runpre[t])]; }
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int i = i0 + u * TPB + threadIdx.x;
+            const int i = i0 + u * BT + threadIdx.x;
             if (i < m) stage[i] = wd[u];
         }
     }
     __syncthreads();
     bool full = false;
     const unsigned long long fmask = (1ULL << P.fb) - 1ULL;
-    for (int i = threadIdx.x; i < m; i += TPB) {
+    for (int i = threadIdx.x; i < m; i += BT) {
         const unsigned long long wd = stage[i];
         const unsigned long long key = wd >> P.fb;
         int s = part_slot(mix64(key), P.bb, P.sb);
@@ -1013,12 +1037,12 @@ k_lat_bucket(LatPart P, const int *__restrict__ n_dev, int n_cap, int *__restric
     __syncthreads();
     // segments: exclusive scan of the slot counts (and of the occupied flags: the bucket-local vertex numbers)
     {
-        const int per = (S + TPB - 1) / TPB;
+        const int per = (S + BT - 1) / BT;
         const int s0 = threadIdx.x * per;
         int2 mine = make_int2(0, 0);
         for (int q = 0; q < per; ++q) if (s0 + q < S) { const int c = tcnt[s0 + q]; mine.x += c; mine.y += c > 0; }
         int2 tot;
-        int2 ex = block_exclusive_scan2(mine, &tot);
+        int2 ex = block_exclusive_scan2_n<BT>(mine, &tot);
         for (int q = 0; q < per; ++q) if (s0 + q < S) {
             const int c = tcnt[s0 + q];
             tstart[s0 + q] = ex.x; tgid[s0 + q] = ex.y;
@@ -1028,21 +1052,21 @@ k_lat_bucket(LatPart P, const int *__restrict__ n_dev, int n_cap, int *__restric
     }
     __syncthreads();
     unsigned short *larr = P.larr + (int64_t)b * MAXE;
-    for (int i = threadIdx.x; i < m; i += TPB) {
+    for (int i = threadIdx.x; i < m; i += BT) {
         const unsigned long long v = stage[i];
         const unsigned sr = (unsigned)(v >> 32);
         const int s = (int)(sr >> 16);
         const int pos = tstart[s] + (int)(sr & 0xFFFFu);
         lst[pos] = (int)(unsigned)v;
         lslot[pos] = (unsigned short)s;
-        larr[i] = (unsigned short)tgid[s];
+        if (P.want_off) larr[i] = (unsigned short)tgid[s];
     }
     __syncthreads();
     // place of every entry inside its vertex's list = number of smaller flat positions there (positions are distinct); the head of
     // the list is the vertex's first-seen entry.  Neighbouring threads hold neighbouring list positions, i.e. mostly the same
     // vertex: the LDS reads of the count loop are broadcasts.
     int *glist = list + (int64_t)b * MAXE;
-    for (int q = threadIdx.x; q < m; q += TPB) {
+    for (int q = threadIdx.x; q < m; q += BT) {
         const int s = lslot[q];
         const int st = tstart[s], c = tcnt[s];
         const int me = lst[q];
@@ -1055,7 +1079,7 @@ k_lat_bucket(LatPart P, const int *__restrict__ n_dev, int n_cap, int *__restric
         }
     }
     int4 *tab = P.table + (int64_t)b * S;
-    for (int s = threadIdx.x; s < S; s += TPB) {
+    for (int s = threadIdx.x; s < S; s += BT) {
         const unsigned long long k = tkey[s];
         tab[s] = make_int4((int)(unsigned)k, (int)(unsigned)(k >> 32), -1, 0);
     }
@@ -1413,8 +1437,9 @@ bool part_args_ok(int32_t n_cap, int32_t nb, int32_t S) {
            cdiv(n_cap, STP * part_ppt(n_cap)) <= NTMAX;
 }
 
-LatPart part_ptrs(char *ws, char *zeroed, const PartLayout &w, int32_t n_cap, int nb, int S) {
+LatPart part_ptrs(char *ws, char *zeroed, const PartLayout &w, int32_t n_cap, int nb, int S, int want_off = 1) {
     LatPart P;
+    P.want_off = want_off;
     P.ent = (unsigned long long *)(ws + w.ent);
     P.toff = (int *)(ws + w.toff);
     P.cumul = (int *)(ws + w.cumul);
@@ -1444,6 +1469,8 @@ float part_std32() {
 
 }  // namespace
 
+static int g_bucket_threads = 256;
+extern "C" void efgh_lattice_part_tune(int32_t bucket_threads) { g_bucket_threads = bucket_threads; }
 extern "C" int32_t efgh_lattice_part_max_entries(int32_t n_cap) { return part_maxe(n_cap); }
 
 extern "C" int32_t efgh_lattice_part_buckets(int32_t n_cap) {
@@ -1468,7 +1495,7 @@ extern "C" int64_t efgh_lattice_part_zeroed_bytes(int32_t n_cap) {
 extern "C" int efgh_lattice_part_build(const float *pts, int64_t pts_cstride, const int32_t *n_dev, int32_t n_cap,
                                        const int32_t *sid, int32_t pts_per_sample, int32_t nsamples, float scale32,
                                        float *bary, float *emg, int32_t *list, int32_t h_cap, int32_t *info, void *workspace,
-                                       void *zeroed, int32_t nbuckets, int32_t slots, void *stream_) {
+                                       void *zeroed, int32_t nbuckets, int32_t slots, int32_t want_off, void *stream_) {
     hipStream_t st = (hipStream_t)stream_;
     EFGH_CHECK_ARG(n_cap > 0 && n_cap < (1 << 27) && h_cap > 0 && nsamples >= 1 && nsamples <= EFGH_LATTICE_MAX_SAMPLES);
     EFGH_CHECK_ARG(sid || pts_per_sample > 0);
@@ -1476,7 +1503,7 @@ extern "C" int efgh_lattice_part_build(const float *pts, int64_t pts_cstride, co
     EFGH_CHECK_ARG(part_args_ok(n_cap, nbuckets, slots));
     const PartLayout w = part_layout(n_cap, h_cap, nsamples, nbuckets, slots);
     char *ws = (char *)workspace;
-    const LatPart P = part_ptrs(ws, (char *)zeroed, w, n_cap, nbuckets, slots);
+    const LatPart P = part_ptrs(ws, (char *)zeroed, w, n_cap, nbuckets, slots, want_off ? 1 : 0);
     int *mm = (int *)(ws + w.mm), *part = (int *)(ws + w.part);
     const float std32 = part_std32();
     const int nbp = cdiv(n_cap, TPB);
@@ -1487,10 +1514,12 @@ extern "C" int efgh_lattice_part_build(const float *pts, int64_t pts_cstride, co
         k_lat_scatter<8><<<w.ntiles, STP, 0, st>>>(pts, pts_cstride, n_dev, n_cap, scale32, std32, mm, sid, pps, nsamples, P, info);
     else
         k_lat_scatter<2><<<w.ntiles, STP, 0, st>>>(pts, pts_cstride, n_dev, n_cap, scale32, std32, mm, sid, pps, nsamples, P, info);
-    if (P.maxe == 2048)
-        k_lat_bucket<2048><<<nbuckets, TPB, (size_t)slots * 20 + (size_t)2048 * 14, st>>>(P, n_dev, n_cap, list, info);
+    if (P.maxe == 2048 && g_bucket_threads == 512)
+        k_lat_bucket<2048, 512><<<nbuckets, 512, (size_t)slots * 20 + (size_t)2048 * 14, st>>>(P, n_dev, n_cap, list, info);
+    else if (P.maxe == 2048)
+        k_lat_bucket<2048, 256><<<nbuckets, 256, (size_t)slots * 20 + (size_t)2048 * 14, st>>>(P, n_dev, n_cap, list, info);
     else
-        k_lat_bucket<4096><<<nbuckets, TPB, (size_t)slots * 20 + (size_t)4096 * 14, st>>>(P, n_dev, n_cap, list, info);
+        k_lat_bucket<4096, 512><<<nbuckets, 512, (size_t)slots * 20 + (size_t)4096 * 14, st>>>(P, n_dev, n_cap, list, info);
     k_lat_rank<<<w.nblk, TPB, 0, st>>>(P, w.W, info, h_cap);
     k_lat_number<<<cdiv((int64_t)nbuckets * slots, TPB), TPB, 0, st>>>(P, h_cap);
     EFGH_CHECK_LAUNCH();
@@ -1503,7 +1532,7 @@ extern "C" int efgh_lattice_part_neighbors(const void *workspace, const float *p
                                            int32_t *nbr, int32_t *alist, int32_t alias_cap, int32_t *off, int32_t *vseg,
                                            float *pts_next, int32_t *vsid, int32_t nbuckets, int32_t slots, void *stream_) {
     hipStream_t st = (hipStream_t)stream_;
-    EFGH_CHECK_ARG(workspace && pts && info && vsid && nbr && alist && off && vseg && pts_next && n_cap > 0 && h_cap > 0 &&
+    EFGH_CHECK_ARG(workspace && pts && info && vsid && nbr && alist && vseg && pts_next && n_cap > 0 && h_cap > 0 &&
                    h_cap <= h_cap_build && alias_cap > 0 && (sid || pts_per_sample > 0));
     EFGH_CHECK_ARG(part_args_ok(n_cap, nbuckets, slots));
     const PartLayout w = part_layout(n_cap, h_cap_build, nsamples, nbuckets, slots);
@@ -1514,7 +1543,7 @@ extern "C" int efgh_lattice_part_neighbors(const void *workspace, const float *p
     G.pps = sid ? 1 : pts_per_sample;
     int gn = cdiv((int64_t)h_cap * 16, TPB);
     if (gn > 8192) gn = 8192;
-    const int go = cdiv(n_cap, TPB);
+    const int go = off ? cdiv(n_cap, TPB) : 0;       // (off == NULL: the build was told want_off = 0)
     int gv = cdiv(h_cap, TPB);
     if (gv > 2048) gv = 2048;
     k_lat_nbr<<<gn + go + gv, TPB, 0, st>>>(P, G, (const int *)(ws + w.mm), info, h_cap, nbr, nsamples, (int2 *)alist, alias_cap, gn, go,

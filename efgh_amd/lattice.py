@@ -45,6 +45,8 @@ class LatticeLevel:
 
     @property
     def off(self):
+        if self.off_pm is None:
+            raise _C.EfghError('this lattice was built with need_off=False (inference): lattice_offset was not produced')
         return self.off_pm[:self.n_in].t()
 
     @property
@@ -98,14 +100,14 @@ def _ctrl_bytes(L, n_cap, B, mode):
     return info_b, (L.efgh_lattice_part_zeroed_bytes(_C.c_int32(n_cap)) if mode[0] == 'part' else 0)
 
 
-def _level_arrays(L, dev, n_cap, h_cap, B, mode=('hash', 0), ctrl=None):
+def _level_arrays(L, dev, n_cap, h_cap, B, mode=('hash', 0), ctrl=None, need_off=True):
     """arrays of one level.  ctrl: a ZEROED uint8 tensor of sum(_ctrl_bytes) bytes (one fill serves all levels of a pyramid);
-    None = allocate and zero one here"""
+    None = allocate and zero one here.  need_off=False (partitioned build only): lattice_offset is not produced"""
     lv = LatticeLevel()
     lv._mode = mode
     lv.bary_pm = torch.empty((n_cap, 4), dtype=torch.float32, device=dev)
     lv.emg_pm = torch.empty((n_cap, 4), dtype=torch.float32, device=dev)
-    lv.off_pm = torch.empty((n_cap, 4), dtype=torch.int32, device=dev)
+    lv.off_pm = torch.empty((n_cap, 4), dtype=torch.int32, device=dev) if (need_off or mode[0] != 'part') else None
     if mode[0] == 'part':       # every bucket owns a fixed window of the list array
         lv.list = torch.empty(mode[1] * L.efgh_lattice_part_max_entries(_C.c_int32(n_cap)), dtype=torch.int32, device=dev)
         ws_bytes = L.efgh_lattice_part_workspace_bytes(n_cap, h_cap, B, mode[1], mode[2])
@@ -134,7 +136,7 @@ def _launch_build(L, lv, pts, cstride, n_dev, sid, pps, B, s, st):
     if lv._mode[0] == 'part':
         _C.check(L.efgh_lattice_part_build(*head, _C.ptr(lv.bary_pm), _C.ptr(lv.emg_pm), _C.ptr(lv.list), _C.c_int32(h_cap),
                                            _C.ptr(lv.info), _C.ptr(lv._ws), _C.ptr(lv._zeroed), _C.c_int32(lv._mode[1]),
-                                           _C.c_int32(lv._mode[2]), st))
+                                           _C.c_int32(lv._mode[2]), _C.c_int32(0 if lv.off_pm is None else 1), st))
     else:
         _C.check(L.efgh_lattice_level_build(*head, _C.c_float(np.float32(EXPECTED_STD * s)), _C.ptr(lv.bary_pm), _C.ptr(lv.emg_pm),
                                             _C.ptr(lv.off_pm), _C.ptr(lv.list), _C.c_int32(h_cap), _C.ptr(lv.vseg),
@@ -170,8 +172,9 @@ def _finish(lv, host, n_in, seg_in, B):
         lv.nbr = lv.nbr[:H]
 
 
-def build_pyramid_batched(pc, scales):
-    """pc: (B,3,N) fp32 CUDA tensor -> list of LatticeLevel (one per scale)."""
+def build_pyramid_batched(pc, scales, need_off=True):
+    """pc: (B,3,N) fp32 CUDA tensor -> list of LatticeLevel (one per scale).  need_off=False: lattice_offset (`off`) is left out -
+    the splat walks the vertex lists, only its backward reads `off` (inference saves a gather pass and three arrays per level)."""
     _C.require_cuda(pc)
     L = _C.lib()
     dev = pc.device
@@ -201,7 +204,7 @@ def build_pyramid_batched(pc, scales):
         ctrl = torch.zeros(sum(a + b for a, b in sizes), dtype=torch.uint8, device=dev)
         coff = 0
         for s, (n_cap, h_cap, mode), (ib, zb) in zip(scales, caps, sizes):
-            lv = _level_arrays(L, dev, n_cap, h_cap, B, mode, ctrl[coff:coff + ib + zb])
+            lv = _level_arrays(L, dev, n_cap, h_cap, B, mode, ctrl[coff:coff + ib + zb], need_off)
             coff += ib + zb
             _launch_build(L, lv, pts, cstride, n_dev, sid, N, B, s, st)
             _launch_neighbors(L, lv, B, h_cap, st)
@@ -222,7 +225,7 @@ def build_pyramid_batched(pc, scales):
         seg_in = [b * N for b in range(B + 1)]
         for s in scales:
             for mode in (_plan(L, n, None), ('hash', 0)):
-                lv = _level_arrays(L, dev, n, 4 * n, B, mode)
+                lv = _level_arrays(L, dev, n, 4 * n, B, mode, None, need_off)
                 _launch_build(L, lv, pts, cstride, None, sid, N, B, s, st)
                 head = lv.info[:2].tolist()           # host sync (sizes the next level)
                 if not head[INFO_ERR] & 4 or mode == ('hash', 0):

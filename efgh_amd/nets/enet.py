@@ -47,7 +47,7 @@ class Enet(nn.Module):
         cins = [m.num_input for m in bcns]
         # all samples in one launch sequence per level, all five levels enqueued before the one read-back of their sizes
         # (every sample keeps its own lattice)
-        lv = lattice.build_pyramid_batched(pc, scales)
+        lv = lattice.build_pyramid_batched(pc, scales, need_off=ctx.grad or keep is not None)      # (`off` serves the splat's backward only)
         if keep is not None:
             keep['lattice'] = lv
         # conv_in on [B*N][4] (x,y,z,0)

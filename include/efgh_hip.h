@@ -112,9 +112,11 @@ int64_t efgh_lattice_part_zeroed_bytes(int32_t n_cap);
 int efgh_lattice_part_build(const float *pts, int64_t pts_cstride, const int32_t *n_dev, int32_t n_cap,
                             const int32_t *sid, int32_t pts_per_sample, int32_t nsamples, float scale32,
                             float *bary, float *emg, int32_t *list, int32_t h_cap, int32_t *info, void *workspace,
-                            void *zeroed, int32_t nbuckets, int32_t slots, void *stream);
+                            void *zeroed, int32_t nbuckets, int32_t slots, int32_t want_off, void *stream);
 /* one launch: nbr + alist (as efgh_lattice_level_neighbors), off, and the vertex records vseg / pts_next / vsid / info[SEG..]
- * (pts ... div32 as passed to the build; pts_next has h_cap_build columns) */
+ * (pts ... div32 as passed to the build; pts_next has h_cap_build columns).  want_off = 0 in the build and off = NULL here skip
+ * lattice_offset and the three arrays that only serve it (inference: the splat walks the vertex lists; off is needed by the
+ * splat's backward). */
 int efgh_lattice_part_neighbors(const void *workspace, const float *pts, int64_t pts_cstride, const int32_t *n_dev,
                                 int32_t n_cap, const int32_t *sid, int32_t pts_per_sample, int32_t nsamples,
                                 float scale32, float div32, int32_t h_cap_build, int32_t *info, int32_t h_cap,

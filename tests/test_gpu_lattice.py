@@ -216,3 +216,23 @@ def test_partitioned_build_overflow_is_flagged_not_fatal():
         for d, r in zip(lv, ref):
             assert d.H == r['H'] and np.array_equal(d.off.cpu().numpy().astype(np.int64), r['off'])
             assert np.array_equal(d.nbr.cpu().numpy()[:, :15].T.astype(np.int64), r['nbr'])
+
+
+def test_inference_build_without_lattice_offset():
+    """need_off=False (what the eval forward asks for): everything but `off` is produced and identical; asking for `off` is an
+    error, not garbage"""
+    from efgh_amd import _C, lattice
+    pc = torch.from_numpy(np.stack([syn.lidar_sweep(4096, 0), syn.lidar_sweep(4096, 7)])).cuda()
+    lattice._SIZES.clear()
+    for _ in range(2):                                             # level by level, then speculative
+        a = lattice.build_pyramid_batched(pc, SCALES)
+        b = lattice.build_pyramid_batched(pc, SCALES, need_off=False)
+        for u, v in zip(a, b):
+            assert u.H == v.H and u.seg == v.seg and v.off_pm is None
+            assert torch.equal(u.nbr, v.nbr) and torch.equal(u.bary, v.bary) and torch.equal(u.pts_next, v.pts_next)
+            assert torch.equal(u.vseg[:u.H, 1], v.vseg[:v.H, 1])
+            for h in (0, u.H // 2, u.H - 1):
+                su, sv = u.vseg[h].tolist(), v.vseg[h].tolist()
+                assert torch.equal(u.list[su[0]:su[0] + su[1]], v.list[sv[0]:sv[0] + sv[1]])
+            with pytest.raises(_C.EfghError):
+                v.off

@@ -8,7 +8,7 @@ import collections, csv, glob, json, sys
 
 FAMILIES = {
     'gemm': ['k_gather_gemm<1,', 'k_gather_gemm<2,', 'k_gather_gemm<3,', 'k_gather_gemm<0, 256', 'k_gather_gemm<0, 128, 64'],
-    'wino': ['k_wino43('],
+    'wino': ['k_wino43<'],
     'wgrad': ['k_gather_wgrad<1,', 'k_gather_wgrad<2,', 'k_gather_wgrad<0, 64'],
     'wino_wgrad': ['k_wino_wgrad('],
     'wino2d_gemm': ['k_gather_gemm<0, 128, 128', 'k_gather_wgrad<0, 128'],
