@@ -620,9 +620,9 @@ def neighbor_gather_adjoint(lv, src, C):
 
 
 # BatchNorm-backward column sums in the epilogue of the Winograd dgrad that produces dy (saves the reduction pass's read of dy).
-# OPT-IN: measured on a batch-8 training step it LOSES 3 ms (317.0 vs 313.7 ms on four streams, 348.0 vs 345.2 on one): the
-# epilogue's 64 extra 4-byte loads per thread of the producer's raw output sit at the end of the kernel, behind the MFMA loop, and
-# cost k_wino43 more than the 1-GB read the reduction pass no longer does.
+# OPT-IN: measured on a batch-8 training step it LOSES 6 ms (313.8 vs 307.8 ms, same box, alternating runs): the epilogue's 64
+# extra 4-byte loads per thread of the producer's raw output sit at the end of the kernel, behind the MFMA loop, and cost
+# k_wino43<true> more than the 1-GB read the reduction pass no longer does.
 BN_BWD_FUSED = _os.environ.get('EFGH_BN_BWD_FUSED', '0') == '1'
 
 
