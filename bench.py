@@ -199,8 +199,9 @@ def rooflines(prof, steps, workload='train'):
             a = parts.setdefault(what, [0.0, 0.0])
             a[0] += e0.elapsed_time(e1); a[1] += b
         out['roofline_bcl'] = {'bound': 'hbm', 'kernel': 'BCL index + splat pipeline, all five levels and all samples of the batch: '
-                               'lattice build (keys, hash, first-seen numbering, neighbours, vertex lists) and splat gather'
-                               + (' + splat / neighbour-gather adjoints' if any(k.endswith('bwd') for k in parts) else ''),
+                               'lattice build (keys, tile-local bucket sort, per-bucket grouping in LDS, first-seen numbering, '
+                               'neighbours, vertex lists) and splat gather'
+                               + (' + splat adjoint' if any(k.endswith('bwd') for k in parts) else ''),
                                'achieved': ach, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': ach / PEAK_HBM_GBS,
                                'traffic': committed_traffic('bcl', workload),
                                'traffic_unit': 'HBM-side bytes per STEP, all lattice.hip + bcl.hip launches (profiles/r03_hbm_traffic_*.json)',

@@ -1518,8 +1518,19 @@ extern "C" int efgh_lattice_part_build(const float *pts, int64_t pts_cstride, co
         k_lat_bucket<2048, 512><<<nbuckets, 512, (size_t)slots * 20 + (size_t)2048 * 14, st>>>(P, n_dev, n_cap, list, info);
     else if (P.maxe == 2048)
         k_lat_bucket<2048, 256><<<nbuckets, 256, (size_t)slots * 20 + (size_t)2048 * 14, st>>>(P, n_dev, n_cap, list, info);
-    else
-        k_lat_bucket<4096, 512><<<nbuckets, 512, (size_t)slots * 20 + (size_t)4096 * 14, st>>>(P, n_dev, n_cap, list, info);
+    else {
+        const size_t lds = (size_t)slots * 20 + (size_t)4096 * 14;          // up to 98 KB: above the 64 KB a launch gets by default
+        static bool raised = false;
+        if (!raised) {
+            if (hipFuncSetAttribute((const void *)k_lat_bucket<4096, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 20 * SMAX + 14 * 4096)
+                != hipSuccess) {
+                efgh_set_error("%s:%d: cannot raise the dynamic LDS limit of k_lat_bucket", __FILE__, __LINE__);
+                return EFGH_E_LAUNCH;
+            }
+            raised = true;
+        }
+        k_lat_bucket<4096, 512><<<nbuckets, 512, lds, st>>>(P, n_dev, n_cap, list, info);
+    }
     k_lat_rank<<<w.nblk, TPB, 0, st>>>(P, w.W, info, h_cap);
     k_lat_number<<<cdiv((int64_t)nbuckets * slots, TPB), TPB, 0, st>>>(P, h_cap);
     EFGH_CHECK_LAUNCH();

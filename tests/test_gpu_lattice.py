@@ -163,7 +163,8 @@ def _build_level(pc, mode, scale=1.0):
     return lv, lv.info.cpu().tolist()
 
 
-@pytest.mark.parametrize('B,n,scale', [(1, 1, 1.0), (1, 777, 1.0), (3, 4096, 0.5), (2, 40000, 1.0), (8, 16384, 0.125)])
+@pytest.mark.parametrize('B,n,scale', [(1, 1, 1.0), (1, 777, 1.0), (3, 4096, 0.5), (2, 40000, 1.0), (8, 16384, 0.125),
+                                       (1, 2200000, 1.0)])           # (the last one: 4096-entry buckets, 98 KB of LDS)
 def test_partitioned_build_equals_hash_build(B, n, scale):
     """the two builds of lattice.hip (buckets grouped in LDS vs global hash insert) give the same level: vertex numbering, offsets,
     neighbours + alias marks, next-level points, and the same ascending list per vertex"""

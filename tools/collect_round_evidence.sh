@@ -1,9 +1,9 @@
 #!/bin/bash
 # Collects the rocprofv3 evidence bench.py's roofline fields refer to, on the GPU box (run through gpurun from the repo root):
-#   bash tools/collect_round_evidence.sh r02          -> gpurun_out/evidence_r02/{*.json,*.csv}
+#   bash tools/collect_round_evidence.sh r03          -> gpurun_out/evidence_r03/{*.json,*.csv}
 # Separate passes, as the MI355X guide prescribes: --kernel-trace --stats alone; --pmc passes with --kernel-trace only.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/evidence_$TAG
 SCR=/tmp/efgh_evidence_$$

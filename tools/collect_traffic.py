@@ -13,7 +13,7 @@ FAMILIES = {
     'wino_wgrad': ['k_wino_wgrad('],
     'wino2d_gemm': ['k_gather_gemm<0, 128, 128', 'k_gather_wgrad<0, 128'],
     'wino2d_transforms': ['k_w2_input', 'k_w2_output', 'k_w2_dy'],
-    'bcl': ['k_lat_keys', 'k_lat_minmax', 'k_lat_scatter', 'k_lat_bucket', 'k_lat_rank', 'k_lat_number', 'k_lat_nbr',
+    'bcl': ['k_lat_keys', 'k_lat_minmax', 'k_lat_scatter', 'k_lat_bucket', 'k_lat_rank', 'k_lat_number', 'k_lat_nbr', 'k_blur_dgrad_alias',
             'k_level_init', 'k_point_keys', 'k_minmax_finalize', 'k_insert', 'k_seg_count', 'k_seg_scan', 'k_seg_assign', 'k_place',
             'k_sortmin', 'k_flag_count', 'k_scan_sums', 'k_assign', 'k_offsets', 'k_neighbors', 'k_splat_gather', 'k_splat_bwd',
             'k_table_gather_t', 'k_table_alias_add'],
