@@ -56,6 +56,8 @@ def lib():
         _lib.efgh_lattice_workspace_bytes.argtypes = [c_int32, c_int32, c_int32]
         _lib.efgh_lattice_part_max_entries.argtypes = [c_int32]
         _lib.efgh_lattice_part_buckets.argtypes = [c_int32]
+        _lib.efgh_lattice_part_list_len.restype = c_int64
+        _lib.efgh_lattice_part_list_len.argtypes = [c_int32, c_int32]
         _lib.efgh_lattice_part_zeroed_bytes.restype = c_int64
         _lib.efgh_lattice_part_zeroed_bytes.argtypes = [c_int32]
         _lib.efgh_lattice_part_workspace_bytes.restype = c_int64

@@ -647,6 +647,8 @@ constexpr int SMAX = 2048;          // slots of a bucket's table
 constexpr int NBMAX = 8192;         // buckets (LDS counters of k_lat_scatter)
 constexpr int NTMAX = 1024;         // tiles (LDS run table of k_lat_bucket)
 constexpr int STP = 512;            // threads of k_lat_scatter
+constexpr int MAXE_BIG = 8192;      // entries of a bucket k_lat_bucket_big can hold (152 KB of LDS, 1024 threads)
+constexpr int BIGCAP = 1024;        // such buckets per level
 
 struct LatPart {                    // workspace of the partitioned build
     unsigned long long *ent;        // [ntiles][tile entries]  key integer << fb | flat position, bucket-sorted inside a tile
@@ -655,6 +657,9 @@ struct LatPart {                    // workspace of the partitioned build
     unsigned *where;                // [4 n_cap]         bucket << 14 | rank inside the (tile, bucket) run
     unsigned short *larr;           // [nb][maxe]        bucket-local vertex of arrival position i
     int *cursor;                    // [nb]              entries of bucket b
+    int *wbase;                     // [nb]              first position of bucket b's window in `list` / `larr`
+    int *big;                       // big[0] = buckets with more than maxe entries, big[1] = positions handed out in the overflow area
+    int *biglist;                   // [BIGCAP]          those buckets (k_lat_bucket_big serves them: up to MAXE_BIG entries each)
     int *gcount;                    // [nb]              vertices of bucket b
     int4 *grec;                     // [nb][S]           (slot, start, length, first-seen flat position) of bucket-local vertex g
     int *gvix;                      // [nb][S]           vertex number of bucket-local vertex g
@@ -667,6 +672,7 @@ struct LatPart {                    // workspace of the partitioned build
     int nb, bb, S, sb, maxe;        // buckets = 1 << bb, slots per bucket = 1 << sb, entries per bucket
     int ntiles, tp;                 // tiles (capacity), points per tile
     int fb;                         // bits of a flat position (4 n_cap <= 1 << fb); a key integer must fit the other 64 - fb
+    int use_big;                    // 0: k_lat_bucket_big is not launched - a bucket above maxe entries flags the level instead
     int want_off;                   // 0: lattice_offset is not needed (inference: the splat walks the vertex lists) - where / larr / cumul stay unwritten
 };
 
@@ -920,10 +926,11 @@ __device__ __forceinline__ int2 block_exclusive_scan2_n(int2 v, int2 *total) {
     return make_int2(base.x + x.x - v.x, base.y + x.y - v.y);
 }
 
-template <int MAXE, int BT>
-__global__ void __launch_bounds__(BT)
-k_lat_bucket(LatPart P, const int *__restrict__ n_dev, int n_cap, int *__restrict__ list, int *__restrict__ info) {
-    extern __shared__ unsigned char smem_[];
+template <int MAXE, int BT, bool BIG>
+__device__ __forceinline__ void
+bucket_body(const LatPart &P, const int b, const int *__restrict__ n_dev, int n_cap, int *__restrict__ list, int *__restrict__ info) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_[];   // (64-bit LDS atomics on tkey: the dynamic area must not
+                                                                              //  start at the odd end of the static one)
     const int S = P.S;
     unsigned long long *tkey = reinterpret_cast<unsigned long long *>(smem_);     // [S]
     unsigned long long *stage = tkey + S;                                         // [MAXE] entry words in arrival order; after the insert:
@@ -938,13 +945,12 @@ k_lat_bucket(LatPart P, const int *__restrict__ n_dev, int n_cap, int *__restric
     int *runpre = lst + NTMAX;                                                    // [NTMAX] arrival position of its head
     unsigned short *rid = reinterpret_cast<unsigned short *>(lst + 2 * NTMAX);    // [MAXE]  run of arrival position i
     static_assert(NTMAX * 8 + MAXE * 2 <= MAXE * 6, "run table must fit the list area");
-    const int b = blockIdx.x;
     const int n = n_of(n_dev, n_cap);
     const int ntl = (n + P.tp - 1) / P.tp;                                        // tiles that hold points
     for (int s = threadIdx.x; s < S; s += BT) { tkey[s] = EMPTY; tcnt[s] = 0; }
     for (int i = threadIdx.x; i < MAXE; i += BT) rid[i] = 0;
     __syncthreads();
-    int m;
+    int m, wbase;
     {
         const int te = 4 * P.tp;
         constexpr int PER = NTMAX / BT;
@@ -973,11 +979,31 @@ k_lat_bucket(LatPart P, const int *__restrict__ n_dev, int n_cap, int *__restric
             }
             ex += c[q];
         }
-        if (threadIdx.x == 0) {
-            if (tot > MAXE) atomicOr(&info[EFGH_LATTICE_INFO_ERR], 4);
-            P.cursor[b] = min(tot, MAXE);
+        __shared__ __attribute__((aligned(16))) int wb_s4[4];
+        int &wb_s = wb_s4[0];
+        if (tot > MAXE) {
+            // more entries than this kernel's LDS holds (a lattice cell near the sensor of a real sweep collects thousands of
+            // points): the bucket is handed to k_lat_bucket_big - or, beyond that kernel's capacity, flagged for the hash build
+            if (threadIdx.x == 0) {
+                P.cursor[b] = 0; P.gcount[b] = 0; P.wbase[b] = 0;
+                bool listed = false;
+                if (!BIG && P.use_big) {
+                    const int k = atomicAdd(&P.big[0], 1);
+                    if (k < BIGCAP) { P.biglist[k] = b; listed = true; }
+                }
+                if (!listed) atomicOr(&info[EFGH_LATTICE_INFO_ERR], 4);
+            }
+            return;
         }
-        m = min(tot, MAXE);
+        if (threadIdx.x == 0) {
+            // normal buckets own window b of the list; the big ones are packed behind those windows
+            wb_s = BIG ? P.nb * P.maxe + atomicAdd(&P.big[1], tot) : b * MAXE;
+            P.cursor[b] = tot;
+            P.wbase[b] = wb_s;
+        }
+        m = tot;
+        __syncthreads();
+        wbase = wb_s;
     }
     __syncthreads();
     // run of every arrival position: running maximum of the head marks (runs are laid out in tile order)
@@ -1017,6 +1043,9 @@ k_lat_bucket(LatPart P, const int *__restrict__ n_dev, int n_cap, int *__restric
         }
     }
     __syncthreads();
+    constexpr int LONGL = 256, WGL = 1024;            // list lengths: counting sort up to LONGL, one wave's network up to WGL
+    __shared__ int maxc_s;
+    if (threadIdx.x == 0) maxc_s = 0;
     bool full = false;
     const unsigned long long fmask = (1ULL << P.fb) - 1ULL;
     for (int i = threadIdx.x; i < m; i += BT) {
@@ -1040,7 +1069,9 @@ k_lat_bucket(LatPart P, const int *__restrict__ n_dev, int n_cap, int *__restric
         const int per = (S + BT - 1) / BT;
         const int s0 = threadIdx.x * per;
         int2 mine = make_int2(0, 0);
-        for (int q = 0; q < per; ++q) if (s0 + q < S) { const int c = tcnt[s0 + q]; mine.x += c; mine.y += c > 0; }
+        int cmax = 0;
+        for (int q = 0; q < per; ++q) if (s0 + q < S) { const int c = tcnt[s0 + q]; mine.x += c; mine.y += c > 0; cmax = max(cmax, c); }
+        if (cmax > LONGL) maxc_s = 1;                 // (some list of this bucket needs the sorting network)
         int2 tot;
         int2 ex = block_exclusive_scan2_n<BT>(mine, &tot);
         for (int q = 0; q < per; ++q) if (s0 + q < S) {
@@ -1051,7 +1082,7 @@ k_lat_bucket(LatPart P, const int *__restrict__ n_dev, int n_cap, int *__restric
         if (threadIdx.x == 0) P.gcount[b] = tot.y;
     }
     __syncthreads();
-    unsigned short *larr = P.larr + (int64_t)b * MAXE;
+    unsigned short *larr = P.larr + wbase;
     for (int i = threadIdx.x; i < m; i += BT) {
         const unsigned long long v = stage[i];
         const unsigned sr = (unsigned)(v >> 32);
@@ -1062,16 +1093,66 @@ k_lat_bucket(LatPart P, const int *__restrict__ n_dev, int n_cap, int *__restric
         if (P.want_off) larr[i] = (unsigned short)tgid[s];
     }
     __syncthreads();
-    // place of every entry inside its vertex's list = number of smaller flat positions there (positions are distinct); the head of
-    // the list is the vertex's first-seen entry.  Neighbouring threads hold neighbouring list positions, i.e. mostly the same
-    // vertex: the LDS reads of the count loop are broadcasts.
-    int *glist = list + (int64_t)b * MAXE;
+    // Every vertex's list in ascending flat position (the splat's fixed summation order; its head is the vertex's first-seen entry).
+    // Short lists: place of an entry = number of smaller positions in its list (positions are distinct) - neighbouring threads
+    // hold neighbouring list positions, i.e. mostly the same vertex, so the count loop reads LDS as broadcasts; O(c^2), which is
+    // what a real sweep punishes (cells near the sensor collect hundreds to thousands of points).  Lists longer than LONGL are
+    // sorted in place first by a bitonic network whose compare-exchanges all point the same way (partner i ^ (k - 1) in the first
+    // step of every merge), so a list of any length sorts as if padded with +inf: one wave per list up to WGL entries (a wave's LDS
+    // operations execute in order: no barrier between the steps), the whole workgroup on the few longer ones.  Buckets without
+    // a long list (all of them on the random-range bench scene) skip the block.
+    if (maxc_s) {
+        __shared__ int nlong_s, longs_s[64];              // the lists longer than WGL (at most MAXE / WGL <= 8 of them... 64 is generous)
+        if (threadIdx.x == 0) nlong_s = 0;
+        __syncthreads();
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        for (int s = wv; s < S; s += BT / 64) {
+            const int c = tcnt[s];
+            if (c <= LONGL) continue;
+            if (c > WGL) { if (lane == 0) { const int k = atomicAdd(&nlong_s, 1); if (k < 64) longs_s[k] = s; } continue; }
+            int *a = lst + tstart[s];
+            int p2 = 1;
+            while (p2 < c) p2 <<= 1;
+            for (int k = 2; k <= p2; k <<= 1)
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    for (int p = lane; p < (p2 >> 1); p += 64) {
+                        const int lo = ((p / j) * (2 * j)) + (p % j);
+                        const int hi = (j == (k >> 1)) ? (lo ^ (k - 1)) : (lo + j);
+                        if (hi < c) { const int x = a[lo], y = a[hi]; if (x > y) { a[lo] = y; a[hi] = x; } }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                }
+        }
+        __syncthreads();
+        const int nl = min(nlong_s, 64);
+        for (int q = 0; q < nl; ++q) {
+            const int s = longs_s[q], c = tcnt[s];
+            int *a = lst + tstart[s];
+            int p2 = 1;
+            while (p2 < c) p2 <<= 1;
+            for (int k = 2; k <= p2; k <<= 1)
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    for (int p = threadIdx.x; p < (p2 >> 1); p += BT) {
+                        const int lo = ((p / j) * (2 * j)) + (p % j);
+                        const int hi = (j == (k >> 1)) ? (lo ^ (k - 1)) : (lo + j);
+                        if (hi < c) { const int x = a[lo], y = a[hi]; if (x > y) { a[lo] = y; a[hi] = x; } }
+                    }
+                    __syncthreads();
+                }
+        }
+    }
+    int *glist = list + wbase;
     for (int q = threadIdx.x; q < m; q += BT) {
         const int s = lslot[q];
         const int st = tstart[s], c = tcnt[s];
         const int me = lst[q];
-        int r = 0;
-        for (int k = 0; k < c; ++k) r += lst[st + k] < me ? 1 : 0;
+        int r = q - st;                                   // (a sorted list: the place IS the rank)
+        if (c <= LONGL) {
+            r = 0;
+            for (int k = 0; k < c; ++k) r += lst[st + k] < me ? 1 : 0;
+        }
         glist[st + r] = me;
         if (r == 0) {
             atomicOr(&P.fbits[(unsigned)me >> 5], 1u << ((unsigned)me & 31u));
@@ -1082,6 +1163,23 @@ k_lat_bucket(LatPart P, const int *__restrict__ n_dev, int n_cap, int *__restric
     for (int s = threadIdx.x; s < S; s += BT) {
         const unsigned long long k = tkey[s];
         tab[s] = make_int4((int)(unsigned)k, (int)(unsigned)(k >> 32), -1, 0);
+    }
+}
+
+template <int MAXE, int BT>
+__global__ void __launch_bounds__(BT)
+k_lat_bucket(LatPart P, const int *__restrict__ n_dev, int n_cap, int *__restrict__ list, int *__restrict__ info) {
+    bucket_body<MAXE, BT, false>(P, blockIdx.x, n_dev, n_cap, list, info);
+}
+
+// the buckets k_lat_bucket left out (more than maxe entries): the same grouping with 152 KB of LDS and 1024 threads per bucket,
+// windows handed out behind the regular ones.  Usually there are none: the launch then costs its latency only.
+__global__ void __launch_bounds__(1024)
+k_lat_bucket_big(LatPart P, const int *__restrict__ n_dev, int n_cap, int *__restrict__ list, int *__restrict__ info) {
+    const int nbig = min(P.big[0], BIGCAP);
+    for (int k = blockIdx.x; k < nbig; k += gridDim.x) {
+        bucket_body<MAXE_BIG, 1024, true>(P, P.biglist[k], n_dev, n_cap, list, info);
+        __syncthreads();
     }
 }
 
@@ -1179,7 +1277,7 @@ k_lat_nbr(LatPart P, LatGeom G, const int *__restrict__ mm, int *__restrict__ in
             int k[4], smp, p, rem;
             int4 rec;
             vertex_key(P, G, h, k, smp, rec, p, rem);
-            vseg[h] = make_int2((P.vrec[h] >> P.sb) * P.maxe + rec.y, rec.z);
+            vseg[h] = make_int2(P.wbase[P.vrec[h] >> P.sb] + rec.y, rec.z);
             vsid[h] = smp;
             // vertices are numbered sample-major, and the very first key of a sample is always new: its number is the sample's first
             if (rem == 0 && (p == 0 || sample_of(G.sid, G.pps, p - 1) != smp)) info[EFGH_LATTICE_INFO_SEG + smp] = h;
@@ -1209,7 +1307,8 @@ k_lat_nbr(LatPart P, LatGeom G, const int *__restrict__ mm, int *__restrict__ in
         for (int r = 0; r < 4; ++r) {
             const int bk = (int)(wv[r] >> 14);
             const int pos = P.cumul[(int64_t)bk * P.ntiles + t] + (int)(wv[r] & 0x3FFFu);
-            o[r] = pos < P.maxe ? P.gvix[(int64_t)bk * P.S + P.larr[(int64_t)bk * P.maxe + pos]] : 0;       // (else: flagged by k_lat_bucket)
+            // (a flagged bucket has window 0 and whatever lies there: the mask keeps the lookup inside the bucket's own vertices)
+            o[r] = P.gvix[(int64_t)bk * P.S + (P.larr[P.wbase[bk] + pos] & (P.S - 1))];
         }
         off[p] = make_int4(o[0], o[1], o[2], o[3]);
         return;
@@ -1392,7 +1491,7 @@ extern "C" int efgh_lattice_level_neighbors(const void *workspace, int32_t n_cap
 namespace {
 
 struct PartLayout {
-    int64_t ent, toff, cumul, where, larr, cursor, gcount, grec, gvix, vrec, table, wprefix, bsum, mm, part, total;
+    int64_t ent, toff, cumul, where, larr, cursor, wbase, biglist, gcount, grec, gvix, vrec, table, wprefix, bsum, mm, part, total;
     int W, nblk, ntiles, tp, ppt;
 };
 
@@ -1417,8 +1516,10 @@ PartLayout part_layout(int32_t n_cap, int32_t h_cap, int32_t nsamples, int nb, i
     w.toff = o;    o += align256((int64_t)w.ntiles * (nb + 1) * 4);
     w.cumul = o;   o += align256((int64_t)nb * w.ntiles * 4);
     w.where = o;   o += align256((int64_t)n_cap * 16);
-    w.larr = o;    o += align256((int64_t)nb * maxe * 2);
+    w.larr = o;    o += align256(((int64_t)nb * maxe + (int64_t)n_cap * 4) * 2);      // (regular windows + the overflow area)
     w.cursor = o;  o += align256((int64_t)nb * 4);
+    w.wbase = o;   o += align256((int64_t)nb * 4);
+    w.biglist = o; o += align256((int64_t)BIGCAP * 4);
     w.gcount = o;  o += align256((int64_t)nb * 4);
     w.grec = o;    o += align256((int64_t)nb * S * 16);
     w.gvix = o;    o += align256((int64_t)nb * S * 4);
@@ -1437,15 +1538,19 @@ bool part_args_ok(int32_t n_cap, int32_t nb, int32_t S) {
            cdiv(n_cap, STP * part_ppt(n_cap)) <= NTMAX;
 }
 
-LatPart part_ptrs(char *ws, char *zeroed, const PartLayout &w, int32_t n_cap, int nb, int S, int want_off = 1) {
+LatPart part_ptrs(char *ws, char *zeroed, const PartLayout &w, int32_t n_cap, int nb, int S, int want_off = 1, int use_big = 0) {
     LatPart P;
     P.want_off = want_off;
+    P.use_big = use_big;
     P.ent = (unsigned long long *)(ws + w.ent);
     P.toff = (int *)(ws + w.toff);
     P.cumul = (int *)(ws + w.cumul);
     P.where = (unsigned *)(ws + w.where);
     P.larr = (unsigned short *)(ws + w.larr);
     P.cursor = (int *)(ws + w.cursor);
+    P.wbase = (int *)(ws + w.wbase);
+    P.biglist = (int *)(ws + w.biglist);
+    P.big = (int *)zeroed + 1;
     P.gcount = (int *)(ws + w.gcount);
     P.grec = (int4 *)(ws + w.grec);
     P.gvix = (int *)(ws + w.gvix);
@@ -1472,6 +1577,10 @@ float part_std32() {
 static int g_bucket_threads = 256;
 extern "C" void efgh_lattice_part_tune(int32_t bucket_threads) { g_bucket_threads = bucket_threads; }
 extern "C" int32_t efgh_lattice_part_max_entries(int32_t n_cap) { return part_maxe(n_cap); }
+/* elements of `list`: one window of max_entries per bucket + an overflow area for the buckets that hold more */
+extern "C" int64_t efgh_lattice_part_list_len(int32_t n_cap, int32_t nbuckets) {
+    return (int64_t)nbuckets * part_maxe(n_cap) + (int64_t)n_cap * 4;
+}
 
 extern "C" int32_t efgh_lattice_part_buckets(int32_t n_cap) {
     // ~1000 entries per bucket on average (half of the 2048 a bucket holds: room for the spread of the bucket sizes), ~2000 of
@@ -1495,7 +1604,8 @@ extern "C" int64_t efgh_lattice_part_zeroed_bytes(int32_t n_cap) {
 extern "C" int efgh_lattice_part_build(const float *pts, int64_t pts_cstride, const int32_t *n_dev, int32_t n_cap,
                                        const int32_t *sid, int32_t pts_per_sample, int32_t nsamples, float scale32,
                                        float *bary, float *emg, int32_t *list, int32_t h_cap, int32_t *info, void *workspace,
-                                       void *zeroed, int32_t nbuckets, int32_t slots, int32_t want_off, void *stream_) {
+                                       void *zeroed, int32_t nbuckets, int32_t slots, int32_t want_off, int32_t big_buckets,
+                                       void *stream_) {
     hipStream_t st = (hipStream_t)stream_;
     EFGH_CHECK_ARG(n_cap > 0 && n_cap < (1 << 27) && h_cap > 0 && nsamples >= 1 && nsamples <= EFGH_LATTICE_MAX_SAMPLES);
     EFGH_CHECK_ARG(sid || pts_per_sample > 0);
@@ -1503,7 +1613,7 @@ extern "C" int efgh_lattice_part_build(const float *pts, int64_t pts_cstride, co
     EFGH_CHECK_ARG(part_args_ok(n_cap, nbuckets, slots));
     const PartLayout w = part_layout(n_cap, h_cap, nsamples, nbuckets, slots);
     char *ws = (char *)workspace;
-    const LatPart P = part_ptrs(ws, (char *)zeroed, w, n_cap, nbuckets, slots, want_off ? 1 : 0);
+    const LatPart P = part_ptrs(ws, (char *)zeroed, w, n_cap, nbuckets, slots, want_off ? 1 : 0, big_buckets ? 1 : 0);
     int *mm = (int *)(ws + w.mm), *part = (int *)(ws + w.part);
     const float std32 = part_std32();
     const int nbp = cdiv(n_cap, TPB);
@@ -1530,6 +1640,19 @@ extern "C" int efgh_lattice_part_build(const float *pts, int64_t pts_cstride, co
             raised = true;
         }
         k_lat_bucket<4096, 512><<<nbuckets, 512, lds, st>>>(P, n_dev, n_cap, list, info);
+    }
+    if (big_buckets) {
+        const size_t lds = (size_t)slots * 20 + (size_t)MAXE_BIG * 14;      // 121-155 KB: above the 64 KB a launch gets by default
+        static bool raised_big = false;
+        if (!raised_big) {
+            if (hipFuncSetAttribute((const void *)k_lat_bucket_big, hipFuncAttributeMaxDynamicSharedMemorySize, 20 * SMAX + 14 * MAXE_BIG)
+                != hipSuccess) {
+                efgh_set_error("%s:%d: cannot raise the dynamic LDS limit of k_lat_bucket_big", __FILE__, __LINE__);
+                return EFGH_E_LAUNCH;
+            }
+            raised_big = true;
+        }
+        k_lat_bucket_big<<<256, 1024, lds, st>>>(P, n_dev, n_cap, list, info);         // (one 152-KB workgroup per CU)
     }
     k_lat_rank<<<w.nblk, TPB, 0, st>>>(P, w.W, info, h_cap);
     k_lat_number<<<cdiv((int64_t)nbuckets * slots, TPB), TPB, 0, st>>>(P, h_cap);

@@ -22,6 +22,8 @@ INFO_H, INFO_ERR, INFO_ALIAS, INFO_SEG = 0, 1, 2, 4          # include/efgh_hip.
 
 PROFILE = None          # bench.py: list of (start_event, end_event, algorithmic_bytes, 'lattice build') per pyramid
 _SIZES = {}             # (device, B, N, scales) -> vertex counts of the last build with that signature
+_BIG_LEVELS = {}        # the same key -> levels where a bucket of the partitioned build overflowed: built with the big-bucket kernel from then on
+_HASH_LEVELS = {}       # the same key -> levels where that overflowed as well: they take the hash build
 
 
 class LatticeLevel:
@@ -109,7 +111,7 @@ def _level_arrays(L, dev, n_cap, h_cap, B, mode=('hash', 0), ctrl=None, need_off
     lv.emg_pm = torch.empty((n_cap, 4), dtype=torch.float32, device=dev)
     lv.off_pm = torch.empty((n_cap, 4), dtype=torch.int32, device=dev) if (need_off or mode[0] != 'part') else None
     if mode[0] == 'part':       # every bucket owns a fixed window of the list array
-        lv.list = torch.empty(mode[1] * L.efgh_lattice_part_max_entries(_C.c_int32(n_cap)), dtype=torch.int32, device=dev)
+        lv.list = torch.empty(L.efgh_lattice_part_list_len(n_cap, mode[1]), dtype=torch.int32, device=dev)
         ws_bytes = L.efgh_lattice_part_workspace_bytes(n_cap, h_cap, B, mode[1], mode[2])
     else:
         lv.list = torch.empty(4 * n_cap, dtype=torch.int32, device=dev)
@@ -136,7 +138,8 @@ def _launch_build(L, lv, pts, cstride, n_dev, sid, pps, B, s, st):
     if lv._mode[0] == 'part':
         _C.check(L.efgh_lattice_part_build(*head, _C.ptr(lv.bary_pm), _C.ptr(lv.emg_pm), _C.ptr(lv.list), _C.c_int32(h_cap),
                                            _C.ptr(lv.info), _C.ptr(lv._ws), _C.ptr(lv._zeroed), _C.c_int32(lv._mode[1]),
-                                           _C.c_int32(lv._mode[2]), _C.c_int32(0 if lv.off_pm is None else 1), st))
+                                           _C.c_int32(lv._mode[2]), _C.c_int32(0 if lv.off_pm is None else 1),
+                                           _C.c_int32(1 if len(lv._mode) > 3 and lv._mode[3] else 0), st))
     else:
         _C.check(L.efgh_lattice_level_build(*head, _C.c_float(np.float32(EXPECTED_STD * s)), _C.ptr(lv.bary_pm), _C.ptr(lv.emg_pm),
                                             _C.ptr(lv.off_pm), _C.ptr(lv.list), _C.c_int32(h_cap), _C.ptr(lv.vseg),
@@ -189,16 +192,25 @@ def build_pyramid_batched(pc, scales, need_off=True):
         e0.record()
     out = lvs = None
     prev = _SIZES.get(key)
-    if prev is not None:
+    forced, bigl = _HASH_LEVELS.setdefault(key, set()), _BIG_LEVELS.setdefault(key, set())
+    for attempt in range(3 if prev is not None else 0):
         # speculative path: capacities from the previous build of this signature, no read-back between levels
         lvs, pts, cstride, n_dev, sid, n_cap = [], pts0, B * N, None, None, B * N
         # capacities and plans of all levels first: their control blocks (device counters, first-seen bitmaps) are zeroed by ONE fill.
-        # Tables are sized for the expected vertex count; one that turns out too small sets ERR bit 2 and the level-by-level
-        # path below rebuilds the pyramid
+        # Tables are sized for the expected vertex count.  A partitioned level that overflows (ERR bit 2: a bucket with more entries
+        # than its window, a table too small) is escalated for this signature - first to the build with the big-bucket kernel
+        # (one more launch; spatially dense sweeps need it, the random-range bench scene never does), then to the hash build -
+        # and the pyramid is enqueued once more; a vertex count beyond its capacity (bit 0) sends the batch to the
+        # level-by-level path below
         caps, nc = [], n_cap
-        for hp in prev:
+        for l, hp in enumerate(prev):
             hc = min(4 * nc, hp + hp // 4 + 1024)
-            caps.append((nc, hc, _plan(L, nc, hc)))
+            md = _plan(L, nc, hc)
+            if l in forced and md[0] == 'part':
+                md = ('hash', max(4096, 1 << (2 * hc - 1).bit_length()) if SMALL_HASH else 0)
+            elif l in bigl and md[0] == 'part':
+                md = md + (True,)
+            caps.append((nc, hc, md))
             nc = hc
         sizes = [_ctrl_bytes(L, nc_, B, md) for nc_, _, md in caps]
         ctrl = torch.zeros(sum(a + b for a, b in sizes), dtype=torch.uint8, device=dev)
@@ -219,17 +231,23 @@ def build_pyramid_batched(pc, scales, need_off=True):
                 _finish(lv, h, n_in, seg_in, B)
                 n_in, seg_in = lv.H, lv.seg
             out = lvs
+            break
+        over = [l for l, (h, lv) in enumerate(zip(host, lvs)) if h[INFO_ERR] & 4 and lv._mode[0] == 'part']
+        if not over or any(h[INFO_ERR] & 1 for h in host):
+            break
+        (forced if over[0] in bigl else bigl).add(over[0])      # (levels behind the first overflow were built on its garbage)
     if out is None:
         # level-by-level path: each level's count is read before the next level is sized (exact capacities)
         out, pts, cstride, sid, n = [], pts0, B * N, None, B * N
         seg_in = [b * N for b in range(B + 1)]
-        for s in scales:
-            for mode in (_plan(L, n, None), ('hash', 0)):
+        for l, s in enumerate(scales):
+            for mode in ((('hash', 0),) if l in forced else (_plan(L, n, None) + (l in bigl,), _plan(L, n, None) + (True,), ('hash', 0))):
                 lv = _level_arrays(L, dev, n, 4 * n, B, mode, None, need_off)
                 _launch_build(L, lv, pts, cstride, None, sid, N, B, s, st)
                 head = lv.info[:2].tolist()           # host sync (sizes the next level)
                 if not head[INFO_ERR] & 4 or mode == ('hash', 0):
-                    break                             # (a bucket of the partitioned build overflowed: the hash build serves the level)
+                    break                             # (else: a bucket of the partitioned build overflowed - escalate)
+                (forced if (l in bigl or mode[-1] is True) else bigl).add(l)
             H = head[INFO_H]
             _launch_neighbors(L, lv, B, H, st)
             host = lv.info.cpu().tolist()

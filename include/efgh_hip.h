@@ -96,23 +96,28 @@ int efgh_lattice_level_neighbors(const void *workspace, int32_t n_cap, int32_t h
  * gathers its runs and groups them in LDS, the first-seen numbering is a prefix count over one bit per entry, the neighbour
  * lookup probes a read-only image of the buckets' tables and lattice_offset is gathered per point - no global atomics per entry,
  * no scattered global stores.  Results are identical to efgh_lattice_level_build / _neighbors (same arrays, same meaning) except:
- *      list has efgh_lattice_part_max_entries(n_cap) * nbuckets elements (vseg starts point into per-bucket windows);
+ *      list has efgh_lattice_part_list_len(n_cap, nbuckets) elements: a window of efgh_lattice_part_max_entries(n_cap) per
+ *      bucket + an overflow area (vseg starts point into the windows);
  *      off, vseg, pts_next, vsid and info[SEG..] are written by the NEIGHBOURS call, not by the build.
  * nbuckets: power of two in [2, 8192], normally efgh_lattice_part_buckets(n_cap) (0: more points than the bucket limit - use the
  * hash build); slots: table slots per bucket, power of two in [16, 2048], >= ~2.5x the expected vertices per bucket.
- * A bucket with more than efgh_lattice_part_max_entries(n_cap) entries, or more vertices than slots, sets bit 2 of
- * info[EFGH_LATTICE_INFO_ERR] (nothing is written out of bounds): rebuild with more slots or with the hash build.          */
+ * big_buckets != 0: buckets with more than max_entries entries (lattice cells near the sensor of a real sweep collect thousands
+ * of points) are grouped by a second kernel with 152 KB of LDS per bucket (up to 8 192 entries; one more launch).  A bucket
+ * beyond what the call can hold, or more vertices than slots, sets bit 2 of info[EFGH_LATTICE_INFO_ERR] (nothing is written out
+ * of bounds): rebuild with big_buckets, with more slots, or with the hash build.                                            */
 int32_t efgh_lattice_part_max_entries(int32_t n_cap);
+int64_t efgh_lattice_part_list_len(int32_t n_cap, int32_t nbuckets);
 int32_t efgh_lattice_part_buckets(int32_t n_cap);
 int64_t efgh_lattice_part_workspace_bytes(int32_t n_cap, int32_t h_cap, int32_t nsamples, int32_t nbuckets, int32_t slots);
 /* bytes of `zeroed` (first-seen bitmap + an election counter): must be ALL ZERO when efgh_lattice_part_build is enqueued, and so
  * must info - so that one fill can serve every level of a pyramid */
 int64_t efgh_lattice_part_zeroed_bytes(int32_t n_cap);
-/* six launches: keys + barycentric weights, key extrema, tile-local bucket sort, per-bucket grouping, first-seen numbering */
+/* six launches (seven with big_buckets): keys + barycentric weights, key extrema, tile-local bucket sort, per-bucket grouping,
+ * first-seen numbering */
 int efgh_lattice_part_build(const float *pts, int64_t pts_cstride, const int32_t *n_dev, int32_t n_cap,
                             const int32_t *sid, int32_t pts_per_sample, int32_t nsamples, float scale32,
                             float *bary, float *emg, int32_t *list, int32_t h_cap, int32_t *info, void *workspace,
-                            void *zeroed, int32_t nbuckets, int32_t slots, int32_t want_off, void *stream);
+                            void *zeroed, int32_t nbuckets, int32_t slots, int32_t want_off, int32_t big_buckets, void *stream);
 /* one launch: nbr + alist (as efgh_lattice_level_neighbors), off, and the vertex records vseg / pts_next / vsid / info[SEG..]
  * (pts ... div32 as passed to the build; pts_next has h_cap_build columns).  want_off = 0 in the build and off = NULL here skip
  * lattice_offset and the three arrays that only serve it (inference: the splat walks the vertex lists; off is needed by the

@@ -237,3 +237,33 @@ def test_inference_build_without_lattice_offset():
                 assert torch.equal(u.list[su[0]:su[0] + su[1]], v.list[sv[0]:sv[0] + sv[1]])
             with pytest.raises(_C.EfghError):
                 v.off
+
+
+@pytest.mark.parametrize('n,spread', [(6000, 3.0), (30000, 2.0), (60000, 1.2), (60000, 0.6), (200000, 1.0), (200000, 0.3)])
+def test_partitioned_build_long_vertex_lists(n, spread):
+    """spatially dense scenes (what a real sweep looks like near the sensor): vertex lists of hundreds to thousands of entries go
+    through the in-LDS bitonic sorts (one wave per list, the whole workgroup on lists above 1 024 entries) and, for buckets above
+    2 048 entries, through k_lat_bucket_big (8 192 entries); beyond that the level is flagged.  Whatever was built must equal the
+    hash build: numbering, offsets, neighbours and every ascending list."""
+    from efgh_amd import _C, lattice
+    rs = np.random.RandomState(n)
+    pc = torch.from_numpy((rs.randn(1, 3, n) * spread).astype(np.float32)).cuda()
+    L = _C.lib()
+    nb = L.efgh_lattice_part_buckets(_C.c_int32(n))
+    a, ia = _build_level(pc, ('hash', 0))
+    b, ib = _build_level(pc, ('part', nb, 512, True))
+    H = ia[lattice.INFO_H]
+    longest = int(a.vseg[:H, 1].max())
+    print('n', n, 'spread', spread, 'H', H, 'longest list', longest, 'flagged', bool(ib[lattice.INFO_ERR] & 4))
+    if ib[lattice.INFO_ERR] & 4:
+        assert longest > 2048          # only an over-long list (or several of them in one bucket) may be refused
+        return
+    assert ib[:3] == ia[:3]
+    for name in ('bary_pm', 'emg_pm', 'off_pm'):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    assert torch.equal(a.nbr[:H], b.nbr[:H]) and torch.equal(a.vseg[:H, 1], b.vseg[:H, 1])
+    la, lb = a.list.cpu().numpy(), b.list.cpu().numpy()
+    sa, sb_ = a.vseg[:H].cpu().numpy(), b.vseg[:H].cpu().numpy()
+    idx = np.repeat(np.arange(H), sa[:, 1])
+    within = np.arange(idx.size) - np.repeat(np.cumsum(sa[:, 1]) - sa[:, 1], sa[:, 1])
+    assert np.array_equal(la[sa[idx, 0] + within], lb[sb_[idx, 0] + within])

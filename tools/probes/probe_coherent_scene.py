@@ -1,0 +1,52 @@
+"""the partitioned lattice build on a spatially COHERENT sweep (ground plane + walls: neighbouring beams hit continuous
+surfaces, so lattice cells near the sensor hold hundreds of points) - how long do the vertex lists get, do buckets overflow,
+how fast is the build compared with the random-range bench scene (debug aid)"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np, torch
+from efgh_amd import lattice, _C, synthetic as syn
+
+
+def coherent_sweep(n_points, seed=0, beams=64, pitch=(-24.8 / 180 * np.pi, 2.0 / 180 * np.pi)):
+    rs = np.random.RandomState(seed)
+    na = n_points // beams
+    el = np.linspace(pitch[0], pitch[1], beams)[:, None]
+    az = np.linspace(-np.pi, np.pi, na, endpoint=False)[None, :]
+    d = np.stack([np.cos(el) * np.cos(az), np.cos(el) * np.sin(az), np.sin(el) * np.ones_like(az)])     # (3, beams, na)
+    r = np.full((beams, na), 80.0)
+    with np.errstate(divide='ignore', invalid='ignore'):
+        rg = np.where(d[2] < -1e-3, -1.73 / d[2], np.inf)               # ground plane z = -1.73
+    r = np.minimum(r, rg)
+    for k in range(12):                                                  # a few walls / boxes (vertical planes)
+        th = rs.uniform(-np.pi, np.pi)
+        nrm = np.array([np.cos(th), np.sin(th), 0.0])
+        dist = rs.uniform(6, 40)
+        den = d[0] * nrm[0] + d[1] * nrm[1]
+        with np.errstate(divide='ignore', invalid='ignore'):
+            rw = np.where(den > 1e-3, dist / den, np.inf)
+        lat = (d[0] * -nrm[1] + d[1] * nrm[0]) * rw                      # lateral extent of the wall: +-8 m
+        hz = d[2] * rw
+        rw = np.where((np.abs(lat) < 8) & (hz < 3.0), rw, np.inf)
+        r = np.minimum(r, rw)
+    r = r * (1 + 0.002 * rs.randn(beams, na))
+    return np.float32((d * r).reshape(3, -1))
+
+
+SC = (1.0, 0.75, 0.5, 0.25, 0.125)
+B = 8
+for name, gen in (('random ranges (bench scene)', lambda b: syn.lidar_sweep(131072, b)), ('coherent scene', lambda b: coherent_sweep(131072, b))):
+    pc = torch.from_numpy(np.stack([gen(b) for b in range(B)])).cuda()
+    lattice._SIZES.clear()
+    for _ in range(3):
+        lv = lattice.build_pyramid_batched(pc, SC)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        lv = lattice.build_pyramid_batched(pc, SC)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 10
+    print(name, ': %.0f us per pyramid' % (dt * 1e6))
+    for l, d in enumerate(lv):
+        ln = d.vseg[:d.H, 1]
+        print('   level %d: n=%d H=%d mode=%s max list %d, mean %.1f, lists > 2048: %d' % (
+            l, d.n_in, d.H, d._mode, int(ln.max()), float(ln.float().mean()), int((ln > 2048).sum())))
