@@ -235,8 +235,22 @@ def c4_eligible(mode, C, N, geom, wgrad=False):
             and list(dh) == [t // 3 - 1 for t in range(9)] and list(dw) == [t % 3 - 1 for t in range(9)])
 
 
+USE_SMALLC = _os.environ.get('EFGH_SMALLC', '1') != '0'       # dedicated kernels for the 16- / 32-channel 3x3 layers (smallc.hip)
+
+
+def sc_eligible(mode, C, N, geom):
+    """the layers efgh_sc_conv3x3 / efgh_sc_wgrad serve (mirror of efgh_sc_supported): 3x3, stride 1, pad 1, C and N in {16, 32}"""
+    if not USE_SMALLC or mode != 1 or geom is None or C not in (16, 32) or N not in (16, 32) or MATH != 'f32':
+        return False
+    (B, Hin, Win, Hv, Wv, sh, sw, dh, dw, Ho, Wo, osh, osw, oh0, ow0) = geom
+    return (len(dh) == 9 and (sh, sw, osh, osw, oh0, ow0) == (1, 1, 1, 1, 0, 0) and Hv == Hin == Ho and Wv == Win == Wo
+            and list(dh) == [t // 3 - 1 for t in range(9)] and list(dw) == [t % 3 - 1 for t in range(9)])
+
+
 def stats_rows(mode, C, N, geom, M):
     """rows of the per-tile BatchNorm statistics buffer the GEMM launch for this layer writes"""
+    if sc_eligible(mode, C, N, geom):
+        return _L().efgh_sc_stats_rows(c_int32(geom[0]), c_int32(geom[1]), c_int32(geom[2]))
     if c4_eligible(mode, C, N, geom):
         return _L().efgh_c4_stats_rows(c_int32(geom[0]), c_int32(geom[9]), c_int32(geom[10]))
     if wino2d_eligible(mode, C, N, geom):
@@ -367,6 +381,8 @@ def gather_gemm(A, lda, C, T, Wp, N, M, out, ldo, mode=0, geom=None, table=None,
         assert lda % 4 == 0
         thin = True             # (for the profile lists: an HBM-bound launch, not part of the MFMA GEMM family)
         _C.check(_L().efgh_c4_conv3x3(ctypes.byref(d), _st()))
+    elif M_dev is None and batch is None and lda % 4 == 0 and ldo % 4 == 0 and sc_eligible(mode, C, N, geom):
+        _C.check(_L().efgh_sc_conv3x3(ctypes.byref(d), _st()))
     elif M_dev is None and batch is None and wino2d_eligible(mode, C, N, geom):
         wino = '2d'
         _wino2d_forward(d, A, a_off, lda, C, N, geom, Wp)
@@ -844,6 +860,9 @@ def gather_wgrad(A, lda, C, T, N, M, G, ldg, dWp, mode=0, geom=None, table=None)
     elif not DETERMINISTIC and c4_eligible(mode, C, N, geom, wgrad=True):
         thin = True             # (profile lists, as above)
         _C.check(_L().efgh_c4_wgrad(ctypes.byref(d), ptr(G), c_int64(ldg), ptr(dWp), _st()))
+    elif sc_eligible(mode, C, N, geom) and lda % 4 == 0 and ldg % 4 == 0:
+        _C.check(_L().efgh_sc_wgrad(ctypes.byref(d), ptr(G), c_int64(ldg), ptr(dWp),
+                                    ptr(_scratch(_L().efgh_sc_wgrad_workspace(ctypes.byref(d)), dWp.device)), _st()))
     elif USE_WINO_WGRAD and wino2d_eligible(mode, C, N, geom, wgrad=True):
         wino = '2d'
         B, H, W = geom[0], geom[1], geom[2]

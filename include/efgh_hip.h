@@ -419,6 +419,15 @@ int efgh_thin_wgrad(const efgh_gemm_desc *d, const float *G, int64_t ldg, float 
  * input rows of 128 output pixels are staged in LDS once, the 36 x N weights stay in registers of a persistent workgroup.  Same
  * descriptor and epilogue as efgh_gather_gemm; `stats` has efgh_c4_stats_rows(B, Ho, Wo) rows.  efgh_c4_wgrad: the weight
  * gradient dWp [N][9][4] of the same layers (N % 16 == 0, 32 <= N <= 128) on v_mfma_f32_16x16x4_f32, G [M][ldg] read once.      */
+/* 3x3 / stride-1 / pad-1 layers with 16 or 32 channels on both sides (csrc/smallc.hip: F's up-sampling stages, nets/fnet.py:22-31):
+ * same descriptor and epilogue as efgh_gather_gemm, W packed [N][9][C]; `stats` has efgh_sc_stats_rows(B, H, W) rows.
+ * efgh_sc_wgrad: dWp [N][9][C], workspace of efgh_sc_wgrad_workspace(d) floats (one partial plane per wave, folded in a fixed
+ * order: no atomics). */
+int efgh_sc_supported(const efgh_gemm_desc *d);
+int32_t efgh_sc_stats_rows(int32_t B, int32_t H, int32_t W);
+int efgh_sc_conv3x3(const efgh_gemm_desc *d, void *stream);
+int64_t efgh_sc_wgrad_workspace(const efgh_gemm_desc *d);
+int efgh_sc_wgrad(const efgh_gemm_desc *d, const float *G, int64_t ldg, float *dWp, float *workspace, void *stream);
 int efgh_c4_supported(const efgh_gemm_desc *d);
 int32_t efgh_c4_stats_rows(int32_t B, int32_t Ho, int32_t Wo);
 int efgh_c4_conv3x3(const efgh_gemm_desc *d, void *stream);

@@ -416,6 +416,59 @@ def test_c4_mfma_conv_vs_generic_and_fp64(L, cin, cout, stride, hw, B):
     assert _rel(bng.weight.grad.cpu(), bn.weight.grad) < 2e-4 and _rel(bng.bias.grad.cpu(), bn.bias.grad) < 2e-4
 
 
+@pytest.mark.parametrize('cin,cout,hw,B', [(16, 16, (24, 40), 2), (32, 32, (37, 301), 1), (16, 32, (18, 26), 2),
+                                          (32, 16, (9, 263), 1), (16, 16, (5, 131), 3)])
+def test_small_channel_conv_vs_generic_and_fp64(L, cin, cout, hw, B):
+    """efgh_sc_conv3x3 / efgh_sc_wgrad (3x3, stride 1, 16 / 32 channels on both sides: F's up-sampling stages) against the generic
+    implicit-GEMM kernels and float64: odd sizes, several 32-pixel units per row with a ragged last one, residual epilogue,
+    train-mode BatchNorm statistics, data gradient with a skip gradient added in the epilogue, weight gradient (bit-reproducible)"""
+    from efgh_amd import ops
+    torch.manual_seed(4)
+    conv = nn.Conv2d(cin, cout, 3, 1, 1, bias=True)
+    x = torch.randn(B, cin, *hw)
+    res = torch.randn(B, cout, *hw)
+    ref = F.leaky_relu(F.conv2d(x.double(), conv.weight.double(), conv.bias.double(), padding=1) + res.double(), 0.2)
+    cg = nn.Conv2d(cin, cout, 3, 1, 1, bias=True).cuda()
+    cg.load_state_dict(conv.state_dict())
+    xg, rg = ops.nchw_to_nhwc(x.cuda(), cin), ops.nchw_to_nhwc(res.cuda(), cout)
+    taps = ([t // 3 - 1 for t in range(9)], [t % 3 - 1 for t in range(9)])
+    geom = (B, hw[0], hw[1], hw[0], hw[1], 1, 1, taps[0], taps[1], hw[0], hw[1], 1, 1, 0, 0)
+    out = {}
+    for sc in (True, False):
+        ops.USE_SMALLC = sc
+        try:
+            assert ops.sc_eligible(1, cin, cout, geom) == sc
+            with torch.no_grad():
+                y = L.conv2d(L.Ctx(False), xg, cg, None, L.ACT_LEAKY, 0.2, residual=rg)
+            out[sc] = y.permute(0, 3, 1, 2).double().cpu()
+        finally:
+            ops.USE_SMALLC = True
+    assert _rel(out[True], ref) < 2e-6 and _rel(out[False], ref) < 2e-6, (_rel(out[True], ref), _rel(out[False], ref))
+    # train-mode BatchNorm on top (one statistics row per persistent workgroup), data and weight gradients through autograd
+    bn = nn.BatchNorm2d(cout)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.2)
+    bng = nn.BatchNorm2d(cout).cuda()
+    bng.load_state_dict(bn.state_dict())
+    bn.train(); bng.train()
+    gy = torch.randn(B, cout, *hw)
+    xr = x.clone().requires_grad_(True)
+    refb = F.relu(bn(conv(xr)))
+    refb.backward(gy)
+    grads = []
+    for _ in range(2):
+        cg.weight.grad = cg.bias.grad = bng.weight.grad = bng.bias.grad = None
+        xq = xg.clone().requires_grad_(True)
+        yb = L.conv2d(L.Ctx(True), xq, cg, bng, L.ACT_RELU, 0.0)          # grad mode: the autograd Functions of nets/fn.py
+        yb.backward(ops.nchw_to_nhwc(gy.cuda(), cout))
+        grads.append(cg.weight.grad.clone())
+    assert torch.equal(grads[0], grads[1])                                  # partial planes folded in a fixed order
+    assert _rel(yb.detach().permute(0, 3, 1, 2).cpu(), refb.detach()) < 2e-5
+    assert _rel(cg.weight.grad.cpu(), conv.weight.grad) < 2e-4, _rel(cg.weight.grad.cpu(), conv.weight.grad)
+    assert _rel(xq.grad.permute(0, 3, 1, 2).cpu(), xr.grad) < 2e-4
+    assert _rel(bng.weight.grad.cpu(), bn.weight.grad) < 2e-4 and _rel(bng.bias.grad.cpu(), bn.bias.grad) < 2e-4
+
+
 @pytest.mark.parametrize('C', [36, 68, 132, 260, 4, 256])
 @pytest.mark.parametrize('emg', [False, True])
 def test_splat_gather_vs_float64_scatter_add(C, emg):
