@@ -1574,8 +1574,6 @@ float part_std32() {
 
 }  // namespace
 
-static int g_bucket_threads = 256;
-extern "C" void efgh_lattice_part_tune(int32_t bucket_threads) { g_bucket_threads = bucket_threads; }
 extern "C" int32_t efgh_lattice_part_max_entries(int32_t n_cap) { return part_maxe(n_cap); }
 /* elements of `list`: one window of max_entries per bucket + an overflow area for the buckets that hold more */
 extern "C" int64_t efgh_lattice_part_list_len(int32_t n_cap, int32_t nbuckets) {
@@ -1624,9 +1622,7 @@ extern "C" int efgh_lattice_part_build(const float *pts, int64_t pts_cstride, co
         k_lat_scatter<8><<<w.ntiles, STP, 0, st>>>(pts, pts_cstride, n_dev, n_cap, scale32, std32, mm, sid, pps, nsamples, P, info);
     else
         k_lat_scatter<2><<<w.ntiles, STP, 0, st>>>(pts, pts_cstride, n_dev, n_cap, scale32, std32, mm, sid, pps, nsamples, P, info);
-    if (P.maxe == 2048 && g_bucket_threads == 512)
-        k_lat_bucket<2048, 512><<<nbuckets, 512, (size_t)slots * 20 + (size_t)2048 * 14, st>>>(P, n_dev, n_cap, list, info);
-    else if (P.maxe == 2048)
+    if (P.maxe == 2048)             // (512 threads per bucket measured the same as 256: 259 vs 261 us at level 0)
         k_lat_bucket<2048, 256><<<nbuckets, 256, (size_t)slots * 20 + (size_t)2048 * 14, st>>>(P, n_dev, n_cap, list, info);
     else {
         const size_t lds = (size_t)slots * 20 + (size_t)4096 * 14;          // up to 98 KB: above the 64 KB a launch gets by default

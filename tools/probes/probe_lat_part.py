@@ -14,8 +14,7 @@ n = pc.shape[0] * pc.shape[2]
 pts = pc.permute(1, 0, 2).reshape(3, n).contiguous()
 st = _C.stream_ptr()
 modes = [lattice._plan(L, n, 313000)]
-for dbg in [int(x) for x in (sys.argv[1:] or ['256'])]:
-    L.efgh_lattice_part_tune(_C.c_int32(dbg))
+for dbg in [int(x) for x in (sys.argv[1:] or ['0'])]:
     for mode in modes:
         ts = []
         for it in range(6):
