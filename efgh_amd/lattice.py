@@ -34,7 +34,7 @@ class LatticeLevel:
     per vertex: nbr [H][16] (15 neighbours + alias mask), vseg [H][2] + list [4n] (vertex -> ascending flat positions
     4p + r), pts_next [3][H]; info = the level's device counters (INFO_*), alist = aliased neighbour records."""
     __slots__ = ('n_in', 'H', 'bary_pm', 'emg_pm', 'off_pm', 'nbr', 'vseg', 'list', 'pts_next_buf', 'info', 'alist',
-                 'seg_in', 'seg', 'vsid', '_ws', '_caps', '_mode', '_geom', '_zeroed')
+                 'seg_in', 'seg', 'vsid', '_ws', '_caps', '_mode', '_geom', '_zeroed', 'n_alias')
 
     # the reference's (4, n) / (3, H) arrays as views
     @property
@@ -168,6 +168,7 @@ def _finish(lv, host, n_in, seg_in, B):
     if host[INFO_ERR] & 2:
         raise _C.EfghError('lattice: more than %d aliased neighbour hits on one level' % ALIAS_CAP)
     H = host[INFO_H]
+    lv.n_alias = host[INFO_ALIAS]      # (on the host with the one read-back: a level without aliased hits - every real sweep - needs no patch launch)
     lv.n_in, lv.H, lv.seg_in = n_in, H, seg_in
     lv.seg = list(host[INFO_SEG:INFO_SEG + B]) + [H]
     lv._ws = None                      # scratch no longer needed (the stream orders its reuse)

@@ -557,6 +557,7 @@ def _inject_aliased_hits(lv, count, seed):
     lv.alist = torch.from_numpy(alist).cuda()
     lv.info = lv.info.clone()
     lv.info[lattice.INFO_ALIAS] = len(recs)
+    lv.n_alias = len(recs)
     return len(recs)
 
 
