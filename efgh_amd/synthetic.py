@@ -42,6 +42,31 @@ def lidar_sweep(n_points, seed=0, beams=64, pitch_range=(-0.12 * np.pi, 0.12 * n
     return np.float32(np.stack([x, y, z]).reshape(3, -1))
 
 
+def coherent_sweep(n_points, seed=0, beams=64, pitch_range=(-24.8 / 180 * np.pi, 2.0 / 180 * np.pi)):
+    """64-beam organised sweep over a ground plane and a dozen walls -> (3,N) float32.  Unlike `lidar_sweep` (independent random
+    ranges: no two neighbouring returns share a lattice cell) this one is spatially coherent like a real scan - lattice cells near
+    the sensor collect hundreds to thousands of points - which is the hard case for the lattice build (long vertex lists) and the
+    easy one for the splat's cache locality."""
+    rs = np.random.RandomState(seed)
+    na = n_points // beams
+    el = np.linspace(pitch_range[0], pitch_range[1], beams)[:, None]
+    az = np.linspace(-np.pi, np.pi, na, endpoint=False)[None, :]
+    d = np.stack([np.cos(el) * np.cos(az), np.cos(el) * np.sin(az), np.sin(el) * np.ones_like(az)])     # (3, beams, na)
+    with np.errstate(divide='ignore', invalid='ignore'):
+        r = np.minimum(80.0, np.where(d[2] < -1e-3, -1.73 / d[2], np.inf))      # ground plane z = -1.73, 80 m maximum range
+        for _ in range(12):                                                     # vertical walls, 16 m wide, 3 m above the sensor
+            th = rs.uniform(-np.pi, np.pi)
+            nrm = np.array([np.cos(th), np.sin(th), 0.0])
+            dist = rs.uniform(6, 40)
+            den = d[0] * nrm[0] + d[1] * nrm[1]
+            rw = np.where(den > 1e-3, dist / den, np.inf)
+            lat = (d[0] * -nrm[1] + d[1] * nrm[0]) * rw
+            rw = np.where((np.abs(lat) < 8) & (d[2] * rw < 3.0), rw, np.inf)
+            r = np.minimum(r, rw)
+    r = r * (1 + 0.002 * rs.randn(beams, na))
+    return np.float32((d * r).reshape(3, -1))
+
+
 def camera_image(raw_hw, seed=0):
     """uint8-valued RGB at half the raw camera size -> (3,H/2,W/2) float32."""
     h, w = raw_hw[0] // 2, raw_hw[1] // 2

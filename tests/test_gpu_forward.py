@@ -191,6 +191,40 @@ def test_odd_point_count_and_strided_inputs_vs_oracle(manifest):
                 assert _rel(o_v[k][s:s + 1].cpu().numpy(), reth[k].numpy()) < 1e-4, (k, s)
 
 
+def test_point_branch_on_a_spatially_coherent_sweep_vs_oracle(manifest):
+    """the bench scene draws every range at random (no two returns share a lattice cell by locality); a real scan is coherent:
+    `synthetic.coherent_sweep` (ground plane + walls) has vertex lists of hundreds to thousands of entries at level 0.  The E
+    branch on two such sweeps (65 536 points each: the long-list sorts and, after one flagged build, the big-bucket kernel of
+    lattice.hip) against the oracle, first call and the speculative second one"""
+    from efgh_amd import lattice
+    from oracle import efgh_oracle as O
+    from oracle import lattice as olat
+    m = _model(manifest, False)
+    pcs = np.stack([syn.coherent_sweep(65536, s) for s in (1, 2)])
+    pc = torch.from_numpy(pcs).cuda()
+    P = syn.synthetic_state_dict(manifest['state_dict'], 1)
+    lattice._SIZES.clear()
+    with torch.no_grad():
+        outs = []
+        for _ in range(3):
+            keep = {}
+            outs.append((m.E(pc, keep=keep), keep['lattice']))
+        longest = int(outs[-1][1][0].vseg[:outs[-1][1][0].H, 1].max())
+        assert longest > 512, longest
+        ref0 = olat.generate_data(pcs[0])
+        for l, r in enumerate(ref0):
+            d = outs[-1][1][l].sample(0)
+            assert d.H == r['H'] and np.array_equal(d.off.cpu().numpy().astype(np.int64), r['off']), l
+            assert np.array_equal(d.nbr.cpu().numpy()[:, :15].T.astype(np.int64), r['nbr']), l
+        for s in range(2):
+            rete = O.enet(P, torch.from_numpy(pcs[s:s + 1]), False)
+            for o, _ in outs:
+                for k in ('e_gn_sgn', 'e_gn_abs'):
+                    assert _rel(o[k][s:s + 1].cpu().numpy(), rete[k].numpy()) < 1e-4, (k, s)
+        for k in ('e_gn_sgn', 'e_gn_abs'):                   # the builds differ in plan (escalation), not in result
+            assert torch.equal(outs[1][0][k], outs[2][0][k]), k
+
+
 def test_fused_pose_heads_equal_the_tensor_expressions():
     """csrc/pose.hip (inference path) against the tensor expressions the training path keeps (common/pose.py), which are checked
     against the oracle above: both heads, the yaw head, the calibration chain; incl. the degenerate 'same' / 'opposite' vectors"""

@@ -7,29 +7,7 @@ import numpy as np, torch
 from efgh_amd import lattice, _C, synthetic as syn
 
 
-def coherent_sweep(n_points, seed=0, beams=64, pitch=(-24.8 / 180 * np.pi, 2.0 / 180 * np.pi)):
-    rs = np.random.RandomState(seed)
-    na = n_points // beams
-    el = np.linspace(pitch[0], pitch[1], beams)[:, None]
-    az = np.linspace(-np.pi, np.pi, na, endpoint=False)[None, :]
-    d = np.stack([np.cos(el) * np.cos(az), np.cos(el) * np.sin(az), np.sin(el) * np.ones_like(az)])     # (3, beams, na)
-    r = np.full((beams, na), 80.0)
-    with np.errstate(divide='ignore', invalid='ignore'):
-        rg = np.where(d[2] < -1e-3, -1.73 / d[2], np.inf)               # ground plane z = -1.73
-    r = np.minimum(r, rg)
-    for k in range(12):                                                  # a few walls / boxes (vertical planes)
-        th = rs.uniform(-np.pi, np.pi)
-        nrm = np.array([np.cos(th), np.sin(th), 0.0])
-        dist = rs.uniform(6, 40)
-        den = d[0] * nrm[0] + d[1] * nrm[1]
-        with np.errstate(divide='ignore', invalid='ignore'):
-            rw = np.where(den > 1e-3, dist / den, np.inf)
-        lat = (d[0] * -nrm[1] + d[1] * nrm[0]) * rw                      # lateral extent of the wall: +-8 m
-        hz = d[2] * rw
-        rw = np.where((np.abs(lat) < 8) & (hz < 3.0), rw, np.inf)
-        r = np.minimum(r, rw)
-    r = r * (1 + 0.002 * rs.randn(beams, na))
-    return np.float32((d * r).reshape(3, -1))
+coherent_sweep = syn.coherent_sweep
 
 
 SC = (1.0, 0.75, 0.5, 0.25, 0.125)
