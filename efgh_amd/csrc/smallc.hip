@@ -15,7 +15,9 @@
 //   * epilogue of k_gather_gemm (bias, BatchNorm statistics of the pre-activation value, scale / shift, residual, activation)
 //     through a wave-private LDS tile, leaving as 16-byte stores.
 // Weight gradient: dW[n][t][c] = sum_p G[p][n] X[p + tap t][c] with k = 4 pixels per MFMA, G and X staged the same way, one
-// partial [N][9 C] plane per workgroup, planes added in a fixed order by k_fold_splits (no atomics: bit-reproducible).
+// partial [N][9 C] plane per wave, planes added in a fixed order by k_fold_splits (no atomics: bit-reproducible).  The same
+// kernel serves the 4-channel INPUT layers at stride 1 (RGB / range / depth -> 32 or 64 channels: 36 columns, the last tile
+// masked) in place of k_c4_wgrad, which loads G four bytes at a time and combines its partial sums with fp32 atomics.
 #include "common.h"
 
 void efgh_launch_fold_splits(const float *part, int zs, long long total, float *dst, hipStream_t st);   // wgrad.hip
@@ -234,7 +236,7 @@ __global__ void __launch_bounds__(64 * WAVES, 2) k_sc_conv(const SCArgs p) {
 // every split walks all units and keeps its half of the columns (the 125-MB operands of these layers are read twice)
 template <int C, int N, int CS>
 __global__ void __launch_bounds__(64 * WAVES, 2) k_sc_wgrad(const SCArgs p) {
-    constexpr int NG = C / 4, NT = N / 16, CT = 9 * C / 16 / CS;
+    constexpr int NG = C / 4, NT = N / 16, CT = (9 * C + 15) / 16 / CS;        // (C = 4: 36 columns = 2.25 -> 3 tiles, the rest masked)
     const int ct0 = blockIdx.y * CT;
     constexpr int NQ = 3 * LW * NG, NPF = (NQ + 63) / 64;
     __shared__ __attribute__((aligned(16))) float4 Qw[WAVES][3 * NG * LW];
@@ -251,11 +253,13 @@ __global__ void __launch_bounds__(64 * WAVES, 2) k_sc_wgrad(const SCArgs p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[a][c][e] = 0.f;
     // LDS float offset of this lane's column (t, c) in each column tile, relative to the group's first pixel
-    int coff[CT];
+    constexpr bool MASK = (9 * C) % 16 != 0;                           // (only C = 4 has a ragged last column tile)
+    int coff[CT]; bool cok[CT];
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
         const int col = 16 * (ct0 + c) + q16, t = col / C, ch = col % C;
-        coff[c] = (((t / 3) * NG + ch / 4) * LW + t % 3) * 4 + (ch & 3);
+        cok[c] = !MASK || col < 9 * C;
+        coff[c] = cok[c] ? (((t / 3) * NG + ch / 4) * LW + t % 3) * 4 + (ch & 3) : 0;
     }
     const long long nwaves = (long long)gridDim.x * WAVES;
     long long unit = (long long)blockIdx.x * WAVES + wave;
@@ -304,7 +308,7 @@ __global__ void __launch_bounds__(64 * WAVES, 2) k_sc_wgrad(const SCArgs p) {
             for (int a = 0; a < NT; ++a) ga[a] = Gs[pl][16 * a + q16];
 #pragma unroll
             for (int c = 0; c < CT; ++c) {
-                const float xb = Qf[coff[c] + pl * 4];
+                const float xb = (!MASK || cok[c]) ? Qf[coff[c] + pl * 4] : 0.f;
 #pragma unroll
                 for (int a = 0; a < NT; ++a) acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[a], xb, acc[a][c], 0, 0, 0);
             }
@@ -315,14 +319,17 @@ __global__ void __launch_bounds__(64 * WAVES, 2) k_sc_wgrad(const SCArgs p) {
 #pragma unroll
     for (int a = 0; a < NT; ++a)
 #pragma unroll
-        for (int c = 0; c < CT; ++c)
+        for (int c = 0; c < CT; ++c) {
+            if (MASK && !cok[c]) continue;
 #pragma unroll
             for (int e = 0; e < 4; ++e) plane[(16 * a + 4 * kq + e) * (9 * C) + 16 * (ct0 + c) + q16] = acc[a][c][e];
+        }
 }
 
-bool sc_geometry_ok(const efgh_gemm_desc *d) {
+bool sc_geometry_ok(const efgh_gemm_desc *d, bool four_in = false) {
     if (!d || d->mode != 1 || d->T != 9 || d->M_dev || d->nbatch > 1) return false;
-    if (!((d->C == 16 || d->C == 32) && (d->N == 16 || d->N == 32))) return false;
+    if (four_in) { if (!(d->C == 4 && (d->N == 32 || d->N == 64))) return false; }
+    else if (!((d->C == 16 || d->C == 32) && (d->N == 16 || d->N == 32))) return false;
     if (d->sh != 1 || d->sw != 1 || d->osh != 1 || d->osw != 1 || d->oh0 || d->ow0) return false;
     if (d->Hv != d->Ho || d->Wv != d->Wo || d->Ho != d->Hin || d->Wo != d->Win || d->B <= 0) return false;
     if (d->M != (int64_t)d->B * d->Ho * d->Wo) return false;
@@ -375,9 +382,12 @@ extern "C" int efgh_sc_conv3x3(const efgh_gemm_desc *d, void *stream_) {
     return EFGH_OK;
 }
 
+/* the weight gradient also serves the 4-channel input layers at stride 1 (32 or 64 outputs): the same staging, 36 columns */
+extern "C" int efgh_sc_wgrad_supported(const efgh_gemm_desc *d) { return (sc_geometry_ok(d) || sc_geometry_ok(d, true)) ? 1 : 0; }
+
 /* floats of scratch efgh_sc_wgrad needs: one [N][9][C] partial per wave of the launch */
 extern "C" int64_t efgh_sc_wgrad_workspace(const efgh_gemm_desc *d) {
-    if (!sc_geometry_ok(d)) return 0;
+    if (!efgh_sc_wgrad_supported(d)) return 0;
     SCArgs a;
     fill(a, d);
     return (int64_t)grid_of(a.units) * WAVES * d->N * 9 * d->C;
@@ -385,12 +395,14 @@ extern "C" int64_t efgh_sc_wgrad_workspace(const efgh_gemm_desc *d) {
 
 extern "C" int efgh_sc_wgrad(const efgh_gemm_desc *d, const float *G, int64_t ldg, float *dWp, float *workspace, void *stream_) {
     hipStream_t st = (hipStream_t)stream_;
-    EFGH_CHECK_ARG(efgh_sc_supported(d) && G && dWp && workspace && ldg >= d->N && ldg % 4 == 0 && (((uintptr_t)G) & 15) == 0);
+    EFGH_CHECK_ARG(efgh_sc_wgrad_supported(d) && G && dWp && workspace && ldg >= d->N && ldg % 4 == 0 && (((uintptr_t)G) & 15) == 0);
     SCArgs a;
     fill(a, d);
     a.G = G; a.ldg = ldg; a.part = workspace;
     const int grid = grid_of(a.units);
-    if (d->C == 16 && d->N == 16) k_sc_wgrad<16, 16, 1><<<grid, 64 * WAVES, 0, st>>>(a);
+    if (d->C == 4 && d->N == 32) k_sc_wgrad<4, 32, 1><<<grid, 64 * WAVES, 0, st>>>(a);
+    else if (d->C == 4) k_sc_wgrad<4, 64, 1><<<grid, 64 * WAVES, 0, st>>>(a);
+    else if (d->C == 16 && d->N == 16) k_sc_wgrad<16, 16, 1><<<grid, 64 * WAVES, 0, st>>>(a);
     else if (d->C == 16 && d->N == 32) k_sc_wgrad<16, 32, 1><<<grid, 64 * WAVES, 0, st>>>(a);
     else if (d->C == 32 && d->N == 16) k_sc_wgrad<32, 16, 2><<<dim3(grid, 2), 64 * WAVES, 0, st>>>(a);
     else k_sc_wgrad<32, 32, 2><<<dim3(grid, 2), 64 * WAVES, 0, st>>>(a);

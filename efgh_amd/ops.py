@@ -859,6 +859,13 @@ def gather_wgrad(A, lda, C, T, N, M, G, ldg, dWp, mode=0, geom=None, table=None)
     wino = False
     if thin:
         _C.check(_L().efgh_thin_wgrad(ctypes.byref(d), ptr(G), c_int64(ldg), ptr(dWp), _st()))
+    elif (USE_SMALLC and C == 4 and N in (32, 64) and lda % 4 == 0 and ldg % 4 == 0 and geom is not None and geom[5] == 1
+          and sc_eligible(mode, 16, 16, geom)):
+        # 4-channel input layers at stride 1: the small-channel weight-gradient kernel (G staged by 16-byte loads, per-wave partial
+        # planes folded in a fixed order) instead of k_c4_wgrad (4-byte G loads, fp32 atomics)
+        thin = True             # (profile lists: an HBM-bound launch)
+        _C.check(_L().efgh_sc_wgrad(ctypes.byref(d), ptr(G), c_int64(ldg), ptr(dWp),
+                                    ptr(_scratch(_L().efgh_sc_wgrad_workspace(ctypes.byref(d)), dWp.device)), _st()))
     elif not DETERMINISTIC and c4_eligible(mode, C, N, geom, wgrad=True):
         thin = True             # (profile lists, as above)
         _C.check(_L().efgh_c4_wgrad(ctypes.byref(d), ptr(G), c_int64(ldg), ptr(dWp), _st()))

@@ -426,6 +426,7 @@ int efgh_thin_wgrad(const efgh_gemm_desc *d, const float *G, int64_t ldg, float 
 int efgh_sc_supported(const efgh_gemm_desc *d);
 int32_t efgh_sc_stats_rows(int32_t B, int32_t H, int32_t W);
 int efgh_sc_conv3x3(const efgh_gemm_desc *d, void *stream);
+int efgh_sc_wgrad_supported(const efgh_gemm_desc *d);      /* also C == 4 with N in {32, 64} at stride 1 (the RGB / range / depth input layers) */
 int64_t efgh_sc_wgrad_workspace(const efgh_gemm_desc *d);
 int efgh_sc_wgrad(const efgh_gemm_desc *d, const float *G, int64_t ldg, float *dWp, float *workspace, void *stream);
 int efgh_c4_supported(const efgh_gemm_desc *d);
