@@ -1,4 +1,4 @@
-// 3x3 / stride-1 / pad-1 convolutions with 16 or 32 channels on BOTH sides on fp32 MFMA (gfx950): the up-sampling stages of F's two
+// 3x3 / stride-1 / pad-1 convolutions with 16 or 32 channels on BOTH sides (and two 1x1 shapes, below) on fp32 MFMA (gfx950): the up-sampling stages of F's two
 // trunks (nets/fnet.py:22-31 through nets/net_utils.py:66-98: conv_bn_relu after every convt_bn_relu), forward, data gradient (the
 // same kernel on the gradient with the transposed, tap-reversed weights) and weight gradient.
 //
@@ -18,6 +18,9 @@
 // partial [N][9 C] plane per wave, planes added in a fixed order by k_fold_splits (no atomics: bit-reproducible).  The same
 // kernel serves the 4-channel INPUT layers at stride 1 (RGB / range / depth -> 32 or 64 channels: 36 columns, the last tile
 // masked) in place of k_c4_wgrad, which loads G four bytes at a time and combines its partial sums with fp32 atomics.
+// TAPS == 1: the 1x1 / stride-1 layers with 32 or 64 channels (64 -> 32 at full resolution and its data gradient 32 -> 64): one
+// staged row without a halo, 1.5 GB of operands for 16 GFLOP - HBM-bound at any MFMA rate, so what counts is that every byte moves
+// once, as 16-byte accesses, with the next unit's loads in flight during the MFMAs.
 #include "common.h"
 
 void efgh_launch_fold_splits(const float *part, int zs, long long total, float *dst, hipStream_t st);   // wgrad.hip
@@ -27,7 +30,9 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int TP = 32;                  // output pixels per unit (one wave)
-constexpr int LW = TP + 2;              // staged input pixels per row
+constexpr int lw_of(int taps) { return taps == 9 ? TP + 2 : TP + 1; } // staged row pitch in pixels (3x3: one halo pixel either side; 1x1: one pad
+                                                                      // pixel, which keeps the 16 channel quads of a pixel on different banks)
+constexpr int rows_of(int taps) { return taps == 9 ? 3 : 1; }         // staged input rows
 constexpr int WAVES = 4;
 
 struct SCArgs {
@@ -56,22 +61,24 @@ __device__ __forceinline__ void unit_coords(const SCArgs &p, long long unit, lon
 }
 
 // staged float4 number idx of a unit: idx = (kh * LW + x) * NG + g  (g fastest: contiguous 16-byte chunks along the image row)
-template <int NG>
+template <int NG, int TAPS>
 __device__ __forceinline__ float4 load_quad(const SCArgs &p, int idx, int i, long long b, int j0) {
+    constexpr int LW = lw_of(TAPS), HALO = TAPS == 9 ? 1 : 0;
     const int g = idx % NG, r = idx / NG;
     const int kh = r / LW, x = r - kh * LW;
-    const int yin = i - 1 + kh, xin = j0 - 1 + x;
-    if (kh < 3 && (unsigned)yin < (unsigned)p.H && (unsigned)xin < (unsigned)p.W)
+    const int yin = i - HALO + kh, xin = j0 - HALO + x;
+    if (kh < rows_of(TAPS) && (unsigned)yin < (unsigned)p.H && (unsigned)xin < (unsigned)p.W)
         return *reinterpret_cast<const float4 *>(p.A + ((b * p.H + yin) * p.W + xin) * p.lda + 4 * g);
     return make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
-template <int C, int N, bool RES>
+template <int C, int N, int TAPS, bool RES>
 __global__ void __launch_bounds__(64 * WAVES, 2) k_sc_conv(const SCArgs p) {
-    constexpr int NG = C / 4, NT = N / 16, STEPS = 9 * NG;
-    constexpr int NQ = 3 * LW * NG, NPF = (NQ + 63) / 64;          // float4s per unit, per lane
+    constexpr int LW = lw_of(TAPS), ROWS = rows_of(TAPS);
+    constexpr int NG = C / 4, NT = N / 16, STEPS = TAPS * NG;
+    constexpr int NQ = ROWS * LW * NG, NPF = (NQ + 63) / 64;       // float4s per unit, per lane
     constexpr int TPITCH = N + 4;                                   // floats per pixel row of the transpose tile
-    __shared__ __attribute__((aligned(16))) float4 Qw[WAVES][3 * NG * LW];
+    __shared__ __attribute__((aligned(16))) float4 Qw[WAVES][ROWS * NG * LW];
     __shared__ __attribute__((aligned(16))) float Tw[WAVES][TP * TPITCH];
     __shared__ float red[2][WAVES][N];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q16 = lane & 15, kq = lane >> 4;
@@ -86,7 +93,7 @@ __global__ void __launch_bounds__(64 * WAVES, 2) k_sc_conv(const SCArgs p) {
     for (int nt = 0; nt < NT; ++nt) {
         const int n = 16 * nt + q16;
 #pragma unroll
-        for (int s = 0; s < STEPS; ++s) bw[s][nt] = p.Wp[((long long)n * 9 + s / NG) * C + 4 * (s % NG) + kq];
+        for (int s = 0; s < STEPS; ++s) bw[s][nt] = p.Wp[((long long)n * TAPS + s / NG) * C + 4 * (s % NG) + kq];
         bi[nt] = p.bias ? p.bias[n] : 0.f;
         sc[nt] = p.scale ? p.scale[n] : 1.f;
         sf[nt] = p.shift ? p.shift[n] : 0.f;
@@ -108,7 +115,7 @@ __global__ void __launch_bounds__(64 * WAVES, 2) k_sc_conv(const SCArgs p) {
 #pragma unroll
         for (int q = 0; q < NPF; ++q) {
             const int idx = lane + 64 * q;
-            pf[q] = idx < NQ ? load_quad<NG>(p, idx, i, b, j0) : make_float4(0.f, 0.f, 0.f, 0.f);
+            pf[q] = idx < NQ ? load_quad<NG, TAPS>(p, idx, i, b, j0) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     auto stage = [&]() {
@@ -123,9 +130,9 @@ __global__ void __launch_bounds__(64 * WAVES, 2) k_sc_conv(const SCArgs p) {
             }
         }
     };
-    // C = 16: the next unit's quads are prefetched into registers during the MFMAs (7 float4s); C = 32 has no registers left for
-    // that (144 of them hold the weights): its waves load, stage and compute in turn and overlap with each other
-    constexpr bool PRE = C == 16;
+    // C = 16 and the 1x1 layers: the next unit's quads are prefetched into registers during the MFMAs (7-8 float4s); 3x3 with C = 32
+    // has no registers left for that (144 of them hold the weights): its waves load, stage and compute in turn and overlap with each other
+    constexpr bool PRE = C == 16 || TAPS == 1;
     if (PRE && unit < p.units) {
         fetch(unit);
         stage();
@@ -142,7 +149,7 @@ __global__ void __launch_bounds__(64 * WAVES, 2) k_sc_conv(const SCArgs p) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int idx = lane + 64 * (q0 + u);
-                    v[u] = (q0 + u < NPF && idx < NQ) ? load_quad<NG>(p, idx, i, b, j0) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    v[u] = (q0 + u < NPF && idx < NQ) ? load_quad<NG, TAPS>(p, idx, i, b, j0) : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -166,7 +173,7 @@ __global__ void __launch_bounds__(64 * WAVES, 2) k_sc_conv(const SCArgs p) {
                 for (int e = 0; e < 4; ++e) acc[pt][nt][e] = 0.f;
 #pragma unroll
         for (int s = 0; s < STEPS; ++s) {
-            const int t = s / NG, g = s % NG, kh = t / 3, kw = t % 3;
+            const int t = s / NG, g = s % NG, kh = TAPS == 9 ? t / 3 : 0, kw = TAPS == 9 ? t % 3 : 0;
             // A operand: pixel 16 pt + q16 (+ kw), channel 4 g + kq
             const float a0 = Qf[((kh * NG + g) * LW + q16 + kw) * 4 + kq];
             const float a1 = Qf[((kh * NG + g) * LW + 16 + q16 + kw) * 4 + kq];
@@ -234,12 +241,13 @@ __global__ void __launch_bounds__(64 * WAVES, 2) k_sc_conv(const SCArgs p) {
 // of the [9][C] plane.  Accumulators: NT x (9 C / 16) tiles, kept over all units of the (persistent) wave.
 // CS column splits (blockIdx.y): with 32 input channels the 18 column tiles do not fit one wave's registers next to the operands;
 // every split walks all units and keeps its half of the columns (the 125-MB operands of these layers are read twice)
-template <int C, int N, int CS>
+template <int C, int N, int TAPS, int CS>
 __global__ void __launch_bounds__(64 * WAVES, 2) k_sc_wgrad(const SCArgs p) {
-    constexpr int NG = C / 4, NT = N / 16, CT = (9 * C + 15) / 16 / CS;        // (C = 4: 36 columns = 2.25 -> 3 tiles, the rest masked)
+    constexpr int LW = lw_of(TAPS), ROWS = rows_of(TAPS);
+    constexpr int NG = C / 4, NT = N / 16, CT = (TAPS * C + 15) / 16 / CS;     // (C = 4: 36 columns = 2.25 -> 3 tiles, the rest masked)
     const int ct0 = blockIdx.y * CT;
-    constexpr int NQ = 3 * LW * NG, NPF = (NQ + 63) / 64;
-    __shared__ __attribute__((aligned(16))) float4 Qw[WAVES][3 * NG * LW];
+    constexpr int NQ = ROWS * LW * NG, NPF = (NQ + 63) / 64;
+    __shared__ __attribute__((aligned(16))) float4 Qw[WAVES][ROWS * NG * LW];
     __shared__ float Gw[WAVES][TP][N + 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q16 = lane & 15, kq = lane >> 4;
     float4 *Q = Qw[wave];
@@ -253,13 +261,13 @@ __global__ void __launch_bounds__(64 * WAVES, 2) k_sc_wgrad(const SCArgs p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[a][c][e] = 0.f;
     // LDS float offset of this lane's column (t, c) in each column tile, relative to the group's first pixel
-    constexpr bool MASK = (9 * C) % 16 != 0;                           // (only C = 4 has a ragged last column tile)
+    constexpr bool MASK = (TAPS * C) % 16 != 0;                           // (only C = 4 has a ragged last column tile)
     int coff[CT]; bool cok[CT];
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
         const int col = 16 * (ct0 + c) + q16, t = col / C, ch = col % C;
-        cok[c] = !MASK || col < 9 * C;
-        coff[c] = cok[c] ? (((t / 3) * NG + ch / 4) * LW + t % 3) * 4 + (ch & 3) : 0;
+        cok[c] = !MASK || col < TAPS * C;
+        coff[c] = cok[c] ? (((TAPS == 9 ? t / 3 : 0) * NG + ch / 4) * LW + (TAPS == 9 ? t % 3 : 0)) * 4 + (ch & 3) : 0;
     }
     const long long nwaves = (long long)gridDim.x * WAVES;
     long long unit = (long long)blockIdx.x * WAVES + wave;
@@ -272,7 +280,7 @@ __global__ void __launch_bounds__(64 * WAVES, 2) k_sc_wgrad(const SCArgs p) {
 #pragma unroll
         for (int q = 0; q < NPF; ++q) {
             const int idx = lane + 64 * q;
-            pf[q] = idx < NQ ? load_quad<NG>(p, idx, i, b, j0) : make_float4(0.f, 0.f, 0.f, 0.f);
+            pf[q] = idx < NQ ? load_quad<NG, TAPS>(p, idx, i, b, j0) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int q = 0; q < NGF; ++q) {
@@ -315,25 +323,27 @@ __global__ void __launch_bounds__(64 * WAVES, 2) k_sc_wgrad(const SCArgs p) {
         }
     }
     // acc[a][c][e]: n = 16 a + 4 kq + e, column = 16 c + q16.  One partial plane per WAVE (plain stores), folded in a fixed order.
-    float *plane = p.part + ((long long)blockIdx.x * WAVES + wave) * (N * 9 * C);
+    float *plane = p.part + ((long long)blockIdx.x * WAVES + wave) * (N * TAPS * C);
 #pragma unroll
     for (int a = 0; a < NT; ++a)
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
             if (MASK && !cok[c]) continue;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) plane[(16 * a + 4 * kq + e) * (9 * C) + 16 * (ct0 + c) + q16] = acc[a][c][e];
+            for (int e = 0; e < 4; ++e) plane[(16 * a + 4 * kq + e) * (TAPS * C) + 16 * (ct0 + c) + q16] = acc[a][c][e];
         }
 }
 
 bool sc_geometry_ok(const efgh_gemm_desc *d, bool four_in = false) {
-    if (!d || d->mode != 1 || d->T != 9 || d->M_dev || d->nbatch > 1) return false;
-    if (four_in) { if (!(d->C == 4 && (d->N == 32 || d->N == 64))) return false; }
+    if (!d || d->mode != 1 || (d->T != 9 && d->T != 1) || d->M_dev || d->nbatch > 1) return false;
+    if (d->T == 1) { if (four_in || !((d->C == 64 && d->N == 32) || (d->C == 32 && d->N == 64))) return false; }
+    else if (four_in) { if (!(d->C == 4 && (d->N == 32 || d->N == 64))) return false; }
     else if (!((d->C == 16 || d->C == 32) && (d->N == 16 || d->N == 32))) return false;
     if (d->sh != 1 || d->sw != 1 || d->osh != 1 || d->osw != 1 || d->oh0 || d->ow0) return false;
     if (d->Hv != d->Ho || d->Wv != d->Wo || d->Ho != d->Hin || d->Wo != d->Win || d->B <= 0) return false;
     if (d->M != (int64_t)d->B * d->Ho * d->Wo) return false;
-    for (int t = 0; t < 9; ++t) if (d->dh[t] != t / 3 - 1 || d->dw[t] != t % 3 - 1) return false;
+    if (d->T == 1) { if (d->dh[0] || d->dw[0]) return false; }
+    else for (int t = 0; t < 9; ++t) if (d->dh[t] != t / 3 - 1 || d->dw[t] != t % 3 - 1) return false;
     if (d->residual && (d->ldr % 4 != 0 || (((uintptr_t)d->residual) & 15) != 0)) return false;
     return d->lda % 4 == 0 && (((uintptr_t)d->A) & 15) == 0;
 }
@@ -368,15 +378,17 @@ extern "C" int efgh_sc_conv3x3(const efgh_gemm_desc *d, void *stream_) {
     fill(a, d);
     const int grid = grid_of(a.units);
     const bool res = d->residual != nullptr;
-#define EFGH_GO(C_, N_)                                                              \
+#define EFGH_GO(C_, N_, T_)                                                          \
     {                                                                               \
-        if (res) k_sc_conv<C_, N_, true><<<grid, 64 * WAVES, 0, st>>>(a);           \
-        else k_sc_conv<C_, N_, false><<<grid, 64 * WAVES, 0, st>>>(a);              \
+        if (res) k_sc_conv<C_, N_, T_, true><<<grid, 64 * WAVES, 0, st>>>(a);       \
+        else k_sc_conv<C_, N_, T_, false><<<grid, 64 * WAVES, 0, st>>>(a);          \
     }
-    if (d->C == 16 && d->N == 16) EFGH_GO(16, 16)
-    else if (d->C == 16 && d->N == 32) EFGH_GO(16, 32)
-    else if (d->C == 32 && d->N == 16) EFGH_GO(32, 16)
-    else EFGH_GO(32, 32)
+    if (d->T == 1 && d->C == 64) EFGH_GO(64, 32, 1)
+    else if (d->T == 1) EFGH_GO(32, 64, 1)
+    else if (d->C == 16 && d->N == 16) EFGH_GO(16, 16, 9)
+    else if (d->C == 16 && d->N == 32) EFGH_GO(16, 32, 9)
+    else if (d->C == 32 && d->N == 16) EFGH_GO(32, 16, 9)
+    else EFGH_GO(32, 32, 9)
 #undef EFGH_GO
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
@@ -385,12 +397,12 @@ extern "C" int efgh_sc_conv3x3(const efgh_gemm_desc *d, void *stream_) {
 /* the weight gradient also serves the 4-channel input layers at stride 1 (32 or 64 outputs): the same staging, 36 columns */
 extern "C" int efgh_sc_wgrad_supported(const efgh_gemm_desc *d) { return (sc_geometry_ok(d) || sc_geometry_ok(d, true)) ? 1 : 0; }
 
-/* floats of scratch efgh_sc_wgrad needs: one [N][9][C] partial per wave of the launch */
+/* floats of scratch efgh_sc_wgrad needs: one [N][T][C] partial per wave of the launch */
 extern "C" int64_t efgh_sc_wgrad_workspace(const efgh_gemm_desc *d) {
     if (!efgh_sc_wgrad_supported(d)) return 0;
     SCArgs a;
     fill(a, d);
-    return (int64_t)grid_of(a.units) * WAVES * d->N * 9 * d->C;
+    return (int64_t)grid_of(a.units) * WAVES * d->N * d->T * d->C;
 }
 
 extern "C" int efgh_sc_wgrad(const efgh_gemm_desc *d, const float *G, int64_t ldg, float *dWp, float *workspace, void *stream_) {
@@ -400,16 +412,18 @@ extern "C" int efgh_sc_wgrad(const efgh_gemm_desc *d, const float *G, int64_t ld
     fill(a, d);
     a.G = G; a.ldg = ldg; a.part = workspace;
     const int grid = grid_of(a.units);
-    if (d->C == 4 && d->N == 32) k_sc_wgrad<4, 32, 1><<<grid, 64 * WAVES, 0, st>>>(a);
-    else if (d->C == 4) k_sc_wgrad<4, 64, 1><<<grid, 64 * WAVES, 0, st>>>(a);
-    else if (d->C == 16 && d->N == 16) k_sc_wgrad<16, 16, 1><<<grid, 64 * WAVES, 0, st>>>(a);
-    else if (d->C == 16 && d->N == 32) k_sc_wgrad<16, 32, 1><<<grid, 64 * WAVES, 0, st>>>(a);
-    else if (d->C == 32 && d->N == 16) k_sc_wgrad<32, 16, 2><<<dim3(grid, 2), 64 * WAVES, 0, st>>>(a);
-    else k_sc_wgrad<32, 32, 2><<<dim3(grid, 2), 64 * WAVES, 0, st>>>(a);
+    if (d->T == 1 && d->C == 64) k_sc_wgrad<64, 32, 1, 1><<<grid, 64 * WAVES, 0, st>>>(a);
+    else if (d->T == 1) k_sc_wgrad<32, 64, 1, 1><<<grid, 64 * WAVES, 0, st>>>(a);
+    else if (d->C == 4 && d->N == 32) k_sc_wgrad<4, 32, 9, 1><<<grid, 64 * WAVES, 0, st>>>(a);
+    else if (d->C == 4) k_sc_wgrad<4, 64, 9, 1><<<grid, 64 * WAVES, 0, st>>>(a);
+    else if (d->C == 16 && d->N == 16) k_sc_wgrad<16, 16, 9, 1><<<grid, 64 * WAVES, 0, st>>>(a);
+    else if (d->C == 16 && d->N == 32) k_sc_wgrad<16, 32, 9, 1><<<grid, 64 * WAVES, 0, st>>>(a);
+    else if (d->C == 32 && d->N == 16) k_sc_wgrad<32, 16, 9, 2><<<dim3(grid, 2), 64 * WAVES, 0, st>>>(a);
+    else k_sc_wgrad<32, 32, 9, 2><<<dim3(grid, 2), 64 * WAVES, 0, st>>>(a);
     // waves without a unit never ran: their planes are garbage - only the planes of waves that had work are folded
     const long long nw = (long long)grid * WAVES;
     const long long used = a.units < nw ? a.units : nw;
-    efgh_launch_fold_splits(workspace, (int)used, (long long)d->N * 9 * d->C, dWp, st);
+    efgh_launch_fold_splits(workspace, (int)used, (long long)d->N * d->T * d->C, dWp, st);
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
 }

@@ -157,6 +157,154 @@ k_thin_n4(const TArgs p) {
     }
 }
 
+// ---- N == 4, C == 64, 3x3 / stride 1 / pad 1 on fp32 MFMA: the data gradient of the 4 -> 64 input layer of F's range trunk (15.7 M
+// pixels at batch 8: 4 GB of gradient for 72 GFLOP).  k_thin_n4 fetches every 256-byte gradient row nine times through L1 (one per
+// tap) and runs its 36 G FMAs on the VALU: 3.0 ms.  Here one WAVE owns a strip of 30 output columns and walks down RC image rows; for
+// every input row it computes the 36 products P[pixel][(kh, kw, n)] = x[pixel][:] . W[n][kh][kw][:] of 32 pixels (30 + one halo pixel
+// either side) with v_mfma_f32_16x16x4_f32 - columns (kw, n) = 12 of 16 per kernel row kh - and then adds them into the three output
+// rows they belong to (y[i][j] = sum P_{i + kh - 1}[j + kw - 1][kh][kw]): the column shift goes through a wave-private LDS tile, the
+// row shift is a rotation of two partial-row registers.  Every gradient row is read once (+ 7 % halo columns, + 2 / RC halo rows).
+// The contraction axis is permuted so that a lane's MFMA operands are four contiguous float4s of its pixel (lane group kq owns
+// channels 16 kq .. 16 kq + 15).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int N4_TP = 30, N4_RC = 32, N4_WAVES = 4, N4_QP = 33;       // strip width, rows per unit, waves per block, LDS pitch
+// (units are NOT walked by persistent waves: 8 k - 16 k units over 2048 wave slots leave a tail of a whole unit; one wave per unit,
+// dispatched as slots free up, ends within a fraction of one)
+
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__global__ void __launch_bounds__(64 * N4_WAVES, 3)
+k_n4_conv3x3_c64(const TArgs p, int strips, int chunks, long long units) {
+    constexpr int C = 64, NG = C / 4;
+    // per wave: the staged row Q[channel quad][pixel] (float4) and, in the same bytes once its operands are in registers, the product
+    // tile T[kh][column][pixel] (pitch N4_TPI: a lane's four consecutive pixels leave as one 16-byte write)
+    constexpr int N4_TPI = 36;
+    static_assert(3 * 16 * N4_TPI <= NG * N4_QP * 4, "the product tile must fit the staged row's bytes");
+    __shared__ __attribute__((aligned(16))) float4 Qw[N4_WAVES][NG * N4_QP];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), q16 = lane & 15, kq = lane >> 4;
+    float4 *Q = Qw[wave];
+    float *T = reinterpret_cast<float *>(Qw[wave]);
+    // B operand of (kh, step s): column q16 = kw * 4 + n (12 used), channel 16 kq + s
+    float bw[3][16];
+    {
+        const int kw = q16 >> 2, n = q16 & 3;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (kw < 3) w = *reinterpret_cast<const float4 *>(p.W + ((long long)n * 9 + kh * 3 + kw) * C + 16 * kq + 4 * s4);
+                bw[kh][4 * s4] = w.x; bw[kh][4 * s4 + 1] = w.y; bw[kh][4 * s4 + 2] = w.z; bw[kh][4 * s4 + 3] = w.w;
+            }
+    }
+    // this lane's two outputs of a row: pixel jj of the strip, channels n0, n0 + 1
+    const int jj = lane & 31, n0 = (lane >> 5) * 2;
+    float ebi[2], esc[2], esf[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        ebi[u] = p.bias ? p.bias[n0 + u] : 0.f;
+        esc[u] = p.scale ? p.scale[n0 + u] : 1.f;
+        esf[u] = p.shift ? p.shift[n0 + u] : 0.f;
+    }
+    const int H = p.Hin, W = p.Win;
+    for (long long unit = (long long)blockIdx.x * N4_WAVES + wave; unit < units; unit += (long long)gridDim.x * N4_WAVES) {
+        const int js = (int)(unit % strips);
+        const long long r1 = unit / strips;
+        const int rc = (int)(r1 % chunks);
+        const long long b = r1 / chunks;
+        const int j0 = js * N4_TP, i0 = rc * N4_RC;
+        const int iend = i0 + N4_RC < H ? i0 + N4_RC : H;            // output rows [i0, iend)
+        // one buffer resource per input row: pixels left / right of the image fall outside its num_records and rows above / below
+        // it get an empty one - the hardware's range check returns zeros, so there is no select or branch around the loads
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 pf[8];
+        const int voff = (((j0 - 1 + (lane >> 4)) * (int)p.lda) + 4 * (lane & 15)) * 4;      // bytes; lane's pixel of load 0, its quad
+        const int vstep = 4 * (int)p.lda * 4;                                               // four pixels on per load
+        const unsigned rowbytes = (unsigned)W * (unsigned)p.lda * 4u;
+        auto fetch = [&](int r) {                                    // input row r, pixels j0 - 1 .. j0 + 30
+            const bool rok = (unsigned)r < (unsigned)H;
+            const float *rowp = p.A + (b * H + (rok ? r : 0)) * W * p.lda;
+            const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(rowp), 0, rok ? rowbytes : 0u, 0x00020000);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) pf[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + q * vstep, 0, 0);
+        };
+        float R0[2] = {0.f, 0.f}, R1[2] = {0.f, 0.f};               // partial sums of output rows r and r - 1
+        fetch(i0 - 1);
+        for (int r = i0 - 1; r <= iend; ++r) {                       // input rows; output row r - 1 completes with input row r
+            const bool rok = (unsigned)r < (unsigned)H;              // (wave-uniform)
+            float S[3][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+            if (rok) {
+                wave_lds_sync();                                     // the previous row's operand / tile reads are done
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int idx = lane + 64 * q, g = idx & 15, px = idx >> 4;
+                    Q[g * N4_QP + px] = make_float4(__uint_as_float(pf[q].x), __uint_as_float(pf[q].y), __uint_as_float(pf[q].z),
+                                                    __uint_as_float(pf[q].w));
+                }
+                wave_lds_sync();
+            }
+            if (r < iend) fetch(r + 1);                              // in flight during the MFMAs
+            if (rok) {
+                f32x4 acc[2][3];
+#pragma unroll
+                for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+                    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[pt][kh][e] = 0.f;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const float4 a0 = Q[(4 * kq + m) * N4_QP + q16], a1 = Q[(4 * kq + m) * N4_QP + 16 + q16];
+                    const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int kh = 0; kh < 3; ++kh) {
+                            acc[0][kh] = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[e], bw[kh][4 * m + e], acc[0][kh], 0, 0, 0);
+                            acc[1][kh] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[e], bw[kh][4 * m + e], acc[1][kh], 0, 0, 0);
+                        }
+                }
+                // acc[pt][kh][e]: pixel 16 pt + 4 kq + e, column q16
+                wave_lds_sync();                                     // (every lane's operand reads of Q are complete)
+#pragma unroll
+                for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+                    for (int kh = 0; kh < 3; ++kh)
+                        *reinterpret_cast<float4 *>(&T[(kh * 16 + q16) * N4_TPI + 16 * pt + 4 * kq]) =
+                            make_float4(acc[pt][kh][0], acc[pt][kh][1], acc[pt][kh][2], acc[pt][kh][3]);
+                wave_lds_sync();
+                if (jj < N4_TP) {
+#pragma unroll
+                    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                            for (int u = 0; u < 2; ++u) S[kh][u] += T[(kh * 16 + kw * 4 + n0 + u) * N4_TPI + jj + kw];
+                }
+            }
+            const int io = r - 1;                                    // the output row that is complete now
+            if (io >= i0 && jj < N4_TP && j0 + jj < W) {
+                const long long orow = (b * H + io) * W + j0 + jj;
+                float o[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    float x = R1[u] + S[2][u] + ebi[u];
+                    x = x * esc[u] + esf[u];
+                    if (p.residual) x += p.residual[orow * p.ldr + n0 + u];
+                    o[u] = act_f(x, p.act, p.slope);
+                }
+                *reinterpret_cast<float2 *>(p.out + orow * p.ldo + n0) = make_float2(o[0], o[1]);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) { R1[u] = R0[u] + S[1][u]; R0[u] = S[0][u]; }
+        }
+    }
+}
+
 // ---- wgrad, C == 4:  dW[n][t][0..3] += sum_m G[orow(m)][n] * A[row(m,t)][0..3] -----------------------
 // thread = (row lane, n-quad); 16*T accumulators; block-level LDS reduction, then global atomics.
 template <int T>
@@ -262,6 +410,18 @@ int fill(TArgs &a, const efgh_gemm_desc *d) {
     return 0;
 }
 
+// k_n4_conv3x3_c64: 64 -> 4 channels, 3x3, stride 1, pad 1, "same" size, 16-byte input rows, 8-byte output pairs
+bool n4_mfma_ok(const efgh_gemm_desc *d) {
+    if (d->N != 4 || d->C != 64 || d->T != 9 || d->M_dev || d->nbatch > 1) return false;
+    if (d->sh != 1 || d->sw != 1 || d->osh != 1 || d->osw != 1 || d->oh0 || d->ow0) return false;
+    if (d->Hv != d->Ho || d->Wv != d->Wo || d->Ho != d->Hin || d->Wo != d->Win || d->B <= 0) return false;
+    for (int t = 0; t < 9; ++t) if (d->dh[t] != t / 3 - 1 || d->dw[t] != t % 3 - 1) return false;
+    if (d->residual && d->ldr % 2 != 0) return false;
+    if ((int64_t)(d->Win + 32) * d->lda * 4 >= (1ll << 31)) return false;                 // 32-bit byte offsets within an image row
+    return d->lda % 4 == 0 && (((uintptr_t)d->A) & 15) == 0 && (((uintptr_t)d->W) & 15) == 0 && d->ldo % 2 == 0 &&
+           (((uintptr_t)d->out) & 7) == 0;
+}
+
 int grid_for(long long total, int per) {
     long long g = (total + per - 1) / per;
     return (int)(g > 32768 ? 32768 : (g < 1 ? 1 : g));
@@ -272,7 +432,7 @@ extern "C" int efgh_thin_supported(const efgh_gemm_desc *d) {
     if (!d || d->mode != 1 || d->N % 4 != 0 || d->C % 4 != 0 || d->stats) return 0;
     if (d->C == 4 && d->N <= 256 && (d->T == 1 || d->T == 2 || d->T == 4 || d->T == 9) &&
         (int64_t)d->T * d->N * 16 + 4 * 64 * 36 * 4 <= 64 * 1024) return 1;
-    if (d->N == 4 && (int64_t)d->T * d->C * 16 <= 60 * 1024) return 2;
+    if (d->N == 4 && (int64_t)d->T * d->C * 16 <= 60 * 1024) return n4_mfma_ok(d) ? 3 : 2;
     return 0;
 }
 
@@ -293,6 +453,10 @@ extern "C" int efgh_thin_gemm(const efgh_gemm_desc *d, void *stream_) {
         case 9: k_thin_c4<9><<<grid, TPB, lds, st>>>(a); break;
         default: efgh_set_error("thin c4: unsupported tap count %d", a.T); return EFGH_E_INVALID;
         }
+    } else if (kind == 3) {
+        const int strips = (a.Win + N4_TP - 1) / N4_TP, chunks = (a.Hin + N4_RC - 1) / N4_RC;
+        const long long units = (long long)d->B * strips * chunks, g = (units + N4_WAVES - 1) / N4_WAVES;
+        k_n4_conv3x3_c64<<<(int)g, 64 * N4_WAVES, 0, st>>>(a, strips, chunks, units);
     } else
         k_thin_n4<<<grid_for(a.M, TPB / 8), TPB, (size_t)a.K * 16, st>>>(a);
     EFGH_CHECK_LAUNCH();

@@ -238,12 +238,23 @@ def c4_eligible(mode, C, N, geom, wgrad=False):
 USE_SMALLC = _os.environ.get('EFGH_SMALLC', '1') != '0'       # dedicated kernels for the 16- / 32-channel 3x3 layers (smallc.hip)
 
 
-def sc_eligible(mode, C, N, geom):
-    """the layers efgh_sc_conv3x3 / efgh_sc_wgrad serve (mirror of efgh_sc_supported): 3x3, stride 1, pad 1, C and N in {16, 32}"""
-    if not USE_SMALLC or mode != 1 or geom is None or C not in (16, 32) or N not in (16, 32) or MATH != 'f32':
+SC_MIN_PIXELS_32 = 60000        # per image, so that the choice of kernel (and with it the rounding) does not depend on the batch size
+
+
+def sc_eligible(mode, C, N, geom, wgrad=False):
+    """the layers efgh_sc_conv3x3 / efgh_sc_wgrad serve (mirror of efgh_sc_supported): stride 1, "same" size; 3x3 / pad 1 with C and N in
+    {16, 32}, or 1x1 with (C, N) = (64, 32) / (32, 64).  The 32 -> 32 forward / data-gradient launch keeps 144 weight registers per
+    lane, which only pays on large maps (tools/bench_smallc.py: 0.092 vs 0.075 ms at 8 x 94 x 322 pixels, 0.244 vs 0.270 at 8 x 190 x 637)"""
+    if not USE_SMALLC or mode != 1 or geom is None or MATH != 'f32':
         return False
     (B, Hin, Win, Hv, Wv, sh, sw, dh, dw, Ho, Wo, osh, osw, oh0, ow0) = geom
-    return (len(dh) == 9 and (sh, sw, osh, osw, oh0, ow0) == (1, 1, 1, 1, 0, 0) and Hv == Hin == Ho and Wv == Win == Wo
+    if not ((sh, sw, osh, osw, oh0, ow0) == (1, 1, 1, 1, 0, 0) and Hv == Hin == Ho and Wv == Win == Wo):
+        return False
+    if len(dh) == 1:
+        return (C, N) in ((64, 32), (32, 64)) and dh[0] == 0 and dw[0] == 0
+    if C == 32 and N == 32 and not wgrad and Hin * Win < SC_MIN_PIXELS_32:
+        return False
+    return (C in (16, 32) and N in (16, 32) and len(dh) == 9
             and list(dh) == [t // 3 - 1 for t in range(9)] and list(dw) == [t % 3 - 1 for t in range(9)])
 
 
@@ -307,6 +318,7 @@ def thin_eligible(mode, C, N, T):
     return N == 4 and T * C * 16 <= 60 * 1024
 
 
+TRACE_THIN = None       # tests set this to a list: efgh_thin_supported's answer per thin launch
 PROFILE_WINO = None     # launches served by the Winograd kernel (else they are listed in PROFILE)
 PROFILE = None          # bench.py sets this to a list: (start_event, end_event, algorithmic_flops) per launch
 
@@ -376,6 +388,8 @@ def gather_gemm(A, lda, C, T, Wp, N, M, out, ldo, mode=0, geom=None, table=None,
     thin = stats is None and M_dev is None and thin_eligible(mode, C, N, T)
     wino = False
     if thin:
+        if TRACE_THIN is not None:
+            TRACE_THIN.append(int(_L().efgh_thin_supported(ctypes.byref(d))))      # (tests: which form serves the launch)
         _C.check(_L().efgh_thin_gemm(ctypes.byref(d), _st()))
     elif M_dev is None and batch is None and c4_eligible(mode, C, N, geom):
         assert lda % 4 == 0
@@ -860,7 +874,7 @@ def gather_wgrad(A, lda, C, T, N, M, G, ldg, dWp, mode=0, geom=None, table=None)
     if thin:
         _C.check(_L().efgh_thin_wgrad(ctypes.byref(d), ptr(G), c_int64(ldg), ptr(dWp), _st()))
     elif (USE_SMALLC and C == 4 and N in (32, 64) and lda % 4 == 0 and ldg % 4 == 0 and geom is not None and geom[5] == 1
-          and sc_eligible(mode, 16, 16, geom)):
+          and sc_eligible(mode, 16, 16, geom, wgrad=True)):
         # 4-channel input layers at stride 1: the small-channel weight-gradient kernel (G staged by 16-byte loads, per-wave partial
         # planes folded in a fixed order) instead of k_c4_wgrad (4-byte G loads, fp32 atomics)
         thin = True             # (profile lists: an HBM-bound launch)
@@ -869,7 +883,7 @@ def gather_wgrad(A, lda, C, T, N, M, G, ldg, dWp, mode=0, geom=None, table=None)
     elif not DETERMINISTIC and c4_eligible(mode, C, N, geom, wgrad=True):
         thin = True             # (profile lists, as above)
         _C.check(_L().efgh_c4_wgrad(ctypes.byref(d), ptr(G), c_int64(ldg), ptr(dWp), _st()))
-    elif sc_eligible(mode, C, N, geom) and lda % 4 == 0 and ldg % 4 == 0:
+    elif sc_eligible(mode, C, N, geom, wgrad=True) and lda % 4 == 0 and ldg % 4 == 0:
         _C.check(_L().efgh_sc_wgrad(ctypes.byref(d), ptr(G), c_int64(ldg), ptr(dWp),
                                     ptr(_scratch(_L().efgh_sc_wgrad_workspace(ctypes.byref(d)), dWp.device)), _st()))
     elif USE_WINO_WGRAD and wino2d_eligible(mode, C, N, geom, wgrad=True):

@@ -409,7 +409,8 @@ int efgh_adam_step(float *w, const float *g, float *m, float *v, int64_t n, floa
 
 /* "thin" layers (<= 4 channels on one side: RGB/range/depth input convs, the 1-/2-channel heads and
  * their dgrad/wgrad): HBM-bound VALU kernels with the descriptor, gather modes and epilogue of
- * efgh_gather_gemm (mode 1 only, no `stats`).  efgh_thin_supported: 0 = no, 1 = C==4 form, 2 = N==4. */
+ * efgh_gather_gemm (mode 1 only, no `stats`).  efgh_thin_supported: 0 = no, 1 = C==4 form, 2 = N==4 (VALU), 3 = N==4 on MFMA
+ * (64 channels, 3x3, stride 1, pad 1: k_n4_conv3x3_c64). */
 int efgh_thin_supported(const efgh_gemm_desc *d);
 int efgh_thin_gemm(const efgh_gemm_desc *d, void *stream);
 int efgh_thin_wgrad(const efgh_gemm_desc *d, const float *G, int64_t ldg, float *dWp, void *stream);

@@ -416,22 +416,25 @@ def test_c4_mfma_conv_vs_generic_and_fp64(L, cin, cout, stride, hw, B):
     assert _rel(bng.weight.grad.cpu(), bn.weight.grad) < 2e-4 and _rel(bng.bias.grad.cpu(), bn.bias.grad) < 2e-4
 
 
-@pytest.mark.parametrize('cin,cout,hw,B', [(16, 16, (24, 40), 2), (32, 32, (37, 301), 1), (16, 32, (18, 26), 2),
-                                          (32, 16, (9, 263), 1), (16, 16, (5, 131), 3)])
-def test_small_channel_conv_vs_generic_and_fp64(L, cin, cout, hw, B):
-    """efgh_sc_conv3x3 / efgh_sc_wgrad (3x3, stride 1, 16 / 32 channels on both sides: F's up-sampling stages) against the generic
-    implicit-GEMM kernels and float64: odd sizes, several 32-pixel units per row with a ragged last one, residual epilogue,
-    train-mode BatchNorm statistics, data gradient with a skip gradient added in the epilogue, weight gradient (bit-reproducible)"""
+@pytest.mark.parametrize('cin,cout,hw,B,k', [(16, 16, (24, 40), 2, 3), (32, 32, (37, 301), 1, 3), (16, 32, (18, 26), 2, 3),
+                                            (32, 16, (9, 263), 1, 3), (16, 16, (5, 131), 3, 3),
+                                            (64, 32, (11, 157), 2, 1), (64, 32, (3, 32), 1, 1), (64, 32, (40, 333), 1, 1)])
+def test_small_channel_conv_vs_generic_and_fp64(L, cin, cout, hw, B, k, monkeypatch):
+    """efgh_sc_conv3x3 / efgh_sc_wgrad (stride 1; 3x3 with 16 / 32 channels on both sides: F's up-sampling stages; 1x1 64 -> 32 and
+    its data gradient 32 -> 64) against the generic implicit-GEMM kernels and float64: odd sizes, several 32-pixel units per row with
+    a ragged last one, residual epilogue, train-mode BatchNorm statistics, data gradient with a skip gradient added in the epilogue,
+    weight gradient (bit-reproducible)"""
     from efgh_amd import ops
+    monkeypatch.setattr(ops, 'SC_MIN_PIXELS_32', 0)          # (the 32 -> 32 launch is reserved for large maps: test it at any size)
     torch.manual_seed(4)
-    conv = nn.Conv2d(cin, cout, 3, 1, 1, bias=True)
+    conv = nn.Conv2d(cin, cout, k, 1, k // 2, bias=True)
     x = torch.randn(B, cin, *hw)
     res = torch.randn(B, cout, *hw)
-    ref = F.leaky_relu(F.conv2d(x.double(), conv.weight.double(), conv.bias.double(), padding=1) + res.double(), 0.2)
-    cg = nn.Conv2d(cin, cout, 3, 1, 1, bias=True).cuda()
+    ref = F.leaky_relu(F.conv2d(x.double(), conv.weight.double(), conv.bias.double(), padding=k // 2) + res.double(), 0.2)
+    cg = nn.Conv2d(cin, cout, k, 1, k // 2, bias=True).cuda()
     cg.load_state_dict(conv.state_dict())
     xg, rg = ops.nchw_to_nhwc(x.cuda(), cin), ops.nchw_to_nhwc(res.cuda(), cout)
-    taps = ([t // 3 - 1 for t in range(9)], [t % 3 - 1 for t in range(9)])
+    taps = ([t // 3 - 1 for t in range(9)], [t % 3 - 1 for t in range(9)]) if k == 3 else ([0], [0])
     geom = (B, hw[0], hw[1], hw[0], hw[1], 1, 1, taps[0], taps[1], hw[0], hw[1], 1, 1, 0, 0)
     out = {}
     for sc in (True, False):
@@ -467,6 +470,31 @@ def test_small_channel_conv_vs_generic_and_fp64(L, cin, cout, hw, B):
     assert _rel(cg.weight.grad.cpu(), conv.weight.grad) < 2e-4, _rel(cg.weight.grad.cpu(), conv.weight.grad)
     assert _rel(xq.grad.permute(0, 3, 1, 2).cpu(), xr.grad) < 2e-4
     assert _rel(bng.weight.grad.cpu(), bn.weight.grad) < 2e-4 and _rel(bng.bias.grad.cpu(), bn.bias.grad) < 2e-4
+
+
+@pytest.mark.parametrize('hw,B', [((70, 95), 2), ((3, 30), 1), ((64, 31), 1), ((131, 7), 3)])
+def test_n4_mfma_conv_vs_fp64(L, hw, B):
+    """k_n4_conv3x3_c64 (64 -> <= 4 channels, 3x3, stride 1: the data gradient of the range trunk's 4 -> 64 input layer) against
+    float64: several 30-column strips with a ragged last one, more rows than one 64-row unit, bias + residual + activation epilogue"""
+    from efgh_amd import ops
+    torch.manual_seed(5)
+    conv = nn.Conv2d(64, 3, 3, 1, 1, bias=True)
+    x = torch.randn(B, 64, *hw)
+    res = torch.randn(B, 3, *hw)
+    ref = F.leaky_relu(F.conv2d(x.double(), conv.weight.double(), conv.bias.double(), padding=1) + res.double(), 0.2)
+    cg = nn.Conv2d(64, 3, 3, 1, 1, bias=True).cuda()
+    cg.load_state_dict(conv.state_dict())
+    xg, rg = ops.nchw_to_nhwc(x.cuda(), 64), ops.nchw_to_nhwc(res.cuda(), 4)
+    ops.TRACE_THIN = []
+    try:
+        with torch.no_grad():
+            y = L.conv2d(L.Ctx(False), xg, cg, None, L.ACT_LEAKY, 0.2, residual=rg)
+        assert ops.TRACE_THIN == [3], ops.TRACE_THIN
+    finally:
+        ops.TRACE_THIN = None
+    assert y.shape[-1] == 4
+    got = y[..., :3].permute(0, 3, 1, 2).double().cpu()
+    assert _rel(got, ref) < 2e-6, _rel(got, ref)
 
 
 @pytest.mark.parametrize('C', [36, 68, 132, 260, 4, 256])
