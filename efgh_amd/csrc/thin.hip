@@ -9,6 +9,8 @@
 // (bias, scale/shift, residual, activation) as k_gather_gemm; packed weights [N][T][C].
 #include "common.h"
 
+void efgh_launch_fold_splits(const float *part, int zs, long long total, float *dst, hipStream_t st);   // wgrad.hip
+
 namespace {
 constexpr int TPB = 256;
 
@@ -305,6 +307,142 @@ k_n4_conv3x3_c64(const TArgs p, int strips, int chunks, long long units) {
     }
 }
 
+// ---- C == 4 -> N == 4, 3x3 / stride 1 / pad 1 ("same"): the 1- and 2-channel convolutions behind G's transposed depth / mask heads
+// (gnet.py:56-68 through net_utils.py:66-98) at full raw resolution: 15.7 M pixels at batch 8, 16 bytes in and 16 bytes out per pixel
+// - a pure stencil, 0.5 GB per launch.  k_thin_c4 / k_thin_c4_wgrad spend their time on addressing (two 64-bit divisions and nine
+// bounds-checked 64-bit row addresses per pixel: 0.44 ms forward / data gradient, 0.82 ms weight gradient with its atomics).  Here the
+// grid is the image (x: 256 columns, y: a band of rows, z: sample), a thread walks down one column of its band with the 3x3 window in
+// registers, and every image row is a buffer resource whose range check supplies the zero padding left, right, above and below.
+constexpr int CN_RP = 4;                // output rows per thread, forward / data gradient
+constexpr int CN_RPW = 32;              // rows per thread, weight gradient
+typedef unsigned cn_u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float4 cn_load(const float *rowp, unsigned bytes, int voff) {
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(rowp), 0, bytes, 0x00020000);
+    const cn_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
+__global__ void __launch_bounds__(256, 4)
+k_c4n4_conv3x3(const TArgs p) {
+    __shared__ __attribute__((aligned(16))) float4 wl[36];             // [t][n] -> W[n][t][0..3]
+    if (threadIdx.x < 36) {
+        const int t = threadIdx.x >> 2, n = threadIdx.x & 3;
+        wl[threadIdx.x] = *reinterpret_cast<const float4 *>(p.W + ((long long)n * 9 + t) * 4);
+    }
+    __syncthreads();
+    const int H = p.Hin, W = p.Win, lda4 = (int)p.lda * 4;
+    const int j = blockIdx.x * 256 + threadIdx.x, i0 = blockIdx.y * CN_RP;
+    const long long b = blockIdx.z;
+    const unsigned rowbytes = (unsigned)W * (unsigned)lda4;
+    float4 a[CN_RP + 2][3];
+#pragma unroll
+    for (int rr = 0; rr < CN_RP + 2; ++rr) {
+        const int r = i0 - 1 + rr;
+        const bool rok = (unsigned)r < (unsigned)H;                    // (uniform)
+        const float *rowp = p.A + (b * H + (rok ? r : 0)) * W * p.lda;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) a[rr][kw] = cn_load(rowp, rok ? rowbytes : 0u, (j + kw - 1) * lda4);
+    }
+    float acc[CN_RP][4];
+#pragma unroll
+    for (int rr = 0; rr < CN_RP; ++rr)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[rr][n] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const float4 w = wl[t * 4 + n];                            // (wave-uniform address: an LDS broadcast)
+#pragma unroll
+            for (int rr = 0; rr < CN_RP; ++rr) {
+                const float4 x = a[rr + t / 3][t % 3];
+                acc[rr][n] += x.x * w.x + x.y * w.y + x.z * w.z + x.w * w.w;
+            }
+        }
+        // pin the sums here: otherwise the whole computation is sunk into the per-row store branches below, behind ALL 36 weight
+        // reads (144 live registers and, under an occupancy bound, a spilled kernel)
+#pragma unroll
+        for (int rr = 0; rr < CN_RP; ++rr)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) asm volatile("" : "+v"(acc[rr][n]));
+    }
+    if (j >= W) return;
+#pragma unroll
+    for (int rr = 0; rr < CN_RP; ++rr)
+        if (i0 + rr < H)
+            epilogue_store(p, (b * H + i0 + rr) * W + j, 0, make_float4(acc[rr][0], acc[rr][1], acc[rr][2], acc[rr][3]));
+}
+
+// weight gradient: dW[n][t][c] = sum_p G[p][n] x[p + t][c]; 144 accumulators per thread over its column of CN_RPW rows (the window
+// rolls down: three new 16-byte loads of x and one of G per pixel), one partial [4][9][4] plane per workgroup, planes folded in a
+// fixed order (no atomics: bit-reproducible)
+__global__ void __launch_bounds__(256)
+k_c4n4_wgrad3x3(const TArgs p, float *part) {
+    __shared__ float red[4][144];
+    const int H = p.Hin, W = p.Win, lda4 = (int)p.lda * 4, ldg4 = (int)p.ldg * 4;
+    const int j = blockIdx.x * 256 + threadIdx.x, i0 = blockIdx.y * CN_RPW;
+    const long long b = blockIdx.z;
+    const unsigned rowbytes = (unsigned)W * (unsigned)lda4, growbytes = (unsigned)W * (unsigned)ldg4;
+    const int iend = i0 + CN_RPW < H ? i0 + CN_RPW : H;
+    float acc[4][9][4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[n][t][c] = 0.f;
+    float4 win[3][3];                                                  // x rows i - 1, i, i + 1 at columns j - 1 .. j + 1
+    auto load_row = [&](int r, float4 (&dst)[3]) {
+        const bool rok = (unsigned)r < (unsigned)H;
+        const float *rowp = p.A + (b * H + (rok ? r : 0)) * W * p.lda;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) dst[kw] = cn_load(rowp, rok ? rowbytes : 0u, (j + kw - 1) * lda4);
+    };
+    auto load_g = [&](int r) {                                         // (columns >= W and rows >= iend: zeros)
+        return cn_load(p.G + (b * H + (r < iend ? r : 0)) * W * p.ldg, r < iend ? growbytes : 0u, j * ldg4);
+    };
+    load_row(i0 - 1, win[0]);
+    load_row(i0, win[1]);
+    load_row(i0 + 1, win[2]);
+    float4 g = load_g(i0);
+    for (int i = i0; i < iend; ++i) {
+        float4 nxt[3];
+        load_row(i + 2, nxt);                                          // one row ahead: in flight during this row's 144 FMAs
+        const float4 gn = load_g(i + 1);
+        const float gv[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const float4 x = win[t / 3][t % 3];
+            const float xv[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[n][t][c] = fmaf(gv[n], xv[c], acc[n][t][c]);
+        }
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) { win[0][kw] = win[1][kw]; win[1][kw] = win[2][kw]; win[2][kw] = nxt[kw]; }
+        g = gn;
+    }
+    // workgroup sum: lanes by xor-shuffles, the four waves through LDS; plane of this workgroup in a fixed order
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float v = acc[n][t][c];
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+                if (lane == 0) red[wave][(n * 9 + t) * 4 + c] = v;
+            }
+    __syncthreads();
+    const long long blk = ((long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    if (threadIdx.x < 144)
+        part[blk * 144 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
 // ---- wgrad, C == 4:  dW[n][t][0..3] += sum_m G[orow(m)][n] * A[row(m,t)][0..3] -----------------------
 // thread = (row lane, n-quad); 16*T accumulators; block-level LDS reduction, then global atomics.
 template <int T>
@@ -410,6 +548,21 @@ int fill(TArgs &a, const efgh_gemm_desc *d) {
     return 0;
 }
 
+// 3x3, stride 1, pad 1, "same" size, one launch, image rows addressable with 32-bit byte offsets
+bool same3x3_ok(const efgh_gemm_desc *d) {
+    if (!d || d->mode != 1 || d->T != 9 || d->M_dev || d->nbatch > 1) return false;
+    if (d->sh != 1 || d->sw != 1 || d->osh != 1 || d->osw != 1 || d->oh0 || d->ow0) return false;
+    if (d->Hv != d->Ho || d->Wv != d->Wo || d->Ho != d->Hin || d->Wo != d->Win || d->B <= 0) return false;
+    for (int t = 0; t < 9; ++t) if (d->dh[t] != t / 3 - 1 || d->dw[t] != t % 3 - 1) return false;
+    return (int64_t)(d->Win + 512) * d->lda * 4 < (1ll << 31) && d->lda % 4 == 0 && (((uintptr_t)d->A) & 15) == 0;
+}
+
+// k_c4n4_conv3x3 / k_c4n4_wgrad3x3
+bool c4n4_ok(const efgh_gemm_desc *d) {
+    return same3x3_ok(d) && d->C == 4 && d->N == 4 && d->B <= 65535 && (((uintptr_t)d->W) & 15) == 0 && d->ldo % 4 == 0 &&
+           (((uintptr_t)d->out) & 15) == 0 && (!d->residual || d->ldr % 4 == 0);
+}
+
 // k_n4_conv3x3_c64: 64 -> 4 channels, 3x3, stride 1, pad 1, "same" size, 16-byte input rows, 8-byte output pairs
 bool n4_mfma_ok(const efgh_gemm_desc *d) {
     if (d->N != 4 || d->C != 64 || d->T != 9 || d->M_dev || d->nbatch > 1) return false;
@@ -430,6 +583,7 @@ int grid_for(long long total, int per) {
 
 extern "C" int efgh_thin_supported(const efgh_gemm_desc *d) {
     if (!d || d->mode != 1 || d->N % 4 != 0 || d->C % 4 != 0 || d->stats) return 0;
+    if (c4n4_ok(d)) return 4;
     if (d->C == 4 && d->N <= 256 && (d->T == 1 || d->T == 2 || d->T == 4 || d->T == 9) &&
         (int64_t)d->T * d->N * 16 + 4 * 64 * 36 * 4 <= 64 * 1024) return 1;
     if (d->N == 4 && (int64_t)d->T * d->C * 16 <= 60 * 1024) return n4_mfma_ok(d) ? 3 : 2;
@@ -443,7 +597,9 @@ extern "C" int efgh_thin_gemm(const efgh_gemm_desc *d, void *stream_) {
     EFGH_CHECK_ARG(d->A && d->W && d->out && d->M == (int64_t)d->B * d->Hv * d->Wv && d->lda % 4 == 0 && d->ldo % 4 == 0);
     TArgs a;
     fill(a, d);
-    if (kind == 1) {
+    if (kind == 4) {
+        k_c4n4_conv3x3<<<dim3((a.Win + 255) / 256, (a.Hin + CN_RP - 1) / CN_RP, d->B), 256, 0, st>>>(a);
+    } else if (kind == 1) {
         size_t lds = (size_t)a.T * a.N * 16 + 4 * 64 * 36 * 4;
         int grid = grid_for(a.M, TPB);
         switch (a.T) {
@@ -491,6 +647,28 @@ extern "C" int efgh_thin_wgrad(const efgh_gemm_desc *d, const float *G, int64_t 
         efgh_set_error("thin wgrad: unsupported shape C=%d N=%d T=%d", d->C, d->N, d->T);
         return EFGH_E_INVALID;
     }
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}
+
+/* 4 -> 4 channels, 3x3, stride 1, pad 1: deterministic weight gradient (k_c4n4_wgrad3x3); workspace in floats */
+extern "C" int efgh_c4n4_supported(const efgh_gemm_desc *d) { return c4n4_ok(d) ? 1 : 0; }
+
+extern "C" int64_t efgh_c4n4_wgrad_workspace(const efgh_gemm_desc *d) {
+    if (!c4n4_ok(d)) return 0;
+    return (int64_t)((d->Win + 255) / 256) * ((d->Hin + CN_RPW - 1) / CN_RPW) * d->B * 144;
+}
+
+extern "C" int efgh_c4n4_wgrad(const efgh_gemm_desc *d, const float *G, int64_t ldg, float *dWp, float *workspace, void *stream_) {
+    hipStream_t st = (hipStream_t)stream_;
+    EFGH_CHECK_ARG(c4n4_ok(d) && G && dWp && workspace && ldg % 4 == 0 && (((uintptr_t)G) & 15) == 0 &&
+                   (int64_t)(d->Win + 512) * ldg * 4 < (1ll << 31));
+    TArgs a;
+    fill(a, d);
+    a.G = G; a.ldg = ldg;
+    const dim3 grid((a.Win + 255) / 256, (a.Hin + CN_RPW - 1) / CN_RPW, d->B);
+    k_c4n4_wgrad3x3<<<grid, 256, 0, st>>>(a, workspace);
+    efgh_launch_fold_splits(workspace, (int)(grid.x * grid.y * grid.z), 144, dWp, st);
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
 }

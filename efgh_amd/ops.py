@@ -871,7 +871,14 @@ def gather_wgrad(A, lda, C, T, N, M, G, ldg, dWp, mode=0, geom=None, table=None)
     # added in a fixed order - every gradient of a training step is then bit-reproducible run to run
     thin = thin_eligible(mode, C, N, T) and (N == 4 or T in (1, 2, 4, 9)) and not DETERMINISTIC
     wino = False
-    if thin:
+    if (C == 4 and N == 4 and T == 9 and mode == 1 and lda % 4 == 0 and ldg % 4 == 0 and dWp.data_ptr() % 16 == 0
+            and _L().efgh_c4n4_supported(ctypes.byref(d))):
+        # the 1- / 2-channel 3x3 convolutions behind G's transposed heads: column-walking stencil, per-workgroup partial planes folded
+        # in a fixed order (also under EFGH_DETERMINISTIC: no atomics)
+        thin = True             # (profile lists: an HBM-bound launch)
+        _C.check(_L().efgh_c4n4_wgrad(ctypes.byref(d), ptr(G), c_int64(ldg), ptr(dWp),
+                                      ptr(_scratch(_L().efgh_c4n4_wgrad_workspace(ctypes.byref(d)), dWp.device)), _st()))
+    elif thin:
         _C.check(_L().efgh_thin_wgrad(ctypes.byref(d), ptr(G), c_int64(ldg), ptr(dWp), _st()))
     elif (USE_SMALLC and C == 4 and N in (32, 64) and lda % 4 == 0 and ldg % 4 == 0 and geom is not None and geom[5] == 1
           and sc_eligible(mode, 16, 16, geom, wgrad=True)):

@@ -410,10 +410,16 @@ int efgh_adam_step(float *w, const float *g, float *m, float *v, int64_t n, floa
 /* "thin" layers (<= 4 channels on one side: RGB/range/depth input convs, the 1-/2-channel heads and
  * their dgrad/wgrad): HBM-bound VALU kernels with the descriptor, gather modes and epilogue of
  * efgh_gather_gemm (mode 1 only, no `stats`).  efgh_thin_supported: 0 = no, 1 = C==4 form, 2 = N==4 (VALU), 3 = N==4 on MFMA
- * (64 channels, 3x3, stride 1, pad 1: k_n4_conv3x3_c64). */
+ * (64 channels, 3x3, stride 1, pad 1: k_n4_conv3x3_c64), 4 = the 4 -> 4 channel 3x3 stencil (k_c4n4_conv3x3). */
 int efgh_thin_supported(const efgh_gemm_desc *d);
 int efgh_thin_gemm(const efgh_gemm_desc *d, void *stream);
 int efgh_thin_wgrad(const efgh_gemm_desc *d, const float *G, int64_t ldg, float *dWp, void *stream);
+/* 4 -> 4 channels (the 1- / 2-channel convolutions behind G's transposed heads, gnet.py:56-68), 3x3, stride 1, pad 1: weight gradient
+ * without atomics - one partial [4][9][4] plane per workgroup in `workspace` (efgh_c4n4_wgrad_workspace floats), folded in a fixed
+ * order into dWp. */
+int efgh_c4n4_supported(const efgh_gemm_desc *d);
+int64_t efgh_c4n4_wgrad_workspace(const efgh_gemm_desc *d);
+int efgh_c4n4_wgrad(const efgh_gemm_desc *d, const float *G, int64_t ldg, float *dWp, float *workspace, void *stream);
 
 /* 3x3 convolutions with C == 4 input channels per tap, stride 1 or 2, pad 1, N in {32, 64, 128} on fp32 MFMA (the RGB / range /
  * depth input layers: nets/vgg.py:77 first conv, nets/gnet.py:21,80; and the data gradient of G's transposed heads): the three

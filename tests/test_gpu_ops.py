@@ -472,6 +472,53 @@ def test_small_channel_conv_vs_generic_and_fp64(L, cin, cout, hw, B, k, monkeypa
     assert _rel(bng.weight.grad.cpu(), bn.weight.grad) < 2e-4 and _rel(bng.bias.grad.cpu(), bn.bias.grad) < 2e-4
 
 
+@pytest.mark.parametrize('c,hw,B', [(2, (37, 301), 2), (1, (5, 9), 1), (2, (64, 256), 1), (3, (33, 600), 3)])
+def test_c4n4_stencil_conv_vs_fp64_and_autograd(L, c, hw, B):
+    """k_c4n4_conv3x3 / k_c4n4_wgrad3x3 (<= 4 channels on both sides, 3x3, stride 1: the 1- / 2-channel convolutions behind G's
+    transposed heads) against float64 and torch autograd: ragged last column block, row bands that end inside the image, bias +
+    residual + activation epilogue, train-mode BatchNorm on top, data gradient, weight gradient bit-identical run to run"""
+    from efgh_amd import ops
+    torch.manual_seed(6)
+    conv = nn.Conv2d(c, c, 3, 1, 1, bias=True)
+    x = torch.randn(B, c, *hw)
+    res = torch.randn(B, c, *hw)
+    ref = F.leaky_relu(F.conv2d(x.double(), conv.weight.double(), conv.bias.double(), padding=1) + res.double(), 0.2)
+    cg = nn.Conv2d(c, c, 3, 1, 1, bias=True).cuda()
+    cg.load_state_dict(conv.state_dict())
+    xg, rg = ops.nchw_to_nhwc(x.cuda(), 4), ops.nchw_to_nhwc(res.cuda(), 4)
+    ops.TRACE_THIN = []
+    try:
+        with torch.no_grad():
+            y = L.conv2d(L.Ctx(False), xg, cg, None, L.ACT_LEAKY, 0.2, residual=rg)
+        assert ops.TRACE_THIN == [4], ops.TRACE_THIN
+    finally:
+        ops.TRACE_THIN = None
+    got = y[..., :c].permute(0, 3, 1, 2).double().cpu()
+    assert _rel(got, ref) < 2e-6, _rel(got, ref)
+    bn = nn.BatchNorm2d(c)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.2)
+    bng = nn.BatchNorm2d(c).cuda()
+    bng.load_state_dict(bn.state_dict())
+    bn.train(); bng.train()
+    gy = torch.randn(B, c, *hw)
+    xr = x.clone().requires_grad_(True)
+    refb = F.leaky_relu(bn(conv(xr)), 0.2)
+    refb.backward(gy)
+    grads = []
+    for _ in range(2):
+        cg.weight.grad = cg.bias.grad = bng.weight.grad = bng.bias.grad = None
+        xq = xg.clone().requires_grad_(True)
+        yb = L.conv2d(L.Ctx(True), xq, cg, bng, L.ACT_LEAKY, 0.2)
+        yb.backward(ops.nchw_to_nhwc(gy.cuda(), 4))
+        grads.append(cg.weight.grad.clone())
+    assert torch.equal(grads[0], grads[1])
+    assert _rel(yb.detach()[..., :c].permute(0, 3, 1, 2).cpu(), refb.detach()) < 2e-5
+    assert _rel(cg.weight.grad.cpu(), conv.weight.grad) < 2e-4, _rel(cg.weight.grad.cpu(), conv.weight.grad)
+    assert _rel(xq.grad[..., :c].permute(0, 3, 1, 2).cpu(), xr.grad) < 2e-4
+    assert _rel(bng.weight.grad.cpu(), bn.weight.grad) < 2e-4 and _rel(bng.bias.grad.cpu(), bn.bias.grad) < 2e-4
+
+
 @pytest.mark.parametrize('hw,B', [((70, 95), 2), ((3, 30), 1), ((64, 31), 1), ((131, 7), 3)])
 def test_n4_mfma_conv_vs_fp64(L, hw, B):
     """k_n4_conv3x3_c64 (64 -> <= 4 channels, 3x3, stride 1: the data gradient of the range trunk's 4 -> 64 input layer) against
