@@ -368,6 +368,25 @@ k_softmax2_bwd(const float *__restrict__ y, const float *__restrict__ dy, int B,
     }
 }
 
+// backward of k_heads_to_nchw: dx[pixel] = (d depth, y0 (g0 - dot), y1 (g1 - dot), 0) as one 16-byte store; either gradient may be absent
+__global__ void __launch_bounds__(TPB)
+k_heads_bwd(const float *__restrict__ y, const float *__restrict__ dmask, const float *__restrict__ ddepth, int B, long long HW,
+            float4 *__restrict__ dx) {
+    long long total = (long long)B * HW;
+    for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
+        long long b = i / HW, p = i - b * HW;
+        float4 o = make_float4(ddepth ? ddepth[i] : 0.f, 0.f, 0.f, 0.f);
+        if (dmask) {
+            float y0 = y[(b * 2) * HW + p], y1 = y[(b * 2 + 1) * HW + p];
+            float g0 = dmask[(b * 2) * HW + p], g1 = dmask[(b * 2 + 1) * HW + p];
+            float dot = g0 * y0 + g1 * y1;
+            o.y = y0 * (g0 - dot);
+            o.z = y1 * (g1 - dot);
+        }
+        dx[i] = o;
+    }
+}
+
 // ---- correlation backward -------------------------------------------------------------------------
 // dcam_n[b][y][x][c] = sum_j dl[b][j] * rp[b][y][j+x][c]
 __global__ void __launch_bounds__(TPB)
@@ -556,6 +575,14 @@ extern "C" int efgh_segment_colmean_bwd(const float *dy, int32_t P, int32_t nseg
                                         void *stream_) {
     EFGH_CHECK_ARG(dy && dx && P > 0 && nseg > 0 && C > 0);
     k_segment_colmean_bwd<<<grid_for((long long)nseg * P * C), TPB, 0, (hipStream_t)stream_>>>(dy, P, nseg, C, dx, ld);
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}
+
+extern "C" int efgh_heads_bwd(const float *y, const float *dmask, const float *ddepth, int32_t B, int64_t HW, float *dx,
+                              void *stream_) {
+    EFGH_CHECK_ARG(y && dx && B > 0 && HW > 0 && (((uintptr_t)dx) & 15) == 0);
+    k_heads_bwd<<<grid_for((long long)B * HW), TPB, 0, (hipStream_t)stream_>>>(y, dmask, ddepth, B, HW, (float4 *)dx);
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
 }

@@ -241,6 +241,22 @@ k_softmax2_to_nchw(const float *__restrict__ x, long long ld, float *__restrict_
     }
 }
 
+// G's two heads as ONE 4-channel map (channel 0: depth, channels 1-2: mask logits; gnet.py:121-124): planar depth (B,1,HW) and the
+// 2-way softmax (B,2,HW) from one 16-byte read per pixel
+__global__ void __launch_bounds__(TPB)
+k_heads_to_nchw(const float4 *__restrict__ x, float *__restrict__ depth, float *__restrict__ mask, int B, long long HW) {
+    long long total = (long long)B * HW;
+    for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
+        long long b = i / HW, p = i - b * HW;
+        const float4 v = x[i];
+        depth[i] = v.x;
+        float m = fmaxf(v.y, v.z);
+        float ea = expf(v.y - m), ec = expf(v.z - m), inv = 1.f / (ea + ec);
+        mask[(b * 2) * HW + p] = ea * inv;
+        mask[(b * 2 + 1) * HW + p] = ec * inv;
+    }
+}
+
 int grid_for(long long total) {
     long long g = (total + TPB - 1) / TPB;
     return (int)(g > 16384 ? 16384 : (g < 1 ? 1 : g));
@@ -343,6 +359,13 @@ extern "C" int efgh_segment_colmean(const float *x, int64_t ld, int32_t C, int32
 extern "C" int efgh_softmax2_to_nchw(const float *x, int64_t ld, float *y, int32_t B, int64_t HW, void *stream) {
     EFGH_CHECK_ARG(x && y && B > 0 && HW > 0 && ld >= 2);
     k_softmax2_to_nchw<<<grid_for((long long)B * HW), TPB, 0, (hipStream_t)stream>>>(x, ld, y, B, HW);
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}
+
+extern "C" int efgh_heads_to_nchw(const float *x, float *depth, float *mask, int32_t B, int64_t HW, void *stream) {
+    EFGH_CHECK_ARG(x && depth && mask && B > 0 && HW > 0 && (((uintptr_t)x) & 15) == 0);
+    k_heads_to_nchw<<<grid_for((long long)B * HW), TPB, 0, (hipStream_t)stream>>>((const float4 *)x, depth, mask, B, HW);
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
 }

@@ -476,6 +476,21 @@ class Softmax2ToNchwFn(torch.autograd.Function):
         return dx
 
 
+class HeadsToNchwFn(torch.autograd.Function):
+    """G's depth and mask heads carried as one 4-channel map (layers.run_convt_heads) -> g_depth, g_mask (gnet.py:121-124)"""
+    @staticmethod
+    def forward(ctx, x):
+        depth, mask = ops.heads_to_nchw(x.contiguous())
+        ctx.save_for_backward(mask)
+        ctx.set_materialize_grads(False)
+        return depth, mask
+
+    @staticmethod
+    def backward(ctx, gd, gm):
+        (mask,) = ctx.saved_tensors
+        return ops.heads_bwd(mask, None if gm is None else gm.contiguous(), None if gd is None else gd.contiguous())
+
+
 class NhwcToNchwFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, Cs):

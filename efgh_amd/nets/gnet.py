@@ -8,6 +8,9 @@ from . import fn as FN
 from . import layers as L
 from .builders import conv_bn_relu, convt_bn_relu, resnet18_layers
 
+import os as _os
+HEADS_FUSED = _os.environ.get('EFGH_HEADS_FUSED', '1') != '0'    # depth + mask heads as one 3-channel pipeline (layers.run_convt_heads)
+
 
 class Gnet(nn.Module):
     def __init__(self, args):
@@ -98,15 +101,20 @@ class Gnet(nn.Module):
             ready = torch.cuda.Event()
             ready.record()
         cv = cat(cat1, [t2, c2])
-        dimg, cv = L.run_convt_bn_relu(ctx, self.convt_dimg, cv, skip_out=True)    # (B,2H,2W,4) ch0
-        mask = L.run_convt_bn_relu(ctx, self.convt_mask, cv)                       # (B,2H,2W,4) ch0,1
         cat0 = cat0_early()                   # [conv_i1 | conv_d1]
-        if ctx.grad:
-            g_depth = FN.NhwcToNchwFn.apply(dimg, 1)
-            g_mask = FN.Softmax2ToNchwFn.apply(mask)
+        if HEADS_FUSED and x.is_cuda and L.convt_heads_fusable(self.convt_dimg, self.convt_mask):
+            # both heads as one 3-channel pipeline (layers.run_convt_heads): channel 0 depth, channels 1-2 mask logits
+            hm = L.run_convt_heads(ctx, self.convt_dimg, self.convt_mask, cv)      # (B,2H,2W,4)
+            g_depth, g_mask = FN.HeadsToNchwFn.apply(hm) if ctx.grad else ops.heads_to_nchw(hm)
         else:
-            g_depth = ops.nhwc_to_nchw(dimg, 1)
-            g_mask = ops.softmax2_to_nchw(mask)
+            dimg, cv = L.run_convt_bn_relu(ctx, self.convt_dimg, cv, skip_out=True)    # (B,2H,2W,4) ch0
+            mask = L.run_convt_bn_relu(ctx, self.convt_mask, cv)                       # (B,2H,2W,4) ch0,1
+            if ctx.grad:
+                g_depth = FN.NhwcToNchwFn.apply(dimg, 1)
+                g_mask = FN.Softmax2ToNchwFn.apply(mask)
+            else:
+                g_depth = ops.nhwc_to_nchw(dimg, 1)
+                g_mask = ops.softmax2_to_nchw(mask)
         return {'g_depth': g_depth, 'g_mask': g_mask, 'ci1': ci1, 'cat0': cat0, 'ready': ready}
 
     def forward(self, pc, img, ret, check=False, img_nhwc=None, keep=None, pre=None):

@@ -6,6 +6,7 @@ reference's); their own forward() is never called.
 """
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from .. import ops
 from ..ops import ACT_LEAKY, ACT_NONE, ACT_RELU, ceil4
@@ -185,7 +186,7 @@ def _convt_small_forward(x, convt, out_raw, scale=None, shift=None, act=ACT_NONE
 
 def conv_transpose2d(ctx, x, convt, bn=None, act=ACT_NONE, slope=0.0, out=None, skip_out=False):
     """nn.ConvTranspose2d(k=3, s=2) as four stride-1 sub-convolutions, one per output parity class
-    (or, for <= 2 output channels, as ONE GEMM over the input pixels + a col2im fold)."""
+    (or, for <= 3 output channels, as ONE GEMM over the input pixels + a col2im fold)."""
     B, H, W, ldx = x.shape
     Cw, O = convt.in_channels, convt.out_channels
     assert convt.kernel_size == (3, 3) and convt.stride == (2, 2) and ldx == Cw and Cw % 4 == 0
@@ -193,7 +194,7 @@ def conv_transpose2d(ctx, x, convt, bn=None, act=ACT_NONE, slope=0.0, out=None, 
     oph, opw = convt.output_padding
     Ho, Wo = (H - 1) * 2 - 2 * ph + 3 + oph, (W - 1) * 2 - 2 * pw + 3 + opw
     Np = ceil4(O)
-    if O <= 2 and ph == pw and convt.bias is None and bn is not None and out is None and not ctx.grad:
+    if O <= 3 and ph == pw and convt.bias is None and bn is not None and out is None and not ctx.grad:
         out_t = torch.empty((B, Ho, Wo, 4), dtype=torch.float32, device=x.device)
         if not ctx.train:
             sc, sh = _bn_eval_affine(bn, 4)
@@ -314,6 +315,116 @@ def run_convt_bn_relu(ctx, seq, x, out=None, skip_out=False):
     y = conv_transpose2d(ctx, x, seq[0], seq[1], ACT_LEAKY, 0.2)
     y = conv2d(ctx, y, seq[3], seq[4], ACT_LEAKY, 0.2, out=out)
     return (y, x) if skip_out else y
+
+
+# ---- G's depth and mask heads (gnet.py:56-68, 121-124) as ONE three-channel pipeline -------------------------------------------
+# convt_dimg (128 -> 1) and convt_mask (128 -> 2) are two convt_bn_relu stacks over the same input.  Every tensor behind their
+# transposed convolutions is 16 bytes per pixel at full raw resolution whether it carries one, two or three channels (channels are
+# padded to four), and every pass over it is HBM-bound - so the two stacks run as one: transposed weights concatenated along the
+# output channel, the per-channel BatchNorms concatenated, the two 3x3 convolutions as one block-diagonal 3 -> 3 convolution (the
+# off-diagonal weights are constant zeros: x + 0*y is exact).  Per channel the arithmetic is the one of the separate stacks; the 128-
+# channel input is read once instead of twice (forward GEMM, weight gradient) and its gradient is written once instead of written,
+# read and re-written.  The combined parameters are built with torch.cat / pad under autograd, so each module's own parameters
+# receive their gradients through the usual accumulate hooks; the modules and the state_dict are untouched.
+class _Shim:
+    pass
+
+
+class _NbtPair:
+    """`bn.num_batches_tracked += 1` on a concatenated BatchNorm: forwarded to the real modules (or their FlatParams tick slots)"""
+
+    def __init__(self, bns):
+        self.bns = bns
+
+    @property
+    def _version(self):
+        return tuple(b.num_batches_tracked._version for b in self.bns if b.num_batches_tracked is not None)
+
+    def __iadd__(self, k):
+        for b in self.bns:
+            slot = getattr(b, '_efgh_nbt', None)
+            if slot is not None and slot[0].collect_ticks:
+                slot[0].tick(slot[1])
+            elif b.num_batches_tracked is not None:
+                b.num_batches_tracked += k
+        return self
+
+
+def _bn_cat(bns, grad):
+    a = bns[0]
+    assert all(b.eps == a.eps and b.momentum == a.momentum and b.affine and b.track_running_stats for b in bns)
+    bn = _Shim()
+    cat = (lambda ts: torch.cat(list(ts))) if grad else (lambda ts: torch.cat([t.detach() for t in ts]))
+    bn.weight, bn.bias = cat(b.weight for b in bns), cat(b.bias for b in bns)
+    with torch.no_grad():
+        bn.running_mean = torch.cat([b.running_mean for b in bns])
+        bn.running_var = torch.cat([b.running_var for b in bns])
+    bn.eps, bn.momentum, bn.num_features = a.eps, a.momentum, sum(b.num_features for b in bns)
+    bn.num_batches_tracked = _NbtPair(bns)
+    bn._efgh_nbt = None
+
+    def sync():                              # train mode: the running statistics the kernels updated, back into the modules
+        o = 0
+        with torch.no_grad():
+            for b in bns:
+                b.running_mean.copy_(bn.running_mean[o:o + b.num_features])
+                b.running_var.copy_(bn.running_var[o:o + b.num_features])
+                o += b.num_features
+    bn.sync = sync
+    return bn
+
+
+def convt_heads_fusable(seq_d, seq_m):
+    try:
+        ct_d, ct_m, cv_d, cv_m = seq_d[0], seq_m[0], seq_d[3], seq_m[3]
+        return (isinstance(ct_d, nn.ConvTranspose2d) and isinstance(ct_m, nn.ConvTranspose2d) and ct_d.out_channels + ct_m.out_channels <= 3
+                and ct_d.in_channels == ct_m.in_channels and ct_d.bias is None and ct_m.bias is None
+                and (ct_d.kernel_size, ct_d.stride, ct_d.padding, ct_d.output_padding) == (ct_m.kernel_size, ct_m.stride, ct_m.padding, ct_m.output_padding)
+                and isinstance(cv_d, nn.Conv2d) and isinstance(cv_m, nn.Conv2d) and cv_d.bias is None and cv_m.bias is None
+                and cv_d.kernel_size == cv_m.kernel_size == (3, 3) and cv_d.stride == cv_m.stride == (1, 1)
+                and cv_d.padding == cv_m.padding == (1, 1) and cv_d.in_channels == cv_d.out_channels == ct_d.out_channels
+                and cv_m.in_channels == cv_m.out_channels == ct_m.out_channels
+                and isinstance(seq_d[1], nn.BatchNorm2d) and isinstance(seq_m[4], nn.BatchNorm2d))
+    except (IndexError, TypeError):
+        return False
+
+
+def _heads_modules(ctx, seq_d, seq_m):
+    ct_d, ct_m, cv_d, cv_m = seq_d[0], seq_m[0], seq_d[3], seq_m[3]
+    od, om = ct_d.out_channels, ct_m.out_channels
+
+    def make():
+        g = ctx.grad
+        det = (lambda t: t) if g else (lambda t: t.detach())
+        ct = _Shim()
+        ct.in_channels, ct.out_channels = ct_d.in_channels, od + om
+        ct.kernel_size, ct.stride, ct.padding, ct.output_padding, ct.bias = ct_d.kernel_size, ct_d.stride, ct_d.padding, ct_d.output_padding, None
+        ct.weight = torch.cat([det(ct_d.weight), det(ct_m.weight)], 1)                      # (in, out, 3, 3)
+        cv = _Shim()
+        cv.in_channels = cv.out_channels = od + om
+        cv.kernel_size, cv.stride, cv.padding, cv.bias = (3, 3), (1, 1), (1, 1), None
+        cv.weight = torch.cat([F.pad(det(cv_d.weight), (0, 0, 0, 0, 0, om)), F.pad(det(cv_m.weight), (0, 0, 0, 0, od, 0))], 0)
+        return ct, _bn_cat((seq_d[1], seq_m[1]), g), cv, _bn_cat((seq_d[4], seq_m[4]), g)
+    if ctx.grad or ctx.train:
+        return make()                        # (new autograd leaves / fresh running statistics every step)
+    ps = [ct_d.weight, ct_m.weight, cv_d.weight, cv_m.weight]
+    for b in (seq_d[1], seq_m[1], seq_d[4], seq_m[4]):
+        ps += [b.weight, b.bias, b.running_mean, b.running_var]
+    vers = ops._ver(*ps) + tuple(b.num_batches_tracked._version for b in (seq_d[1], seq_m[1], seq_d[4], seq_m[4])
+                                  if b.num_batches_tracked is not None)
+    return ops._cached(seq_d, ('heads', id(seq_m)), vers, make)
+
+
+def run_convt_heads(ctx, seq_d, seq_m, x):
+    """the two convt_bn_relu stacks `seq_d` (depth) and `seq_m` (mask) over the same input -> [B][2H][2W][4]: channel 0 = seq_d's
+    output, channels 1.. = seq_m's (see above)"""
+    ct, bn1, cv, bn2 = _heads_modules(ctx, seq_d, seq_m)
+    y = conv_transpose2d(ctx, x, ct, bn1, ACT_LEAKY, 0.2)
+    y = conv2d(ctx, y, cv, bn2, ACT_LEAKY, 0.2)
+    if ctx.train:
+        bn1.sync()
+        bn2.sync()
+    return y
 
 
 def run_basic_block(ctx, blk, x, out=None, alias_in=False):
@@ -463,7 +574,7 @@ def _convt_grad(ctx, x, convt, bn, act, slope, geoms, dims, passthrough=False):
         return dx
 
     custom_fwd = custom_wgrad = None
-    if O <= 2 and ph == pw and convt.bias is None and bn is not None:
+    if O <= 3 and ph == pw and convt.bias is None and bn is not None:
         def custom_fwd(xin, w, out_raw):
             _convt_small_forward(xin, convt, out_raw)
 

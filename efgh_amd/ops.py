@@ -585,6 +585,24 @@ def segment_colmean(x, ld, C, rows_per_seg, nseg):
     return y
 
 
+def heads_to_nchw(x):
+    """x (B,H,W,4): channel 0 depth, channels 1-2 mask logits -> g_depth (B,1,H,W), g_mask = softmax (B,2,H,W)"""
+    B, H, W, ld = x.shape
+    assert ld == 4 and x.is_contiguous()
+    depth = torch.empty((B, 1, H, W), dtype=torch.float32, device=x.device)
+    mask = torch.empty((B, 2, H, W), dtype=torch.float32, device=x.device)
+    _C.check(_L().efgh_heads_to_nchw(ptr(x), ptr(depth), ptr(mask), c_int32(B), c_int64(H * W), _st()))
+    return depth, mask
+
+
+def heads_bwd(mask, dmask, ddepth):
+    B, _, H, W = mask.shape
+    dx = torch.empty((B, H, W, 4), dtype=torch.float32, device=mask.device)
+    _C.check(_L().efgh_heads_bwd(ptr(mask), ptr(dmask) if dmask is not None else None, ptr(ddepth) if ddepth is not None else None,
+                                 c_int32(B), c_int64(H * W), ptr(dx), _st()))
+    return dx
+
+
 def softmax2_to_nchw(x):
     B, H, W, ld = x.shape
     y = torch.empty((B, 2, H, W), dtype=torch.float32, device=x.device)

@@ -272,6 +272,9 @@ int efgh_segment_colmean(const float *x, int64_t ld, int32_t C, int32_t rows_per
                          float *y, void *stream);
 /* nn.Softmax(dim=1) over 2 channels, written planar (B,2,H,W) (gnet.py:124) */
 int efgh_softmax2_to_nchw(const float *x, int64_t ld, float *y, int32_t B, int64_t HW, void *stream);
+/* G's depth and mask heads carried as ONE map x[B*HW][4] (channel 0 depth, channels 1-2 mask logits): g_depth (B,1,HW) and
+ * g_mask = softmax over the two logits (B,2,HW) of gnet.py:121-124 from one read. */
+int efgh_heads_to_nchw(const float *x, float *depth, float *mask, int32_t B, int64_t HW, void *stream);
 
 /* ------------------------------------------------------------------ rasterisers / rotate ----
  * range image: common/torch_utils.py:11-59 applied to e_l.[pc;1] (nets/fnet.py:43-45).
@@ -394,6 +397,8 @@ int efgh_segment_colmax_bwd(const float *dy, const int32_t *argrow, int32_t nseg
 int efgh_segment_colmean_bwd(const float *dy, int32_t P, int32_t nseg, int32_t C, float *dx, int64_t ld,
                              void *stream);
 int efgh_softmax2_bwd(const float *y, const float *dy, int32_t B, int64_t HW, float *dx, int64_t ld, void *stream);
+/* backward of efgh_heads_to_nchw: y = the softmax output; dmask (B,2,HW) / ddepth (B,1,HW) may be NULL; dx[B*HW][4]. */
+int efgh_heads_bwd(const float *y, const float *dmask, const float *ddepth, int32_t B, int64_t HW, float *dx, void *stream);
 /* correlation head: dcam_n (gradient w.r.t. cam/(max-min)) and drp (w.r.t. the padded, normalised
  * range features); efgh_corr_unpad folds drp back onto the un-padded map.                      */
 int efgh_corr1d_bwd(const float *rp, const float *cam, const float *cam_mm, const float *dlogit, int32_t B,

@@ -472,6 +472,52 @@ def test_small_channel_conv_vs_generic_and_fp64(L, cin, cout, hw, B, k, monkeypa
     assert _rel(bng.weight.grad.cpu(), bn.weight.grad) < 2e-4 and _rel(bng.bias.grad.cpu(), bn.bias.grad) < 2e-4
 
 
+@pytest.mark.parametrize('train', [False, True])
+def test_fused_convt_heads_equal_separate_stacks(L, train):
+    """layers.run_convt_heads (G's depth and mask heads as one 3-channel pipeline: concatenated transposed weights and BatchNorms,
+    block-diagonal 3x3 convolution) against the two convt_bn_relu stacks run separately: outputs, running statistics, and in train
+    mode the gradients of every parameter of both stacks and of the shared input"""
+    import copy
+    from efgh_amd import ops
+    from efgh_amd.nets import fn as FN
+    from efgh_amd.nets.builders import convt_bn_relu
+    torch.manual_seed(11)
+    sd, sm = convt_bn_relu(128, 1, 3, 2, 1, 1).cuda(), convt_bn_relu(128, 2, 3, 2, 1, 1).cuda()
+    for seq in (sd, sm):
+        for m in seq.modules():
+            if isinstance(m, nn.BatchNorm2d):
+                with torch.no_grad():
+                    m.weight.uniform_(0.5, 1.5); m.bias.normal_(0, 0.2); m.running_mean.normal_(0, 0.1); m.running_var.uniform_(0.5, 1.5)
+    sd2, sm2 = copy.deepcopy(sd), copy.deepcopy(sm)
+    for seq in (sd, sm, sd2, sm2):
+        seq.train(train)
+    assert L.convt_heads_fusable(sd, sm)
+    B, H, W = 2, 9, 21
+    x = torch.randn(B, H, W, 128, device='cuda')
+    gd, gm = torch.randn(B, 1, 2 * H, 2 * W, device='cuda'), torch.randn(B, 2, 2 * H, 2 * W, device='cuda')
+    with torch.set_grad_enabled(train):
+        ctx = L.Ctx(train)
+        xa = x.clone().requires_grad_(train)
+        hm = L.run_convt_heads(ctx, sd, sm, xa)
+        d1, m1 = FN.HeadsToNchwFn.apply(hm) if train else ops.heads_to_nchw(hm)
+        xb = x.clone().requires_grad_(train)
+        dimg, alias = L.run_convt_bn_relu(ctx, sd2, xb, skip_out=True)
+        mask = L.run_convt_bn_relu(ctx, sm2, alias)
+        if train:
+            d2, m2 = FN.NhwcToNchwFn.apply(dimg, 1), FN.Softmax2ToNchwFn.apply(mask)
+        else:
+            d2, m2 = ops.nhwc_to_nchw(dimg, 1), ops.softmax2_to_nchw(mask)
+    assert _rel(d1, d2) < 1e-6 and _rel(m1, m2) < 1e-6, (_rel(d1, d2), _rel(m1, m2))
+    for a, b in zip(list(sd.buffers()) + list(sm.buffers()), list(sd2.buffers()) + list(sm2.buffers())):
+        assert torch.equal(a, b) if a.dtype != torch.float32 else _rel(a, b) < 1e-6
+    if train:
+        ((d1 * gd).sum() + (m1 * gm).sum()).backward()
+        ((d2 * gd).sum() + (m2 * gm).sum()).backward()
+        assert _rel(xa.grad, xb.grad) < 2e-5, _rel(xa.grad, xb.grad)
+        for (n, pa), pb in zip(list(sd.named_parameters()) + list(sm.named_parameters()), list(sd2.parameters()) + list(sm2.parameters())):
+            assert pa.grad is not None and _rel(pa.grad, pb.grad) < 5e-5 + 0, (n, _rel(pa.grad, pb.grad))
+
+
 @pytest.mark.parametrize('c,hw,B', [(2, (37, 301), 2), (1, (5, 9), 1), (2, (64, 256), 1), (3, (33, 600), 3)])
 def test_c4n4_stencil_conv_vs_fp64_and_autograd(L, c, hw, B):
     """k_c4n4_conv3x3 / k_c4n4_wgrad3x3 (<= 4 channels on both sides, 3x3, stride 1: the 1- / 2-channel convolutions behind G's
