@@ -431,6 +431,142 @@ __global__ void __launch_bounds__(256, 2) k_wino_wgrad(const WinoWArgs p) {
 }
 
 // dWp[n][kh*3 + kw][c] = sum_alpha A3^T[kw][alpha] * S[alpha][n][kh*C + c]
+// ---- the same contraction with every operand row read ONCE.  k_wino_wgrad gives each (n, kh, c) block its own workgroup: the three
+// kernel rows kh of a tile range are three workgroups that each read the gradient tiles and their own input row y + kh - 1 (measured:
+// 3.9 GB from HBM per launch for 2.0 GB of operands - the ranges of the resident workgroups, 27 MB per XCD, do not live in a 4 MB L2
+// long enough to be shared).  Here ONE workgroup of 12 waves owns a strip of 16 tiles (64 pixels) and walks DOWN the image rows:
+// per row it transforms one gradient tile row (G4 dy) and one new input row (B^T x) into LDS; the transformed input rows stay in a
+// ring of three, so the row staged for y + 1 is kernel row 2 of this step, row 1 of the next and row 0 of the one after.  Wave group
+// kh (4 waves, 32 n x 32 c x 6 alpha each, as before) contracts the gradient image with ring slot y + kh - 1.  Per step the workgroup
+// loads 40 KB for 3 x the MFMA work of a k_wino_wgrad step.
+constexpr int WR_WAVES = 12;
+
+__global__ void __launch_bounds__(64 * WR_WAVES, 1) k_wino_wgrad_rows(const WinoWArgs p, int strips, int chunks, int rh, int ct) {
+    __shared__ __attribute__((aligned(16))) float Gs[6 * TT * 64];
+    __shared__ __attribute__((aligned(16))) float Vr[3][6 * TT * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kg = wave >> 2, wn = (wave >> 1) & 1, wc = wave & 1, l31 = lane & 31, lh = lane >> 5;
+    const int unit = blockIdx.x, strip = unit % strips, ur = unit / strips, chk = ur % chunks;
+    const long long b = ur / chunks;
+    const int y0 = chk * rh, y1 = y0 + rh < p.H ? y0 + rh : p.H;
+    const int c0 = (blockIdx.y % ct) * 64, n0 = (blockIdx.y / ct) * 64;
+    if (y0 >= y1) return;
+    // staging: waves 0-3 the input row, waves 4-7 the gradient row; thread = (tile ts of the strip, channel quad q4)
+    const int role = wave >> 2, st = tid & 255, ts = st >> 4, q4 = (st & 15) * 4;
+    const int xt = strip * TT + ts, x0 = 4 * xt - 1, xg = 4 * xt;
+    const bool tv = xt < p.TW;
+    const float *zpage = g_zero_page;
+    float4 r0, r1, r2, r3, r4, r5;                   // raw pixels of the row being staged next (role 0: six of x; role 1: four of dy)
+    auto load_x = [&](int r) {
+        const bool rok = tv && (unsigned)r < (unsigned)p.H;
+        const float *xrow = p.A + (((b * p.H + r) * p.W + x0) * p.lda + c0 + q4);
+#define EFGH_LDX(q, dst) dst = *reinterpret_cast<const float4 *>((rok && (unsigned)(x0 + q) < (unsigned)p.W) ? xrow + (long long)q * p.lda : zpage);
+        EFGH_LDX(0, r0) EFGH_LDX(1, r1) EFGH_LDX(2, r2) EFGH_LDX(3, r3) EFGH_LDX(4, r4) EFGH_LDX(5, r5)
+#undef EFGH_LDX
+    };
+    auto load_g = [&](int r) {
+        const float *grow = p.G + (((b * p.H + r) * p.W + xg) * p.ldg + n0 + q4);
+#define EFGH_LDG(i, dst) dst = *reinterpret_cast<const float4 *>((tv && (xg + i) < p.W) ? grow + (long long)i * p.ldg : zpage);
+        EFGH_LDG(0, r0) EFGH_LDG(1, r1) EFGH_LDG(2, r2) EFGH_LDG(3, r3)
+#undef EFGH_LDG
+    };
+    auto stage_x = [&](float *V) {
+        float4 v0, v1, v2, v3, v4, v5;
+#define EFGH_TR(e)                                                                                    \
+        {                                                                                            \
+            const float d0 = r0.e, d1 = r1.e, d2 = r2.e, d3 = r3.e, d4 = r4.e, d5 = r5.e;            \
+            const float p42 = d4 - 4.f * d2, p31 = d3 - 4.f * d1;                                    \
+            const float q42 = d4 - d2, q31 = 2.f * (d3 - d1);                                        \
+            v0.e = 4.f * d0 - 5.f * d2 + d4;                                                         \
+            v1.e = p42 + p31; v2.e = p42 - p31; v3.e = q42 + q31; v4.e = q42 - q31;                  \
+            v5.e = 4.f * d1 - 5.f * d3 + d5;                                                         \
+        }
+        EFGH_TR(x) EFGH_TR(y) EFGH_TR(z) EFGH_TR(w)
+#undef EFGH_TR
+#define EFGH_STW(a, vv) *reinterpret_cast<float4 *>(&V[(a * TT + ts) * 64 + q4]) = vv;
+        EFGH_STW(0, v0) EFGH_STW(1, v1) EFGH_STW(2, v2) EFGH_STW(3, v3) EFGH_STW(4, v4) EFGH_STW(5, v5)
+    };
+    auto stage_g = [&]() {
+        float4 u0, u1, u2, u3, u4, u5;
+#define EFGH_TR(e)                                                                                    \
+        {                                                                                            \
+            const float g0 = r0.e, g1 = r1.e, g2 = r2.e, g3 = r3.e;                                  \
+            const float ev = g0 + g2, od = g1 + g3, e2 = g0 + 4.f * g2, o2 = 2.f * g1 + 8.f * g3;     \
+            u0.e = 0.25f * g0;                                                                       \
+            u1.e = (ev + od) * (-1.f / 6.f); u2.e = (ev - od) * (-1.f / 6.f);                        \
+            u3.e = (e2 + o2) * (1.f / 24.f); u4.e = (e2 - o2) * (1.f / 24.f);                        \
+            u5.e = g3;                                                                               \
+        }
+        EFGH_TR(x) EFGH_TR(y) EFGH_TR(z) EFGH_TR(w)
+#undef EFGH_TR
+        float *V = Gs;
+        EFGH_STW(0, u0) EFGH_STW(1, u1) EFGH_STW(2, u2) EFGH_STW(3, u3) EFGH_STW(4, u4) EFGH_STW(5, u5)
+#undef EFGH_STW
+    };
+
+    f32x16 acc[6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+
+    // ring slot of input row r: (r - (y0 - 1)) % 3.  Prologue: rows y0 - 1 and y0
+    if (role == 0) {
+        load_x(y0 - 1); stage_x(Vr[0]);
+        load_x(y0); stage_x(Vr[1]);
+        load_x(y0 + 1);
+    } else if (role == 1) {
+        load_g(y0);
+    }
+    int s0 = 0;                                      // slot of row y - 1
+    for (int y = y0; y < y1; ++y) {
+        const int s2 = s0 == 0 ? 2 : s0 - 1;         // slot of row y + 1 = (s0 + 2) % 3
+        if (role == 0) stage_x(Vr[s2]);
+        else if (role == 1) stage_g();
+        __syncthreads();
+        const bool more = y + 1 < y1;
+        if (more) {                                  // the next row's pixels: in flight during the MFMAs
+            if (role == 0) load_x(y + 2);
+            else if (role == 1) load_g(y + 1);
+        }
+        {   // contraction index = tile: lane half lh takes tile 2s + lh; operands are single dwords of the images
+            const int sk = s0 + kg >= 3 ? s0 + kg - 3 : s0 + kg;       // slot of row y + kg - 1
+            const float *gp = &Gs[lh * 64 + wn * 32 + l31];
+            const float *vp = &Vr[sk][lh * 64 + wc * 32 + l31];
+            float fg[2][8], fv[2][8];
+#pragma unroll
+            for (int s8 = 0; s8 < 8; ++s8) { fg[0][s8] = gp[s8 * 128]; fv[0][s8] = vp[s8 * 128]; }
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                const int cur = a & 1, nxt = cur ^ 1;
+                if (a < 5) {
+#pragma unroll
+                    for (int s8 = 0; s8 < 8; ++s8) {
+                        fg[nxt][s8] = gp[(a + 1) * TT * 64 + s8 * 128];
+                        fv[nxt][s8] = vp[(a + 1) * TT * 64 + s8 * 128];
+                    }
+                }
+#pragma unroll
+                for (int s8 = 0; s8 < 8; ++s8)
+                    acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(fg[cur][s8], fv[cur][s8], acc[a], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+        s0 = s0 == 2 ? 0 : s0 + 1;
+    }
+    // D[row = n][col = c]: lanes run along c (contiguous in S)
+    const long long K3 = 3LL * p.C;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+        float *sa = p.S + (((long long)unit * 6 + a) * p.N + n0 + wn * 32) * K3 + kg * p.C + c0 + wc * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int nl = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            sa[nl * K3] = acc[a][r];
+        }
+    }
+}
+
 __global__ void k_wino_wgrad_finish(const float *__restrict__ S, int zs, float *__restrict__ dWp, int N, int C) {
     const long long K3 = 3LL * C, total = (long long)N * K3, plane = total;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -514,10 +650,35 @@ static long long wino_wgrad_ranges(const efgh_gemm_desc *d, long long *chunk_out
     return (Mt + chunk - 1) / chunk;
 }
 
+// k_wino_wgrad_rows: units = samples x strips of 16 tiles x row chunks; one 12-wave workgroup per CU, so the number of row chunks is
+// the one (<= 8, >= 8 rows each) that fills whole rounds of 256 workgroups best
+static bool wino_wgrad_rows_enabled() {
+    static const int on = [] { const char *e = getenv("EFGH_WINO_WGRAD_ROWS"); return (e && e[0] == '0') ? 0 : 1; }();
+    return on != 0;
+}
+
+static long long wino_wgrad_row_units(const efgh_gemm_desc *d, int *strips_out, int *chunks_out, int *rh_out) {
+    const int strips = ((d->Win + 3) / 4 + TT - 1) / TT, blocks = (d->C / 64) * (d->N / 64);
+    int best = 1; double beste = -1.0;
+    for (int c = 1; c <= 8; ++c) {
+        const int rh = (d->Hin + c - 1) / c;
+        if (c > 1 && rh < 8) break;
+        const long long wg = (long long)d->B * strips * ((d->Hin + rh - 1) / rh) * blocks;
+        const double eff = (double)wg / (double)(((wg + 255) / 256) * 256) * (double)rh / (double)(rh + 2);
+        if (eff > beste + 1e-9) { beste = eff; best = c; }
+    }
+    const int rh = (d->Hin + best - 1) / best, chunks = (d->Hin + rh - 1) / rh;
+    if (strips_out) *strips_out = strips;
+    if (chunks_out) *chunks_out = chunks;
+    if (rh_out) *rh_out = rh;
+    return (long long)d->B * strips * chunks;
+}
+
 /* floats of scratch `S` efgh_wino_wgrad needs: one [6][N][3C] partial per tile range */
 extern "C" int64_t efgh_wino_wgrad_workspace(const efgh_gemm_desc *d) {
     if (!supported(d) || d->C % 64 != 0 || d->B <= 0) return 0;
-    return wino_wgrad_ranges(d, nullptr) * 6 * (int64_t)d->N * 3 * d->C;
+    const long long zs = wino_wgrad_rows_enabled() ? wino_wgrad_row_units(d, nullptr, nullptr, nullptr) : wino_wgrad_ranges(d, nullptr);
+    return zs * 6 * (int64_t)d->N * 3 * d->C;
 }
 
 extern "C" int efgh_wino_wgrad(const efgh_gemm_desc *d, const float *G, int64_t ldg, float *S, float *dWp,
@@ -532,12 +693,21 @@ extern "C" int efgh_wino_wgrad(const efgh_gemm_desc *d, const float *G, int64_t 
     a.Mt = (long long)d->B * d->Hin * a.TW;
     a.S = S;
     const int kt = 3 * d->C / 64, nt = d->N / 64;
-    long long chunk = 0;
-    const long long zs = wino_wgrad_ranges(d, &chunk);
-    a.tchunk = chunk;
-    EFGH_CHECK_ARG(zs * kt * nt < 0x7fffffffLL);
-    a.kt = (unsigned)kt; a.nt = (unsigned)nt;
-    k_wino_wgrad<<<(unsigned)(zs * kt * nt), 256, 0, st>>>(a);
+    long long zs = 0;
+    if (wino_wgrad_rows_enabled()) {
+        int strips = 0, chunks = 0, rh = 0;
+        zs = wino_wgrad_row_units(d, &strips, &chunks, &rh);
+        EFGH_CHECK_ARG(zs < 0x7fffffffLL && (long long)(d->C / 64) * nt < 65536);
+        a.tchunk = 0; a.kt = (unsigned)kt; a.nt = (unsigned)nt;
+        k_wino_wgrad_rows<<<dim3((unsigned)zs, (unsigned)((d->C / 64) * nt)), 64 * WR_WAVES, 0, st>>>(a, strips, chunks, rh, d->C / 64);
+    } else {
+        long long chunk = 0;
+        zs = wino_wgrad_ranges(d, &chunk);
+        a.tchunk = chunk;
+        EFGH_CHECK_ARG(zs * kt * nt < 0x7fffffffLL);
+        a.kt = (unsigned)kt; a.nt = (unsigned)nt;
+        k_wino_wgrad<<<(unsigned)(zs * kt * nt), 256, 0, st>>>(a);
+    }
     EFGH_CHECK_LAUNCH();
     if (zs > 1) efgh_launch_fold_splits(S, (int)zs, 6LL * d->N * 3 * d->C, S, st);      // into the first partial, fixed order
     const long long total = (long long)d->N * 3 * d->C;

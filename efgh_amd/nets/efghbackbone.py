@@ -22,10 +22,14 @@ G_SIDE = os.environ.get('EFGH_G_SIDE', '1') != '0'          # G's image part nex
 F_SIDE = os.environ.get('EFGH_F_SIDE', '1') != '0'          # H and F's camera trunk on a side stream, E and F's range trunk on the current one
 
 
+_SIDE_PRIO = [int(v) for v in os.environ.get('EFGH_SIDE_PRIO', '0,0,0').split(',')]      # H / G image part / weight gradients
+
+
 def _side_stream(device, i=0):
     s = _SIDE.get((device.index, i))
     if s is None:
-        s = _SIDE[(device.index, i)] = torch.cuda.Stream(device=device)
+        pr = _SIDE_PRIO[i] if i < len(_SIDE_PRIO) else 0
+        s = _SIDE[(device.index, i)] = torch.cuda.Stream(device=device, priority=pr) if pr else torch.cuda.Stream(device=device)
     return s
 
 
