@@ -736,6 +736,75 @@ k_convt_im2col(const float *__restrict__ G, long long ldg, int B, int Hin, int W
         for (int c = 9 * O; c < ldy; ++c) y[c] = 0.f;
     }
 }
+// the same two folds with the grid as the image (no divisions), the nine gradient taps as 16-byte buffer loads whose range check
+// supplies the zeros outside the output, and the column row assembled in registers and written as 16-byte stores
+template <int O>
+__global__ void __launch_bounds__(256)
+k_convt_im2col_v(const float *__restrict__ G, long long ldg, int Hin, int Win, int Ho, int Wo, int pad, float *__restrict__ Ycol,
+                 int ldy4) {
+    const int iw = blockIdx.x * 256 + threadIdx.x, ih = blockIdx.y;
+    const long long b = blockIdx.z;
+    const int ldg4 = (int)ldg * 4;
+    const unsigned rowbytes = (unsigned)Wo * (unsigned)ldg4;
+    float v[40];
+#pragma unroll
+    for (int q = 0; q < 40; ++q) v[q] = 0.f;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+        const int oh = 2 * ih - pad + kh;
+        const bool rok = (unsigned)oh < (unsigned)Ho;                 // (uniform)
+        const float *rowp = G + (b * Ho + (rok ? oh : 0)) * Wo * ldg;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const float4 g = cn_load(rowp, rok ? rowbytes : 0u, (2 * iw - pad + kw) * ldg4);
+            const float gv[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+            for (int o = 0; o < O; ++o) v[(kh * 3 + kw) * O + o] = gv[o];
+        }
+    }
+    if (iw >= Win) return;
+    float4 *y = reinterpret_cast<float4 *>(Ycol + ((b * Hin + ih) * Win + iw) * (long long)(ldy4 * 4));
+#pragma unroll
+    for (int q = 0; q < 10; ++q)
+        if (q < ldy4) y[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+}
+
+template <int O>
+__global__ void __launch_bounds__(256)
+k_convt_col2im_v(const float *__restrict__ Y, long long ldy, int Hin, int Win, int Ho, int Wo, int pad,
+                 const float *__restrict__ scale, const float *__restrict__ shift, int act, float slope, float *__restrict__ out,
+                 long long ldo) {
+    const int ow = blockIdx.x * 256 + threadIdx.x, oh = blockIdx.y;
+    const long long b = blockIdx.z;
+    if (ow >= Wo) return;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+        const int th = oh + pad - kh;                                 // (uniform)
+        if (th < 0 || (th & 1) || (th >> 1) >= Hin) continue;
+        const float *yrow = Y + ((b * Hin + (th >> 1)) * Win) * ldy + kh * 3 * O;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int tw = ow + pad - kw;
+            if (tw < 0 || (tw & 1) || (tw >> 1) >= Win) continue;
+            const float *y = yrow + (long long)(tw >> 1) * ldy + kw * O;
+#pragma unroll
+            for (int o = 0; o < O; ++o) acc[o] += y[o];
+        }
+    }
+    float4 v;
+    float *vp = &v.x;
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+        float x = acc[o];
+        if (o < O) {
+            x = x * (scale ? scale[o] : 1.f) + (shift ? shift[o] : 0.f);
+            x = act_f(x, act, slope);
+        } else x = 0.f;
+        vp[o] = x;
+    }
+    *reinterpret_cast<float4 *>(out + ((b * Ho + oh) * Wo + ow) * ldo) = v;
+}
 }  // namespace
 
 extern "C" int efgh_convt_col2im(const float *Y, int64_t ldy, int32_t B, int32_t Hin, int32_t Win, int32_t Ho,
@@ -743,8 +812,18 @@ extern "C" int efgh_convt_col2im(const float *Y, int64_t ldy, int32_t B, int32_t
                                  int32_t act, float slope, float *out, int64_t ldo, void *stream_) {
     EFGH_CHECK_ARG(Y && out && B > 0 && Hin > 0 && Win > 0 && Ho > 0 && Wo > 0 && O >= 1 && O <= 4);
     EFGH_CHECK_ARG(ldy >= 9 * O && ldo >= 4 && ldo % 4 == 0);
-    k_convt_col2im<<<grid_for((long long)B * Ho * Wo, 256), 256, 0, (hipStream_t)stream_>>>(
-        Y, ldy, B, Hin, Win, Ho, Wo, O, pad, scale, shift, act, slope, out, ldo);
+    hipStream_t st = (hipStream_t)stream_;
+    if (B <= 65535 && Ho <= 65535) {
+        const dim3 grid((Wo + 255) / 256, Ho, B);
+        switch (O) {
+        case 1: k_convt_col2im_v<1><<<grid, 256, 0, st>>>(Y, ldy, Hin, Win, Ho, Wo, pad, scale, shift, act, slope, out, ldo); break;
+        case 2: k_convt_col2im_v<2><<<grid, 256, 0, st>>>(Y, ldy, Hin, Win, Ho, Wo, pad, scale, shift, act, slope, out, ldo); break;
+        case 3: k_convt_col2im_v<3><<<grid, 256, 0, st>>>(Y, ldy, Hin, Win, Ho, Wo, pad, scale, shift, act, slope, out, ldo); break;
+        default: k_convt_col2im_v<4><<<grid, 256, 0, st>>>(Y, ldy, Hin, Win, Ho, Wo, pad, scale, shift, act, slope, out, ldo); break;
+        }
+    } else
+        k_convt_col2im<<<grid_for((long long)B * Ho * Wo, 256), 256, 0, st>>>(
+            Y, ldy, B, Hin, Win, Ho, Wo, O, pad, scale, shift, act, slope, out, ldo);
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
 }
@@ -752,8 +831,20 @@ extern "C" int efgh_convt_col2im(const float *Y, int64_t ldy, int32_t B, int32_t
 extern "C" int efgh_convt_im2col(const float *G, int64_t ldg, int32_t B, int32_t Hin, int32_t Win, int32_t Ho,
                                  int32_t Wo, int32_t O, int32_t pad, float *Ycol, int64_t ldy, void *stream_) {
     EFGH_CHECK_ARG(G && Ycol && B > 0 && Hin > 0 && Win > 0 && Ho > 0 && Wo > 0 && O >= 1 && O <= 4 && ldy >= 9 * O);
-    k_convt_im2col<<<grid_for((long long)B * Hin * Win, 256), 256, 0, (hipStream_t)stream_>>>(G, ldg, B, Hin, Win, Ho,
-                                                                                             Wo, O, pad, Ycol, ldy);
+    hipStream_t st = (hipStream_t)stream_;
+    const bool vec = B <= 65535 && Hin <= 65535 && ldy % 4 == 0 && ldy <= 40 && ldg % 4 == 0 && (((uintptr_t)G) & 15) == 0 &&
+                     (((uintptr_t)Ycol) & 15) == 0 && (int64_t)(2 * Win + 8) * ldg * 4 < (1ll << 31);
+    if (vec) {
+        const dim3 grid((Win + 255) / 256, Hin, B);
+        const int ldy4 = (int)(ldy / 4);
+        switch (O) {
+        case 1: k_convt_im2col_v<1><<<grid, 256, 0, st>>>(G, ldg, Hin, Win, Ho, Wo, pad, Ycol, ldy4); break;
+        case 2: k_convt_im2col_v<2><<<grid, 256, 0, st>>>(G, ldg, Hin, Win, Ho, Wo, pad, Ycol, ldy4); break;
+        case 3: k_convt_im2col_v<3><<<grid, 256, 0, st>>>(G, ldg, Hin, Win, Ho, Wo, pad, Ycol, ldy4); break;
+        default: k_convt_im2col_v<4><<<grid, 256, 0, st>>>(G, ldg, Hin, Win, Ho, Wo, pad, Ycol, ldy4); break;
+        }
+    } else
+        k_convt_im2col<<<grid_for((long long)B * Hin * Win, 256), 256, 0, st>>>(G, ldg, B, Hin, Win, Ho, Wo, O, pad, Ycol, ldy);
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
 }

@@ -64,7 +64,8 @@ def test_conv_bn_act(L, cin, cout, k, s, p, hw, train):
 
 @pytest.mark.parametrize('cin,cout,pad,opad,hw', [(512, 128, 1, 0, (4, 8)), (128, 32, 0, 0, (7, 15)),
                                                   (32, 16, 1, 0, (15, 31)), (512, 256, 1, 1, (6, 10)),
-                                                  (128, 1, 1, 1, (12, 20)), (128, 2, 1, 1, (12, 20))])
+                                                  (128, 1, 1, 1, (12, 20)), (128, 2, 1, 1, (12, 20)), (128, 3, 1, 1, (12, 20)),
+                                                  (64, 3, 0, 0, (7, 9)), (128, 2, 1, 1, (5, 300))])
 @pytest.mark.parametrize('train', [False, True])
 def test_conv_transpose(L, cin, cout, pad, opad, hw, train):
     torch.manual_seed(1)
@@ -79,10 +80,22 @@ def test_conv_transpose(L, cin, cout, pad, opad, hw, train):
     ref = F.leaky_relu(bn(ct(x)), 0.2)
     ct_g, bn_g = nn.ConvTranspose2d(cin, cout, 3, 2, pad, opad, bias=False).cuda(), nn.BatchNorm2d(cout).cuda()
     ct_g.load_state_dict(ct.state_dict()); bn_g.load_state_dict(sd_bn); bn_g.train(train)
-    y = L.conv_transpose2d(L.Ctx(train), _nhwc(x).cuda(), ct_g, bn_g, L.ACT_LEAKY, 0.2)
+    xg = _nhwc(x).cuda().requires_grad_(train and cout <= 3)
+    y = L.conv_transpose2d(L.Ctx(train), xg, ct_g, bn_g, L.ACT_LEAKY, 0.2)
     got = y[..., :cout].permute(0, 3, 1, 2).cpu()
     assert got.shape == ref.shape
-    assert _rel(got, ref) < 2e-5
+    assert _rel(got.detach(), ref.detach()) < 2e-5
+    if train and cout <= 3:
+        # the GEMM + col2im form of the narrow heads: data and weight gradient (im2col of the gradient + plain GEMMs) vs autograd
+        gy = torch.randn_like(ref)
+        xr = x.clone().requires_grad_(True)
+        ct.weight.grad = None
+        F.leaky_relu(bn(ct(xr)), 0.2).backward(gy)
+        gyp = torch.zeros(y.shape)
+        gyp[..., :cout] = gy.permute(0, 2, 3, 1)
+        y.backward(gyp.cuda())
+        assert _rel(ct_g.weight.grad.cpu(), ct.weight.grad) < 2e-4, _rel(ct_g.weight.grad.cpu(), ct.weight.grad)
+        assert _rel(xg.grad[..., :cin].permute(0, 3, 1, 2).cpu(), xr.grad) < 2e-4
 
 
 def test_conv_1x2_and_residual_and_concat(L):
