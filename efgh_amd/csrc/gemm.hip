@@ -18,6 +18,7 @@
 // One ds_read_b128 feeds four MFMAs: lanes 0-31 hold k = g*8+j, lanes 32-63 hold k = g*8+4+j.
 // Numerics: exact fp32 products, fp32 accumulation (a k-ordered fma chain per output).
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -396,35 +397,67 @@ k_gather_gemm(const KArgs p_in) {
     }
 
     // ---- epilogue -----------------------------------------------------------------------
+    // rows outside, columns inside: the output row index, its two 64-bit row addresses and the mask are formed once per row (16 MI
+    // of them per lane) instead of once per element, the per-column terms once per column block
     float *ssum = As;            // [WM][BN] column sums, [WM][BN] sums of squares (LDS reuse)
     float *ssq = As + WM * BN;
+    float bi[NI], sc[NI], sf[NI], s1[NI], s2[NI];
+    bool cok[NI];
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
-        const int coll = (wn * NI + j) * 32 + l31, col = n0 + coll;
-        const bool cok = col < p.N;
-        const float bi = (p.bias && cok) ? p.bias[col] : 0.f;
-        const float sc = (p.scale && cok) ? p.scale[col] : 1.f;
-        const float sf = (p.shift && cok) ? p.shift[col] : 0.f;
-        float s1 = 0.f, s2 = 0.f;
+        const int col = n0 + (wn * NI + j) * 32 + l31;
+        cok[j] = col < p.N;
+        bi[j] = (p.bias && cok[j]) ? p.bias[col] : 0.f;
+        sc[j] = (p.scale && cok[j]) ? p.scale[col] : 1.f;
+        sf[j] = (p.shift && cok[j]) ? p.shift[col] : 0.f;
+        s1[j] = 0.f; s2[j] = 0.f;
+    }
+    const int colb = n0 + wn * NI * 32 + l31;
+    const float neg = p.act == 1 ? 0.f : (p.act == 2 ? p.slope : 1.f);      // act(v) = max(v, 0) + neg * min(v, 0)
+    // two workgroup-uniform switches pick one of four straight-line bodies: with / without a residual operand (its NI loads of a row
+    // are issued together, ahead of the arithmetic), and all columns of the tile inside N (no per-element predicate) or not
+    auto rows = [&](auto res_c, auto full_c) {
+        constexpr bool RES = decltype(res_c)::value, FULL = decltype(full_c)::value;
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rl = (wm * MI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 const long long orow = rowout[rl];
-                if (orow < 0 || !cok) continue;
-                float v = acc[i][j][r] + bi;
-                s1 += v; s2 += v * v;
-                v = v * sc + sf;
-                if (p.residual) v += p.residual[orow * p.ldr + col];
-                if (p.act == 1) v = v > 0.f ? v : 0.f;
-                else if (p.act == 2) v = v > 0.f ? v : v * p.slope;
-                p.out[orow * p.ldo + col] = v;
+                if (orow < 0) continue;
+                float *op = p.out + orow * p.ldo + colb;
+                float rv[NI];
+                if (RES) {
+                    const float *rp = p.residual + orow * p.ldr + colb;
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) rv[j] = (FULL || cok[j]) ? rp[j * 32] : 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    float v = acc[i][j][r] + bi[j];
+                    if (FULL || cok[j]) { s1[j] += v; s2[j] += v * v; }
+                    v = v * sc[j] + sf[j];
+                    if (RES) v += rv[j];
+                    v = fmaxf(v, 0.f) + neg * fminf(v, 0.f);
+                    if (FULL || cok[j]) op[j * 32] = v;
+                }
             }
         }
-        if (p.stats) {
-            s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
-            if (lh == 0) { ssum[wm * BN + coll] = s1; ssq[wm * BN + coll] = s2; }
+    };
+    const bool fulln = n0 + BN <= p.N;
+    if (p.residual) {
+        if (fulln) rows(std::true_type{}, std::true_type{});
+        else rows(std::true_type{}, std::false_type{});
+    } else {
+        if (fulln) rows(std::false_type{}, std::true_type{});
+        else rows(std::false_type{}, std::false_type{});
+    }
+    if (p.stats) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int coll = (wn * NI + j) * 32 + l31;
+            s1[j] += __shfl_xor(s1[j], 32); s2[j] += __shfl_xor(s2[j], 32);
+            if (lh == 0) { ssum[wm * BN + coll] = s1[j]; ssq[wm * BN + coll] = s2[j]; }
         }
     }
     if (p.stats) {

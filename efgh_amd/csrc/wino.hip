@@ -18,6 +18,7 @@
 // 48 v_mfma_f32_32x32x2_f32 per wave.  Epilogue = that of k_gather_gemm (bias, BN scale/shift, residual,
 // activation, per-tile column statistics).
 #include "common.h"
+#include <type_traits>
 
 void efgh_launch_fold_splits(const float *part, int zs, long long total, float *dst, hipStream_t st);   // wgrad.hip
 
@@ -219,33 +220,47 @@ __global__ void __launch_bounds__(256, 2) k_wino43(const WinoArgs p) {
         if (!p.bn_y) { b_psc = p.bn_psc[col]; b_psh = p.bn_psh[col]; }
         b_mu = p.bn_mean[col]; b_is = p.bn_invstd[col];
     }
+    // per tile row: the pixel index, the row addresses and the count of valid pixels are formed once; a workgroup-uniform switch picks
+    // the body with / without a residual operand (its four loads of a tile are issued together, ahead of the arithmetic)
+    const float neg = p.act == 1 ? 0.f : (p.act == 2 ? p.slope : 1.f);      // act(v) = max(v, 0) + neg * min(v, 0)
+    auto rows = [&](auto res_c) {
+        constexpr bool RES = decltype(res_c)::value;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int rl = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const long long opix = tpix[rl];
-        const int cnt = tcnt[rl];
-        if (opix < 0) continue;
-        const float m0_ = acc[0][r], m1 = acc[1][r], m2 = acc[2][r], m3 = acc[3][r], m4 = acc[4][r], m5 = acc[5][r];
-        const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
-        const float y0 = m0_ + s12 + s34, y1 = d12 + 2.f * d34, y2 = s12 + 4.f * s34, y3 = d12 + 8.f * d34 + m5;
+        for (int r = 0; r < 16; ++r) {
+            const int rl = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const long long opix = tpix[rl];
+            const int cnt = tcnt[rl];
+            if (opix < 0) continue;
+            float *op = p.out + opix * p.ldo + col;
+            float rv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (RES) {
+                const float *rp = p.residual + opix * p.ldr + col;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if (i >= cnt) continue;
-            float v = (i == 0 ? y0 : i == 1 ? y1 : i == 2 ? y2 : y3) + bi;
-            if (!bnm) { s1 += v; s2 += v * v; }
-            v = v * sc + sf;
-            if (p.residual) v += p.residual[(opix + i) * p.ldr + col];
-            if (p.act == 1) v = v > 0.f ? v : 0.f;
-            else if (p.act == 2) v = v > 0.f ? v : v * p.slope;
-            p.out[(opix + i) * p.ldo + col] = v;
-            if (bnm) {
-                const float rw = p.bn_raw[(opix + i) * p.bn_ldraw + col];
-                const float yy = p.bn_y ? p.bn_y[(opix + i) * p.bn_ldy + col] : rw * b_psc + b_psh;
-                const float g = p.bn_act == 1 ? (yy > 0.f ? v : 0.f) : p.bn_act == 2 ? (yy > 0.f ? v : v * p.bn_slope) : v;
-                s1 += g; s2 += g * ((rw - b_mu) * b_is);
+                for (int i = 0; i < 4; ++i) if (i < cnt) rv[i] = rp[i * p.ldr];
+            }
+            const float m0_ = acc[0][r], m1 = acc[1][r], m2 = acc[2][r], m3 = acc[3][r], m4 = acc[4][r], m5 = acc[5][r];
+            const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+            const float yv[4] = {m0_ + s12 + s34, d12 + 2.f * d34, s12 + 4.f * s34, d12 + 8.f * d34 + m5};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (i >= cnt) continue;
+                float v = yv[i] + bi;
+                if (!bnm) { s1 += v; s2 += v * v; }
+                v = v * sc + sf;
+                if (RES) v += rv[i];
+                v = fmaxf(v, 0.f) + neg * fminf(v, 0.f);
+                op[i * p.ldo] = v;
+                if (bnm) {
+                    const float rw = p.bn_raw[(opix + i) * p.bn_ldraw + col];
+                    const float yy = p.bn_y ? p.bn_y[(opix + i) * p.bn_ldy + col] : rw * b_psc + b_psh;
+                    const float g = p.bn_act == 1 ? (yy > 0.f ? v : 0.f) : p.bn_act == 2 ? (yy > 0.f ? v : v * p.bn_slope) : v;
+                    s1 += g; s2 += g * ((rw - b_mu) * b_is);
+                }
             }
         }
-    }
+    };
+    if (p.residual) rows(std::true_type{});
+    else rows(std::false_type{});
     if (p.stats) {
         s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
         if (lh == 0) { ssum[wm * TN + coll] = s1; ssq[wm * TN + coll] = s2; }

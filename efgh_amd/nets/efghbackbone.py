@@ -57,6 +57,7 @@ class EFGHBackbone(nn.Module):
         # packed weights that went stale with the last optimizer step are rewritten in place by ONE launch; every branch below
         # reads them, so that launch goes out here, on the current stream, before the streams fork
         ops.repack_stale(pc.device)
+        ops.TRAIN_STEP = bool(self.training and torch.is_grad_enabled())      # (stays set for the backward pass of this step)
         if self.training:
             ops.w2v_clear()
         shared_img = ops.nchw_to_nhwc(img, 4)                # channels-last copy used by both H and G

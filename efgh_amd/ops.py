@@ -194,6 +194,13 @@ def wino_eligible(mode, C, N, geom, T=None):
 USE_WINO2D = _os.environ.get('EFGH_WINO2D', '1') != '0'   # F(4x4,3x3) as transform / batched GEMM / transform (wino2d.hip)
 WINO2D_MIN_C = int(_os.environ.get('EFGH_WINO2D_MIN_C', '256'))            # forward / data gradient
 WINO2D_MIN_C_WGRAD = int(_os.environ.get('EFGH_WINO2D_MIN_C_WGRAD', '128'))  # weight gradient
+# forward / data gradient inside a training step (EFGHBackbone sets TRAIN_STEP): EFGH_WINO2D_MIN_C_TRAIN=128 moves the 128-channel
+# layers to the 2-D form there - their weight gradient is 2-D anyway and re-uses the forward's transformed input, and the extra
+# transform passes run underneath MFMA kernels of the other streams: -0.9 ms per step for +10 GB (the eval forward alone is 0.5 %
+# faster on the 1-D kernel).  Not the default: a sub-percent gain that re-rounds F's trunks, whose arg-max heads turn a 1e-6
+# difference of the logits into a different yaw bin on near-ties (tests/test_gpu_train.py::test_winograd_and_direct_kernels...)
+WINO2D_MIN_C_TRAIN = int(_os.environ.get('EFGH_WINO2D_MIN_C_TRAIN', '256'))
+TRAIN_STEP = False
 
 
 def _pow2(v):
@@ -203,10 +210,10 @@ def _pow2(v):
 def wino2d_eligible(mode, C, N, geom, wgrad=False):
     """the layers the 2-D Winograd path serves (mirror of efgh_wino2d_supported + the channel threshold below which the
     transform passes cost more than the saved MFMAs, measured with tools/bench_wino.py): 3x3, stride 1, pad 1, C and N powers
-    of two, >= 256 channels (forward / data gradient) or >= 128 (weight gradient)"""
+    of two, >= 256 channels (forward / data gradient; >= 128 inside a training step) or >= 128 (weight gradient)"""
     if not USE_WINO2D or not wino_eligible(mode, C, N, geom):
         return False
-    lim = WINO2D_MIN_C_WGRAD if wgrad else WINO2D_MIN_C
+    lim = WINO2D_MIN_C_WGRAD if wgrad else (min(WINO2D_MIN_C, WINO2D_MIN_C_TRAIN) if TRAIN_STEP else WINO2D_MIN_C)
     if geom[1] < 8 or geom[2] < 8:          # maps of fewer than 2 x 2 tiles: mostly padding (and nothing to gain)
         return False
     return min(C, N) >= lim and _pow2(C // 4) and _pow2(N // 4) and C <= 512 and N <= 512
