@@ -445,7 +445,21 @@ k_gather_gemm(const KArgs p_in) {
         }
     };
     const bool fulln = n0 + BN <= p.N;
-    if (p.residual) {
+    if (fulln && !p.bias && !p.scale && !p.shift && !p.residual && !p.stats && p.act == 0) {
+        // bare products (the 36 planes of a 2-D Winograd layer, the GEMM + col2im heads): one store per element
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rl = (wm * MI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const long long orow = rowout[rl];
+                if (orow < 0) continue;
+                float *op = p.out + orow * p.ldo + colb;
+#pragma unroll
+                for (int j = 0; j < NI; ++j) op[j * 32] = acc[i][j][r];
+            }
+        }
+    } else if (p.residual) {
         if (fulln) rows(std::true_type{}, std::true_type{});
         else rows(std::true_type{}, std::false_type{});
     } else {
