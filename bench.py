@@ -163,7 +163,7 @@ KERNELS = {
     'gemm': 'k_gather_gemm (fp32 MFMA implicit GEMM: every contraction that is not a "same" 3x3 convolution)',
     'wino': 'k_wino43 (Winograd F(4,3) on fp32 MFMA: the 3x3 / stride-1 convolutions and their data gradients)',
     'wgrad': 'k_gather_wgrad (fp32 MFMA weight gradient)',
-    'wino_wgrad': 'k_wino_wgrad (Winograd F(3,4) weight gradient of the 3x3 / stride-1 convolutions, fp32 MFMA)',
+    'wino_wgrad': 'k_wino_wgrad_rows (Winograd F(3,4) weight gradient of the 3x3 / stride-1 convolutions, fp32 MFMA)',
 }
 
 

@@ -10,7 +10,7 @@ FAMILIES = {
     'gemm': ['k_gather_gemm<1,', 'k_gather_gemm<2,', 'k_gather_gemm<3,', 'k_gather_gemm<0, 256', 'k_gather_gemm<0, 128, 64'],
     'wino': ['k_wino43<'],
     'wgrad': ['k_gather_wgrad<1,', 'k_gather_wgrad<2,', 'k_gather_wgrad<0, 64'],
-    'wino_wgrad': ['k_wino_wgrad('],
+    'wino_wgrad': ['k_wino_wgrad(', 'k_wino_wgrad_rows('],
     'wino2d_gemm': ['k_gather_gemm<0, 128, 128', 'k_gather_wgrad<0, 128'],
     'wino2d_transforms': ['k_w2_input', 'k_w2_output', 'k_w2_dy'],
     'bcl': ['k_lat_keys', 'k_lat_minmax', 'k_lat_scatter', 'k_lat_bucket', 'k_lat_rank', 'k_lat_number', 'k_lat_nbr', 'k_blur_dgrad_alias',
