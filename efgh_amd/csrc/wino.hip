@@ -223,27 +223,27 @@ __global__ void __launch_bounds__(256, 2) k_wino43(const WinoArgs p) {
     // per tile row: the pixel index, the row addresses and the count of valid pixels are formed once; a workgroup-uniform switch picks
     // the body with / without a residual operand (its four loads of a tile are issued together, ahead of the arithmetic)
     const float neg = p.act == 1 ? 0.f : (p.act == 2 ? p.slope : 1.f);      // act(v) = max(v, 0) + neg * min(v, 0)
-    auto rows = [&](auto res_c) {
-        constexpr bool RES = decltype(res_c)::value;
-#pragma unroll
+    auto rows = [&](auto res_c, auto full_c) {
+        constexpr bool RES = decltype(res_c)::value, FULL = decltype(full_c)::value;     // FULL: every tile of the workgroup exists
+#pragma unroll                                                                            // and has its four pixels
         for (int r = 0; r < 16; ++r) {
             const int rl = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
             const long long opix = tpix[rl];
-            const int cnt = tcnt[rl];
-            if (opix < 0) continue;
+            const int cnt = FULL ? 4 : tcnt[rl];
+            if (!FULL && opix < 0) continue;
             float *op = p.out + opix * p.ldo + col;
             float rv[4] = {0.f, 0.f, 0.f, 0.f};
             if (RES) {
                 const float *rp = p.residual + opix * p.ldr + col;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) if (i < cnt) rv[i] = rp[i * p.ldr];
+                for (int i = 0; i < 4; ++i) if (FULL || i < cnt) rv[i] = rp[i * p.ldr];
             }
             const float m0_ = acc[0][r], m1 = acc[1][r], m2 = acc[2][r], m3 = acc[3][r], m4 = acc[4][r], m5 = acc[5][r];
             const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
             const float yv[4] = {m0_ + s12 + s34, d12 + 2.f * d34, s12 + 4.f * s34, d12 + 8.f * d34 + m5};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                if (i >= cnt) continue;
+                if (!FULL && i >= cnt) continue;
                 float v = yv[i] + bi;
                 if (!bnm) { s1 += v; s2 += v * v; }
                 v = v * sc + sf;
@@ -259,8 +259,14 @@ __global__ void __launch_bounds__(256, 2) k_wino43(const WinoArgs p) {
             }
         }
     };
-    if (p.residual) rows(std::true_type{});
-    else rows(std::false_type{});
+    const bool full = m0 + TM <= p.Mt && (p.W & 3) == 0;
+    if (p.residual) {
+        if (full) rows(std::true_type{}, std::true_type{});
+        else rows(std::true_type{}, std::false_type{});
+    } else {
+        if (full) rows(std::false_type{}, std::true_type{});
+        else rows(std::false_type{}, std::false_type{});
+    }
     if (p.stats) {
         s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
         if (lh == 0) { ssum[wm * TN + coll] = s1; ssq[wm * TN + coll] = s2; }
