@@ -415,7 +415,7 @@ k_gather_gemm(const KArgs p_in) {
     const int colb = n0 + wn * NI * 32 + l31;
     const float neg = p.act == 1 ? 0.f : (p.act == 2 ? p.slope : 1.f);      // act(v) = max(v, 0) + neg * min(v, 0)
     // two workgroup-uniform switches pick one of four straight-line bodies: with / without a residual operand (its NI loads of a row
-    // are issued together, ahead of the arithmetic), and all columns of the tile inside N (no per-element predicate) or not
+    // are issued together, ahead of the arithmetic), and the whole tile inside M x N (no row mask, no per-element predicate) or not
     auto rows = [&](auto res_c, auto full_c) {
         constexpr bool RES = decltype(res_c)::value, FULL = decltype(full_c)::value;
 #pragma unroll
@@ -424,7 +424,7 @@ k_gather_gemm(const KArgs p_in) {
             for (int r = 0; r < 16; ++r) {
                 const int rl = (wm * MI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 const long long orow = rowout[rl];
-                if (orow < 0) continue;
+                if (!FULL && orow < 0) continue;
                 float *op = p.out + orow * p.ldo + colb;
                 float rv[NI];
                 if (RES) {
@@ -444,7 +444,7 @@ k_gather_gemm(const KArgs p_in) {
             }
         }
     };
-    const bool fulln = n0 + BN <= p.N;
+    const bool fulln = n0 + BN <= p.N && m0 + BM <= M;      // the whole tile exists: no row mask, no column predicate
     if (fulln && !p.bias && !p.scale && !p.shift && !p.residual && !p.stats && p.act == 0) {
         // bare products (the 36 planes of a 2-D Winograd layer, the GEMM + col2im heads): one store per element
 #pragma unroll
@@ -452,9 +452,7 @@ k_gather_gemm(const KArgs p_in) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rl = (wm * MI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const long long orow = rowout[rl];
-                if (orow < 0) continue;
-                float *op = p.out + orow * p.ldo + colb;
+                float *op = p.out + rowout[rl] * p.ldo + colb;
 #pragma unroll
                 for (int j = 0; j < NI; ++j) op[j * 32] = acc[i][j][r];
             }
