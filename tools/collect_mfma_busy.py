@@ -4,7 +4,7 @@ busy = SQ_VALU_MFMA_BUSY_CYCLES / (4 * SQ_BUSY_CU_CYCLES)   (four SIMDs per CU; 
 clock = SQ_BUSY_CU_CYCLES / 256 CUs / kernel time from the same trace."""
 import collections, csv, glob, json, sys
 
-FAMILIES = {'k_wino43': 'k_wino43<', 'k_wino_wgrad': 'k_wino_wgrad(', 'k_gather_gemm<1>': 'k_gather_gemm<1,',
+FAMILIES = {'k_wino43': 'k_wino43<', 'k_wino_wgrad_rows': 'k_wino_wgrad_rows(', 'k_gather_gemm<1>': 'k_gather_gemm<1,',
             'k_gather_gemm<0,128,128> (batched planes of F(4x4,3x3) + plain GEMMs)': 'k_gather_gemm<0, 128, 128',
             'k_gather_wgrad<0,128> (batched weight-gradient planes of F(4x4,3x3))': 'k_gather_wgrad<0, 128',
             'k_gather_wgrad<1>': 'k_gather_wgrad<1,'}
