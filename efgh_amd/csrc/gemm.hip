@@ -135,7 +135,7 @@ k_gather_gemm(const KArgs p_in) {
     if (m0 >= M) return;
 
     // ---- per-thread row state for the staging loads --------------------------------------
-    // mode 0: abase = row offset (floats) | mode 1: abase = centre pixel index, amask bit t = tap t in bounds
+    // mode 0: abase = row offset (floats) | mode 1: abase = centre pixel offset (floats), amask bit t = tap t in bounds
     // mode 2: abase = m*16 (neighbour-table row)
     const int arow = tid >> 3, kv = (tid & 7) * 4;
     long long abase[NA];
@@ -160,7 +160,7 @@ k_gather_gemm(const KArgs p_in) {
                 int j = (int)(m % p.Wv); long long r = m / p.Wv;
                 int i = (int)(r % p.Hv); long long b = r / p.Hv;
                 const int ih0 = i * p.sh, iw0 = j * p.sw;
-                abase[q] = (b * p.Hin + ih0) * p.Win + iw0;
+                abase[q] = ((b * p.Hin + ih0) * p.Win + iw0) * p.lda;
                 unsigned mk = 0;
                 for (int t = 0; t < p.T; ++t) {
                     int ih = ih0 + (int)((p.dhpack >> (4 * t)) & 15) - 8, iw = iw0 + (int)((p.dwpack >> (4 * t)) & 15) - 8;
@@ -199,11 +199,11 @@ k_gather_gemm(const KArgs p_in) {
         if (MODE == 1) {
             // branch-free: out-of-image taps read a valid dummy address (row 0) and are zeroed by select
             const int dh = (int)((p.dhpack >> (4 * (t & 15))) & 15) - 8, dw = (int)((p.dwpack >> (4 * (t & 15))) & 15) - 8;
-            const long long delta = (long long)dh * p.Win + dw;
-#pragma unroll
+            const long long dl = ((long long)dh * p.Win + dw) * p.lda + c;      // (abase already carries the factor lda: one product
+#pragma unroll                                                               //  per chunk instead of one per row)
             for (int q = 0; q < NA; ++q) {
                 const bool ok = kin && ((amask[q] >> t) & 1u);
-                const long long off = ok ? (abase[q] + delta) * p.lda + c : 0;
+                const long long off = ok ? abase[q] + dl : 0;
                 float4 v = *reinterpret_cast<const float4 *>(p.A + off);
                 ra[q] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
             }

@@ -76,15 +76,41 @@ k_gather_wgrad(const WArgs p0) {
     constexpr int GRS = 256 / (TN / 4);          // rows covered per G slot pass (8 or 16)
     const bool nin = (n0 + gc4) < p.N;
 
-    // incremental (b,i,j) of each staged row (mode 1)
-    int rj[4], ri[4]; long long rb[4];
+    // mode 1: every staged row carries its position (b, i, j) in the virtual output grid, the pointer to its gradient row and the
+    // pointer to the tap's input pixel.  A step advances all three by TM pixels of the same grid row - three adds; only when j runs
+    // past the row end (once per Wv / TM steps, all rows of a step within one or two steps of each other) are they re-derived with
+    // the 64-bit products that used to be paid per row and step (~90 multiply instructions per step next to 64 MFMAs)
+    struct RowIt { int j, i; long long b; const float *g, *a; bool rowok; };
+    auto point = [&](RowIt &it, int gcol) {                          // pointers and row validity from (b, i, j)
+        const long long orow = (it.b * p.Ho + (it.i * p.osh + p.oh0)) * p.Wo + (it.j * p.osw + p.ow0);
+        it.g = p.G + orow * p.ldg + gcol;
+        const int ih = it.i * p.sh + dh;
+        it.rowok = (unsigned)ih < (unsigned)p.Hin;
+        it.a = p.A + ((it.b * p.Hin + ih) * p.Win + (it.j * p.sw + dw)) * p.lda + c;
+    };
+    auto place = [&](RowIt &it, long long m, int gcol) {             // from the row number (start of the chunk)
+        it.j = (int)(m % p.Wv); const long long r = m / p.Wv;
+        it.i = (int)(r % p.Hv); it.b = r / p.Hv;
+        point(it, gcol);
+    };
+    const long long gstep = (long long)TM * p.osw * p.ldg, astep = (long long)TM * p.sw * p.lda;
+    const bool narrow = p.Wv < 4 * TM;           // grid rows of less than four steps wrap so often that the test is not worth it
+    auto advance = [&](RowIt &it, int gcol) {
+        it.j += TM; it.g += gstep; it.a += astep;
+        if (narrow || it.j >= p.Wv) {
+            while (it.j >= p.Wv) { it.j -= p.Wv; ++it.i; }
+            while (it.i >= p.Hv) { it.i -= p.Hv; ++it.b; }
+            point(it, gcol);
+        }
+    };
+    RowIt rit[4], git[NGQ];
+    if (MODE == 1) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        long long m = mbeg + r0 + 8 * q;
-        if (MODE == 1) {
-            rj[q] = (int)(m % p.Wv); long long r = m / p.Wv;
-            ri[q] = (int)(r % p.Hv); rb[q] = r / p.Hv;
-        } else { rj[q] = ri[q] = 0; rb[q] = 0; }
+        for (int q = 0; q < 4; ++q) place(rit[q], mbeg + r0 + 8 * q, n0 + c4);
+        if (TN != 128) {
+#pragma unroll
+            for (int q = 0; q < NGQ; ++q) place(git[q], mbeg + gr0 + GRS * q, n0 + gc4);
+        }
     }
     float4 rg[NGQ], ra[4];
     auto load_step = [&](long long ms) {
@@ -93,16 +119,9 @@ k_gather_wgrad(const WArgs p0) {
             for (int q = 0; q < NGQ; ++q) {
                 long long m = ms + gr0 + GRS * q;
                 float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (m < mend && nin) {
-                    long long orow = m;
-                    if (MODE == 1) {
-                        int j = (int)(m % p.Wv); long long r = m / p.Wv;
-                        int i = (int)(r % p.Hv); long long b = r / p.Hv;
-                        orow = (b * p.Ho + (i * p.osh + p.oh0)) * p.Wo + (j * p.osw + p.ow0);
-                    }
-                    g = *reinterpret_cast<const float4 *>(p.G + orow * p.ldg + n0 + gc4);
-                }
+                if (m < mend && nin) g = *reinterpret_cast<const float4 *>(MODE == 1 ? git[q].g : p.G + m * p.ldg + n0 + gc4);
                 rg[q] = g;
+                if (MODE == 1) advance(git[q], n0 + gc4);
             }
         }
 #pragma unroll
@@ -110,25 +129,21 @@ k_gather_wgrad(const WArgs p0) {
             long long m = ms + r0 + 8 * q;
             float4 g = make_float4(0.f, 0.f, 0.f, 0.f), a = g;
             if (m < mend) {
-                long long orow = m, arow = -1;
-                if (MODE == 0) arow = m;
-                else if (MODE == 2) { if (kin) arow = p.table[m * 16 + t]; }
-                else {
-                    orow = (rb[q] * p.Ho + (ri[q] * p.osh + p.oh0)) * p.Wo + (rj[q] * p.osw + p.ow0);
-                    int ih = ri[q] * p.sh + dh, iw = rj[q] * p.sw + dw;
-                    if ((unsigned)ih < (unsigned)p.Hin && (unsigned)iw < (unsigned)p.Win)
-                        arow = (rb[q] * p.Hin + ih) * p.Win + iw;
+                if (MODE == 1) {
+                    if (TN == 128 && nin) g = *reinterpret_cast<const float4 *>(rit[q].g);
+                    if (kin && rit[q].rowok && (unsigned)(rit[q].j * p.sw + dw) < (unsigned)p.Win)
+                        a = *reinterpret_cast<const float4 *>(rit[q].a);
+                } else {
+                    long long arow = -1;
+                    if (MODE == 0) arow = m;
+                    else if (kin) arow = p.table[m * 16 + t];
+                    if (TN == 128 && nin) g = *reinterpret_cast<const float4 *>(p.G + m * p.ldg + n0 + c4);
+                    if (kin && arow >= 0) a = *reinterpret_cast<const float4 *>(p.A + arow * p.lda + c);
                 }
-                if (TN == 128 && nin) g = *reinterpret_cast<const float4 *>(p.G + orow * p.ldg + n0 + c4);
-                if (kin && arow >= 0) a = *reinterpret_cast<const float4 *>(p.A + arow * p.lda + c);
             }
             if (TN == 128) rg[q] = g;
             ra[q] = a;
-            if (MODE == 1) {         // advance this row by TM for the next step
-                rj[q] += TM;
-                while (rj[q] >= p.Wv) { rj[q] -= p.Wv; ++ri[q]; }
-                while (ri[q] >= p.Hv) { ri[q] -= p.Hv; ++rb[q]; }
-            }
+            if (MODE == 1) advance(rit[q], n0 + c4);
         }
     };
 
