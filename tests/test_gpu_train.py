@@ -366,8 +366,9 @@ def test_training_step_is_not_torch_glue(manifest):
 
 def test_gradients_are_reproducible_run_to_run(manifest):
     """weight gradients add their row-chunk partials in a fixed order (no fp32 atomics in the contraction kernels, none at all in the
-    BCL): two backward passes from the same weights give bit-identical gradients - all 353 with EFGH_DETERMINISTIC, all but the
-    4-channel-input / 1-2-channel-head layers (their kernels still use atomics) by default"""
+    BCL): two backward passes from the same weights give bit-identical gradients - all 353 with EFGH_DETERMINISTIC; by default all
+    but two (F.conv_range and G.conv_d1: the (1,2)-kernel and the stride-2 4-channel input layers, whose weight-gradient kernels
+    still combine workgroup sums with atomics; tools/check_default_determinism.py lists them)"""
     from efgh_amd import ops
     from efgh_amd.losses import EFGHCriterion
     from efgh_amd.nets import EFGHBackbone
@@ -390,7 +391,7 @@ def test_gradients_are_reproducible_run_to_run(manifest):
         return {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
     old = ops.DETERMINISTIC
     try:
-        for flag, allowed in ((True, 0), (False, 8)):
+        for flag, allowed in ((True, 0), (False, 2)):
             ops.DETERMINISTIC = flag
             a, c = grads(), grads()
             differ = [n for n in a if not torch.equal(a[n], c[n])]
