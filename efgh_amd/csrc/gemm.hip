@@ -507,15 +507,31 @@ __global__ void k_pack_weight(const float *__restrict__ W, float *__restrict__ W
 // search over the prefix sums of the jobs' output sizes
 __global__ void __launch_bounds__(256) k_pack_weight_batched(const efgh_pack_job *__restrict__ jobs, const long long *__restrict__ prefix,
                                                              int njobs, long long total) {
+    __shared__ int job_s;
     for (long long i0 = (long long)blockIdx.x * 256; i0 < total; i0 += (long long)gridDim.x * 256) {
+        // one search per workgroup (the job of its first element); only the few workgroups that straddle a job boundary let their
+        // later threads step forward from there
+        if (threadIdx.x == 0) {
+            int lo = 0, hi = njobs - 1;                  // largest j with prefix[j] <= i0
+            while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (prefix[mid] <= i0) lo = mid; else hi = mid - 1; }
+            job_s = lo;
+        }
+        __syncthreads();
+        int jb = job_s;
+        __syncthreads();
         const long long i = i0 + threadIdx.x;
         if (i >= total) continue;
-        int lo = 0, hi = njobs - 1;                      // largest j with prefix[j] <= i
-        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (prefix[mid] <= i) lo = mid; else hi = mid - 1; }
-        const efgh_pack_job &j = jobs[lo];
-        const long long e = i - prefix[lo];
-        const int c = (int)(e % j.Cp); const long long r = e / j.Cp;
-        const int t = (int)(r % j.T); const int n = (int)(r / j.T);
+        while (jb + 1 < njobs && prefix[jb + 1] <= i) ++jb;
+        const efgh_pack_job &j = jobs[jb];
+        const long long e = i - prefix[jb];
+        int n, t, c;
+        if (e < 0x7fffffffLL) {                          // (every layout of this network: 32-bit divisions)
+            const unsigned eu = (unsigned)e, r = eu / (unsigned)j.Cp;
+            c = (int)(eu - r * (unsigned)j.Cp); n = (int)(r / (unsigned)j.T); t = (int)(r - (unsigned)n * (unsigned)j.T);
+        } else {
+            c = (int)(e % j.Cp); const long long r = e / j.Cp;
+            t = (int)(r % j.T); n = (int)(r / j.T);
+        }
         j.Wp[e] = (n < j.N && c < j.C) ? j.W[n * j.sn + c * j.sc + j.taps[t] * j.st] : 0.f;
     }
 }
