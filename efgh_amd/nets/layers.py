@@ -412,7 +412,10 @@ def _heads_modules(ctx, seq_d, seq_m):
         ps += [b.weight, b.bias, b.running_mean, b.running_var]
     vers = ops._ver(*ps) + tuple(b.num_batches_tracked._version for b in (seq_d[1], seq_m[1], seq_d[4], seq_m[4])
                                   if b.num_batches_tracked is not None)
-    return ops._cached(seq_d, ('heads', id(seq_m)), vers, make)
+    ent = ops._cached(seq_d, ('heads',), vers, lambda: (seq_m, make()))      # (cached on the depth stack; the partner is part of the entry)
+    if ent[0] is not seq_m:
+        return make()
+    return ent[1]
 
 
 def run_convt_heads(ctx, seq_d, seq_m, x):
