@@ -384,7 +384,10 @@ def convt_heads_fusable(seq_d, seq_m):
                 and cv_d.kernel_size == cv_m.kernel_size == (3, 3) and cv_d.stride == cv_m.stride == (1, 1)
                 and cv_d.padding == cv_m.padding == (1, 1) and cv_d.in_channels == cv_d.out_channels == ct_d.out_channels
                 and cv_m.in_channels == cv_m.out_channels == ct_m.out_channels
-                and isinstance(seq_d[1], nn.BatchNorm2d) and isinstance(seq_m[4], nn.BatchNorm2d))
+                and all(isinstance(b, nn.BatchNorm2d) and b.affine and b.track_running_stats
+                        for b in (seq_d[1], seq_m[1], seq_d[4], seq_m[4]))
+                and seq_d[1].eps == seq_m[1].eps and seq_d[1].momentum == seq_m[1].momentum
+                and seq_d[4].eps == seq_m[4].eps and seq_d[4].momentum == seq_m[4].momentum)
     except (IndexError, TypeError):
         return False
 
