@@ -36,6 +36,7 @@ def _mk_bn(c):
     (1, 1, 3, 1, 1, (10, 12), False), (512, 512, 1, 1, 0, (4, 6), False),
     (64, 192, 3, 1, 1, (5, 13), False), (256, 64, 3, 1, 1, (3, 3), True), (128, 64, 3, 1, 1, (33, 70), False),
     (64, 64, 3, 1, 1, (70, 150), False), (64, 128, 3, 1, 1, (9, 200), True),     # several strips / row chunks / n-blocks of k_wino_wgrad_rows
+    (64, 128, 3, 2, 1, (20, 300), False), (64, 64, 1, 2, 0, (11, 520), False),   # k_gather_wgrad mode 1 on wide grids: incremental row pointers with wraps
 ])
 @pytest.mark.parametrize('train', [True, False])
 def test_conv_bn_act_backward(cin, cout, k, s, p, hw, res, train):
