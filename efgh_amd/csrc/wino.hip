@@ -575,16 +575,29 @@ __global__ void __launch_bounds__(64 * WR_WAVES, 1) k_wino_wgrad_rows(const Wino
         __syncthreads();
         s0 = s0 == 2 ? 0 : s0 + 1;
     }
-    // D[row = n][col = c]: lanes run along c (contiguous in S)
+    // A3^T is applied HERE, per unit (it commutes with the sum over units): three kw planes per unit instead of six alpha planes -
+    // half the bytes the fold has to read.  D[row = n][col = c]: lanes run along c (contiguous in S)
     const long long K3 = 3LL * p.C;
+    float *sb = p.S + (((long long)unit * 3) * p.N + n0 + wn * 32) * K3 + kg * p.C + c0 + wc * 32 + l31;
+    const long long plane = (long long)p.N * K3;
 #pragma unroll
-    for (int a = 0; a < 6; ++a) {
-        float *sa = p.S + (((long long)unit * 6 + a) * p.N + n0 + wn * 32) * K3 + kg * p.C + c0 + wc * 32 + l31;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int nl = (r & 3) + 8 * (r >> 2) + 4 * lh;
-            sa[nl * K3] = acc[a][r];
-        }
+    for (int r = 0; r < 16; ++r) {
+        const int nl = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const float s0 = acc[0][r], s1 = acc[1][r], s2 = acc[2][r], s3 = acc[3][r], s4 = acc[4][r], s5 = acc[5][r];
+        sb[nl * K3] = s0 + s1 + s2 + s3 + s4;
+        sb[plane + nl * K3] = (s1 - s2) + 2.f * (s3 - s4);
+        sb[2 * plane + nl * K3] = (s1 + s2) + 4.f * (s3 + s4) + s5;
+    }
+}
+
+// the folded kw planes [3][N][3C] -> packed [N][9][C]
+__global__ void k_wino_wgrad_finish3(const float *__restrict__ S, float *__restrict__ dWp, int N, int C) {
+    const long long K3 = 3LL * C, total = (long long)N * K3;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int kc = (int)(i % K3); const long long n = i / K3;
+        const int kh = kc / C, c = kc - kh * C;
+        float *o = dWp + (n * 9 + kh * 3) * C + c;
+        o[0] = S[i]; o[C] = S[total + i]; o[2 * (long long)C] = S[2 * total + i];
     }
 }
 
@@ -698,8 +711,8 @@ static long long wino_wgrad_row_units(const efgh_gemm_desc *d, int *strips_out, 
 /* floats of scratch `S` efgh_wino_wgrad needs: one [6][N][3C] partial per tile range */
 extern "C" int64_t efgh_wino_wgrad_workspace(const efgh_gemm_desc *d) {
     if (!supported(d) || d->C % 64 != 0 || d->B <= 0) return 0;
-    const long long zs = wino_wgrad_rows_enabled() ? wino_wgrad_row_units(d, nullptr, nullptr, nullptr) : wino_wgrad_ranges(d, nullptr);
-    return zs * 6 * (int64_t)d->N * 3 * d->C;
+    if (wino_wgrad_rows_enabled()) return wino_wgrad_row_units(d, nullptr, nullptr, nullptr) * 3 * (int64_t)d->N * 3 * d->C;
+    return wino_wgrad_ranges(d, nullptr) * 6 * (int64_t)d->N * 3 * d->C;
 }
 
 extern "C" int efgh_wino_wgrad(const efgh_gemm_desc *d, const float *G, int64_t ldg, float *S, float *dWp,
@@ -730,10 +743,12 @@ extern "C" int efgh_wino_wgrad(const efgh_gemm_desc *d, const float *G, int64_t 
         k_wino_wgrad<<<(unsigned)(zs * kt * nt), 256, 0, st>>>(a);
     }
     EFGH_CHECK_LAUNCH();
-    if (zs > 1) efgh_launch_fold_splits(S, (int)zs, 6LL * d->N * 3 * d->C, S, st);      // into the first partial, fixed order
+    const bool rows = wino_wgrad_rows_enabled();
+    if (zs > 1) efgh_launch_fold_splits(S, (int)zs, (rows ? 3LL : 6LL) * d->N * 3 * d->C, S, st);      // into the first partial, fixed order
     const long long total = (long long)d->N * 3 * d->C;
     long long g = (total + 255) / 256;
-    k_wino_wgrad_finish<<<(int)(g > 4096 ? 4096 : g), 256, 0, st>>>(S, 1, dWp, d->N, d->C);
+    if (rows) k_wino_wgrad_finish3<<<(int)(g > 4096 ? 4096 : g), 256, 0, st>>>(S, dWp, d->N, d->C);
+    else k_wino_wgrad_finish<<<(int)(g > 4096 ? 4096 : g), 256, 0, st>>>(S, 1, dWp, d->N, d->C);
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
 }
