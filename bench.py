@@ -38,6 +38,10 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-forward-section', action='store_true')
     ap.add_argument('--small', action='store_true', help='debug: 128x256 / 2048 points')
+    ap.add_argument('--rotate-inputs', type=int, default=4,
+                    help='cycle this many resident batches of DIFFERENT synthetic frame-pairs through the steps (1 = the same batch '
+                         'every step): every sweep has its own lattice sizes, so the speculative sizing of the pyramid (previous '
+                         'sizes + 25 %%) and its fallback are part of what is timed, as in a real training loop (iterater.py:26-43)')
     return ap.parse_args()
 
 
@@ -111,14 +115,39 @@ def dump_shapes(prof, path):
             fh.write('%s | %d %.2f %.1f\n' % (' '.join(map(str, key)), n, ms, f / (ms * 1e-3) / 1e12 if ms > 0 else 0))
 
 
-def committed_traffic(family, workload='train'):
+def committed_traffic(family, workload='train', launches_per_step=None, kernel=None):
     """HBM-side bytes per launch of one kernel family (`bcl`: per step) from the committed rocprofv3 PMC passes (FETCH_SIZE doubled
     as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE; tools/collect_traffic.py), collected offline on the same bench
-    command, see profiles/README.md.  PMC collection cannot run inside the timed region."""
+    command, see profiles/README.md.  PMC collection cannot run inside the timed region, so the figure is only as good as the
+    committed file is current: the file's sha256 goes into the line (`traffic_source`), and when the number of launches per step
+    the file was folded from differs from what THIS run launched the figure is withheld (None) and the mismatch reported - a
+    traffic number of another kernel mix must not look measured.  -> (bytes | None, error | None)"""
     try:
-        d = json.load(open(os.path.join(ROOT, 'profiles', TRAFFIC_FILE[workload])))['per_launch']
-        return d[family]['traffic_bytes']
-    except Exception:
+        raw = open(os.path.join(ROOT, 'profiles', TRAFFIC_FILE[workload]), 'rb').read()
+        doc = json.loads(raw)
+        ent = doc['per_launch'][family]
+    except Exception as e:          # noqa: BLE001
+        return None, 'no committed PMC fold for this family (%s)' % type(e).__name__
+    census = doc.get('bench_launches_per_step')          # bench.py's own launch census of the PMC run (tools/collect_traffic.py)
+    if census is None:
+        return ent['traffic_bytes'], 'unchecked: the committed fold carries no launch census'
+    if launches_per_step is not None:
+        theirs = [v[1] for v in census.values() if kernel and v[0] == kernel[:24]]
+        if not theirs or abs(theirs[0] - launches_per_step) > 1e-6:
+            msg = ('STALE: profiles/%s was folded from a run with %s launches per step of this family, this run made %s - re-run '
+                   'tools/collect_round_evidence.sh' % (TRAFFIC_FILE[workload], theirs[0] if theirs else 'no', launches_per_step))
+            sys.stderr.write('bench.py: traffic[%s] withheld: %s\n' % (family, msg))
+            return None, msg
+    return ent['traffic_bytes'], None
+
+
+def traffic_source(workload):
+    import hashlib
+    try:
+        raw = open(os.path.join(ROOT, 'profiles', TRAFFIC_FILE[workload]), 'rb').read()
+        return {'file': 'profiles/' + TRAFFIC_FILE[workload], 'sha256_16': hashlib.sha256(raw).hexdigest()[:16],
+                'steps_in_trace': json.loads(raw).get('steps_in_trace')}
+    except Exception:               # noqa: BLE001
         return None
 
 
@@ -179,7 +208,9 @@ def rooflines(prof, steps, workload='train'):
             continue
         if lst:
             r = gemm_roofline(lst, steps, KERNELS[name])
-            r['traffic'] = committed_traffic(name, workload)
+            r['traffic'], err = committed_traffic(name, workload, r['launches_per_step'], r['kernel'])
+            if err:
+                r['traffic_error'] = err
             r['algorithmic_tflops'] = r['achieved']
             if name in ('wino', 'wino_wgrad'):
                 r['achieved'] = r['achieved'] / 2
@@ -203,15 +234,21 @@ def rooflines(prof, steps, workload='train'):
                                'neighbours, vertex lists) and splat gather'
                                + (' + splat adjoint' if any(k.endswith('bwd') for k in parts) else ''),
                                'achieved': ach, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': ach / PEAK_HBM_GBS,
-                               'traffic': committed_traffic('bcl', workload),
+                               'traffic': None,
                                'traffic_unit': 'HBM-side bytes per STEP, all lattice.hip + bcl.hip launches (profiles/r03_hbm_traffic_*.json)',
                                'launches_per_step': len(bcl) / max(1, steps), 'kernel_ms_per_step': ms / max(1, steps),
                                'algorithmic_mb_per_step': by / max(1, steps) / 1e6,
                                'parts': {k: {'ms_per_step': v[0] / max(1, steps), 'algorithmic_mb_per_step': v[1] / max(1, steps) / 1e6,
                                              'gbs': (v[1] / (v[0] * 1e-3) / 1e9 if v[0] > 0 else 0.0)} for k, v in parts.items()}}
+    if bcl:
+        rb = out['roofline_bcl']
+        rb['traffic'], err = committed_traffic('bcl', workload, rb['launches_per_step'], rb['kernel'])
+        if err:
+            rb['traffic_error'] = err
     for k, v in rl.items():
         if k != top:
             out['roofline_' + k] = v
+    out['traffic_source'] = traffic_source(workload)
     if w2:      # whole F(4x4,3x3) layers (input transform + batched GEMM + output transform), direct-form FLOPs
         ms = sum(p[0].elapsed_time(p[1]) for p in w2)
         fl = sum(p[2] for p in w2)
@@ -288,11 +325,17 @@ def main():
             return float(t.item())
         return dt
 
+    nrot = max(1, a.rotate_inputs)
+
     def load(B):
-        batch = syn.make_batch(raw, npts, B, first_seed=rank * B)       # seed = global sample index
-        inp = [torch.from_numpy(batch[k]).to(dev) for k in ('pc', 'img', 'calib', 'A')]
-        gt = {k: torch.from_numpy(v).to(dev) for k, v in batch['gt'].items()}
-        return inp, gt
+        """`nrot` resident batches of different frame-pairs (seed = global sample index, disjoint over ranks and rotations)"""
+        sets = []
+        for r in range(nrot):
+            batch = syn.make_batch(raw, npts, B, first_seed=(r * world + rank) * B)
+            inp = [torch.from_numpy(batch[k]).to(dev) for k in ('pc', 'img', 'calib', 'A')]
+            gt = {k: torch.from_numpy(v).to(dev) for k, v in batch['gt'].items()}
+            sets.append((inp, gt))
+        return sets
 
     torch.manual_seed(0)                                  # identical weights on every rank
     model = EFGHBackbone(args).to(dev)
@@ -356,10 +399,12 @@ def main():
     fwd = None
     if a.mode == 'fwd' or not a.no_forward_section:
         Bf = a.batch if (a.mode == 'fwd' and a.batch) else 4
-        inp, _ = load(Bf)
+        fsets, fcount = load(Bf), [0]
         model.eval()
 
         def fstep():
+            inp = fsets[fcount[0] % nrot][0]
+            fcount[0] += 1
             with torch.no_grad():
                 return model(*inp)
         dt, prof = timed(fstep, a.steps, a.warmup)
@@ -383,15 +428,19 @@ def main():
                 'value': world * Bf * a.steps / dt3, 'unit': 'frame-pairs/s', 'ms_per_step': dt3 / a.steps * 1e3,
                 'algorithmic_fp32_tflops': gemm_roofline(prof3['gemm'] + prof3['wino'], a.steps, 'k_gather_gemm<MATH>')['achieved'],
                 'note': 'EFGH_MATH=%s' % mode}
-        del inp
+        del fsets
     if a.mode == 'train':
         Bt = a.batch or 8
-        inp, gt = load(Bt)
+        tsets, tcount = load(Bt), [0]
         trainer = Trainer(model, EFGHCriterion(args), lr=1e-4)
 
         def tstep():
+            inp, gt = tsets[tcount[0] % nrot]
+            tcount[0] += 1
             return trainer.step(*inp, gt)
+        lat0 = dict(lattice.STATS)
         dt, prof = timed(tstep, a.steps, a.warmup)
+        lat1 = dict(lattice.STATS)
         if rank == 0:
             out = {
                 'metric': 'frame-pairs/sec EFGHNet fwd+bwd (384x1280 RGB + 64x2048 range), whole job',
@@ -405,6 +454,10 @@ def main():
                            'global_batch': world * Bt, 'points': npts, 'parallelism': 'dp%d' % world},
                 'rccl_ranks': rccl_ranks, 'dist_backend': backend, 'visible_gpus': ndev,
                 'forward_only': fwd,
+                'inputs': {'rotating_batches': nrot,
+                           'lattice_pyramids': {k: lat1[k] - lat0[k] for k in lat1},
+                           'note': 'warm-up + timed steps; speculative = all five levels enqueued from the previous sizes with ONE '
+                                   'read-back, level_by_level = the five-sync fallback, reenqueued = escalated rebuilds'},
             }
             out.update(rooflines(prof, a.steps))
             out['mfma_step_utilisation'] = mfma_step_utilisation(prof, a.steps, out['ms_per_step'])
@@ -434,6 +487,13 @@ def main():
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(raw, npts, a.mode)
+        if fwd is not None and a.mode == 'train':
+            # small copies at the END of the line (a log tail keeps them): the forward-only workload, BASELINE configs[1]
+            out['forward_value'] = fwd['value']
+            out['forward_ms_per_step'] = fwd['ms_per_step']
+            out['forward_mfma_frac'] = fwd['mfma_step_utilisation']['frac']
+            out['forward_roofline_frac'] = fwd.get('roofline', {}).get('frac')
+            out['forward_roofline_bcl_frac'] = fwd.get('roofline_bcl', {}).get('frac')
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

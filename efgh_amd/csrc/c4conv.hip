@@ -173,7 +173,7 @@ __global__ void __launch_bounds__(64 * WAVES, 2) k_c4_conv(const C4Args p) {
                 float v = acc[j][q] + bi[j];
                 if (ok) { s1[j] += v; s2[j] = fmaf(v, v, s2[j]); }
                 v = fmaf(v, sc[j], sf[j]);
-                T[pl * TPITCH + r] = RES ? v : fmaxf(v, 0.f) + neg * fminf(v, 0.f);
+                T[pl * TPITCH + r] = RES ? v : act_neg(v, neg);
             }
             wave_lds_sync();
 #pragma unroll
@@ -182,8 +182,8 @@ __global__ void __launch_bounds__(64 * WAVES, 2) k_c4_conv(const C4Args p) {
                 float4 v = *reinterpret_cast<const float4 *>(&T[pl * TPITCH + c4]);
                 if (RES) {
                     v.x += rr[pass].x; v.y += rr[pass].y; v.z += rr[pass].z; v.w += rr[pass].w;
-                    v.x = fmaxf(v.x, 0.f) + neg * fminf(v.x, 0.f); v.y = fmaxf(v.y, 0.f) + neg * fminf(v.y, 0.f);
-                    v.z = fmaxf(v.z, 0.f) + neg * fminf(v.z, 0.f); v.w = fmaxf(v.w, 0.f) + neg * fminf(v.w, 0.f);
+                    v.x = act_neg(v.x, neg); v.y = act_neg(v.y, neg);
+                    v.z = act_neg(v.z, neg); v.w = act_neg(v.w, neg);
                 }
                 if (full || oj0 + pl < p.Wo)
                     *reinterpret_cast<float4 *>(p.out + (orow0 * p.Wo + oj0 + pl) * p.ldo + 32 * j + c4) = v;

@@ -438,7 +438,7 @@ k_gather_gemm(const KArgs p_in) {
                     if (FULL || cok[j]) { s1[j] += v; s2[j] += v * v; }
                     v = v * sc[j] + sf[j];
                     if (RES) v += rv[j];
-                    v = fmaxf(v, 0.f) + neg * fminf(v, 0.f);
+                    v = act_neg(v, neg);
                     if (FULL || cok[j]) op[j * 32] = v;
                 }
             }

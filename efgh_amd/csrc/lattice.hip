@@ -863,7 +863,7 @@ k_lat_scatter(const float *__restrict__ pts, int64_t cstride, const int *__restr
             }
         }
     }
-    if (wide) atomicOr(&info[EFGH_LATTICE_INFO_ERR], 4);        // key range x positions do not fit 64 bits: the hash build serves the level
+    if (wide) atomicOr(&info[EFGH_LATTICE_INFO_ERR], 4 | 8);    // key range x positions do not fit 64 bits: only the hash build serves the level (bit 3)
     __syncthreads();
     // exclusive prefix of the bucket counts: the tile's row of offsets, and the start of every run inside the tile's window
     {
@@ -1622,9 +1622,19 @@ extern "C" int efgh_lattice_part_build(const float *pts, int64_t pts_cstride, co
         k_lat_scatter<8><<<w.ntiles, STP, 0, st>>>(pts, pts_cstride, n_dev, n_cap, scale32, std32, mm, sid, pps, nsamples, P, info);
     else
         k_lat_scatter<2><<<w.ntiles, STP, 0, st>>>(pts, pts_cstride, n_dev, n_cap, scale32, std32, mm, sid, pps, nsamples, P, info);
-    if (P.maxe == 2048)             // (512 threads per bucket measured the same as 256: 259 vs 261 us at level 0)
-        k_lat_bucket<2048, 256><<<nbuckets, 256, (size_t)slots * 20 + (size_t)2048 * 14, st>>>(P, n_dev, n_cap, list, info);
-    else {
+    if (P.maxe == 2048) {           // (512 threads per bucket measured the same as 256: 259 vs 261 us at level 0)
+        const size_t lds = (size_t)slots * 20 + (size_t)2048 * 14;          // 68 KB with slots = 2048: above the 64 KB a launch gets by default
+        static bool raised_small = false;
+        if (!raised_small && lds > 64 * 1024) {
+            if (hipFuncSetAttribute((const void *)k_lat_bucket<2048, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 20 * SMAX + 14 * 2048)
+                != hipSuccess) {
+                efgh_set_error("%s:%d: cannot raise the dynamic LDS limit of k_lat_bucket", __FILE__, __LINE__);
+                return EFGH_E_LAUNCH;
+            }
+            raised_small = true;
+        }
+        k_lat_bucket<2048, 256><<<nbuckets, 256, lds, st>>>(P, n_dev, n_cap, list, info);
+    } else {
         const size_t lds = (size_t)slots * 20 + (size_t)4096 * 14;          // up to 98 KB: above the 64 KB a launch gets by default
         static bool raised = false;
         if (!raised) {

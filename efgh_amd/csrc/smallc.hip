@@ -200,7 +200,7 @@ __global__ void __launch_bounds__(64 * WAVES, 2) k_sc_conv(const SCArgs p) {
                     float v = acc[pt][nt][e] + bi[nt];
                     if (full || oj0 + pl < p.W) { s1[nt] += v; s2[nt] = fmaf(v, v, s2[nt]); }
                     v = fmaf(v, sc[nt], sf[nt]);
-                    T[pl * TPITCH + 16 * nt + q16] = RES ? v : fmaxf(v, 0.f) + neg * fminf(v, 0.f);
+                    T[pl * TPITCH + 16 * nt + q16] = RES ? v : act_neg(v, neg);
                 }
         wave_lds_sync();
         constexpr int F4 = N / 4;                               // float4s per pixel row
@@ -212,8 +212,8 @@ __global__ void __launch_bounds__(64 * WAVES, 2) k_sc_conv(const SCArgs p) {
             if (RES) {
                 const float4 rr = *reinterpret_cast<const float4 *>(p.residual + (orow0 * p.W + oj0 + pl) * p.ldr + c4);
                 v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
-                v.x = fmaxf(v.x, 0.f) + neg * fminf(v.x, 0.f); v.y = fmaxf(v.y, 0.f) + neg * fminf(v.y, 0.f);
-                v.z = fmaxf(v.z, 0.f) + neg * fminf(v.z, 0.f); v.w = fmaxf(v.w, 0.f) + neg * fminf(v.w, 0.f);
+                v.x = act_neg(v.x, neg); v.y = act_neg(v.y, neg);
+                v.z = act_neg(v.z, neg); v.w = act_neg(v.w, neg);
             }
             *reinterpret_cast<float4 *>(p.out + (orow0 * p.W + oj0 + pl) * p.ldo + c4) = v;
         }

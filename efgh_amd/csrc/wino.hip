@@ -248,7 +248,7 @@ __global__ void __launch_bounds__(256, 2) k_wino43(const WinoArgs p) {
                 if (!bnm) { s1 += v; s2 += v * v; }
                 v = v * sc + sf;
                 if (RES) v += rv[i];
-                v = fmaxf(v, 0.f) + neg * fminf(v, 0.f);
+                v = act_neg(v, neg);
                 op[i * p.ldo] = v;
                 if (bnm) {
                     const float rw = p.bn_raw[(opix + i) * p.bn_ldraw + col];

@@ -7,6 +7,7 @@ the next one - lives in device memory, so when the sizes of a previous call with
 are known the whole pyramid is enqueued without a host read-back between levels (capacities = previous sizes + 25 %) and
 the five counts come back in ONE read; a count that does not fit its capacity (flagged by the device) falls back to the
 level-by-level path, which reads each count before sizing the next level."""
+import logging
 import math
 
 import os
@@ -24,6 +25,13 @@ PROFILE = None          # bench.py: list of (start_event, end_event, algorithmic
 _SIZES = {}             # (device, B, N, scales) -> vertex counts of the last build with that signature
 _BIG_LEVELS = {}        # the same key -> levels where a bucket of the partitioned build overflowed: built with the big-bucket kernel from then on
 _HASH_LEVELS = {}       # the same key -> levels where that overflowed as well: they take the hash build
+_CLEAN = {}             # the same key -> consecutive clean speculative builds since the last change of the escalation sets
+# An outlier frame must not pin a signature to the slow plans for the rest of the process: after this many clean builds in a row
+# the most expensive escalation of the signature is taken back one step (hash -> big buckets -> regular) and the cheaper plan gets
+# another try (a renewed overflow costs one re-enqueue of the pyramid and resets the count)
+ESCALATION_DECAY = int(os.environ.get('EFGH_LATTICE_ESCALATION_DECAY', '64'))
+STATS = {'speculative': 0, 'level_by_level': 0, 'reenqueued': 0}      # pyramids by path (tests, bench --rotate-inputs)
+_log = logging.getLogger('efgh_amd.lattice')
 
 
 class LatticeLevel:
@@ -232,23 +240,57 @@ def build_pyramid_batched(pc, scales, need_off=True):
                 _finish(lv, h, n_in, seg_in, B)
                 n_in, seg_in = lv.H, lv.seg
             out = lvs
+            STATS['speculative'] += 1
+            _CLEAN[key] = _CLEAN.get(key, 0) + 1
+            if (forced or bigl) and ESCALATION_DECAY > 0 and _CLEAN[key] >= ESCALATION_DECAY:
+                _CLEAN[key] = 0
+                if forced:
+                    l = max(forced)
+                    forced.discard(l)
+                    bigl.add(l)
+                    _log.info('lattice %s: level %d back from the hash build to the big-bucket build after %d clean builds', key, l, ESCALATION_DECAY)
+                else:
+                    l = max(bigl)
+                    bigl.discard(l)
+                    _log.info('lattice %s: level %d back to the regular partitioned build after %d clean builds', key, l, ESCALATION_DECAY)
             break
         over = [l for l, (h, lv) in enumerate(zip(host, lvs)) if h[INFO_ERR] & 4 and lv._mode[0] == 'part']
         if not over or any(h[INFO_ERR] & 1 for h in host):
             break
-        (forced if over[0] in bigl else bigl).add(over[0])      # (levels behind the first overflow were built on its garbage)
+        # (levels behind the first overflow were built on its garbage.)  A key range too wide for the partitioned build's entry
+        # word (bit 3) is not a bucket problem: the big-bucket kernel cannot fix it, the level goes straight to the hash build
+        wide = bool(host[over[0]][INFO_ERR] & 8)
+        (forced if (wide or over[0] in bigl) else bigl).add(over[0])
+        _CLEAN[key] = 0
+        STATS['reenqueued'] += 1
+        _log.warning('lattice %s: level %d %s; escalated to the %s build, pyramid re-enqueued', key, over[0],
+                     'has a key range too wide for the partitioned build' if wide else 'overflowed a bucket',
+                     'hash' if over[0] in forced else 'big-bucket')
     if out is None:
         # level-by-level path: each level's count is read before the next level is sized (exact capacities)
+        STATS['level_by_level'] += 1
         out, pts, cstride, sid, n = [], pts0, B * N, None, B * N
         seg_in = [b * N for b in range(B + 1)]
         for l, s in enumerate(scales):
-            for mode in ((('hash', 0),) if l in forced else (_plan(L, n, None) + (l in bigl,), _plan(L, n, None) + (True,), ('hash', 0))):
+            plan = _plan(L, n, None)
+            modes = [('hash', 0)] if (l in forced or plan[0] != 'part') else [plan + (l in bigl,), plan + (True,), ('hash', 0)]
+            i = 0
+            while True:
+                mode = modes[i]
                 lv = _level_arrays(L, dev, n, 4 * n, B, mode, None, need_off)
                 _launch_build(L, lv, pts, cstride, None, sid, N, B, s, st)
                 head = lv.info[:2].tolist()           # host sync (sizes the next level)
                 if not head[INFO_ERR] & 4 or mode == ('hash', 0):
-                    break                             # (else: a bucket of the partitioned build overflowed - escalate)
-                (forced if (l in bigl or mode[-1] is True) else bigl).add(l)
+                    break
+                # a bucket of the partitioned build overflowed - escalate; a key range too wide for its entry word (bit 3) goes
+                # straight to the hash build
+                _CLEAN[key] = 0
+                if head[INFO_ERR] & 8:
+                    forced.add(l)
+                    i = len(modes) - 1
+                else:
+                    (forced if (l in bigl or mode[-1] is True) else bigl).add(l)
+                    i += 1
             H = head[INFO_H]
             _launch_neighbors(L, lv, B, H, st)
             host = lv.info.cpu().tolist()

@@ -28,8 +28,11 @@ _SIDE_PRIO = [int(v) for v in os.environ.get('EFGH_SIDE_PRIO', '0,0,0').split(',
 def _side_stream(device, i=0):
     s = _SIDE.get((device.index, i))
     if s is None:
-        pr = _SIDE_PRIO[i] if i < len(_SIDE_PRIO) else 0
-        s = _SIDE[(device.index, i)] = torch.cuda.Stream(device=device, priority=pr) if pr else torch.cuda.Stream(device=device)
+        with ops._LOCK:                      # (two threads may ask for the same stream first at the same time)
+            s = _SIDE.get((device.index, i))
+            if s is None:
+                pr = _SIDE_PRIO[i] if i < len(_SIDE_PRIO) else 0
+                s = _SIDE[(device.index, i)] = torch.cuda.Stream(device=device, priority=pr) if pr else torch.cuda.Stream(device=device)
     return s
 
 
@@ -52,12 +55,23 @@ class EFGHBackbone(nn.Module):
         self.device = args['DEVICE']
 
     def forward(self, pc, img, calib, A, check=False, keep=None):
+        if getattr(self, '_is_replica', False):
+            # torch.nn.DataParallel over more than one device (main.py:127 with several GPUs visible): its replicas are shallow
+            # per-forward copies whose parameters are broadcast outputs, driven by one Python thread per device.  This path is
+            # one process per GPU: refuse loudly instead of running a slow, half-supported schedule silently
+            raise ops._C.EfghError(
+                'EFGHBackbone was entered from a torch.nn.DataParallel replica (more than one device in device_ids).  This '
+                'framework runs ONE PROCESS PER GPU: start the unchanged entry script with `python -m efgh_amd.run main.py '
+                '<config.yaml>` (pins the process to one device), or '
+                'restrict the process to one device (HIP_VISIBLE_DEVICES=0 / DataParallel(model, device_ids=[0])).  '
+                'See INTEGRATION.md section 4.')
         ops._C.require_cuda(pc, img, calib, A)
         ops._C.require_f32(pc, img, calib, A)
         # packed weights that went stale with the last optimizer step are rewritten in place by ONE launch; every branch below
         # reads them, so that launch goes out here, on the current stream, before the streams fork
-        ops.repack_stale(pc.device)
-        ops.TRAIN_STEP = bool(self.training and torch.is_grad_enabled())      # (stays set for the backward pass of this step)
+        holder = ops.epoch_of(next(self.parameters()))
+        ops.repack_stale(pc.device, holder)
+        ops.TLS.train_step = bool(self.training and torch.is_grad_enabled())   # (GemmLayerFn carries it over to its backward)
         if self.training:
             ops.w2v_clear()
         shared_img = ops.nchw_to_nhwc(img, 4)                # channels-last copy used by both H and G

@@ -141,7 +141,7 @@ class GemmLayerFn(torch.autograd.Function):
         if spec.custom_forward is not None:
             assert bn is not None and bias is None
             spec.custom_forward(x, weight, out)
-        ops.W2V_WANTED = bool(ctx.needs_input_grad[1])
+        ops.TLS.w2v_wanted = bool(ctx.needs_input_grad[1])
         for li, (geom, m) in enumerate(spec.launches if spec.custom_forward is None else []):
             wp = spec.pack_fwd(weight, li)
             T = spec.T if geom is None else len(geom[7])
@@ -157,7 +157,7 @@ class GemmLayerFn(torch.autograd.Function):
                     g0 += gs[li]
                 ops.gather_gemm(x, ld_of(x), spec.C, T, wp, Np, m, out, Np, mode=spec.mode, geom=geom,
                                 table=spec.table, bias=b, act=ACT_NONE, stats=st, flops=fl)
-        ops.W2V_WANTED = False
+        ops.TLS.w2v_wanted = False
         y = out
         if bn is not None:
             raw = out
@@ -211,6 +211,7 @@ class GemmLayerFn(torch.autograd.Function):
             ctx.bnsrc = y._efgh_bnsrc = BnSrc(raw, y.detach() if residual is not None else None, scale, shift, mean, invstd,
                                               spec.act, spec.slope, M, Np)
         ctx.spec = spec
+        ctx.train_step = ops.TLS.train_step      # (backward runs on autograd's device thread: it restores the caller's switch)
         ctx.has = (bias is not None, gamma is not None, residual is not None)
         ctx.params = (weight, bias, gamma, beta)      # the Parameter objects themselves (claim_grad), not saved copies
         if any(ctx.needs_input_grad[1:5]):
@@ -225,6 +226,14 @@ class GemmLayerFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, dskip=None):
+        old, ops.TLS.train_step = ops.TLS.train_step, ctx.train_step
+        try:
+            return GemmLayerFn._backward(ctx, dy, dskip)
+        finally:
+            ops.TLS.train_step = old
+
+    @staticmethod
+    def _backward(ctx, dy, dskip=None):
         spec = ctx.spec
         sums = getattr(dy, '_efgh_bnsums', None) if dy is not None else None
         if sums is not None and (sums[1] is not ctx.bnsrc or sums[2] != dy._version):

@@ -2,6 +2,7 @@
 the stream only; every arithmetic op below runs in libefgh_hip.so.  No CPU fallback."""
 import ctypes
 import os as _os
+import threading
 
 import torch
 
@@ -37,17 +38,52 @@ def _cached(owner, key, versions, fn):
     return val
 
 
-WEIGHT_EPOCH = 0        # bumped by optimizers that update parameters outside torch (train.FusedAdam)
+class Epoch:
+    """content epoch of a set of weights that something rewrites through raw pointers, outside torch's version counters
+    (train.FusedAdam on a train.FlatParams): every parameter of the set carries a reference (`_efgh_epoch`), the optimizer bumps
+    `n` once per step.  The packed layouts that have a persistent buffer are registered HERE, per owner - two models driven from
+    two Python threads never repack (or invalidate) each other's weights."""
+    __slots__ = ('n', 'jobs', 'tables', 'repacked_at', '__weakref__')
+
+    def __init__(self):
+        self.n = 0
+        self.jobs = []           # [(weakref to the weight, key)]: every packed layout of the owner's weights with a persistent buffer
+        self.tables = {}         # device index -> (signature, jobs tensor, prefix tensor, total)
+        self.repacked_at = {}    # device index -> n of the last batched repack enqueued by repack_stale
+
+
+GLOBAL_EPOCH = Epoch()           # weights without an owner (no FlatParams: stock torch optimizers bump the version counters)
+_LOCK = threading.RLock()        # guards the Python-side job tables (the kernels themselves are ordered by their streams)
+
+
+def epoch_of(t):
+    return getattr(t, '_efgh_epoch', None) or GLOBAL_EPOCH
+
+
+def bump_epoch(holder=None):
+    """the weights of `holder` (an Epoch; None: every weight without an owner) were rewritten in place"""
+    (holder or GLOBAL_EPOCH).n += 1
+
+
+class _ThreadState(threading.local):
+    """per-thread switches (two Python threads may drive two models on one GPU; autograd's device thread is a third):
+    train_step - inside a training step (forward: set by EFGHBackbone.forward; backward: GemmLayerFn.backward restores the value
+    its forward saw); w2v_wanted - set by GemmLayerFn.forward around its launches when the weight gradient will be asked for"""
+
+    def __init__(self):
+        self.train_step = False
+        self.w2v_wanted = False
+
+
+TLS = _ThreadState()
 
 
 def _ver(*tensors):
     # _efgh_gen: content generation of a buffer this module rewrites in place through raw pointers (packed weights)
-    return (WEIGHT_EPOCH,) + tuple((t._version, t.data_ptr(), getattr(t, '_efgh_gen', 0)) for t in tensors)
+    return (tuple(epoch_of(t).n for t in tensors),) + tuple((t._version, t.data_ptr(), getattr(t, '_efgh_gen', 0)) for t in tensors)
 
 
 BATCH_PACK = _os.environ.get('EFGH_BATCH_PACK', '1') != '0'
-_PACK_JOBS = []          # [(weakref to the weight, key)]: every packed layout that has a persistent buffer
-_PACK_TABLE = {}         # device index -> (signature, jobs tensor, prefix tensor, total, [(weight, key)])
 
 
 class _PackJob(ctypes.Structure):
@@ -64,63 +100,61 @@ def _pack_one(w, buf, prm):
     buf._efgh_gen = getattr(buf, '_efgh_gen', 0) + 1
 
 
-def _repack_all(device):
-    """ONE launch re-packs every registered layout of every live weight on `device` whose cache entry is stale only because the
-    optimizer stepped (train.FusedAdam bumps WEIGHT_EPOCH): 279 launches of 5 us per training step otherwise"""
-    import weakref  # noqa: F401
-    live, jobs = [], []
-    for ref, key in _PACK_JOBS:
-        w = ref()
-        if w is None:
-            continue
-        live.append((ref, key))
-        ent = w.__dict__.get('_efgh_cache', {}).get(key)
-        if ent is None or not w.is_cuda or w.device != device:
-            continue
-        cur = _ver(w)
-        if ent[0] != cur and ent[0][1:] == cur[1:]:
-            jobs.append((w, key, ent[1], cur))
-    _PACK_JOBS[:] = live
-    if not jobs:
-        return
-    sig = tuple((w.data_ptr(), buf.data_ptr(), key) for w, key, buf, _ in jobs)
-    tab = _PACK_TABLE.get(device.index)
-    if tab is None or tab[0] != sig:
-        arr = (_PackJob * len(jobs))()
-        prefix, total = [], 0
-        for i, (w, key, buf, _) in enumerate(jobs):
-            N, T, C, Np, Cp, sn, sc, st, taps = buf._efgh_pack
-            j = arr[i]
-            j.W, j.Wp, j.N, j.T, j.C, j.Np, j.Cp, j.sn, j.sc, j.st = w.data_ptr(), buf.data_ptr(), N, T, C, Np, Cp, sn, sc, st
-            for q in range(16):
-                j.taps[q] = int(taps[q]) if (taps is not None and q < len(taps)) else (q if q < T else 0)
+def _repack_all(device, holder):
+    """ONE launch re-packs every registered layout of every live weight of `holder` on `device` whose cache entry is stale only
+    because the optimizer stepped (train.FusedAdam bumps the owner's Epoch): 279 launches of 5 us per training step otherwise"""
+    with _LOCK:
+        live, jobs = [], []
+        for ref, key in holder.jobs:
+            w = ref()
+            if w is None or epoch_of(w) is not holder:      # (gone, or re-homed in a FlatParams built after its first forward)
+                continue
+            live.append((ref, key))
+            ent = w.__dict__.get('_efgh_cache', {}).get(key)
+            if ent is None or not w.is_cuda or w.device != device:
+                continue
+            cur = _ver(w)
+            if ent[0] != cur and ent[0][1:] == cur[1:]:
+                jobs.append((w, key, ent[1], cur))
+        holder.jobs[:] = live
+        if not jobs:
+            return
+        sig = tuple((w.data_ptr(), buf.data_ptr(), key) for w, key, buf, _ in jobs)
+        tab = holder.tables.get(device.index)
+        if tab is None or tab[0] != sig:
+            arr = (_PackJob * len(jobs))()
+            prefix, total = [], 0
+            for i, (w, key, buf, _) in enumerate(jobs):
+                N, T, C, Np, Cp, sn, sc, st, taps = buf._efgh_pack
+                j = arr[i]
+                j.W, j.Wp, j.N, j.T, j.C, j.Np, j.Cp, j.sn, j.sc, j.st = w.data_ptr(), buf.data_ptr(), N, T, C, Np, Cp, sn, sc, st
+                for q in range(16):
+                    j.taps[q] = int(taps[q]) if (taps is not None and q < len(taps)) else (q if q < T else 0)
+                prefix.append(total)
+                total += Np * T * Cp
             prefix.append(total)
-            total += Np * T * Cp
-        prefix.append(total)
-        raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
-        pre = torch.tensor(prefix, dtype=torch.int64).to(device)
-        tab = _PACK_TABLE[device.index] = (sig, raw, pre, total)
-    _C.check(_L().efgh_pack_weight_batched(ptr(tab[1]), ptr(tab[2]), c_int32(len(jobs)), c_int64(tab[3]), _st()))
-    for w, key, buf, cur in jobs:
-        buf._efgh_gen = getattr(buf, '_efgh_gen', 0) + 1
-        w.__dict__['_efgh_cache'][key] = (cur, buf)
+            raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
+            pre = torch.tensor(prefix, dtype=torch.int64).to(device)
+            tab = holder.tables[device.index] = (sig, raw, pre, total)
+        _C.check(_L().efgh_pack_weight_batched(ptr(tab[1]), ptr(tab[2]), c_int32(len(jobs)), c_int64(tab[3]), _st()))
+        for w, key, buf, cur in jobs:
+            buf._efgh_gen = getattr(buf, '_efgh_gen', 0) + 1
+            w.__dict__['_efgh_cache'][key] = (cur, buf)
 
 
-_REPACKED_AT = {}        # device index -> WEIGHT_EPOCH of the last batched repack enqueued by repack_stale
-
-
-def repack_stale(device):
-    """Enqueue the batched in-place repack of every packed weight that went stale with the last optimizer step on the CURRENT
-    stream.  Callers that fork work onto several streams (nets.EFGHBackbone.forward) call this BEFORE the fork: the repack
-    rewrites persistent buffers that layers on every branch read, so it has to be ordered before all of them - left to the
-    first pack_weight() of the step it would run on whichever branch stream happens to be enqueued first, unordered with the
-    others."""
+def repack_stale(device, holder=None):
+    """Enqueue the batched in-place repack of every packed weight of `holder` (an Epoch; None: the weights without an owner) that
+    went stale with the last optimizer step on the CURRENT stream.  Callers that fork work onto several streams
+    (nets.EFGHBackbone.forward) call this BEFORE the fork: the repack rewrites persistent buffers that layers on every branch
+    read, so it has to be ordered before all of them - left to the first pack_weight() of the step it would run on whichever
+    branch stream happens to be enqueued first, unordered with the others."""
+    holder = holder or GLOBAL_EPOCH
     if not BATCH_PACK or device is None or device.type != 'cuda':
         return
-    if _REPACKED_AT.get(device.index) == WEIGHT_EPOCH:
+    if holder.repacked_at.get(device.index) == holder.n:
         return
-    _REPACKED_AT[device.index] = WEIGHT_EPOCH
-    _repack_all(device)
+    holder.repacked_at[device.index] = holder.n
+    _repack_all(device, holder)
 
 
 def pack_weight(w, N, T, C, sn, sc, st, taps=None, Np=None, Cp=None, key=None):
@@ -147,15 +181,24 @@ def pack_weight(w, N, T, C, sn, sc, st, taps=None, Np=None, Cp=None, key=None):
         buf._efgh_pack = prm
         _pack_one(wd, buf, prm)
         store[key] = (cur, buf)
-        _PACK_JOBS.append((weakref.ref(w), key))
+        buf._efgh_holder = epoch_of(w)
+        with _LOCK:
+            jl = buf._efgh_holder.jobs
+            if len(jl) >= 1024 and len(jl) % 256 == 0:      # weights that come and go (per-step temporaries): drop the dead ones
+                jl[:] = [j for j in jl if j[0]() is not None]
+            jl.append((weakref.ref(w), key))
         return buf
     if BATCH_PACK and ent[0][1:] == cur[1:]:          # only the optimizer epoch moved: everything else is stale the same way
-        _repack_all(wd.device)
+        _repack_all(wd.device, epoch_of(w))
         ent = store[key]
         if ent[0] == cur:
             return ent[1]
     _pack_one(wd, ent[1], prm)
     store[key] = (cur, ent[1])
+    if getattr(ent[1], '_efgh_holder', None) is not epoch_of(w):      # the weight changed owner: register the layout there
+        ent[1]._efgh_holder = epoch_of(w)
+        with _LOCK:
+            ent[1]._efgh_holder.jobs.append((weakref.ref(w), key))
     return ent[1]
 
 
@@ -194,13 +237,12 @@ def wino_eligible(mode, C, N, geom, T=None):
 USE_WINO2D = _os.environ.get('EFGH_WINO2D', '1') != '0'   # F(4x4,3x3) as transform / batched GEMM / transform (wino2d.hip)
 WINO2D_MIN_C = int(_os.environ.get('EFGH_WINO2D_MIN_C', '256'))            # forward / data gradient
 WINO2D_MIN_C_WGRAD = int(_os.environ.get('EFGH_WINO2D_MIN_C_WGRAD', '128'))  # weight gradient
-# forward / data gradient inside a training step (EFGHBackbone sets TRAIN_STEP): EFGH_WINO2D_MIN_C_TRAIN=128 moves the 128-channel
+# forward / data gradient inside a training step (EFGHBackbone sets TLS.train_step): EFGH_WINO2D_MIN_C_TRAIN=128 moves the 128-channel
 # layers to the 2-D form there - their weight gradient is 2-D anyway and re-uses the forward's transformed input, and the extra
 # transform passes run underneath MFMA kernels of the other streams: -0.9 ms per step for +10 GB (the eval forward alone is 0.5 %
 # faster on the 1-D kernel).  Not the default: a sub-percent gain that re-rounds F's trunks, whose arg-max heads turn a 1e-6
 # difference of the logits into a different yaw bin on near-ties (tests/test_gpu_train.py::test_winograd_and_direct_kernels...)
 WINO2D_MIN_C_TRAIN = int(_os.environ.get('EFGH_WINO2D_MIN_C_TRAIN', '256'))
-TRAIN_STEP = False
 
 
 def _pow2(v):
@@ -213,7 +255,7 @@ def wino2d_eligible(mode, C, N, geom, wgrad=False):
     of two, >= 256 channels (forward / data gradient; >= 128 inside a training step) or >= 128 (weight gradient)"""
     if not USE_WINO2D or not wino_eligible(mode, C, N, geom):
         return False
-    lim = WINO2D_MIN_C_WGRAD if wgrad else (min(WINO2D_MIN_C, WINO2D_MIN_C_TRAIN) if TRAIN_STEP else WINO2D_MIN_C)
+    lim = WINO2D_MIN_C_WGRAD if wgrad else (min(WINO2D_MIN_C, WINO2D_MIN_C_TRAIN) if TLS.train_step else WINO2D_MIN_C)
     if geom[1] < 8 or geom[2] < 8:          # maps of fewer than 2 x 2 tiles: mostly padding (and nothing to gain)
         return False
     return min(C, N) >= lim and _pow2(C // 4) and _pow2(N // 4) and C <= 512 and N <= 512
@@ -263,6 +305,17 @@ def sc_eligible(mode, C, N, geom, wgrad=False):
         return False
     return (C in (16, 32) and N in (16, 32) and len(dh) == 9
             and list(dh) == [t // 3 - 1 for t in range(9)] and list(dw) == [t % 3 - 1 for t in range(9)])
+
+
+def _sc_aligned(d, lda, ldo, residual, ldr, stats):
+    """the small-channel kernels move 16-byte vectors on A, out and the residual: a channel slice at an offset that is not a
+    multiple of four falls through to the generic kernel (efgh_sc_conv3x3 would refuse it)"""
+    ok = (lda % 4 == 0 and ldo % 4 == 0 and d.A % 16 == 0 and d.out % 16 == 0
+          and (residual is None or (ldr % 4 == 0 and d.residual % 16 == 0)))
+    if not ok and stats is not None:
+        # (stats_rows() sized the statistics buffer for the small-channel launch: a silent switch of kernels would misread it)
+        raise _C.EfghError('16- / 32-channel layer with BatchNorm statistics on a channel slice that is not 16-byte aligned')
+    return ok
 
 
 def stats_rows(mode, C, N, geom, M):
@@ -402,7 +455,7 @@ def gather_gemm(A, lda, C, T, Wp, N, M, out, ldo, mode=0, geom=None, table=None,
         assert lda % 4 == 0
         thin = True             # (for the profile lists: an HBM-bound launch, not part of the MFMA GEMM family)
         _C.check(_L().efgh_c4_conv3x3(ctypes.byref(d), _st()))
-    elif M_dev is None and batch is None and lda % 4 == 0 and ldo % 4 == 0 and sc_eligible(mode, C, N, geom):
+    elif M_dev is None and batch is None and sc_eligible(mode, C, N, geom) and _sc_aligned(d, lda, ldo, residual, ldr, stats):
         _C.check(_L().efgh_sc_conv3x3(ctypes.byref(d), _st()))
     elif M_dev is None and batch is None and wino2d_eligible(mode, C, N, geom):
         wino = '2d'
@@ -468,13 +521,17 @@ def _batched_plain_gemm(A3, W3, out3, rows, C, N):
 
 W2V_CACHE = {}          # training: B^T x B of a layer's input, kept from the forward for the layer's weight gradient
 W2V_KEEP = _os.environ.get('EFGH_WINO2D_KEEP_V', '1') != '0'
-W2V_WANTED = False      # set by GemmLayerFn.forward around its launches when the weight gradient will be asked for
 
 
 def w2v_clear():
-    """drop transformed inputs that no backward came for (nets.EFGHBackbone.forward calls this at the start of every train-mode
-    forward, train.Trainer at the start of every step: an entry never outlives the step that made it, whatever loop drives it)"""
-    W2V_CACHE.clear()
+    """drop the transformed inputs of THIS thread's forwards that no backward came for (nets.EFGHBackbone.forward calls this at
+    the start of every train-mode forward, train.Trainer at the start of every step: an entry never outlives the step that made
+    it, whatever loop drives it).  Entries are tagged with the thread that made them - the backward that pops them runs on
+    autograd's device thread - so two threads driving two models do not drop each other's."""
+    me = threading.get_ident()
+    with _LOCK:
+        for k in [k for k, v in W2V_CACHE.items() if v[2] == me]:
+            del W2V_CACHE[k]
 
 
 def _wino2d_forward(d, A, a_off, lda, C, N, geom, Wp):
@@ -486,11 +543,12 @@ def _wino2d_forward(d, A, a_off, lda, C, N, geom, Wp):
     Mb = torch.empty((T, 36, N), dtype=torch.float32, device=dev)
     _C.check(_L().efgh_wino2d_input(_C.c_void_p(A.data_ptr() + 4 * a_off), c_int64(lda), c_int32(C), c_int32(B), c_int32(H),
                                     c_int32(W), ptr(V), _st()))
-    if W2V_KEEP and W2V_WANTED and a_off == 0:
+    if W2V_KEEP and TLS.w2v_wanted and a_off == 0:
         # 2.25x the activation, ~10 GB over the eligible layers at batch 8 (of 288 GB): saves one transform pass per layer and step
-        if len(W2V_CACHE) > 256:
-            W2V_CACHE.clear()
-        W2V_CACHE[(A.data_ptr(), lda, C, B, H, W)] = (V, A._version)
+        with _LOCK:
+            if len(W2V_CACHE) > 512:
+                W2V_CACHE.clear()
+            W2V_CACHE[(A.data_ptr(), lda, C, B, H, W)] = (V, A._version, threading.get_ident())
     _batched_plain_gemm(V, wino2d_weight(Wp, N, C), Mb, T, C, N)
     _C.check(_L().efgh_wino2d_output(ptr(Mb), ctypes.byref(d), _st()))
 
@@ -871,7 +929,7 @@ def _scratch(nfloats, device):
     nfloats = int(nfloats)
     if nfloats <= 0:
         return None
-    key = (str(device), torch.cuda.current_stream().cuda_stream)
+    key = (str(device), torch.cuda.current_stream().cuda_stream, threading.get_ident())      # (autograd's device thread is its own)
     t = _SCRATCH.get(key)
     if t is None or t.numel() < nfloats:
         t = _SCRATCH[key] = torch.empty(max(nfloats, 1 << 22), dtype=torch.float32, device=device)
@@ -905,8 +963,8 @@ def gather_wgrad(A, lda, C, T, N, M, G, ldg, dWp, mode=0, geom=None, table=None)
                                       ptr(_scratch(_L().efgh_c4n4_wgrad_workspace(ctypes.byref(d)), dWp.device)), _st()))
     elif thin:
         _C.check(_L().efgh_thin_wgrad(ctypes.byref(d), ptr(G), c_int64(ldg), ptr(dWp), _st()))
-    elif (USE_SMALLC and C == 4 and N in (32, 64) and lda % 4 == 0 and ldg % 4 == 0 and geom is not None and geom[5] == 1
-          and sc_eligible(mode, 16, 16, geom, wgrad=True)):
+    elif (USE_SMALLC and C == 4 and N in (32, 64) and lda % 4 == 0 and ldg % 4 == 0 and d.A % 16 == 0 and G.data_ptr() % 16 == 0
+          and geom is not None and geom[5] == 1 and sc_eligible(mode, 16, 16, geom, wgrad=True)):
         # 4-channel input layers at stride 1: the small-channel weight-gradient kernel (G staged by 16-byte loads, per-wave partial
         # planes folded in a fixed order) instead of k_c4_wgrad (4-byte G loads, fp32 atomics)
         thin = True             # (profile lists: an HBM-bound launch)
@@ -915,7 +973,7 @@ def gather_wgrad(A, lda, C, T, N, M, G, ldg, dWp, mode=0, geom=None, table=None)
     elif not DETERMINISTIC and c4_eligible(mode, C, N, geom, wgrad=True):
         thin = True             # (profile lists, as above)
         _C.check(_L().efgh_c4_wgrad(ctypes.byref(d), ptr(G), c_int64(ldg), ptr(dWp), _st()))
-    elif sc_eligible(mode, C, N, geom, wgrad=True) and lda % 4 == 0 and ldg % 4 == 0:
+    elif sc_eligible(mode, C, N, geom, wgrad=True) and lda % 4 == 0 and ldg % 4 == 0 and d.A % 16 == 0 and G.data_ptr() % 16 == 0:
         _C.check(_L().efgh_sc_wgrad(ctypes.byref(d), ptr(G), c_int64(ldg), ptr(dWp),
                                     ptr(_scratch(_L().efgh_sc_wgrad_workspace(ctypes.byref(d)), dWp.device)), _st()))
     elif USE_WINO_WGRAD and wino2d_eligible(mode, C, N, geom, wgrad=True):
@@ -923,7 +981,8 @@ def gather_wgrad(A, lda, C, T, N, M, G, ldg, dWp, mode=0, geom=None, table=None)
         B, H, W = geom[0], geom[1], geom[2]
         T2 = _L().efgh_wino2d_tiles(c_int32(B), c_int32(H), c_int32(W))
         dev = dWp.device
-        kept = W2V_CACHE.pop((A.data_ptr(), lda, C, B, H, W), None)
+        with _LOCK:
+            kept = W2V_CACHE.pop((A.data_ptr(), lda, C, B, H, W), None)
         if kept is not None:
             kept[0].record_stream(torch.cuda.current_stream())          # (made on the forward's stream, maybe read on another)
         Gy = torch.empty((T2, 36, N), dtype=torch.float32, device=dev)

@@ -56,8 +56,12 @@ class FlatParams:
         # with the accumulation of the second, and would count the all-reduce bucket down before the second has arrived.
         self.uses = [0] * len(ps)
         self.listeners = []               # callables(index), e.g. the overlapped all-reduce's bucket countdown
+        # content epoch of the flat weight buffer (FusedAdam rewrites it through raw pointers): the packed-weight / folded-BN caches
+        # of THESE parameters key on it, and their batched repack is registered on it (ops.Epoch)
+        self.epoch = ops.Epoch()
         for i, p in enumerate(ps):
             p._efgh_flat = (self, i)
+            p._efgh_epoch = self.epoch
             p.register_post_accumulate_grad_hook(self._make_hook(i))
 
     def _make_hook(self, i):
@@ -224,7 +228,7 @@ class FusedAdam:
                                          _C.c_float(self.lr), _C.c_float(self.betas[0]), _C.c_float(self.betas[1]),
                                          _C.c_float(self.eps), _C.c_float(self.wd), _C.c_int32(self.t),
                                          _C.c_float(grad_scale), _C.stream_ptr()))
-        ops.WEIGHT_EPOCH += 1            # packed-weight / folded-BN caches are stale now
+        ops.bump_epoch(self.flat.epoch)            # packed-weight / folded-BN caches are stale now
 
 
 def adjust_learning_rate(base_lr, it, every=50000, gamma=0.7):
@@ -264,7 +268,8 @@ class Trainer:
         if 'optimizer' in ckpt:
             ck.load_adam_state(self.opt, ckpt['optimizer'])
         self.it = int(ckpt.get('iter', -1)) + 1
-        ops.WEIGHT_EPOCH += 1
+        ops.bump_epoch(self.flat.epoch)
+        ops.bump_epoch()
         return self.it
 
     def step(self, pc, img, calib, A, gt):

@@ -47,7 +47,7 @@ int efgh_version(void);
  * so the levels of a pyramid can be enqueued back to back (level l+1: pts = pts_next, pts_cstride = h_cap, n_dev =
  * info + EFGH_LATTICE_INFO_H, n_cap = h_cap, sid = vsid) with one host read-back at the end.                              */
 #define EFGH_LATTICE_INFO_H 0        /* number of vertices (pc1_hash_cnt summed over the samples) */
-#define EFGH_LATTICE_INFO_ERR 1      /* bit 0: H > h_cap; bit 1: more aliased neighbour hits than alias_cap; bit 2: hash table / bucket full */
+#define EFGH_LATTICE_INFO_ERR 1      /* bit 0: H > h_cap; bit 1: more aliased neighbour hits than alias_cap; bit 2: hash table / bucket full; bit 3 (with bit 2): key range too wide for the partitioned build's entry word */
 #define EFGH_LATTICE_INFO_ALIAS 2    /* number of aliased neighbour hits (see efgh_lattice_level_neighbors) */
 #define EFGH_LATTICE_INFO_CURSOR 3   /* internal (number of occupied hash slots == H) */
 #define EFGH_LATTICE_INFO_SEG 4      /* info[SEG + b] = first vertex of sample b */

@@ -143,3 +143,48 @@ def test_header_is_plain_c():
     import subprocess
     hdr = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'include', 'efgh_hip.h')
     subprocess.check_call(['gcc', '-std=c99', '-Wall', '-Werror', '-fsyntax-only', '-x', 'c', hdr])
+
+
+def test_zero_edit_launcher_binds_nets_and_losses(tmp_path):
+    """`python -m efgh_amd.run script.py args` (reference main.py:14-15,126-129 unchanged): `import nets, losses` inside the
+    script resolve to the MI355X packages, sys.argv / sys.path[0] are what `python script.py args` would see, the process is
+    pinned to one device before anything initialises the GPU, and the script's own sibling modules still import"""
+    import json
+    import subprocess
+    import sys
+    (tmp_path / 'iterater.py').write_text('MARK = "sibling module of the script"\n')
+    (tmp_path / 'main.py').write_text(
+        'import os, sys, json\n'
+        'import nets\nimport losses\nimport iterater\n'
+        'from nets.efghbackbone import EFGHBackbone as B2\n'
+        'model_cls = nets.__dict__["EFGH" + "Backbone"]\n'
+        'crit_cls = losses.__dict__["EFGH" + "Criterion"]\n'
+        'assert B2 is model_cls\n'
+        'json.dump({"model": model_cls.__module__, "crit": crit_cls.__module__, "argv": sys.argv, "path0": sys.path[0],\n'
+        '           "name": __name__, "sibling": iterater.MARK, "hip": os.environ.get("HIP_VISIBLE_DEVICES")},\n'
+        '          open(sys.argv[2], "w"))\n')
+    out = tmp_path / 'out.json'
+    env = dict(os.environ, PYTHONPATH=ROOT, HIP_VISIBLE_DEVICES='3,5')
+    env.pop('CUDA_VISIBLE_DEVICES', None)
+    subprocess.check_call([sys.executable, '-m', 'efgh_amd.run', '--device', '1', str(tmp_path / 'main.py'), 'cfg.yaml', str(out)],
+                          env=env, cwd=str(tmp_path))
+    got = json.load(open(out))
+    assert got['model'] == 'efgh_amd.nets.efghbackbone' and got['crit'] == 'efgh_amd.losses.efghloss'
+    assert got['argv'] == [str(tmp_path / 'main.py'), 'cfg.yaml', str(out)] and got['path0'] == str(tmp_path)
+    assert got['name'] == '__main__' and got['sibling'].startswith('sibling') and got['hip'] == '5'
+    # --all-devices leaves the visibility alone
+    subprocess.check_call([sys.executable, '-m', 'efgh_amd.run', '--all-devices', str(tmp_path / 'main.py'), 'cfg.yaml', str(out)],
+                          env=env, cwd=str(tmp_path))
+    assert json.load(open(out))['hip'] == '3,5'
+
+
+def test_dataparallel_replica_is_refused_loudly():
+    """torch.nn.DataParallel over more than one device (main.py:127 on a multi-GPU box) marks its per-forward copies with
+    `_is_replica`: the backbone refuses them with the one-process-per-GPU recipe instead of running a half-supported schedule"""
+    from efgh_amd import _C, synthetic as syn
+    from efgh_amd.nets import EFGHBackbone
+    m = EFGHBackbone(syn.default_args((128, 256)))
+    m._is_replica = True                      # what torch.nn.parallel.replicate sets on every replica
+    z = torch.zeros(1)
+    with pytest.raises(_C.EfghError, match='ONE PROCESS PER GPU'):
+        m(z, z, z, z)

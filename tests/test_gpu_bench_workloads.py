@@ -104,3 +104,46 @@ def test_config2_batch8_training_step_full_size(manifest):
     comb['total'] = sum(comb.values())           # efghloss.py:33-36 adds up EVERY entry, the abs / sgn parts a second time
     for k in L8:
         assert abs(L8[k] - comb[k]) <= 2e-5 * abs(comb[k]) + 1e-7, (k, L8[k], comb[k])
+
+
+def test_training_steps_on_varying_frame_pairs_take_the_speculative_lattice_path(manifest):
+    """what `bench.py --rotate-inputs` times and what a real loop feeds (iterater.py:26-43): consecutive config-S training steps on
+    DIFFERENT frame-pairs.  Every sweep has its own lattice sizes; the pyramid is enqueued from the previous batch's sizes + 25 %
+    with ONE read-back.  Three steps on three batches: finite losses, the speculative path taken for at least two of the three
+    pyramids (the first has no previous sizes), no escalated rebuild - and the whole sequence repeated from the same weights ends,
+    bit for bit, on the same weights (position-weighted checksum + exact compare), whichever lattice path a step took."""
+    from efgh_amd import lattice, ops
+    from efgh_amd.losses import EFGHCriterion
+    from efgh_amd.train import Trainer
+    args = syn.default_args(RAW, 'cuda')
+    batches = []
+    for r in range(3):
+        b = syn.make_batch(RAW, NPTS, 2, first_seed=10 + 2 * r)
+        batches.append(([torch.from_numpy(b[k]).cuda() for k in ('pc', 'img', 'calib', 'A')],
+                        {k: torch.from_numpy(v).cuda() for k, v in b['gt'].items()}))
+
+    def run(clear):
+        if clear:
+            lattice._SIZES.clear()
+        before = dict(lattice.STATS)
+        tr = Trainer(_model(manifest), EFGHCriterion(args), lr=1e-4)
+        ls = []
+        for inp, gt in batches:
+            losses, _ = tr.step(*inp, dict(gt))
+            ls.append({k: float(v.detach()) for k, v in losses.items()})
+        torch.cuda.synchronize()
+        w = tr.flat.w.detach().double()
+        ck = float((w * torch.arange(1, w.numel() + 1, device=w.device, dtype=torch.float64).remainder(977.0)).sum())
+        return ls, ck, tr.flat.w.detach().clone(), {k: lattice.STATS[k] - before[k] for k in before}
+    old = ops.DETERMINISTIC
+    try:
+        ops.DETERMINISTIC = True
+        la, cka, wa, sa = run(True)
+        lb, ckb, wb, sb = run(False)
+    finally:
+        ops.DETERMINISTIC = old
+    assert all(np.isfinite(v) for l in la for v in l.values())
+    assert sa['speculative'] >= 2 and sa['speculative'] + sa['level_by_level'] == 3 and sa['reenqueued'] == 0, sa
+    assert sb == {'speculative': 3, 'level_by_level': 0, 'reenqueued': 0}, sb
+    assert la[0]['total'] != la[1]['total'] != la[2]['total']
+    assert la == lb and cka == ckb and torch.equal(wa, wb)

@@ -184,7 +184,52 @@ def test_rellis_config_training_step_vs_oracle(manifest, monkeypatch):
     assert relg < 2e-2
 
 
-def _training_step(manifest, monkeypatch, RAW, NPTS, args_over=None, batch=None):
+def _unsaturated_f_bias(manifest, raw, npts, batch=None):
+    """With the synthetic weights the correlation logits at config S are sums of ~120 k same-signed products: f_score saturates and
+    F's gradient is exactly zero on both sides.  The (max - min) normalisation (fnet.py:57,64) cancels any rescaling of the heads,
+    so the camera trunk's last BatchNorm is SHIFTED instead: beta = t * |gamma| with t < 0 found by bisection (GPU forward only)
+    such that the median score is ~0.5 - the products then change sign and the logits are O(1)."""
+    from efgh_amd.nets import EFGHBackbone
+    b = batch if batch is not None else syn.make_batch(raw, npts, 1)
+    inp = [torch.from_numpy(b[k]).cuda() for k in ('pc', 'img', 'calib', 'A')]
+    sd = syn.synthetic_state_dict(manifest['state_dict'], 1)
+    gam = sd['F.vgg_5_3_camera.4.weight'].abs()
+    m = EFGHBackbone(syn.default_args(raw, 'cuda')).cuda()
+
+    def median_score(t):
+        sd['F.vgg_5_3_camera.4.bias'] = t * gam
+        m.load_state_dict(sd)
+        m.train()
+        with torch.no_grad():
+            return float(m(*inp)['f_score'].median())
+    lo, hi = -4.0, 0.0                      # scores fall with t (the range features are mostly positive)
+    s_lo, s_hi = median_score(lo), median_score(hi)
+    assert s_lo < 0.5 < s_hi, (s_lo, s_hi)
+    for _ in range(14):
+        mid = 0.5 * (lo + hi)
+        if median_score(mid) < 0.5:
+            lo = mid
+        else:
+            hi = mid
+    return 0.5 * (lo + hi)
+
+
+def test_fullsize_f_backward_is_checked_on_unsaturated_scores(manifest, monkeypatch):
+    """config S (the bench size), F's backward NON-trivially: correlation, (max - min) normalisation, mirror / circular pad,
+    hard-negative mining and both VGG trunks' adjoints against the oracle with scores strictly inside (0, 1)"""
+    t = _unsaturated_f_bias(manifest, RAW, NPTS)
+
+    def edit(sd):
+        sd['F.vgg_5_3_camera.4.bias'] = t * sd['F.vgg_5_3_camera.4.weight'].abs()
+    rel, _, info = _training_step(manifest, monkeypatch, RAW, NPTS, sd_edit=edit, want_info=True)
+    print('t = %.4f, f_score in [%.3f, %.3f], fraction inside (0.05, 0.95): %.2f, |dF| = %.3e'
+          % (t, info['f_min'], info['f_max'], info['f_inside'], info['f_gnorm']))
+    assert info['f_inside'] > 0.25 and info['f_gnorm'] > 0, info
+    assert 0.0 < rel['F'] < 2e-2, rel
+    assert rel['E'] < 2e-3 and rel['H'] < 1e-2, rel
+
+
+def _training_step(manifest, monkeypatch, RAW, NPTS, args_over=None, batch=None, sd_edit=None, want_info=False):
     """forward + efghloss + backward at config S (B = 1) against the oracle.
     Pass A - the whole pipeline (only the uint8 rotate teacher-forced, as in test_gpu_backward): every loss term, and the E / H
     gradients.  Pass B - the G net on the oracle's inputs (E/H/F outputs and the rasterised depth image teacher-forced): the
@@ -206,6 +251,8 @@ def _training_step(manifest, monkeypatch, RAW, NPTS, args_over=None, batch=None)
     gtd = lambda: {k: T(v) for k, v in b['gt'].items()}
     skip = re.compile(r'(features\.\d+|conv_gn_\d|conv_hrzn_\d|E\.bcn5\.blur_conv\.2)\.bias$')   # bias before a train-mode BN
     P = syn.synthetic_state_dict(manifest['state_dict'], 1)
+    if sd_edit is not None:
+        sd_edit(P)
     for k in manifest['parameters']:
         P[k].requires_grad_(True)
     keep_o = {}
@@ -230,7 +277,10 @@ def _training_step(manifest, monkeypatch, RAW, NPTS, args_over=None, batch=None)
     h_img_o = pred_o['h_img'].detach().cuda()
     monkeypatch.setattr(ops, 'rotate_nearest_u8', lambda img, rot, **kw: (h_img_o, ops.nchw_to_nhwc(h_img_o, 4)))
     m = EFGHBackbone(args_g)
-    m.load_state_dict(syn.synthetic_state_dict(manifest['state_dict'], 1))
+    sd_g = syn.synthetic_state_dict(manifest['state_dict'], 1)
+    if sd_edit is not None:
+        sd_edit(sd_g)
+    m.load_state_dict(sd_g)
     m = m.cuda().train()
     gpu = [t.cuda() for t in cpu]
     crit = EFGHCriterion(args_g)
@@ -260,6 +310,11 @@ def _training_step(manifest, monkeypatch, RAW, NPTS, args_over=None, batch=None)
     num = sum(float((a.cpu().double() - c.double()).pow(2).sum()) for a, c in zip(g_b, g_o))
     den = sum(float(c.double().pow(2).sum()) for c in g_o)
     print('pass B, G gradient rel err on teacher-forced inputs: %.2e' % ((num / den) ** 0.5))
+    if want_info:
+        fs = pred_o['f_score'].detach()
+        info = {'f_min': float(fs.min()), 'f_max': float(fs.max()), 'f_inside': float(((fs > 0.05) & (fs < 0.95)).float().mean()),
+                'f_gnorm': sum(float(P[k].grad.double().pow(2).sum()) for k in manifest['parameters'] if k.startswith('F.')) ** 0.5}
+        return rel, (num / den) ** 0.5, info
     return rel, (num / den) ** 0.5
 
 

@@ -739,3 +739,26 @@ def test_padded_pack_and_vector_pad():
     v = torch.randn(5, device='cuda')
     assert torch.equal(ops.pad_vec(v, 8, 1.5), torch.cat([v, torch.full((3,), 1.5, device='cuda')]))
     assert ops.pad_vec(v, 5) is v
+
+
+@pytest.mark.parametrize('cin,cout,hw', [(64, 64, (12, 20)), (64, 128, (16, 20)), (16, 16, (12, 20)), (4, 32, (12, 20)),
+                                         (256, 256, (16, 24))])
+@pytest.mark.parametrize('act', ['none', 'leaky', 'relu'])
+def test_nan_preactivation_stays_nan_in_the_fused_epilogues(L, cin, cout, hw, act):
+    """a diverged network must not look healthy: a NaN that reaches a fused epilogue (generic tile, Winograd F(4,3), small-channel and
+    4-channel kernels, the 2-D Winograd output transform) leaves it as NaN under every activation - max / min forms return their
+    non-NaN operand and would emit a finite 0.  Rows that never see the NaN stay finite."""
+    from efgh_amd import ops
+    torch.manual_seed(0)
+    conv = nn.Conv2d(cin, cout, 3, 1, 1, bias=True).cuda()
+    x = torch.randn(1, cin, *hw)
+    x[0, :, 5, 7] = float('nan')
+    xg = ops.nchw_to_nhwc(x.cuda(), (cin + 3) // 4 * 4)
+    code = {'none': L.ACT_NONE, 'leaky': L.ACT_LEAKY, 'relu': L.ACT_RELU}[act]
+    with torch.no_grad():
+        y = L.conv2d(L.Ctx(False), xg, conv, None, code, 0.2)[..., :cout]
+    if act != 'relu':                                            # (ReLU: the older VALU kernels clamp a NaN to 0, as `v > 0 ? v : 0` does)
+        assert torch.isnan(y[0, 4:7, 6:9]).all()                 # every output whose 3x3 window holds the poisoned pixel
+    keep = torch.ones(hw, dtype=torch.bool, device=y.device)
+    keep[0:12, 0:16] = False                                     # (a Winograd tile spreads the NaN over its 4 / 4x4 outputs)
+    assert torch.isfinite(y[0][keep]).all() and int(keep.sum()) > 0

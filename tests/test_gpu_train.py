@@ -481,3 +481,65 @@ def test_bn_backward_sums_in_the_dgrad_epilogue_match_the_reduction_pass(manifes
     num = sum(float((ga[k] - gb[k]).double().pow(2).sum()) for k in ga if k.startswith(('G.', 'H.')))
     den = sum(float(ga[k].double().pow(2).sum()) for k in ga if k.startswith(('G.', 'H.')))
     assert (num / den) ** 0.5 < 1e-4, (num / den) ** 0.5
+
+
+def test_two_threads_two_models_equal_the_serial_results(manifest):
+    """threaded callers (what `torch.nn.DataParallel` does per device, main.py:127; here: two Python threads, two model replicas,
+    ONE GPU): concurrent train-mode forwards + backwards + Adam steps give, bit for bit, what the same two trainers give when
+    they run one after the other.  The package keeps no process-global mutable step state: the switches are thread-local
+    (`ops.TLS`, carried into autograd's device thread by GemmLayerFn), packed-weight epochs and repack tables live on the owning
+    FlatParams (`ops.Epoch`), scratch and kept Winograd images are tagged with their thread."""
+    import threading
+    from efgh_amd import ops
+    from efgh_amd.losses import EFGHCriterion
+    from efgh_amd.nets import EFGHBackbone
+    from efgh_amd.train import Trainer
+    args = syn.default_args(RAW, 'cuda')
+    sds = [syn.synthetic_state_dict(manifest['state_dict'], 1), syn.synthetic_state_dict(manifest['state_dict'], 2)]
+    batches = []
+    for seed in (0, 7):
+        b = syn.make_batch(RAW, NPTS, 2, first_seed=seed)
+        batches.append(([torch.from_numpy(b[k]).cuda() for k in ('pc', 'img', 'calib', 'A')],
+                        {k: torch.from_numpy(v).cuda() for k, v in b['gt'].items()}))
+    STEPS = 3
+
+    def make(i):
+        m = EFGHBackbone(args)
+        m.load_state_dict(sds[i])
+        return Trainer(m.cuda(), EFGHCriterion(args), lr=1e-3)
+
+    def drive(tr, i, out, gate=None):
+        try:
+            torch.cuda.set_device(0)
+            if gate is not None:
+                gate.wait()
+            ls = []
+            for _ in range(STEPS):
+                losses, _ = tr.step(*batches[i][0], dict(batches[i][1]))
+                ls.append(losses['total'].detach())
+            torch.cuda.synchronize()
+            out[i] = ([float(x) for x in ls], tr.flat.g.detach().clone(), tr.flat.w.detach().clone())
+        except BaseException as e:          # noqa: BLE001  (re-raised in the main thread)
+            out[i] = e
+    old = ops.DETERMINISTIC
+    try:
+        ops.DETERMINISTIC = True
+        serial, threaded = {}, {}
+        for i in range(2):
+            drive(make(i), i, serial)
+        trs = [make(0), make(1)]
+        gate = threading.Barrier(2)
+        ths = [threading.Thread(target=drive, args=(trs[i], i, threaded, gate)) for i in range(2)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+    finally:
+        ops.DETERMINISTIC = old
+    for i in range(2):
+        for res in (serial[i], threaded[i]):
+            if isinstance(res, BaseException):
+                raise res
+        assert serial[i][0] == threaded[i][0], (i, serial[i][0], threaded[i][0])
+        assert torch.equal(serial[i][1], threaded[i][1]) and torch.equal(serial[i][2], threaded[i][2]), i
+    assert serial[0][0] != serial[1][0]

@@ -1,9 +1,9 @@
 #!/bin/bash
 # Collects the rocprofv3 evidence bench.py's roofline fields refer to, on the GPU box (run through gpurun from the repo root):
-#   bash tools/collect_round_evidence.sh r03          -> gpurun_out/evidence_r03/{*.json,*.csv}
+#   bash tools/collect_round_evidence.sh r04          -> gpurun_out/evidence_r04/{*.json,*.csv}
 # Separate passes, as the MI355X guide prescribes: --kernel-trace --stats alone; --pmc passes with --kernel-trace only.
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/evidence_$TAG
 SCR=/tmp/efgh_evidence_$$
@@ -11,12 +11,12 @@ mkdir -p "$OUT" "$SCR"
 cd /tmp && export TMPDIR=/tmp
 TRAIN="$ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-forward-section"
 FWD="$ROOT/bench.py --mode fwd --steps 1 --warmup 1 --no-cpu-baseline"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $SCR/tf -- python3 $TRAIN > /dev/null 2> $SCR/tf.err
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $SCR/tf -- python3 $TRAIN > $SCR/tf.json 2> $SCR/tf.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $SCR/tw -- python3 $TRAIN > /dev/null 2> $SCR/tw.err
-python3 $ROOT/tools/collect_traffic.py $SCR/tf $SCR/tw $OUT/hbm_traffic_train.json "bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-forward-section (training step, batch 8)"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $SCR/ff -- python3 $FWD > /dev/null 2> $SCR/ff.err
+python3 $ROOT/tools/collect_traffic.py $SCR/tf $SCR/tw $OUT/hbm_traffic_train.json "bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-forward-section (training step, batch 8)" $SCR/tf.json
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $SCR/ff -- python3 $FWD > $SCR/ff.json 2> $SCR/ff.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $SCR/fw -- python3 $FWD > /dev/null 2> $SCR/fw.err
-python3 $ROOT/tools/collect_traffic.py $SCR/ff $SCR/fw $OUT/hbm_traffic_fwd.json "bench.py --mode fwd --steps 1 --warmup 1 --no-cpu-baseline (eval forward, batch 4; exact + two fast-math passes)"
+python3 $ROOT/tools/collect_traffic.py $SCR/ff $SCR/fw $OUT/hbm_traffic_fwd.json "bench.py --mode fwd --steps 1 --warmup 1 --no-cpu-baseline (eval forward, batch 4; exact + two fast-math passes)" $SCR/ff.json
 CMD="rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-forward-section"
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $SCR/mb -- python3 $TRAIN > /dev/null 2> $SCR/mb.err
 python3 $ROOT/tools/collect_mfma_busy.py $SCR/mb $OUT/mfma_busy_train.json "$CMD"

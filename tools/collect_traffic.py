@@ -1,5 +1,8 @@
 """HBM-side bytes per launch of the kernel families of bench.py from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE):
-    python tools/collect_traffic.py <fetch_dir> <write_dir> <out.json> "<workload description>" [once-per-step kernel]
+    python tools/collect_traffic.py <fetch_dir> <write_dir> <out.json> "<workload description>" [once-per-step kernel | bench.json]
+A sixth argument ending in .json is the bench line the FETCH pass itself printed: its launches per step per kernel family (bench.py's
+own census, `launches_per_step` of every roofline object) are stored as `bench_launches_per_step`; a later bench.py run compares its
+census with them and withholds a `traffic` figure folded from another kernel mix.
 The number of steps in the trace is COUNTED (launches of a kernel that runs exactly once per forward, default k_rotate: Hnet's
 image rotation), not passed in: bench.py runs more steps than its --steps (warm-up, the single-stream pass).
 FETCH_SIZE / WRITE_SIZE are in KB; FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950.
@@ -20,7 +23,8 @@ FAMILIES = {
 }
 
 
-STEP_KERNEL = sys.argv[5] if len(sys.argv) > 5 and not sys.argv[5].isdigit() else 'k_rotate('
+BENCH_JSON = sys.argv[5] if len(sys.argv) > 5 and sys.argv[5].endswith('.json') else None
+STEP_KERNEL = sys.argv[5] if len(sys.argv) > 5 and not sys.argv[5].isdigit() and BENCH_JSON is None else 'k_rotate('
 
 
 def per_kernel(d, counter):
@@ -54,5 +58,14 @@ for fam in FAMILIES:
         out['per_launch'][fam] = {'fetch_bytes_reported': fb, 'fetch_bytes_corrected_x2': 2 * fb, 'write_bytes': wb,
                                   'launches': nf[fam], 'traffic_bytes': 2 * fb + wb,
                                   'unit': 'bytes per step (all launches of the family)' if fam == 'bcl' else 'bytes per launch'}
+if BENCH_JSON:
+    def census(doc):
+        c = {}
+        for k, v in doc.items():
+            if k.startswith('roofline') and isinstance(v, dict) and 'launches_per_step' in v:
+                c['top' if k == 'roofline' else k[len('roofline_'):]] = [v['kernel'][:24], v['launches_per_step']]
+        return c
+    line = [l for l in open(BENCH_JSON).read().splitlines() if l.startswith('{')][-1]
+    out['bench_launches_per_step'] = census(json.loads(line))
 json.dump(out, open(sys.argv[3], 'w'), indent=1)
 print(json.dumps(out['per_launch'], indent=1))
