@@ -5,7 +5,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, 'lib', 'libefgh_hip.so')
+SO_PATH = os.environ.get('EFGH_LIB') or os.path.join(_HERE, 'lib', 'libefgh_hip.so')      # EFGH_LIB: A/B runs of two builds
 _lib = None
 
 c_void_p, c_int, c_int32, c_int64, c_float = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int32,

@@ -30,7 +30,7 @@ void efgh_set_error(const char *fmt, ...);
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 // activation of the fused epilogues: v for v > 0, neg * v otherwise (neg = 1: none, 0: ReLU, slope: LeakyReLU) as one compare, one
-// select and one multiply - no branch.  A NaN stays a NaN under every activation (max / min would return their other operand
-// and turn a diverged pre-activation into a finite 0); ReLU(-inf) comes out as NaN as well, which is what a diverged network
-// should look like.
-__device__ __forceinline__ float act_neg(float v, float neg) { return v * (v > 0.f ? 1.f : neg); }
+// fma and one select - no branch.  A NaN stays a NaN under every activation (the max / min form max(v,0) + neg * min(v,0) returns
+// the other operand and turns a diverged pre-activation into a finite 0).  For every non-NaN input the result has the bits of
+// that form (neg * v + 0: a clamped value is +0, never -0).
+__device__ __forceinline__ float act_neg(float v, float neg) { return v > 0.f ? v : fmaf(neg, v, 0.f); }

@@ -435,7 +435,7 @@ k_gather_gemm(const KArgs p_in) {
 #pragma unroll
                 for (int j = 0; j < NI; ++j) {
                     float v = acc[i][j][r] + bi[j];
-                    if (FULL || cok[j]) { s1[j] += v; s2[j] += v * v; }
+                    if (FULL || cok[j]) { s1[j] += v; s2[j] = fmaf(v, v, s2[j]); }      // (explicit fma: the rounding must not follow the vectoriser)
                     v = v * sc[j] + sf[j];
                     if (RES) v += rv[j];
                     v = act_neg(v, neg);

@@ -245,7 +245,7 @@ __global__ void __launch_bounds__(256, 2) k_wino43(const WinoArgs p) {
             for (int i = 0; i < 4; ++i) {
                 if (!FULL && i >= cnt) continue;
                 float v = yv[i] + bi;
-                if (!bnm) { s1 += v; s2 += v * v; }
+                if (!bnm) { s1 += v; s2 = fmaf(v, v, s2); }
                 v = v * sc + sf;
                 if (RES) v += rv[i];
                 v = act_neg(v, neg);

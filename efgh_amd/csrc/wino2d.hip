@@ -268,7 +268,7 @@ k_w2_output(const W2OutArgs p) {
                 vec_t v = Y[a][x];
                 v.x += bi.x; v.y += bi.y;
                 s1.x += v.x; s1.y += v.y;
-                s2.x += v.x * v.x; s2.y += v.y * v.y;
+                s2.x = fmaf(v.x, v.x, s2.x); s2.y = fmaf(v.y, v.y, s2.y);
                 v.x = v.x * sc.x + sf.x; v.y = v.y * sc.y + sf.y;
                 if (p.residual) {
                     const vec_t r = *reinterpret_cast<const vec_t *>(p.residual + pix * p.ldr + col);

@@ -86,10 +86,13 @@ def test_reference_training_loop_with_stock_torch_adam(manifest):
             assert float((p - q).norm()) <= 1e-2 * float(q.norm()) + 1e-6, k
 
 
-def test_winograd_and_direct_kernels_give_the_same_first_training_step(manifest):
+def test_winograd_and_direct_kernels_give_the_same_first_training_step(manifest, monkeypatch):
     """the 3x3 layers on the Winograd kernels (forward, dgrad, wgrad) vs the same step on the direct kernels: same losses and
     the same per-sub-net gradients up to the conditioning bands of DESIGN.md §4 (the first step, before the trajectories can
-    diverge through the discontinuous heads)"""
+    diverge through the discontinuous heads).  The uint8 nearest-neighbour rotation of the camera image by H's own angle is
+    teacher-forced in the second run (as in test_gpu_backward / test_gpu_fullsize): a last-bit difference of the angle flips
+    pixels of h_img, i.e. changes F's INPUT by 0.2-0.5 % - that is the rotate's discontinuity, not a property of the kernels
+    compared here."""
     from efgh_amd import ops
     from efgh_amd.losses import EFGHCriterion
     from efgh_amd.nets import EFGHBackbone
@@ -105,10 +108,13 @@ def test_winograd_and_direct_kernels_give_the_same_first_training_step(manifest)
             m = EFGHBackbone(args)
             m.load_state_dict(syn.synthetic_state_dict(manifest['state_dict'], 1))
             tr = Trainer(m.cuda(), EFGHCriterion(args), lr=1e-3)
-            losses, _ = tr.step(*inp, gt)
+            losses, pred = tr.step(*inp, gt)
             names = [n for n, _ in m.named_parameters()]
-            res[wino] = ({k: float(v) for k, v in losses.items()},
+            res[wino] = ({k: float(v.detach()) for k, v in losses.items()},
                          {n: p.grad.detach().clone() for n, p in zip(names, tr.flat.params)})
+            if wino:
+                h_img = pred['h_img'].detach().clone()
+                monkeypatch.setattr(ops, 'rotate_nearest_u8', lambda img, rot, **kw: (h_img, ops.nchw_to_nhwc(h_img, 4)))
         finally:
             ops.USE_WINO = ops.USE_WINO_WGRAD = ops.USE_WINO2D = True
     for k, v in res[True][0].items():
