@@ -52,6 +52,8 @@ def lib():
         _lib.efgh_wino_wgrad_workspace.restype = c_int64
         _lib.efgh_sc_wgrad_workspace.restype = c_int64
         _lib.efgh_c4n4_wgrad_workspace.restype = c_int64
+        _lib.efgh_c4_wgrad_workspace.restype = c_int64
+        _lib.efgh_thin_wgrad_workspace.restype = c_int64
         _lib.efgh_lattice_hash_capacity.restype = c_int64
         _lib.efgh_lattice_hash_capacity.argtypes = [c_int32]
         _lib.efgh_lattice_workspace_bytes.restype = c_int64

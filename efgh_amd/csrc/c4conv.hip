@@ -13,6 +13,8 @@
 // combined with fp32 atomics.
 #include "common.h"
 
+void efgh_launch_fold_splits(const float *part, int zs, long long total, float *dst, hipStream_t st);   // wgrad.hip
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -283,7 +285,9 @@ __global__ void __launch_bounds__(64 * WAVES) k_c4_wgrad(const C4Args p) {
     }
 #undef EFGH_FETCH
 #undef EFGH_PUT
-    // acc[a][c][e]: n = 16a + 4*(lane>>4) + e, column = 16c + (lane&15)
+    // acc[a][c][e]: n = 16a + 4*(lane>>4) + e, column = 16c + (lane&15).  Every wave leaves its own partial [N][36] plane (a
+    // wave without units leaves zeros); efgh_c4_wgrad folds the planes in wave order: no atomics, bit-reproducible run to run
+    float *plane = p.dW + ((long long)blockIdx.x * WAVES + wave) * (16 * NT16 * 36);
 #pragma unroll
     for (int a = 0; a < NT16; ++a)
 #pragma unroll
@@ -291,7 +295,7 @@ __global__ void __launch_bounds__(64 * WAVES) k_c4_wgrad(const C4Args p) {
             if (!cok[c]) continue;
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                atomicAdd(p.dW + (long long)(16 * a + 4 * k4 + e) * 36 + 16 * c + q16, acc[a][c][e]);
+                plane[(16 * a + 4 * k4 + e) * 36 + 16 * c + q16] = acc[a][c][e];
         }
 }
 
@@ -353,16 +357,21 @@ extern "C" int efgh_c4_wgrad_supported(const efgh_gemm_desc *d) {
     return (c4_geometry_ok(d) && d->N % 16 == 0 && d->N >= 32 && d->N <= 128) ? 1 : 0;
 }
 
-extern "C" int efgh_c4_wgrad(const efgh_gemm_desc *d, const float *G, int64_t ldg, float *dWp, void *stream_) {
-    hipStream_t st = (hipStream_t)stream_;
-    EFGH_CHECK_ARG(efgh_c4_wgrad_supported(d) && G && dWp && ldg >= d->N);
+/* floats of scratch efgh_c4_wgrad needs: one partial [N][36] plane per wave of the launch */
+extern "C" int64_t efgh_c4_wgrad_workspace(const efgh_gemm_desc *d) {
+    if (!efgh_c4_wgrad_supported(d)) return 0;
     C4Args a;
     fill(a, d);
-    a.G = G; a.ldg = ldg; a.dW = dWp;
-    if (hipMemsetAsync(dWp, 0, (size_t)d->N * 36 * 4, st) != hipSuccess) {
-        efgh_set_error("c4 wgrad: memset failed");
-        return EFGH_E_LAUNCH;
-    }
+    return (int64_t)grid_of(a.units) * WAVES * d->N * 36;
+}
+
+extern "C" int efgh_c4_wgrad(const efgh_gemm_desc *d, const float *G, int64_t ldg, float *dWp, float *workspace, void *stream_) {
+    hipStream_t st = (hipStream_t)stream_;
+    EFGH_CHECK_ARG(efgh_c4_wgrad_supported(d) && G && dWp && ldg >= d->N);
+    EFGH_CHECK_ARG(workspace && (((uintptr_t)workspace) & 15) == 0 && (((uintptr_t)dWp) & 15) == 0);
+    C4Args a;
+    fill(a, d);
+    a.G = G; a.ldg = ldg; a.dW = workspace;
     const int grid = grid_of(a.units);
     switch (d->N / 16) {
     case 2: k_c4_wgrad<2><<<grid, 256, 0, st>>>(a); break;
@@ -373,6 +382,7 @@ extern "C" int efgh_c4_wgrad(const efgh_gemm_desc *d, const float *G, int64_t ld
     case 7: k_c4_wgrad<7><<<grid, 256, 0, st>>>(a); break;
     default: k_c4_wgrad<8><<<grid, 256, 0, st>>>(a); break;
     }
+    efgh_launch_fold_splits(workspace, grid * WAVES, (long long)d->N * 36, dWp, st);
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
 }

@@ -443,17 +443,18 @@ k_c4n4_wgrad3x3(const TArgs p, float *part) {
         part[blk * 144 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
-// ---- wgrad, C == 4:  dW[n][t][0..3] += sum_m G[orow(m)][n] * A[row(m,t)][0..3] -----------------------
-// thread = (row lane, n-quad); 16*T accumulators; block-level LDS reduction, then global atomics.
+// ---- wgrad, C == 4:  dW[n][t][0..3] = sum_m G[orow(m)][n] * A[row(m,t)][0..3] -----------------------
+// thread = (row lane, n-quad), the n-quads (a power of two) fastest; 16*T accumulators.  No atomics: the row lanes of a wave are
+// summed by a shuffle butterfly (fixed shape), the four waves in LDS in wave order, and every workgroup leaves its own partial
+// [N][T][4] plane in `p.dW` (= the workspace); efgh_thin_wgrad folds the planes in workgroup order.
 template <int T>
 __global__ void __launch_bounds__(TPB)
 k_thin_c4_wgrad(const TArgs p) {
-    extern __shared__ float red[];                                      // N*T*4 floats
-    const int nq = p.N >> 2;                                            // n-quads (<= 64)
+    extern __shared__ float red[];                                      // [4 waves][N*T*4]
+    const int nq = p.N >> 2;                                            // n-quads: 1, 2, 4, ... 64
     const int RL = TPB / nq;                                            // row lanes
     const int q = threadIdx.x % nq, rl = threadIdx.x / nq;
-    for (int i = threadIdx.x; i < p.N * T * 4; i += TPB) red[i] = 0.f;
-    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float acc[4][T][4];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
@@ -464,39 +465,45 @@ k_thin_c4_wgrad(const TArgs p) {
     const long long mbeg = (long long)blockIdx.x * p.mchunk;
     long long mend = mbeg + p.mchunk;
     if (mend > p.M) mend = p.M;
-    if (rl < RL)
-        for (long long m = mbeg + rl; m < mend; m += RL) {
-            int i, j; long long b;
-            decode(p, m, i, j, b);
-            float4 g = *reinterpret_cast<const float4 *>(p.G + out_row(p, i, j, b) * p.ldg + q * 4);
-            const float gv[4] = {g.x, g.y, g.z, g.w};
+    for (long long m = mbeg + rl; m < mend; m += RL) {
+        int i, j; long long b;
+        decode(p, m, i, j, b);
+        float4 g = *reinterpret_cast<const float4 *>(p.G + out_row(p, i, j, b) * p.ldg + q * 4);
+        const float gv[4] = {g.x, g.y, g.z, g.w};
 #pragma unroll
-            for (int t = 0; t < T; ++t) {
-                long long r = in_row(p, i, j, b, t);
-                if (r < 0) continue;
-                float4 a = *reinterpret_cast<const float4 *>(p.A + r * p.lda);
-                const float av[4] = {a.x, a.y, a.z, a.w};
+        for (int t = 0; t < T; ++t) {
+            long long r = in_row(p, i, j, b, t);
+            if (r < 0) continue;
+            float4 a = *reinterpret_cast<const float4 *>(p.A + r * p.lda);
+            const float av[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
-                for (int nn = 0; nn < 4; ++nn)
+            for (int nn = 0; nn < 4; ++nn)
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) acc[nn][t][c] += gv[nn] * av[c];
-            }
+                for (int c = 0; c < 4; ++c) acc[nn][t][c] += gv[nn] * av[c];
         }
-    if (rl < RL) {
-#pragma unroll
-        for (int nn = 0; nn < 4; ++nn)
-#pragma unroll
-            for (int t = 0; t < T; ++t)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) atomicAdd(&red[((q * 4 + nn) * T + t) * 4 + c], acc[nn][t][c]);
     }
+    const int plane = p.N * T * 4;
+#pragma unroll
+    for (int nn = 0; nn < 4; ++nn)
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float v = acc[nn][t][c];
+                for (int o = 32; o >= nq; o >>= 1) v += __shfl_xor(v, o);          // lanes nq apart hold the same n-quad
+                if (lane < nq) red[wave * plane + ((q * 4 + nn) * T + t) * 4 + c] = v;
+            }
     __syncthreads();
-    for (int i = threadIdx.x; i < p.N * T * 4; i += TPB) atomicAdd(&p.dW[i], red[i]);
+    float *out = p.dW + (long long)blockIdx.x * plane;
+    for (int i = threadIdx.x; i < plane; i += TPB)
+        out[i] = (red[i] + red[plane + i]) + (red[2 * plane + i] + red[3 * plane + i]);
 }
 
-// ---- wgrad, N == 4:  dW[n][k] += sum_m G[orow(m)][n] * A[row(m,t)][c]; thread = (row lane, k-quad) ----
+// ---- wgrad, N == 4:  dW[n][k] = sum_m G[orow(m)][n] * A[row(m,t)][c]; thread = (row lane, k-quad).  No atomics: the row lanes
+// are summed through LDS in row-lane order, every workgroup leaves its partial [4][K] plane in `p.dW` (= the workspace)
 __global__ void __launch_bounds__(TPB)
 k_thin_n4_wgrad(const TArgs p) {
+    __shared__ float red[TPB * 16];
     const int kq = p.K >> 2;                       // k-quads
     const int KL = kq < TPB ? kq : TPB;            // k lanes per block row-lane group
     const int RL = TPB / KL;
@@ -505,14 +512,16 @@ k_thin_n4_wgrad(const TArgs p) {
     const long long mbeg = (long long)blockIdx.x * p.mchunk;
     long long mend = mbeg + p.mchunk;
     if (mend > p.M) mend = p.M;
-    for (int k4 = kl; k4 < kq; k4 += KL) {          // usually one pass (K <= 1024)
-        const int t = k4 / c4n, c = k4 - t * c4n;
+    float *out = p.dW + (long long)blockIdx.x * 4 * p.K;
+    for (int k0 = 0; k0 < kq; k0 += KL) {           // usually one pass (K <= 1024)
+        const int k4 = k0 + kl;
         float acc[4][4];
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
             for (int b = 0; b < 4; ++b) acc[a][b] = 0.f;
-        if (rl < RL)
+        if (rl < RL && k4 < kq) {
+            const int t = k4 / c4n, c = k4 - t * c4n;
             for (long long m = mbeg + rl; m < mend; m += RL) {
                 int i, j; long long b;
                 decode(p, m, i, j, b);
@@ -526,12 +535,22 @@ k_thin_n4_wgrad(const TArgs p) {
 #pragma unroll
                     for (int cc = 0; cc < 4; ++cc) acc[nn][cc] += gv[nn] * av[cc];
             }
-        if (rl < RL) {
+        }
+        __syncthreads();                            // (the previous pass has read red)
+#pragma unroll
+        for (int nn = 0; nn < 4; ++nn)
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) red[(nn * 4 + cc) * TPB + threadIdx.x] = acc[nn][cc];
+        __syncthreads();
+        if (rl == 0 && k4 < kq) {
 #pragma unroll
             for (int nn = 0; nn < 4; ++nn)
 #pragma unroll
-                for (int cc = 0; cc < 4; ++cc)
-                    atomicAdd(&p.dW[(long long)nn * p.K + k4 * 4 + cc], acc[nn][cc]);
+                for (int cc = 0; cc < 4; ++cc) {
+                    float v = 0.f;
+                    for (int r2 = 0; r2 < RL; ++r2) v += red[(nn * 4 + cc) * TPB + r2 * KL + kl];
+                    out[(long long)nn * p.K + k4 * 4 + cc] = v;
+                }
         }
     }
 }
@@ -619,24 +638,39 @@ extern "C" int efgh_thin_gemm(const efgh_gemm_desc *d, void *stream_) {
     return EFGH_OK;
 }
 
-extern "C" int efgh_thin_wgrad(const efgh_gemm_desc *d, const float *G, int64_t ldg, float *dWp, void *stream_) {
+namespace {
+int thin_wgrad_grid(const efgh_gemm_desc *d, long long *chunk_out) {
+    long long chunk = (d->M + 2047) / 2048;
+    if (chunk < 512) chunk = 512;
+    if (chunk_out) *chunk_out = chunk;
+    return (int)((d->M + chunk - 1) / chunk);
+}
+bool thin_wgrad_c4(const efgh_gemm_desc *d) {
+    const int nq = d->N >> 2;
+    return d->C == 4 && d->N <= 256 && !(nq & (nq - 1)) && (d->T == 9 || d->T == 2 || d->T == 1 || d->T == 4) &&
+           (size_t)d->N * d->T * 64 <= 60 * 1024;
+}
+}  // namespace
+
+/* floats of scratch efgh_thin_wgrad needs: one partial [N][K] plane per workgroup, folded in workgroup order (no atomics) */
+extern "C" int64_t efgh_thin_wgrad_workspace(const efgh_gemm_desc *d) {
+    if (!d || d->mode != 1 || d->M < 1 || d->N < 4 || d->C < 4 || d->T < 1) return 0;
+    return (int64_t)thin_wgrad_grid(d, nullptr) * d->N * d->T * d->C;
+}
+
+extern "C" int efgh_thin_wgrad(const efgh_gemm_desc *d, const float *G, int64_t ldg, float *dWp, float *workspace, void *stream_) {
     hipStream_t st = (hipStream_t)stream_;
     EFGH_CHECK_ARG(d && G && dWp && d->mode == 1 && d->N % 4 == 0 && d->C % 4 == 0 && ldg % 4 == 0);
     EFGH_CHECK_ARG(d->M == (int64_t)d->B * d->Hv * d->Wv);
+    EFGH_CHECK_ARG(workspace && (((uintptr_t)workspace) & 15) == 0 && (((uintptr_t)dWp) & 15) == 0);
     TArgs a;
     fill(a, d);
-    a.G = G; a.ldg = ldg; a.dW = dWp;
-    if (hipMemsetAsync(dWp, 0, (size_t)a.N * a.K * 4, st) != hipSuccess) {
-        efgh_set_error("thin wgrad: memset failed");
-        return EFGH_E_LAUNCH;
-    }
-    long long chunk = (a.M + 2047) / 2048;
-    if (chunk < 512) chunk = 512;
+    a.G = G; a.ldg = ldg; a.dW = workspace;
+    long long chunk = 0;
+    const int grid = thin_wgrad_grid(d, &chunk);
     a.mchunk = (int)chunk;
-    int grid = (int)((a.M + chunk - 1) / chunk);
-    if (d->C == 4 && d->N <= 256 && (d->T == 9 || d->T == 2 || d->T == 1 || d->T == 4)) {
-        size_t lds = (size_t)a.N * a.T * 16;
-        EFGH_CHECK_ARG(lds <= 60 * 1024);
+    if (thin_wgrad_c4(d)) {
+        const size_t lds = (size_t)a.N * a.T * 64;
         if (d->T == 9) k_thin_c4_wgrad<9><<<grid, TPB, lds, st>>>(a);
         else if (d->T == 4) k_thin_c4_wgrad<4><<<grid, TPB, lds, st>>>(a);
         else if (d->T == 2) k_thin_c4_wgrad<2><<<grid, TPB, lds, st>>>(a);
@@ -647,6 +681,7 @@ extern "C" int efgh_thin_wgrad(const efgh_gemm_desc *d, const float *G, int64_t 
         efgh_set_error("thin wgrad: unsupported shape C=%d N=%d T=%d", d->C, d->N, d->T);
         return EFGH_E_INVALID;
     }
+    efgh_launch_fold_splits(workspace, grid, (long long)a.N * a.K, dWp, st);
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
 }

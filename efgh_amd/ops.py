@@ -920,7 +920,7 @@ def side_streams():
     """every side stream this package has created (branch streams of the backbone + the weight-gradient stream)"""
     from .nets import efghbackbone as bb
     return list(bb._SIDE.values())
-DETERMINISTIC = _os.environ.get('EFGH_DETERMINISTIC', '0') == '1'
+DETERMINISTIC = _os.environ.get('EFGH_DETERMINISTIC', '0') == '1'      # (kept for callers that set it; a no-op since round 4: see gather_wgrad)
 
 
 def _scratch(nfloats, device):
@@ -949,10 +949,11 @@ def gather_wgrad(A, lda, C, T, N, M, G, ldg, dWp, mode=0, geom=None, table=None)
             d.dh[i], d.dw[i] = a, b
     d.table = 0 if table is None else table.data_ptr()
     d.N, d.M = N, M
-    # EFGH_DETERMINISTIC=1: the handful of layers whose weight gradient still combines partial sums with fp32 atomics (4-channel
-    # input convolutions, 1-/2-channel heads: 5 of 353 parameters) go through the generic kernel, whose row-chunk partials are
-    # added in a fixed order - every gradient of a training step is then bit-reproducible run to run
-    thin = thin_eligible(mode, C, N, T) and (N == 4 or T in (1, 2, 4, 9)) and not DETERMINISTIC
+    # (round 4: no weight-gradient kernel combines partial sums with atomics any more - the thin and the stride-2 4-channel kernels
+    # leave per-workgroup / per-wave partial planes that are folded in a fixed order, like every other one: all 353 gradients of a
+    # training step are bit-reproducible run to run by default, and EFGH_DETERMINISTIC has nothing left to switch)
+    nq = N // 4
+    thin = thin_eligible(mode, C, N, T) and (N == 4 or (T in (1, 2, 4, 9) and nq & (nq - 1) == 0))
     wino = False
     if (C == 4 and N == 4 and T == 9 and mode == 1 and lda % 4 == 0 and ldg % 4 == 0 and dWp.data_ptr() % 16 == 0
             and _L().efgh_c4n4_supported(ctypes.byref(d))):
@@ -962,7 +963,8 @@ def gather_wgrad(A, lda, C, T, N, M, G, ldg, dWp, mode=0, geom=None, table=None)
         _C.check(_L().efgh_c4n4_wgrad(ctypes.byref(d), ptr(G), c_int64(ldg), ptr(dWp),
                                       ptr(_scratch(_L().efgh_c4n4_wgrad_workspace(ctypes.byref(d)), dWp.device)), _st()))
     elif thin:
-        _C.check(_L().efgh_thin_wgrad(ctypes.byref(d), ptr(G), c_int64(ldg), ptr(dWp), _st()))
+        _C.check(_L().efgh_thin_wgrad(ctypes.byref(d), ptr(G), c_int64(ldg), ptr(dWp),
+                                      ptr(_scratch(_L().efgh_thin_wgrad_workspace(ctypes.byref(d)), dWp.device)), _st()))
     elif (USE_SMALLC and C == 4 and N in (32, 64) and lda % 4 == 0 and ldg % 4 == 0 and d.A % 16 == 0 and G.data_ptr() % 16 == 0
           and geom is not None and geom[5] == 1 and sc_eligible(mode, 16, 16, geom, wgrad=True)):
         # 4-channel input layers at stride 1: the small-channel weight-gradient kernel (G staged by 16-byte loads, per-wave partial
@@ -970,9 +972,10 @@ def gather_wgrad(A, lda, C, T, N, M, G, ldg, dWp, mode=0, geom=None, table=None)
         thin = True             # (profile lists: an HBM-bound launch)
         _C.check(_L().efgh_sc_wgrad(ctypes.byref(d), ptr(G), c_int64(ldg), ptr(dWp),
                                     ptr(_scratch(_L().efgh_sc_wgrad_workspace(ctypes.byref(d)), dWp.device)), _st()))
-    elif not DETERMINISTIC and c4_eligible(mode, C, N, geom, wgrad=True):
+    elif c4_eligible(mode, C, N, geom, wgrad=True):
         thin = True             # (profile lists, as above)
-        _C.check(_L().efgh_c4_wgrad(ctypes.byref(d), ptr(G), c_int64(ldg), ptr(dWp), _st()))
+        _C.check(_L().efgh_c4_wgrad(ctypes.byref(d), ptr(G), c_int64(ldg), ptr(dWp),
+                                    ptr(_scratch(_L().efgh_c4_wgrad_workspace(ctypes.byref(d)), dWp.device)), _st()))
     elif sc_eligible(mode, C, N, geom, wgrad=True) and lda % 4 == 0 and ldg % 4 == 0 and d.A % 16 == 0 and G.data_ptr() % 16 == 0:
         _C.check(_L().efgh_sc_wgrad(ctypes.byref(d), ptr(G), c_int64(ldg), ptr(dWp),
                                     ptr(_scratch(_L().efgh_sc_wgrad_workspace(ctypes.byref(d)), dWp.device)), _st()))

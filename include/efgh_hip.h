@@ -418,7 +418,10 @@ int efgh_adam_step(float *w, const float *g, float *m, float *v, int64_t n, floa
  * (64 channels, 3x3, stride 1, pad 1: k_n4_conv3x3_c64), 4 = the 4 -> 4 channel 3x3 stencil (k_c4n4_conv3x3). */
 int efgh_thin_supported(const efgh_gemm_desc *d);
 int efgh_thin_gemm(const efgh_gemm_desc *d, void *stream);
-int efgh_thin_wgrad(const efgh_gemm_desc *d, const float *G, int64_t ldg, float *dWp, void *stream);
+/* weight gradient of the same thin layers (C == 4 with N/4 a power of two and T in {1, 2, 4, 9}; or N == 4): no atomics - every
+ * workgroup leaves a partial [N][T*C] plane in `workspace` (efgh_thin_wgrad_workspace floats), folded in a fixed order into dWp. */
+int64_t efgh_thin_wgrad_workspace(const efgh_gemm_desc *d);
+int efgh_thin_wgrad(const efgh_gemm_desc *d, const float *G, int64_t ldg, float *dWp, float *workspace, void *stream);
 /* 4 -> 4 channels (the 1- / 2-channel convolutions behind G's transposed heads, gnet.py:56-68), 3x3, stride 1, pad 1: weight gradient
  * without atomics - one partial [4][9][4] plane per workgroup in `workspace` (efgh_c4n4_wgrad_workspace floats), folded in a fixed
  * order into dWp. */
@@ -430,7 +433,8 @@ int efgh_c4n4_wgrad(const efgh_gemm_desc *d, const float *G, int64_t ldg, float 
  * depth input layers: nets/vgg.py:77 first conv, nets/gnet.py:21,80; and the data gradient of G's transposed heads): the three
  * input rows of 128 output pixels are staged in LDS once, the 36 x N weights stay in registers of a persistent workgroup.  Same
  * descriptor and epilogue as efgh_gather_gemm; `stats` has efgh_c4_stats_rows(B, Ho, Wo) rows.  efgh_c4_wgrad: the weight
- * gradient dWp [N][9][4] of the same layers (N % 16 == 0, 32 <= N <= 128) on v_mfma_f32_16x16x4_f32, G [M][ldg] read once.      */
+ * gradient dWp [N][9][4] of the same layers (N % 16 == 0, 32 <= N <= 128) on v_mfma_f32_16x16x4_f32, G [M][ldg] read once; one
+ * partial plane per wave in `workspace` (efgh_c4_wgrad_workspace floats), folded in a fixed order: no atomics.                  */
 /* 3x3 / stride-1 / pad-1 layers with 16 or 32 channels on both sides (csrc/smallc.hip: F's up-sampling stages, nets/fnet.py:22-31):
  * same descriptor and epilogue as efgh_gather_gemm, W packed [N][9][C]; `stats` has efgh_sc_stats_rows(B, H, W) rows.
  * efgh_sc_wgrad: dWp [N][9][C], workspace of efgh_sc_wgrad_workspace(d) floats (one partial plane per wave, folded in a fixed
@@ -445,7 +449,8 @@ int efgh_c4_supported(const efgh_gemm_desc *d);
 int32_t efgh_c4_stats_rows(int32_t B, int32_t Ho, int32_t Wo);
 int efgh_c4_conv3x3(const efgh_gemm_desc *d, void *stream);
 int efgh_c4_wgrad_supported(const efgh_gemm_desc *d);
-int efgh_c4_wgrad(const efgh_gemm_desc *d, const float *G, int64_t ldg, float *dWp, void *stream);
+int64_t efgh_c4_wgrad_workspace(const efgh_gemm_desc *d);
+int efgh_c4_wgrad(const efgh_gemm_desc *d, const float *G, int64_t ldg, float *dWp, float *workspace, void *stream);
 
 /* split-bf16 variant of efgh_gather_gemm: every fp32 operand x is used as hi+lo (two bf16 numbers,
  * |x-hi-lo| <= 2^-17|x|) and each product as ah*bh + ah*bl + al*bh on v_mfma_f32_32x32x16_bf16 with fp32

@@ -371,10 +371,10 @@ def test_training_step_is_not_torch_glue(manifest):
 
 
 def test_gradients_are_reproducible_run_to_run(manifest):
-    """weight gradients add their row-chunk partials in a fixed order (no fp32 atomics in the contraction kernels, none at all in the
-    BCL): two backward passes from the same weights give bit-identical gradients - all 353 with EFGH_DETERMINISTIC; by default all
-    but two (F.conv_range and G.conv_d1: the (1,2)-kernel and the stride-2 4-channel input layers, whose weight-gradient kernels
-    still combine workgroup sums with atomics; tools/check_default_determinism.py lists them)"""
+    """weight gradients add their partial sums in a fixed order - no fp32 atomics in any contraction kernel (since round 4 also the
+    thin (1,2)-kernel layer F.conv_range and the stride-2 4-channel input layer G.conv_d1: per-workgroup / per-wave planes + fold),
+    none at all in the BCL: two backward passes from the same weights give bit-identical gradients, all 353, with the default
+    settings; EFGH_DETERMINISTIC is a no-op (tools/check_default_determinism.py lists any that differ)"""
     from efgh_amd import ops
     from efgh_amd.losses import EFGHCriterion
     from efgh_amd.nets import EFGHBackbone
@@ -397,7 +397,7 @@ def test_gradients_are_reproducible_run_to_run(manifest):
         return {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
     old = ops.DETERMINISTIC
     try:
-        for flag, allowed in ((True, 0), (False, 2)):
+        for flag, allowed in ((True, 0), (False, 0)):
             ops.DETERMINISTIC = flag
             a, c = grads(), grads()
             differ = [n for n in a if not torch.equal(a[n], c[n])]
