@@ -6,6 +6,13 @@
 namespace {
 constexpr int TPB = 256;
 
+// the sign bits efgh_scale_shift_act_bits left (bit e = element e of the [M][C] activation is > 0) as a stand-in for the activation:
+// +1 / -1 for the four channels of a quad (C % 32 == 0: a quad never straddles a word)
+__device__ __forceinline__ float4 sign4(const unsigned *__restrict__ bits, long long e) {
+    const unsigned w = bits[e >> 5] >> ((unsigned)e & 31u);
+    return make_float4((w & 1u) ? 1.f : -1.f, (w & 2u) ? 1.f : -1.f, (w & 4u) ? 1.f : -1.f, (w & 8u) ? 1.f : -1.f);
+}
+
 __device__ __forceinline__ float dact(float y, int act, float slope) {
     if (act == 1) return y > 0.f ? 1.f : 0.f;
     if (act == 2) return y > 0.f ? 1.f : slope;
@@ -20,7 +27,7 @@ k_act_bn_bwd_reduce(const float *__restrict__ dy, long long lddy, const float *_
                     const float *__restrict__ raw, long long ldraw, const float *__restrict__ mean,
                     const float *__restrict__ invstd, const float *__restrict__ pscale,
                     const float *__restrict__ pshift, long long M, int C, int act, float slope, int rows_per_block,
-                    int CL, double *__restrict__ part) {
+                    int CL, double *__restrict__ part, const unsigned *__restrict__ ybits) {
     // The column sums are accumulated in float64 (as torch's CPU batch-norm backward does, acc_type<float> = double):
     // mean(dpre) and mean(dpre*xhat) are subtracted from EVERY row, so a 1e-7 relative error in them is a systematic
     // bias of draw that the following weight gradient multiplies by the channel mean of the layer input - with nearly
@@ -34,13 +41,15 @@ k_act_bn_bwd_reduce(const float *__restrict__ dy, long long lddy, const float *_
     if (c < C) {
         float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), is = mu, psc = mu, psh = mu;
         if (mean) { mu = *reinterpret_cast<const float4 *>(mean + c); is = *reinterpret_cast<const float4 *>(invstd + c); }
-        if (!y) { psc = *reinterpret_cast<const float4 *>(pscale + c); psh = *reinterpret_cast<const float4 *>(pshift + c); }
+        const bool from_raw = !y && !ybits;
+        if (from_raw) { psc = *reinterpret_cast<const float4 *>(pscale + c); psh = *reinterpret_cast<const float4 *>(pshift + c); }
         for (long long r = r0 + rl; r < r1; r += RL) {
             float4 g = *reinterpret_cast<const float4 *>(dy + r * lddy + c);
             float4 rw = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (mean || !y) rw = *reinterpret_cast<const float4 *>(raw + r * ldraw + c);
+            if (mean || from_raw) rw = *reinterpret_cast<const float4 *>(raw + r * ldraw + c);
             float4 yy;
-            if (y) yy = *reinterpret_cast<const float4 *>(y + r * ldy + c);
+            if (ybits) yy = sign4(ybits, r * C + c);       // (1 bit per element instead of a second read of the activation)
+            else if (y) yy = *reinterpret_cast<const float4 *>(y + r * ldy + c);
             else yy = make_float4(rw.x * psc.x + psh.x, rw.y * psc.y + psh.y, rw.z * psc.z + psh.z, rw.w * psc.w + psh.w);
             g.x *= dact(yy.x, act, slope); g.y *= dact(yy.y, act, slope);
             g.z *= dact(yy.z, act, slope); g.w *= dact(yy.w, act, slope);
@@ -105,16 +114,18 @@ k_act_bn_bwd_apply(const float *__restrict__ dy, long long lddy, const float *__
                    const double *__restrict__ m1, const double *__restrict__ m2, const float *__restrict__ pscale,
                    const float *__restrict__ pshift, long long M, int C, int act,
                    float slope, float *__restrict__ draw, long long lddraw, float *__restrict__ dres,
-                   long long lddres) {
+                   long long lddres, const unsigned *__restrict__ ybits) {
     const int c4n = C >> 2;
     long long total = M * c4n;
+    const bool from_raw = !y && !ybits;
     for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
         long long r = i / c4n; int c = (int)(i - r * c4n) * 4;
         float4 g = *reinterpret_cast<const float4 *>(dy + r * lddy + c);
         float4 rw = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (mean || !y) rw = *reinterpret_cast<const float4 *>(raw + r * ldraw + c);
+        if (mean || from_raw) rw = *reinterpret_cast<const float4 *>(raw + r * ldraw + c);
         float4 yy;
-        if (y) yy = *reinterpret_cast<const float4 *>(y + r * ldy + c);
+        if (ybits) yy = sign4(ybits, r * C + c);
+        else if (y) yy = *reinterpret_cast<const float4 *>(y + r * ldy + c);
         else yy = make_float4(rw.x * pscale[c] + pshift[c], rw.y * pscale[c + 1] + pshift[c + 1],
                               rw.z * pscale[c + 2] + pshift[c + 2], rw.w * pscale[c + 3] + pshift[c + 3]);
         float gv[4] = {g.x * dact(yy.x, act, slope), g.y * dact(yy.y, act, slope), g.z * dact(yy.z, act, slope),
@@ -481,11 +492,16 @@ extern "C" int efgh_act_bn_bwd_reduce(const float *dy, int64_t lddy, const float
     EFGH_CHECK_ARG(y || (raw && pscale && pshift));
     EFGH_CHECK_ARG(!mean || (raw && invstd));
     EFGH_CHECK_ARG(lddy % 4 == 0 && ldy % 4 == 0 && (!mean || ldraw % 4 == 0));
+    const unsigned *ybits = nullptr;
+    if (y && ldy == 0) {                 // y = the sign bits of the activation (efgh_scale_shift_act_bits)
+        EFGH_CHECK_ARG(C % 32 == 0);
+        ybits = (const unsigned *)y; y = nullptr;
+    }
     int G = efgh_bwd_groups(M);
     int CL = 1;
     while (CL < 64 && CL * 4 < C) CL <<= 1;
     k_act_bn_bwd_reduce<<<dim3(cdiv(C / 4, CL), G), TPB, 0, st>>>(dy, lddy, y, ldy, raw, ldraw, mean, invstd, pscale,
-                                                                 pshift, M, C, act, slope, (int)bwd_rows_per_block(M), CL, part);
+                                                                 pshift, M, C, act, slope, (int)bwd_rows_per_block(M), CL, part, ybits);
     k_bwd_finalize<<<cdiv(C, 32), dim3(32, 32), 0, st>>>(part, G, C, (double)M, sum_dpre, sum_dpre_xhat, mean_dpre,
                                                          mean_dpre_xhat);
     EFGH_CHECK_LAUNCH();
@@ -538,9 +554,14 @@ extern "C" int efgh_act_bn_bwd_apply(const float *dy, int64_t lddy, const float 
     EFGH_CHECK_ARG(y || (raw && pscale && pshift && ldraw % 4 == 0));
     EFGH_CHECK_ARG(lddy % 4 == 0 && ldy % 4 == 0 && (!draw || lddraw % 4 == 0) && (!dres || lddres % 4 == 0));
     EFGH_CHECK_ARG(!mean || (raw && invstd && coef && m1 && m2 && ldraw % 4 == 0));
+    const unsigned *ybits = nullptr;
+    if (y && ldy == 0) {                 // y = the sign bits of the activation (efgh_scale_shift_act_bits)
+        EFGH_CHECK_ARG(C % 32 == 0);
+        ybits = (const unsigned *)y; y = nullptr;
+    }
     k_act_bn_bwd_apply<<<grid_for(M * (C / 4)), TPB, 0, (hipStream_t)stream_>>>(
         dy, lddy, y, ldy, raw, ldraw, mean, invstd, coef, m1, m2, pscale, pshift, M, C, act, slope, draw, lddraw, dres,
-        lddres);
+        lddres, ybits);
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
 }

@@ -93,11 +93,14 @@ k_col_stats(const float *__restrict__ x, long long M, int C, long long ld, int r
     *reinterpret_cast<float4 *>(&stats[((long long)blockIdx.y * 2 + 1) * C + c]) = q;
 }
 
-// y[r][c] = act(x[r][c]*scale[c] + shift[c] + res[r][c]); vector of 4 channels per thread
+// y[r][c] = act(x[r][c]*scale[c] + shift[c] + res[r][c]); vector of 4 channels per thread.
+// BITS: also leaves bit e = (y > 0) of element e = r*C + c in `bits` (C % 32 == 0: eight consecutive lanes hold one 32-bit word) - the
+// activation mask the BatchNorm backward of a RESIDUAL layer needs, at 1/32 of the bytes of reading the activation back twice
+template <bool BITS>
 __global__ void __launch_bounds__(TPB)
 k_scale_shift_act(const float *__restrict__ x, long long ldx, const float *__restrict__ scale,
                   const float *__restrict__ shift, const float *__restrict__ res, long long ldr,
-                  float *__restrict__ y, long long ldy, long long M, int C, int act, float slope) {
+                  float *__restrict__ y, long long ldy, long long M, int C, int act, float slope, unsigned *__restrict__ bits) {
     const int c4 = C >> 2;
     long long total = M * c4;
     for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
@@ -113,6 +116,13 @@ k_scale_shift_act(const float *__restrict__ x, long long ldx, const float *__res
         v.x = act_f(v.x, act, slope); v.y = act_f(v.y, act, slope);
         v.z = act_f(v.z, act, slope); v.w = act_f(v.w, act, slope);
         *reinterpret_cast<float4 *>(y + r * ldy + c) = v;
+        if (BITS) {
+            // (total % 8 == 0 and the loop advances all lanes together: the eight lanes of a word are active together)
+            unsigned w = ((v.x > 0.f) ? 1u : 0u) | ((v.y > 0.f) ? 2u : 0u) | ((v.z > 0.f) ? 4u : 0u) | ((v.w > 0.f) ? 8u : 0u);
+            w <<= 4 * (threadIdx.x & 7);
+            w |= __shfl_xor(w, 1); w |= __shfl_xor(w, 2); w |= __shfl_xor(w, 4);
+            if ((threadIdx.x & 7) == 0) bits[i >> 3] = w;
+        }
     }
 }
 
@@ -299,11 +309,24 @@ extern "C" int efgh_scale_shift_act(const float *x, int64_t ldx, const float *sc
     bool vec = (C % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && (!res || ldr % 4 == 0) &&
                ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)res) | ((uintptr_t)scale) | ((uintptr_t)shift)) & 15) == 0;
     if (vec)
-        k_scale_shift_act<<<grid_for(M * (C / 4)), TPB, 0, (hipStream_t)stream>>>(x, ldx, scale, shift, res, ldr,
-                                                                               y, ldy, M, C, act, slope);
+        k_scale_shift_act<false><<<grid_for(M * (C / 4)), TPB, 0, (hipStream_t)stream>>>(x, ldx, scale, shift, res, ldr,
+                                                                                      y, ldy, M, C, act, slope, nullptr);
     else
         k_scale_shift_act1<<<grid_for(M * C), TPB, 0, (hipStream_t)stream>>>(x, ldx, scale, shift, res, ldr, y,
                                                                            ldy, M, C, act, slope);
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}
+
+/* the same pass, also leaving the sign bits of y: bits[(r*C + c) / 32] bit (r*C + c) % 32 = (y[r][c] > 0); M*C/32 words.  C % 32 == 0 */
+extern "C" int efgh_scale_shift_act_bits(const float *x, int64_t ldx, const float *scale, const float *shift,
+                                         const float *res, int64_t ldr, float *y, int64_t ldy, uint32_t *bits, int64_t M,
+                                         int32_t C, int32_t act, float slope, void *stream) {
+    EFGH_CHECK_ARG(x && y && bits && M > 0 && C > 0 && C % 32 == 0);
+    EFGH_CHECK_ARG((ldx % 4 == 0) && (ldy % 4 == 0) && (!res || ldr % 4 == 0) &&
+                   ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)res) | ((uintptr_t)scale) | ((uintptr_t)shift)) & 15) == 0);
+    k_scale_shift_act<true><<<grid_for(M * (C / 4)), TPB, 0, (hipStream_t)stream>>>(x, ldx, scale, shift, res, ldr, y, ldy, M, C,
+                                                                                 act, slope, bits);
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
 }

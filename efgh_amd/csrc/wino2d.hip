@@ -218,7 +218,7 @@ struct W2OutArgs {
 
 constexpr int ROWS_PER_BLOCK = 1;              // rows of tiles per workgroup of k_w2_output (one statistics row per workgroup)
 
-__global__ void __launch_bounds__(TPB)
+__global__ void __launch_bounds__(TPB, 4)          // (four workgroups per CU: <= 128 VGPRs - the pass is bound by bytes in flight)
 k_w2_output(const W2OutArgs p) {
     __shared__ float red[2][TPB][VW];
     const int q4n = p.N / VW, sh = ilog2(q4n);
@@ -240,44 +240,83 @@ k_w2_output(const W2OutArgs p) {
         const long long t = (long long)rowt * p.g.TW + tx;
         const int y0 = 4 * ty, x0 = 4 * tx;
         const float *mp = p.M + t * 36 * p.N + col;
-        vec_t m[6][6], wx[6][4], Y[4][4];
+        // A^T M A streamed over the rows of M: the row pairs (1,2) and (3,4) belong to the point pairs +-a, +-b, so the column
+        // transform only needs their sum and difference - two rows of M (24 registers) are live at a time instead of all 36
+        // loads (72) + both intermediate arrays: 232 VGPRs / 2 waves per SIMD before, which held this HBM-bound pass at a third
+        // of the rate of k_w2_input.  Same expressions, same order of additions as at4() applied along y.
+        vec_t Y[4][4];
+        {
+            vec_t m0[6], w0[4];
 #pragma unroll
-        for (int i = 0; i < 6; ++i)
+            for (int j = 0; j < 6; ++j) m0[j] = *reinterpret_cast<const vec_t *>(mp + (long long)j * as);
+            at4(m0, w0);
 #pragma unroll
-            for (int j = 0; j < 6; ++j) m[i][j] = *reinterpret_cast<const vec_t *>(mp + (long long)(6 * i + j) * as);
-#pragma unroll
-        for (int i = 0; i < 6; ++i) at4(m[i], wx[i]);           // along x
-#pragma unroll
-        for (int x = 0; x < 4; ++x) {                           // along y
-            vec_t col[6], w[4];
-#pragma unroll
-            for (int i = 0; i < 6; ++i) col[i] = wx[i][x];
-            at4(col, w);
-#pragma unroll
-            for (int a = 0; a < 4; ++a) Y[a][x] = w[a];
+            for (int x = 0; x < 4; ++x) Y[0][x] = w0[x];
         }
+        __builtin_amdgcn_sched_barrier(0);         // (keeps the scheduler from hoisting all 36 loads to the top again)
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            const int y = y0 + a;
-            if (y >= p.g.H) continue;
+        for (int pr = 0; pr < 2; ++pr) {
+            const float c1 = pr ? W2_B : W2_A, c2 = pr ? W2_B2 : W2_A2, c3 = pr ? W2_B3 : W2_A3;
+            vec_t ma[6], mb[6], wa[4], wb[4];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                ma[j] = *reinterpret_cast<const vec_t *>(mp + (long long)(6 * (1 + 2 * pr) + j) * as);
+                mb[j] = *reinterpret_cast<const vec_t *>(mp + (long long)(6 * (2 + 2 * pr) + j) * as);
+            }
+            at4(ma, wa);
+            at4(mb, wb);
 #pragma unroll
             for (int x = 0; x < 4; ++x) {
-                const int xx = x0 + x;
-                if (xx >= p.g.W) continue;
-                const long long pix = (b * p.g.H + y) * p.g.W + xx;
+                vec_t sm, df;
+                sm.x = wa[x].x + wb[x].x; sm.y = wa[x].y + wb[x].y;
+                df.x = wa[x].x - wb[x].x; df.y = wa[x].y - wb[x].y;
+                Y[0][x].x += sm.x; Y[0][x].y += sm.y;
+                if (pr == 0) {
+                    Y[1][x].x = c1 * df.x; Y[1][x].y = c1 * df.y;
+                    Y[2][x].x = c2 * sm.x; Y[2][x].y = c2 * sm.y;
+                    Y[3][x].x = c3 * df.x; Y[3][x].y = c3 * df.y;
+                } else {
+                    Y[1][x].x = fmaf(c1, df.x, Y[1][x].x); Y[1][x].y = fmaf(c1, df.y, Y[1][x].y);
+                    Y[2][x].x = fmaf(c2, sm.x, Y[2][x].x); Y[2][x].y = fmaf(c2, sm.y, Y[2][x].y);
+                    Y[3][x].x = fmaf(c3, df.x, Y[3][x].x); Y[3][x].y = fmaf(c3, df.y, Y[3][x].y);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        {
+            vec_t m5[6], w5[4];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) m5[j] = *reinterpret_cast<const vec_t *>(mp + (long long)(30 + j) * as);
+            at4(m5, w5);
+#pragma unroll
+            for (int x = 0; x < 4; ++x) { Y[3][x].x += w5[x].x; Y[3][x].y += w5[x].y; }
+        }
+        // one 64-bit base per operand, 32-bit element offsets inside the tile (4 rows x 4 pixels: far below 2^31 elements)
+        const long long pix0 = (b * p.g.H + y0) * p.g.W + x0;
+        float *ob = p.out + pix0 * p.ldo + col;
+        const float *rb = p.residual ? p.residual + pix0 * p.ldr + col : nullptr;
+        const int ldo_i = (int)p.ldo, ldr_i = (int)p.ldr;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            if (y0 + a >= p.g.H) continue;
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                if (x0 + x >= p.g.W) continue;
+                const int po = a * p.g.W + x;
                 vec_t v = Y[a][x];
                 v.x += bi.x; v.y += bi.y;
                 s1.x += v.x; s1.y += v.y;
                 s2.x = fmaf(v.x, v.x, s2.x); s2.y = fmaf(v.y, v.y, s2.y);
                 v.x = v.x * sc.x + sf.x; v.y = v.y * sc.y + sf.y;
-                if (p.residual) {
-                    const vec_t r = *reinterpret_cast<const vec_t *>(p.residual + pix * p.ldr + col);
+                if (rb) {
+                    const vec_t r = *reinterpret_cast<const vec_t *>(rb + po * ldr_i);
                     v.x += r.x; v.y += r.y;
                 }
                 if (p.act == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); }
                 else if (p.act == 2) { v.x = v.x > 0.f ? v.x : v.x * p.slope; v.y = v.y > 0.f ? v.y : v.y * p.slope; }
-                *reinterpret_cast<vec_t *>(p.out + pix * p.ldo + col) = v;
+                *reinterpret_cast<vec_t *>(ob + po * ldo_i) = v;
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     if (p.stats) {

@@ -199,8 +199,15 @@ class GemmLayerFn(torch.autograd.Function):
                         y = tb[..., toff:toff + N]
                 if y is None:
                     y = torch.empty_like(raw)
+                # a residual layer's activation mask cannot be re-derived from raw alone: its backward used to read the activation
+                # back in both passes; the forward pass leaves the SIGN BITS instead (M*N/32 words)
+                ybits = None
+                if (res is not None and need_stats and ops.BN_MASK_BITS and Np % 32 == 0 and spec.act != ACT_NONE
+                        and any(ctx.needs_input_grad)):
+                    ybits = torch.empty(M * Np // 32, dtype=torch.int32, device=dev)
                 ops.scale_shift_act(raw, Np, scale, shift, y, ld_of(y), M, Np, spec.act, spec.slope, res=res,
-                                    ldr=0 if res is None else ld_of(res))
+                                    ldr=0 if res is None else ld_of(res), bits=ybits)
+                ctx.ybits = ybits
         if TRACE is not None:
             y._efgh_src = ('bn' if bn is not None else 'plain', spec.N, spec.pool, residual is not None)
         ctx.bnsrc = None
@@ -211,6 +218,8 @@ class GemmLayerFn(torch.autograd.Function):
             ctx.bnsrc = y._efgh_bnsrc = BnSrc(raw, y.detach() if residual is not None else None, scale, shift, mean, invstd,
                                               spec.act, spec.slope, M, Np)
         ctx.spec = spec
+        if not hasattr(ctx, 'ybits'):
+            ctx.ybits = None
         ctx.train_step = ops.TLS.train_step      # (backward runs on autograd's device thread: it restores the caller's switch)
         ctx.has = (bias is not None, gamma is not None, residual is not None)
         ctx.params = (weight, bias, gamma, beta)      # the Parameter objects themselves (claim_grad), not saved copies
@@ -242,6 +251,7 @@ class GemmLayerFn(torch.autograd.Function):
             dy = torch.zeros(tuple(spec.out_shape) + (ceil4(spec.N),), dtype=torch.float32, device=ctx.saved_tensors[0].device)
         x, weight, y, raw, mean, invstd, coef, psc, psh = ctx.saved_tensors
         ymask = None if psc is not None else y
+        ybits = ctx.ybits
         has_bias, has_bn, has_res = ctx.has
         N, Np, M = spec.N, ceil4(spec.N), spec.M
         dev = x.device
@@ -293,6 +303,8 @@ class GemmLayerFn(torch.autograd.Function):
             m1 = torch.empty(Np, dtype=torch.float64, device=dev) if train_bn else None
             m2 = torch.empty(Np, dtype=torch.float64, device=dev) if train_bn else None
             ldy = Np if ymask is None else ld_of(ymask)
+            if ybits is not None:                     # (the mask as sign bits: `y` with ldy = 0, see efgh_act_bn_bwd_reduce)
+                ymask, ldy = ybits, 0
             if sums is not None and train_bn:
                 # the kernel that produced dy took the two column sums in its epilogue: fold its per-block partials
                 f1, f2, m1, m2 = ops.bwd_finalize_f32(sums[0], Np, float(M))

@@ -577,7 +577,15 @@ def col_stats(x, M, C, ld, x_off=0):
 
 
 def scale_shift_act(x, ldx, scale, shift, y, ldy, M, C, act=ACT_NONE, slope=0.0, res=None, ldr=0, x_off=0,
-                    y_off=0, res_off=0):
+                    y_off=0, res_off=0, bits=None):
+    """bits: an int32 tensor of M*C/32 words that receives the sign bits of y (efgh_scale_shift_act_bits; C % 32 == 0)"""
+    if bits is not None:
+        _C.check(_L().efgh_scale_shift_act_bits(
+            _C.c_void_p(x.data_ptr() + 4 * x_off), c_int64(ldx), ptr(scale), ptr(shift),
+            _C.c_void_p(0 if res is None else res.data_ptr() + 4 * res_off), c_int64(ldr),
+            _C.c_void_p(y.data_ptr() + 4 * y_off), c_int64(ldy), ptr(bits), c_int64(M), c_int32(C), c_int32(act), c_float(slope),
+            _st()))
+        return
     _C.check(_L().efgh_scale_shift_act(
         _C.c_void_p(x.data_ptr() + 4 * x_off), c_int64(ldx), ptr(scale), ptr(shift),
         _C.c_void_p(0 if res is None else res.data_ptr() + 4 * res_off), c_int64(ldr),
@@ -752,6 +760,8 @@ def bwd_finalize_f32(stats, C, count):
 
 
 BLUR_DGRAD_FUSED = _os.environ.get('EFGH_BLUR_DGRAD_FUSED', '1') != '0'
+# residual BatchNorm layers keep the activation mask of their backward as sign bits (1/32 of re-reading the activation in both passes)
+BN_MASK_BITS = _os.environ.get('EFGH_BN_MASK_BITS', '1') != '0'
 
 
 def blur_dgrad(lv, draw, C0, w, C):

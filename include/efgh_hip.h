@@ -260,6 +260,11 @@ int efgh_col_stats(const float *x, int64_t M, int32_t C, int64_t ld, float *stat
 int efgh_scale_shift_act(const float *x, int64_t ldx, const float *scale, const float *shift,
                          const float *res, int64_t ldr, float *y, int64_t ldy, int64_t M, int32_t C,
                          int32_t act, float slope, void *stream);
+/* the same pass, also leaving the sign bits of y (C % 32 == 0): bit (r*C + c) % 32 of word (r*C + c) / 32 = (y[r][c] > 0), M*C/32
+ * words - the activation mask of a residual layer for efgh_act_bn_bwd_reduce / _apply (pass it as `y` with ldy = 0)       */
+int efgh_scale_shift_act_bits(const float *x, int64_t ldx, const float *scale, const float *shift,
+                              const float *res, int64_t ldr, float *y, int64_t ldy, uint32_t *bits, int64_t M, int32_t C,
+                              int32_t act, float slope, void *stream);
 int efgh_maxpool2(const float *x, float *y, int32_t B, int32_t H, int32_t W, int32_t C, void *stream);
 /* model-boundary layout changes: (B,Cs,H,W) <-> [B][H][W][Cd] (extra channels zero) */
 int efgh_nchw_to_nhwc(const float *x, float *y, int32_t B, int32_t Cs, int64_t HW, int32_t Cd, void *stream);
@@ -359,7 +364,9 @@ int efgh_table_scatter_add(const float *src, const int32_t *table, int64_t M, in
  * reduce: dpre = dy*act'(y); sum_dpre[c], sum_dpre_xhat[c] (= dbeta, dgamma) and their means;
  *         mean/invstd/raw NULL -> only sum_dpre (bias gradient).  part: [efgh_bwd_groups(M)][2][C] float64 (the column sums and the two means are kept in double, as torch's CPU kernel does).
  *         y == NULL: the activation mask is recomputed from raw*pscale + pshift (layers without a
- *         residual), which saves one full read of the activation in both passes.              */
+ *         residual), which saves one full read of the activation in both passes.
+ *         ldy == 0: `y` points to the SIGN BITS of the activation (uint32 words, efgh_scale_shift_act_bits; C % 32 == 0) - residual
+ *         layers, whose mask cannot be re-derived from raw alone: 1/32 of the bytes of reading the activation back.            */
 int32_t efgh_bwd_groups(int64_t M);
 int efgh_act_bn_bwd_reduce(const float *dy, int64_t lddy, const float *y, int64_t ldy, const float *raw,
                            int64_t ldraw, const float *mean, const float *invstd, const float *pscale,
