@@ -628,7 +628,7 @@ k_neighbors(const int4 *__restrict__ vkeys, const int *__restrict__ mm, const un
 // The hash build above is bound by memory-side atomics (~2 per (point, corner) entry at ~26 G/s chip-wide).  Measured on this
 // part while rebuilding it: 4.2 M random 4-byte STORES cost 80-100 us, 4.2 M random 4-byte LOADS 14 us - so every permutation
 // below is a gather.
-//   k_lat_keys     barycentric weights + one key-extrema record per block; the last block to finish folds the records.
+//   k_lat_keys     barycentric weights + one key-extrema record per block; k_lat_minmax folds the records (one workgroup).
 //   k_lat_scatter  a tile of points computes its 4 entries per point, counts them per bucket in LDS (bucket = top bits of
 //                  mix64(key integer): mix64 is a bijection, so equal keys meet in one bucket and the buckets are balanced whatever
 //                  the key distribution), and writes them bucket-sorted into the TILE's own window of `ent` (a local scatter that
@@ -681,17 +681,10 @@ __device__ __forceinline__ int part_slot(uint64_t mixed, int bb, int sb) { retur
 
 // ---- keys + barycentric weights of the partitioned build: k_point_keys with one extrema record per BLOCK of 256 points
 // (sample, mins, maxs; sample -1: no points, -2: the block straddles a sample boundary)
-template <int NT>
-__device__ void lat_minmax_fold(const int *part, const float *__restrict__ pts, int64_t cstride, int n, float scale32, float std32,
-                                const int *__restrict__ sid, int pps, int nsamples, int *__restrict__ mm, int *lmm, int *strad);
-
-// (round 4: the fold of the records is the tail of this kernel - the last block to finish does it - instead of a launch of its
-// own: a one-workgroup kernel costs 8-12 us on this part however little it does, five times per pyramid)
 __global__ void __launch_bounds__(TPB)
 k_lat_keys(const float *__restrict__ pts, int64_t cstride, const int *__restrict__ n_dev, int n_cap, float scale32,
            float std32, float4 *__restrict__ bary, float4 *__restrict__ emg, int *__restrict__ part,
-           const int *__restrict__ sid, int pps, int *__restrict__ ticket, int nsamples, int *__restrict__ mm) {
-    extern __shared__ int fold_lds[];                                   // [nsamples * 8] extrema + [nsamples] straddling blocks
+           const int *__restrict__ sid, int pps) {
     const int n = n_of(n_dev, n_cap);
     const int p = blockIdx.x * TPB + threadIdx.x;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -735,77 +728,68 @@ k_lat_keys(const float *__restrict__ pts, int64_t cstride, const int *__restrict
         if (t == 0) v = hi < 0 ? -1 : (lo == hi ? lo : -2);
         else if (t <= 4) { v = INT32_MAX; for (int w = 0; w < TPB / 64; ++w) v = min(v, wrec[w][1 + t]); }
         else if (t <= 8) { v = INT32_MIN; for (int w = 0; w < TPB / 64; ++w) v = max(v, wrec[w][1 + t]); }
-        __hip_atomic_store(&part[12 * blockIdx.x + t], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        part[12 * blockIdx.x + t] = v;
     }
-    // the last block to arrive folds every block's record into the per-sample extrema
-    __shared__ int last_s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        last_s = atomicAdd(ticket, 1) == (int)gridDim.x - 1;
-    }
-    __syncthreads();
-    if (!last_s) return;
-    __threadfence();
-    lat_minmax_fold<TPB>(part, pts, cstride, n, scale32, std32, sid, pps, nsamples, mm, fold_lds, fold_lds + nsamples * 8);
 }
 
-// ---- per-sample key extrema from the per-block records of k_lat_keys: ONE workgroup (the last block of k_lat_keys), register
-// folding + shuffle reductions + LDS atomics, plain stores of the result (no global atomics, nothing to initialise).  Blocks
-// that straddle a sample boundary (at most one per boundary; record -2) are revisited point by point.  The records were written
-// by other workgroups of the same launch: they are read with agent-scope loads (served by the memory side, not by a stale L2 line).
-__device__ __forceinline__ int ld_agent(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-template <int NT>
-__device__ void lat_minmax_fold(const int *part, const float *__restrict__ pts, int64_t cstride, int n, float scale32, float std32,
-                                const int *__restrict__ sid, int pps, int nsamples, int *__restrict__ mm, int *lmm, int *strad) {
+// ---- per-sample key extrema from the per-block records of k_lat_keys: ONE workgroup, register folding + shuffle reductions +
+// LDS atomics, plain stores of the result (no global atomics, nothing to initialise).  Blocks that straddle a sample boundary (at
+// most one per boundary; record -2) are revisited point by point.
+constexpr int MMT = 1024;
+__global__ void __launch_bounds__(MMT)
+k_lat_minmax(const int *__restrict__ part, const float *__restrict__ pts, int64_t cstride,
+             const int *__restrict__ n_dev, int n_cap, float scale32, float std32, const int *__restrict__ sid, int pps,
+             int nsamples, int *__restrict__ mm) {
+    __shared__ int lmm[EFGH_LATTICE_MAX_SAMPLES * 8];
+    __shared__ int strad[EFGH_LATTICE_MAX_SAMPLES];
     __shared__ int nstr;
-    for (int i = threadIdx.x; i < nsamples * 8; i += NT) lmm[i] = (i & 7) < 4 ? INT32_MAX : INT32_MIN;
+    for (int i = threadIdx.x; i < nsamples * 8; i += MMT) lmm[i] = (i & 7) < 4 ? INT32_MAX : INT32_MIN;
     if (threadIdx.x == 0) nstr = 0;
     __syncthreads();
+    const int n = n_of(n_dev, n_cap);
     const int nrec = (n + TPB - 1) / TPB;
     {
-        // every thread folds a contiguous run of records (almost always one sample) in registers; a change of sample inside the run
-        // goes to the LDS table directly, the last one through a shuffle reduction per wave
-        const int per = (nrec + NT - 1) / NT;
+        // every thread folds a contiguous run of records (almost always one sample) in registers, four loads in flight; a change of
+        // sample inside the run goes to the LDS table directly, the last one through a shuffle reduction per wave
+        const int per = (nrec + MMT - 1) / MMT;
         int b = -1;
         int kmin[4] = {INT32_MAX, INT32_MAX, INT32_MAX, INT32_MAX};
         int kmax[4] = {INT32_MIN, INT32_MIN, INT32_MIN, INT32_MIN};
         for (int r0 = 0; r0 < per; r0 += 4) {
-            int q[4][9];
+            int4 q0[4], q1[4], q2[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int w = threadIdx.x * per + r0 + u;
-                q[u][0] = -1;
+                q0[u] = make_int4(-1, 0, 0, 0); q1[u] = q2[u] = q0[u];
                 if (r0 + u < per && w < nrec) {
-#pragma unroll
-                    for (int e = 0; e < 9; ++e) q[u][e] = ld_agent(part + 12 * w + e);
+                    const int4 *q = reinterpret_cast<const int4 *>(part + 12 * w);
+                    q0[u] = q[0]; q1[u] = q[1]; q2[u] = q[2];
                 }
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                if (q[u][0] == -2) {
+                if (q0[u].x == -2) {
                     const int k = atomicAdd(&nstr, 1);
-                    if (k < nsamples) strad[k] = threadIdx.x * per + r0 + u;
+                    if (k < EFGH_LATTICE_MAX_SAMPLES) strad[k] = threadIdx.x * per + r0 + u;
                     continue;
                 }
-                if (q[u][0] < 0) continue;
-                if (b >= 0 && q[u][0] != b) {
+                if (q0[u].x < 0) continue;
+                if (b >= 0 && q0[u].x != b) {
 #pragma unroll
                     for (int c = 0; c < 4; ++c) { atomicMin(&lmm[8 * b + c], kmin[c]); atomicMax(&lmm[8 * b + 4 + c], kmax[c]); }
 #pragma unroll
                     for (int c = 0; c < 4; ++c) { kmin[c] = INT32_MAX; kmax[c] = INT32_MIN; }
                 }
-                b = q[u][0];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) { kmin[c] = min(kmin[c], q[u][1 + c]); kmax[c] = max(kmax[c], q[u][5 + c]); }
+                b = q0[u].x;
+                kmin[0] = min(kmin[0], q0[u].y); kmin[1] = min(kmin[1], q0[u].z); kmin[2] = min(kmin[2], q0[u].w); kmin[3] = min(kmin[3], q1[u].x);
+                kmax[0] = max(kmax[0], q1[u].y); kmax[1] = max(kmax[1], q1[u].z); kmax[2] = max(kmax[2], q1[u].w); kmax[3] = max(kmax[3], q2[u].x);
             }
         }
         wave_minmax_by_sample(b, kmin, kmax, lmm);
     }
     __syncthreads();
-    const int ns = min(nstr, nsamples);          // (a block straddles at most one boundary: fewer than nsamples of them)
-    for (int k = threadIdx.x >> 6; k < ns * (TPB / 64); k += NT / 64) {
+    const int ns = min(nstr, EFGH_LATTICE_MAX_SAMPLES);
+    for (int k = threadIdx.x >> 6; k < ns * (TPB / 64); k += MMT / 64) {
         const int p = TPB * strad[k / (TPB / 64)] + 64 * (k % (TPB / 64)) + (threadIdx.x & 63);
         int b = -1;
         int kmin[4] = {INT32_MAX, INT32_MAX, INT32_MAX, INT32_MAX};
@@ -825,7 +809,7 @@ __device__ void lat_minmax_fold(const int *part, const float *__restrict__ pts, 
         wave_minmax_by_sample(b, kmin, kmax, lmm);
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < nsamples * 8; i += NT) mm[i] = lmm[i];
+    for (int i = threadIdx.x; i < nsamples * 8; i += MMT) mm[i] = lmm[i];
 }
 
 // exclusive prefix over the NT threads of a block (NT = 256 or 512), one value each; *total = block sum
@@ -1632,8 +1616,8 @@ extern "C" int efgh_lattice_part_build(const float *pts, int64_t pts_cstride, co
     const float std32 = part_std32();
     const int nbp = cdiv(n_cap, TPB);
     const int pps = sid ? 1 : pts_per_sample;
-    k_lat_keys<<<nbp, TPB, (size_t)nsamples * 36, st>>>(pts, pts_cstride, n_dev, n_cap, scale32, std32, (float4 *)bary, (float4 *)emg, part,
-                                                        sid, pps, P.ticket + 3, nsamples, mm);
+    k_lat_keys<<<nbp, TPB, 0, st>>>(pts, pts_cstride, n_dev, n_cap, scale32, std32, (float4 *)bary, (float4 *)emg, part, sid, pps);
+    k_lat_minmax<<<1, MMT, 0, st>>>(part, pts, pts_cstride, n_dev, n_cap, scale32, std32, sid, pps, nsamples, mm);
     if (w.ppt == 8)
         k_lat_scatter<8><<<w.ntiles, STP, 0, st>>>(pts, pts_cstride, n_dev, n_cap, scale32, std32, mm, sid, pps, nsamples, P, info);
     else
