@@ -350,12 +350,50 @@ class _NbtPair:
         return self
 
 
+class _FusedParamsFn(torch.autograd.Function):
+    """the concatenated parameters of the fused heads: forward = the given `build` of the detached parts (torch.cat / pad),
+    backward = that build's slices handed back to the parts.  Parts that live in a train.FlatParams get their slice written
+    STRAIGHT into the flat gradient buffer on the stream of this backward (FN.claim_grad, as the layer Functions do): no
+    CatBackward -> AccumulateGrad detour - those nodes were created on the first step's stream and made torch warn
+    "AccumulateGrad node's stream does not match" on every later step of the image branch."""
+
+    @staticmethod
+    def forward(ctx, build, split, *parts):
+        ctx.split, ctx.parts = split, parts
+        return build(*[p.detach() for p in parts])
+
+    @staticmethod
+    def backward(ctx, g):
+        outs = []
+        for p, gs in zip(ctx.parts, ctx.split(g)):
+            gv, done = FN.claim_grad(p)
+            if gv is not None:
+                gv.copy_(gs.reshape(gv.shape))
+                done()
+                outs.append(None)
+            else:
+                outs.append(gs.reshape(p.shape).contiguous())
+        return (None, None) + tuple(outs)
+
+
+def _fused(build, split, *parts):
+    if any(p.requires_grad for p in parts) and torch.is_grad_enabled():
+        FN.note_use(*parts)
+        return _FusedParamsFn.apply(build, split, *parts)
+    return build(*[p.detach() for p in parts])
+
+
 def _bn_cat(bns, grad):
     a = bns[0]
     assert all(b.eps == a.eps and b.momentum == a.momentum and b.affine and b.track_running_stats for b in bns)
     bn = _Shim()
-    cat = (lambda ts: torch.cat(list(ts))) if grad else (lambda ts: torch.cat([t.detach() for t in ts]))
-    bn.weight, bn.bias = cat(b.weight for b in bns), cat(b.bias for b in bns)
+    sizes = [b.num_features for b in bns]
+
+    def cat(ts):
+        if grad:
+            return _fused(lambda *t: torch.cat(t), lambda g: torch.split(g, sizes), *ts)
+        return torch.cat([t.detach() for t in ts])
+    bn.weight, bn.bias = cat([b.weight for b in bns]), cat([b.bias for b in bns])
     with torch.no_grad():
         bn.running_mean = torch.cat([b.running_mean for b in bns])
         bn.running_var = torch.cat([b.running_var for b in bns])
@@ -398,15 +436,30 @@ def _heads_modules(ctx, seq_d, seq_m):
 
     def make():
         g = ctx.grad
-        det = (lambda t: t) if g else (lambda t: t.detach())
         ct = _Shim()
         ct.in_channels, ct.out_channels = ct_d.in_channels, od + om
         ct.kernel_size, ct.stride, ct.padding, ct.output_padding, ct.bias = ct_d.kernel_size, ct_d.stride, ct_d.padding, ct_d.output_padding, None
-        ct.weight = torch.cat([det(ct_d.weight), det(ct_m.weight)], 1)                      # (in, out, 3, 3)
         cv = _Shim()
         cv.in_channels = cv.out_channels = od + om
         cv.kernel_size, cv.stride, cv.padding, cv.bias = (3, 3), (1, 1), (1, 1), None
-        cv.weight = torch.cat([F.pad(det(cv_d.weight), (0, 0, 0, 0, 0, om)), F.pad(det(cv_m.weight), (0, 0, 0, 0, od, 0))], 0)
+
+        def build_ct(a, b):                                                                 # (in, out, 3, 3)
+            return torch.cat([a, b], 1)
+
+        def build_cv(a, b):                                                                 # block-diagonal (out, in, 3, 3)
+            return torch.cat([F.pad(a, (0, 0, 0, 0, 0, om)), F.pad(b, (0, 0, 0, 0, od, 0))], 0)
+        if g:
+            ct.weight = _fused(build_ct, lambda gr: (gr[:, :od], gr[:, od:]), ct_d.weight, ct_m.weight)
+            cv.weight = _fused(build_cv, lambda gr: (gr[:od, :od], gr[od:, od:]), cv_d.weight, cv_m.weight)
+            # the packed layouts of these per-step tensors live in persistent buffers: the cache dictionaries are kept on the depth
+            # stack and handed to every step's tensor (ops.pack_weight then re-packs in place instead of allocating and registering
+            # a new set of buffers each step)
+            store = seq_d.__dict__.setdefault('_efgh_heads_pack', {'ct': {}, 'cv': {}})
+            ct.weight.__dict__['_efgh_cache'] = store['ct']
+            cv.weight.__dict__['_efgh_cache'] = store['cv']
+        else:
+            ct.weight = build_ct(ct_d.weight.detach(), ct_m.weight.detach())
+            cv.weight = build_cv(cv_d.weight.detach(), cv_m.weight.detach())
         return ct, _bn_cat((seq_d[1], seq_m[1]), g), cv, _bn_cat((seq_d[4], seq_m[4]), g)
     if ctx.grad or ctx.train:
         return make()                        # (new autograd leaves / fresh running statistics every step)

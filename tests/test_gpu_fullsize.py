@@ -76,7 +76,7 @@ def _stagewise(full, manifest, raw, args_over=None):
     assert (out['h_img'].cpu() != reth['h_img']).float().mean() < 5e-3
     # f_score saturates at this size with these weights, so compare the pre-sigmoid correlation as well.
     # Each logit sums ~1e6 non-negative products: torch's fp32 CPU conv2d is itself 3.8e-4 away from the
-    # exact sum at this size (tests/tools/debug_fullsize_f.py), so the yardstick is the float64 correlation of the
+    # exact sum at this size (measured in round 2 with a one-off script, since removed), so the yardstick is the float64 correlation of the
     # ORACLE's features; the HIP kernel (fp32 MFMA, split-K) is within 1e-5 of it.
     import torch.nn.functional as F
     camf, rngf = keep_o['cam_feat'][0].double(), keep_o['rng_feat'][0].double()
@@ -235,7 +235,7 @@ def _training_step(manifest, monkeypatch, RAW, NPTS, args_over=None, batch=None,
     gradients.  Pass B - the G net on the oracle's inputs (E/H/F outputs and the rasterised depth image teacher-forced): the
     gradient of the three G loss terms.  G has to be teacher-forced because its gradient is physically ill-conditioned in its
     input at this size: last-bit differences of efh_cam_T_velo between two runs of the SAME code move it by 12 % (measured,
-    tools/debug_fullsize_g7.py; frozen inputs reproduce it to 1e-6), while the oracle in float32 is within 0.5 % of float64.
+    measured in round 3 with a one-off script, since removed; frozen inputs reproduce it to 1e-6), while the oracle in float32 is within 0.5 % of float64.
     F gradients are exactly zero on both sides at this size (saturated scores)."""
     import re
     from efgh_amd import ops
