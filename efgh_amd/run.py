@@ -1,6 +1,7 @@
 """Zero-edit drop-in launcher: runs the reference's UNMODIFIED entry script on the MI355X path.
 
-    python -m efgh_amd.run [--device I | --all-devices] main.py configs/train_rellis.yaml
+    python -m efgh_amd.run [--device I | --all-devices] main.py configs/train_rellis.yaml        # one GPU
+    python -m efgh_amd.run --gpus N main.py configs/train_rellis.yaml                            # N GPUs, one process each
 
 The reference binds its model and criterion by module name (`import nets`, `import losses`, main.py:14-15;
 `nets.__dict__[arch + 'Backbone']`, `losses.__dict__[arch + 'Criterion']`, main.py:126,129).  This launcher installs
@@ -12,6 +13,17 @@ and `runpy`-runs the script IN THIS PROCESS as `__main__` - before anything has 
 `--all-devices` is given the process is pinned to ONE device first (`--device I`, default 0, counted in the list that is
 visible now): DataParallel then has `device_ids == [0]` and calls the module directly.  With several devices left visible
 the backbone refuses a replica forward loudly (nets/efghbackbone.py).
+
+`--gpus N` is the data-parallel form of the same drop-in (the reference's multi-GPU mode IS `DataParallel`): the
+parent starts N children (no GPU touched in the parent), child r is pinned to device r, joins a process group (RCCL; gloo when
+ranks share a GPU) and runs the unmodified script with three names rebound for the duration of the run:
+  * `torch.nn.DataParallel` -> `ProcessDataParallel` (below): same `.module` / `module.`-prefixed state_dict, identical start
+    on every rank (broadcast), and the gradients of all ranks averaged in buckets right before every `optimizer.step()`;
+  * `torch.utils.data.DataLoader`: a loader without a sampler gets a DistributedSampler (its rank's share of every epoch,
+    reshuffled per epoch when the script asked for shuffling) and batch_size / N samples per step (at least 1), so that the
+    GLOBAL batch is what the config says - what DataParallel's scatter does;
+  * `torch.save` on ranks > 0 is a no-op (rank 0 writes the checkpoints, as device 0's replica does under DataParallel).
+BatchNorm statistics stay per rank, as per replica under DataParallel.
 """
 import os
 import runpy
@@ -50,16 +62,161 @@ def install_aliases():
     return out
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# --gpus N: one process per GPU behind the reference's DataParallel call
+# ---------------------------------------------------------------------------------------------------------------------
+def _process_data_parallel_class():
+    import torch
+    import torch.distributed as dist
+    import torch.nn as nn
+
+    class ProcessDataParallel(nn.Module):
+        """stands in for `torch.nn.DataParallel(model)` (main.py:127) when every GPU has its own process: holds the model as
+        `.module` (so checkpoints keep their `module.` prefix, main.py:136,153), starts from rank 0's parameters and buffers,
+        and averages the gradients over the ranks - flattened into ~32 MB buckets, one all-reduce each - right before every
+        optimizer step (a global optimizer pre-step hook: the reference's loop calls `optimizer.step()` itself,
+        iterater.py:41-43)."""
+        BUCKET = 8 * 1024 * 1024
+
+        def __init__(self, module, device_ids=None, output_device=None, dim=0):
+            super().__init__()
+            self.module = module
+            self.device_ids, self.output_device, self.dim = [0], 0, dim
+            self.world = dist.get_world_size() if dist.is_initialized() else 1
+            if self.world > 1:
+                with torch.no_grad():
+                    for t in list(module.parameters()) + list(module.buffers()):
+                        dist.broadcast(t.data, 0)
+                from torch.optim.optimizer import register_optimizer_step_pre_hook
+                self._hook = register_optimizer_step_pre_hook(self._average_gradients)
+
+        def forward(self, *args, **kwargs):
+            return self.module(*args, **kwargs)
+
+        def _average_gradients(self, optimizer, args, kwargs):
+            mine = {id(p) for p in self.module.parameters()}
+            ps = [p for g in optimizer.param_groups for p in g['params'] if id(p) in mine and p.grad is not None]
+            if not ps:
+                return
+            if ps[0].is_cuda:
+                # the branches of the network run their backward on side streams (nets/efghbackbone.py): join them first
+                from . import ops
+                for s in ops.side_streams():
+                    torch.cuda.current_stream().wait_stream(s)
+            i = 0
+            while i < len(ps):
+                j, n = i, 0
+                while j < len(ps) and (n == 0 or n + ps[j].numel() <= self.BUCKET):
+                    n += ps[j].numel()
+                    j += 1
+                flat = torch.cat([p.grad.reshape(-1) for p in ps[i:j]])
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+                flat /= self.world
+                o = 0
+                for p in ps[i:j]:
+                    p.grad.copy_(flat[o:o + p.numel()].view_as(p.grad))
+                    o += p.numel()
+                i = j
+
+    return ProcessDataParallel
+
+
+def install_process_parallel(rank, world):
+    """rebinds DataParallel / DataLoader / torch.save for a rank of a `--gpus N` run (see the module docstring)"""
+    import torch
+    import torch.utils.data as tud
+    PDP = _process_data_parallel_class()
+    torch.nn.DataParallel = PDP
+    torch.nn.parallel.DataParallel = PDP
+    RealLoader = tud.DataLoader
+
+    class _EpochSampler(tud.distributed.DistributedSampler):
+        """a DistributedSampler that moves to the next epoch's permutation by itself (the script never calls set_epoch)"""
+
+        def __iter__(self):
+            it = super().__iter__()
+            self.set_epoch(self.epoch + 1)
+            return it
+
+    class ShardedLoader(RealLoader):
+        def __init__(self, dataset, batch_size=1, shuffle=None, sampler=None, batch_sampler=None, **kw):
+            if world > 1 and sampler is None and batch_sampler is None and not isinstance(dataset, tud.IterableDataset):
+                sampler = _EpochSampler(dataset, num_replicas=world, rank=rank, shuffle=bool(shuffle), seed=0, drop_last=False)
+                shuffle = None
+                if batch_size is not None:
+                    batch_size = max(1, int(batch_size) // world)
+            super().__init__(dataset, batch_size=batch_size, shuffle=shuffle, sampler=sampler, batch_sampler=batch_sampler, **kw)
+
+    tud.DataLoader = ShardedLoader
+    torch.utils.data.DataLoader = ShardedLoader
+    if rank != 0:
+        torch.save = lambda *a, **k: None
+    return PDP
+
+
+def spawn(gpus, argv_tail):
+    """the parent of a `--gpus N` run: N children, nothing here touches the GPU"""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    # the devices this job may use, as the children will see them: rank r gets ids[r % len(ids)] as its ONLY device
+    cur = os.environ.get('HIP_VISIBLE_DEVICES') or os.environ.get('CUDA_VISIBLE_DEVICES')
+    if cur:
+        ids = [v for v in cur.split(',') if v.strip() != '']
+    else:
+        import torch
+        ids = [str(i) for i in range(torch.cuda.device_count())]          # (counting devices does not initialise the GPU)
+    procs = []
+    for r in range(gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(gpus), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), EFGH_RUN_CHILD='1', EFGH_RUN_SHARED='1' if gpus > len(ids) else '0')
+        env.pop('CUDA_VISIBLE_DEVICES', None)
+        if ids:
+            env['HIP_VISIBLE_DEVICES'] = ids[r % len(ids)]
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')          # dmabuf IPC only on this pool (RCCL needs it)
+        env.setdefault('OMP_NUM_THREADS', '8')
+        procs.append(subprocess.Popen([sys.executable, '-m', 'efgh_amd.run'] + argv_tail, env=env))
+    rc = 0
+    for p in procs:
+        rc = p.wait() or rc
+    return rc
+
+
+def child_setup():
+    """a rank of a `--gpus N` run: pin the device, join the group, rebind the three names.  Returns (rank, world)"""
+    rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+    import torch
+    import torch.distributed as dist
+    # (the parent made this rank's device the only visible one; more ranks than devices = ranks share GPUs, a plumbing run)
+    shared = os.environ.get('EFGH_RUN_SHARED') == '1' or not os.environ.get('HIP_VISIBLE_DEVICES')
+    backend = os.environ.get('EFGH_DIST_BACKEND', 'gloo' if shared else 'nccl')
+    if backend == 'nccl':
+        dist.init_process_group('nccl', device_id=torch.device('cuda', 0))
+    else:
+        dist.init_process_group(backend)
+    install_process_parallel(rank, world)
+    return rank, world
+
+
 def parse(argv):
-    device, pin = 0, True
+    device, pin, gpus = 0, True, 1
     i = 0
     while i < len(argv):
         a = argv[i]
-        if a == '--device' and i + 1 < len(argv):
-            device = int(argv[i + 1])
+        if a in ('--device', '--gpus') and i + 1 < len(argv):
+            if a == '--device':
+                device = int(argv[i + 1])
+            else:
+                gpus = int(argv[i + 1])
             i += 2
         elif a.startswith('--device='):
             device = int(a.split('=', 1)[1])
+            i += 1
+        elif a.startswith('--gpus='):
+            gpus = int(a.split('=', 1)[1])
             i += 1
         elif a == '--all-devices':
             pin = False
@@ -70,21 +227,33 @@ def parse(argv):
         else:
             break
     if i >= len(argv):
-        raise SystemExit('usage: python -m efgh_amd.run [--device I | --all-devices] <script.py> [script arguments...]')
-    return device, pin, argv[i], argv[i + 1:]
+        raise SystemExit('usage: python -m efgh_amd.run [--gpus N | --device I | --all-devices] <script.py> [script arguments...]')
+    return device, pin, gpus, argv[i], argv[i + 1:]
 
 
 def main(argv=None):
-    device, pin, script, rest = parse(list(sys.argv[1:] if argv is None else argv))
+    argv = list(sys.argv[1:] if argv is None else argv)
+    device, pin, gpus, script, rest = parse(argv)
     if not os.path.isfile(script):
         raise SystemExit('efgh_amd.run: no such script: %s' % script)
-    if pin:
+    child = os.environ.get('EFGH_RUN_CHILD') == '1' and 'RANK' in os.environ
+    if gpus > 1 and not child:
+        raise SystemExit(spawn(gpus, argv))
+    if child:
+        child_setup()
+    elif pin:
         pin_one_device(device)
     install_aliases()
     script = os.path.abspath(script)
     sys.argv = [script] + list(rest)
     sys.path.insert(0, os.path.dirname(script))
-    runpy.run_path(script, run_name='__main__')
+    try:
+        runpy.run_path(script, run_name='__main__')
+    finally:
+        if child:
+            import torch.distributed as dist
+            if dist.is_initialized():
+                dist.destroy_process_group()
 
 
 if __name__ == '__main__':

@@ -188,3 +188,51 @@ def test_dataparallel_replica_is_refused_loudly():
     z = torch.zeros(1)
     with pytest.raises(_C.EfghError, match='ONE PROCESS PER GPU'):
         m(z, z, z, z)
+
+
+def test_launcher_gpus_n_runs_the_unchanged_script_data_parallel(tmp_path):
+    """`python -m efgh_amd.run --gpus 2 script.py`: the reference's multi-GPU mode is `torch.nn.DataParallel(model)` (main.py:127);
+    here every GPU gets its own process and the SAME unmodified script.  Plumbing check on CPU ranks (gloo) with a stand-in
+    model: `torch.nn.DataParallel` is the process-parallel wrapper (`.module`, `module.`-prefixed state_dict), every rank starts
+    from rank 0's weights, a DataLoader without a sampler is sharded (disjoint halves of the epoch, batch_size / world samples
+    per step), the gradients are averaged right before `optimizer.step()` (the ranks stay identical although they see
+    different data), and only rank 0's `torch.save` writes."""
+    import json
+    import subprocess
+    import sys
+    (tmp_path / 'main.py').write_text(
+        'import os, sys, json\n'
+        'import torch, torch.nn as tnn, torch.utils.data as tud\n'
+        'import nets, losses\n'
+        'rank = int(os.environ["RANK"])\n'
+        'torch.manual_seed(100 + rank)                      # different initial weights per rank: the wrapper must broadcast\n'
+        'model = tnn.Sequential(tnn.Linear(4, 3), tnn.BatchNorm1d(3))\n'
+        'model = torch.nn.DataParallel(model)\n'
+        'opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-2)\n'
+        'data = tud.TensorDataset(torch.arange(32, dtype=torch.float32).repeat(4, 1).t().contiguous())\n'
+        'loader = torch.utils.data.DataLoader(data, batch_size=8, shuffle=True)\n'
+        'seen = []\n'
+        'for epoch in range(2):\n'
+        '    for (x,) in loader:\n'
+        '        seen.append([int(v) for v in x[:, 0]])\n'
+        '        opt.zero_grad(); model(x).pow(2).mean().backward(); opt.step()\n'
+        'torch.save({"state_dict": model.state_dict()}, sys.argv[1] + ".ckpt%d" % rank)\n'
+        'w = torch.cat([p.detach().reshape(-1) for p in model.parameters()])\n'
+        'json.dump({"cls": type(model).__name__, "keys": list(model.state_dict().keys()), "w": w.tolist(), "seen": seen,\n'
+        '           "model_cls": nets.__dict__["EFGHBackbone"].__module__}, open(sys.argv[1] + ".r%d" % rank, "w"))\n')
+    out = str(tmp_path / 'out')
+    env = dict(os.environ, PYTHONPATH=ROOT, HIP_VISIBLE_DEVICES='', EFGH_DIST_BACKEND='gloo')
+    env.pop('CUDA_VISIBLE_DEVICES', None)
+    subprocess.check_call([sys.executable, '-m', 'efgh_amd.run', '--gpus', '2', str(tmp_path / 'main.py'), out], env=env,
+                          cwd=str(tmp_path), timeout=300)
+    r0, r1 = json.load(open(out + '.r0')), json.load(open(out + '.r1'))
+    assert r0['cls'] == 'ProcessDataParallel' and r0['model_cls'] == 'efgh_amd.nets.efghbackbone'
+    assert r0['keys'][0].startswith('module.') and r0['keys'] == r1['keys']
+    assert r0['w'] == r1['w']                                  # same start (broadcast) + averaged gradients = identical replicas
+    for e in range(2):                                         # every epoch: 2 steps of 8 // 2 = 4... 16 samples per rank, disjoint, together all 32
+        a = sorted(v for b in r0['seen'][4 * e:4 * e + 4] for v in b)
+        b = sorted(v for b_ in r1['seen'][4 * e:4 * e + 4] for v in b_)
+        assert len(a) == len(b) == 16 and sorted(a + b) == list(range(32))
+    assert all(len(b) == 4 for b in r0['seen'])
+    assert r0['seen'][:4] != r0['seen'][4:8]                   # reshuffled in the second epoch
+    assert os.path.exists(out + '.ckpt0') and not os.path.exists(out + '.ckpt1')
