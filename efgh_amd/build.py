@@ -11,6 +11,10 @@ SO = os.path.join(LIBDIR, 'libefgh_hip.so')
 # per-file extra flags: the lattice float recipe must not be contracted / reassociated
 EXTRA = {'lattice.hip': ['-ffp-contract=off'], 'pose.hip': ['-ffp-contract=off']}
 COMMON = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function']
+# A/B builds (tools): EFGH_BUILD_FLAGS='-DSOMETHING=1' EFGH_BUILD_DIR=lib_ab python -m efgh_amd.build -> efgh_amd/lib_ab/libefgh_hip.so (EFGH_LIB selects it)
+COMMON += os.environ.get('EFGH_BUILD_FLAGS', '').split()
+LIBDIR = os.path.join(HERE, os.environ.get('EFGH_BUILD_DIR', 'lib'))
+SO = os.path.join(LIBDIR, 'libefgh_hip.so')
 
 
 def sources():

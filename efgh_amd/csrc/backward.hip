@@ -22,6 +22,7 @@ __device__ __forceinline__ float dact(float y, int act, float slope) {
 // per-column partial sums of  dpre = dy*act'(y)  and  dpre*xhat,  xhat = (raw-mean)*invstd
 // (mean == NULL: xhat := 0, only sum dpre is meaningful -> bias gradient).
 // block = (CL float4 channel lanes) x (256/CL row lanes), 512 rows per block.
+template <bool NT>
 __global__ void __launch_bounds__(TPB)
 k_act_bn_bwd_reduce(const float *__restrict__ dy, long long lddy, const float *__restrict__ y, long long ldy,
                     const float *__restrict__ raw, long long ldraw, const float *__restrict__ mean,
@@ -44,9 +45,9 @@ k_act_bn_bwd_reduce(const float *__restrict__ dy, long long lddy, const float *_
         const bool from_raw = !y && !ybits;
         if (from_raw) { psc = *reinterpret_cast<const float4 *>(pscale + c); psh = *reinterpret_cast<const float4 *>(pshift + c); }
         for (long long r = r0 + rl; r < r1; r += RL) {
-            float4 g = *reinterpret_cast<const float4 *>(dy + r * lddy + c);
+            float4 g = ld_stream<NT>(dy + r * lddy + c);
             float4 rw = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (mean || from_raw) rw = *reinterpret_cast<const float4 *>(raw + r * ldraw + c);
+            if (mean || from_raw) rw = ld_stream<NT>(raw + r * ldraw + c);
             float4 yy;
             if (ybits) yy = sign4(ybits, r * C + c);       // (1 bit per element instead of a second read of the activation)
             else if (y) yy = *reinterpret_cast<const float4 *>(y + r * ldy + c);
@@ -107,6 +108,7 @@ k_bwd_finalize(const double *__restrict__ part, int G, int C, double count,
 // draw = coef[c] * (dpre - m1[c] - xhat*m2[c])   (train BN; coef = gamma*invstd)
 //      = coef[c] * dpre                          (eval BN / no BN: mean == NULL, coef optional)
 // dres (optional) = dpre
+template <bool NT>
 __global__ void __launch_bounds__(TPB)
 k_act_bn_bwd_apply(const float *__restrict__ dy, long long lddy, const float *__restrict__ y, long long ldy,
                    const float *__restrict__ raw, long long ldraw, const float *__restrict__ mean,
@@ -120,9 +122,9 @@ k_act_bn_bwd_apply(const float *__restrict__ dy, long long lddy, const float *__
     const bool from_raw = !y && !ybits;
     for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
         long long r = i / c4n; int c = (int)(i - r * c4n) * 4;
-        float4 g = *reinterpret_cast<const float4 *>(dy + r * lddy + c);
+        float4 g = ld_stream<NT>(dy + r * lddy + c);
         float4 rw = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (mean || from_raw) rw = *reinterpret_cast<const float4 *>(raw + r * ldraw + c);
+        if (mean || from_raw) rw = ld_stream<NT>(raw + r * ldraw + c);
         float4 yy;
         if (ybits) yy = sign4(ybits, r * C + c);
         else if (y) yy = *reinterpret_cast<const float4 *>(y + r * ldy + c);
@@ -130,7 +132,7 @@ k_act_bn_bwd_apply(const float *__restrict__ dy, long long lddy, const float *__
                               rw.z * pscale[c + 2] + pshift[c + 2], rw.w * pscale[c + 3] + pshift[c + 3]);
         float gv[4] = {g.x * dact(yy.x, act, slope), g.y * dact(yy.y, act, slope), g.z * dact(yy.z, act, slope),
                        g.w * dact(yy.w, act, slope)};
-        if (dres) *reinterpret_cast<float4 *>(dres + r * lddres + c) = make_float4(gv[0], gv[1], gv[2], gv[3]);
+        if (dres) st_stream<NT>(dres + r * lddres + c, make_float4(gv[0], gv[1], gv[2], gv[3]));
         float o[4];
         if (mean) {
             float rv[4] = {rw.x, rw.y, rw.z, rw.w};
@@ -144,7 +146,7 @@ k_act_bn_bwd_apply(const float *__restrict__ dy, long long lddy, const float *__
 #pragma unroll
             for (int q = 0; q < 4; ++q) o[q] = coef ? coef[c + q] * gv[q] : gv[q];
         }
-        if (draw) *reinterpret_cast<float4 *>(draw + r * lddraw + c) = make_float4(o[0], o[1], o[2], o[3]);
+        if (draw) st_stream<NT>(draw + r * lddraw + c, make_float4(o[0], o[1], o[2], o[3]));
     }
 }
 
@@ -176,6 +178,7 @@ __device__ __forceinline__ void pool_cell_dpre(const float4 v[4], const bool ok[
     }
 }
 
+template <bool NT>
 __global__ void __launch_bounds__(TPB)
 k_pool_bn_bwd_reduce(const float *__restrict__ dyp, const float *__restrict__ raw, const float *__restrict__ mean,
                      const float *__restrict__ invstd, const float *__restrict__ pscale, const float *__restrict__ pshift,
@@ -202,7 +205,7 @@ k_pool_bn_bwd_reduce(const float *__restrict__ dyp, const float *__restrict__ ra
             float4 v[4];
             const bool ok[4] = {true, true, true, true};
 #pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const float4 *>(raw + base + offs[q]);
+            for (int q = 0; q < 4; ++q) v[q] = ld_stream<NT>(raw + base + offs[q]);
             const float4 g = *reinterpret_cast<const float4 *>(dyp + (((b * Ho + i) * Wo) + j) * (long long)C + c);
             float dpre[4][4];
             pool_cell_dpre(v, ok, true, g, sc, sf, act, slope, dpre);
@@ -230,6 +233,7 @@ k_pool_bn_bwd_reduce(const float *__restrict__ dyp, const float *__restrict__ ra
     }
 }
 
+template <bool NT>
 __global__ void __launch_bounds__(TPB)
 k_pool_bn_bwd_apply(const float *__restrict__ dyp, const float *__restrict__ raw, const float *__restrict__ mean,
                     const float *__restrict__ invstd, const float *__restrict__ coef, const double *__restrict__ m1,
@@ -247,7 +251,7 @@ k_pool_bn_bwd_apply(const float *__restrict__ dyp, const float *__restrict__ raw
         const bool ok[4] = {true, 2 * j + 1 < W, 2 * i + 1 < H, (2 * j + 1 < W) && (2 * i + 1 < H)};
         float4 v[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = ok[q] ? *reinterpret_cast<const float4 *>(raw + base + offs[q]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int q = 0; q < 4; ++q) v[q] = ok[q] ? ld_stream<NT>(raw + base + offs[q]) : make_float4(0.f, 0.f, 0.f, 0.f);
         float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
         if (pooled) g = *reinterpret_cast<const float4 *>(dyp + (((b * Ho + i) * Wo) + j) * (long long)C + c);
         const float4 psc = *reinterpret_cast<const float4 *>(pscale + c), psh = *reinterpret_cast<const float4 *>(pshift + c);
@@ -263,7 +267,7 @@ k_pool_bn_bwd_apply(const float *__restrict__ dyp, const float *__restrict__ raw
                 const double xh = ((double)((const float *)&v[q])[ch] - (double)mean[c + ch]) * (double)invstd[c + ch];
                 o[ch] = (float)((double)coef[c + ch] * ((double)dpre[q][ch] - m1[c + ch] - xh * m2[c + ch]));
             }
-            *reinterpret_cast<float4 *>(draw + base + offs[q]) = make_float4(o[0], o[1], o[2], o[3]);
+            st_stream<NT>(draw + base + offs[q], make_float4(o[0], o[1], o[2], o[3]));
         }
     }
 }
@@ -500,8 +504,12 @@ extern "C" int efgh_act_bn_bwd_reduce(const float *dy, int64_t lddy, const float
     int G = efgh_bwd_groups(M);
     int CL = 1;
     while (CL < 64 && CL * 4 < C) CL <<= 1;
-    k_act_bn_bwd_reduce<<<dim3(cdiv(C / 4, CL), G), TPB, 0, st>>>(dy, lddy, y, ldy, raw, ldraw, mean, invstd, pscale,
-                                                                 pshift, M, C, act, slope, (int)bwd_rows_per_block(M), CL, part, ybits);
+    if (efgh_stream_nt(M * C * 4ll))
+        k_act_bn_bwd_reduce<true><<<dim3(cdiv(C / 4, CL), G), TPB, 0, st>>>(dy, lddy, y, ldy, raw, ldraw, mean, invstd, pscale, pshift, M,
+                                                                           C, act, slope, (int)bwd_rows_per_block(M), CL, part, ybits);
+    else
+        k_act_bn_bwd_reduce<false><<<dim3(cdiv(C / 4, CL), G), TPB, 0, st>>>(dy, lddy, y, ldy, raw, ldraw, mean, invstd, pscale, pshift, M,
+                                                                            C, act, slope, (int)bwd_rows_per_block(M), CL, part, ybits);
     k_bwd_finalize<<<cdiv(C, 32), dim3(32, 32), 0, st>>>(part, G, C, (double)M, sum_dpre, sum_dpre_xhat, mean_dpre,
                                                          mean_dpre_xhat);
     EFGH_CHECK_LAUNCH();
@@ -559,9 +567,12 @@ extern "C" int efgh_act_bn_bwd_apply(const float *dy, int64_t lddy, const float 
         EFGH_CHECK_ARG(C % 32 == 0);
         ybits = (const unsigned *)y; y = nullptr;
     }
-    k_act_bn_bwd_apply<<<grid_for(M * (C / 4)), TPB, 0, (hipStream_t)stream_>>>(
-        dy, lddy, y, ldy, raw, ldraw, mean, invstd, coef, m1, m2, pscale, pshift, M, C, act, slope, draw, lddraw, dres,
-        lddres, ybits);
+    if (efgh_stream_nt(M * C * 4ll))
+        k_act_bn_bwd_apply<true><<<grid_for(M * (C / 4)), TPB, 0, (hipStream_t)stream_>>>(
+            dy, lddy, y, ldy, raw, ldraw, mean, invstd, coef, m1, m2, pscale, pshift, M, C, act, slope, draw, lddraw, dres, lddres, ybits);
+    else
+        k_act_bn_bwd_apply<false><<<grid_for(M * (C / 4)), TPB, 0, (hipStream_t)stream_>>>(
+            dy, lddy, y, ldy, raw, ldraw, mean, invstd, coef, m1, m2, pscale, pshift, M, C, act, slope, draw, lddraw, dres, lddres, ybits);
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
 }
@@ -655,7 +666,9 @@ extern "C" int efgh_pool_bn_bwd_reduce(const float *dy_pool, const float *raw, c
     const int G = efgh_pool_bwd_groups(B, H, W);
     int CL = 1;
     while (CL < 64 && CL * 4 < C) CL <<= 1;
-    k_pool_bn_bwd_reduce<<<dim3(cdiv(C / 4, CL), G), TPB, 0, st>>>(dy_pool, raw, mean, invstd, pscale, pshift, B, H, W, C, act,
+    if (efgh_stream_nt((long long)B * H * W * C * 4)) k_pool_bn_bwd_reduce<true><<<dim3(cdiv(C / 4, CL), G), TPB, 0, st>>>(dy_pool, raw, mean, invstd, pscale, pshift, B, H, W, C, act,
+                                                                  slope, (int)bwd_rows_per_block(ncell), CL, part);
+    else k_pool_bn_bwd_reduce<false><<<dim3(cdiv(C / 4, CL), G), TPB, 0, st>>>(dy_pool, raw, mean, invstd, pscale, pshift, B, H, W, C, act,
                                                                   slope, (int)bwd_rows_per_block(ncell), CL, part);
     k_bwd_finalize<<<cdiv(C, 32), dim3(32, 32), 0, st>>>(part, G, C, (double)B * H * W, sum_dpre, sum_dpre_xhat, mean_dpre,
                                                          mean_dpre_xhat);
@@ -670,7 +683,9 @@ extern "C" int efgh_pool_bn_bwd_apply(const float *dy_pool, const float *raw, co
     EFGH_CHECK_ARG(dy_pool && raw && mean && invstd && coef && m1 && m2 && pscale && pshift && draw);
     EFGH_CHECK_ARG(B > 0 && H >= 2 && W >= 2 && C > 0 && C % 4 == 0);
     const long long total = (long long)B * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4);
-    k_pool_bn_bwd_apply<<<grid_for(total), TPB, 0, (hipStream_t)stream_>>>(dy_pool, raw, mean, invstd, coef, m1, m2, pscale,
+    if (efgh_stream_nt((long long)B * H * W * C * 4)) k_pool_bn_bwd_apply<true><<<grid_for(total), TPB, 0, (hipStream_t)stream_>>>(dy_pool, raw, mean, invstd, coef, m1, m2, pscale,
+                                                                          pshift, B, H, W, C, act, slope, draw);
+    else k_pool_bn_bwd_apply<false><<<grid_for(total), TPB, 0, (hipStream_t)stream_>>>(dy_pool, raw, mean, invstd, coef, m1, m2, pscale,
                                                                           pshift, B, H, W, C, act, slope, draw);
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;

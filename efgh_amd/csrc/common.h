@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <stdio.h>
 #include <stdarg.h>
 
@@ -34,3 +35,37 @@ static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 // the other operand and turns a diverged pre-activation into a finite 0).  For every non-NaN input the result has the bits of
 // that form (neg * v + 0: a clamped value is +0, never -0).
 __device__ __forceinline__ float act_neg(float v, float neg) { return v > 0.f ? v : fmaf(neg, v, 0.f); }
+
+// streaming accesses of the HBM-bound passes (an activation that is read or written exactly once by the kernel).  NT = true: with
+// the non-temporal hint (the line is not kept in L2 / MALL) - measured +5-10 % on the BatchNorm passes over tensors that do not
+// fit the 256-MB MALL anyway (tools/bench_elementwise.py: reduce 5.25 -> 5.64 TB/s, normalise 5.02 -> 5.26 at 1 GB), and a LOSS
+// on tensors that do (0.13 GB: 6.9 -> 6.0 TB/s) - so the host side picks it by size (efgh_stream_nt).
+template <bool NT>
+__device__ __forceinline__ float4 ld_stream(const float *p) {
+    if (NT) {
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(p));
+        return make_float4(v.x, v.y, v.z, v.w);
+    }
+    return *reinterpret_cast<const float4 *>(p);
+}
+template <bool NT>
+__device__ __forceinline__ void st_stream(float *p, const float4 &v) {
+    if (NT) {
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        v4f w; w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w;
+        __builtin_nontemporal_store(w, reinterpret_cast<v4f *>(p));
+    } else {
+        *reinterpret_cast<float4 *>(p) = v;
+    }
+}
+// tensors of at least this many bytes stream past the caches (EFGH_STREAM_NT_MB in the environment overrides; 0 = never)
+static inline bool efgh_stream_nt(long long bytes) {
+    static long long thr = -1;
+    if (thr < 0) {
+        const char *e = getenv("EFGH_STREAM_NT_MB");
+        thr = e ? atoll(e) * (1ll << 20) : 384ll << 20;
+        if (thr == 0) thr = 1ll << 62;
+    }
+    return bytes >= thr;
+}

@@ -96,7 +96,7 @@ k_col_stats(const float *__restrict__ x, long long M, int C, long long ld, int r
 // y[r][c] = act(x[r][c]*scale[c] + shift[c] + res[r][c]); vector of 4 channels per thread.
 // BITS: also leaves bit e = (y > 0) of element e = r*C + c in `bits` (C % 32 == 0: eight consecutive lanes hold one 32-bit word) - the
 // activation mask the BatchNorm backward of a RESIDUAL layer needs, at 1/32 of the bytes of reading the activation back twice
-template <bool BITS>
+template <bool BITS, bool NT>
 __global__ void __launch_bounds__(TPB)
 k_scale_shift_act(const float *__restrict__ x, long long ldx, const float *__restrict__ scale,
                   const float *__restrict__ shift, const float *__restrict__ res, long long ldr,
@@ -105,7 +105,7 @@ k_scale_shift_act(const float *__restrict__ x, long long ldx, const float *__res
     long long total = M * c4;
     for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
         long long r = i / c4; int c = (int)(i - r * c4) * 4;
-        float4 v = *reinterpret_cast<const float4 *>(x + r * ldx + c);
+        float4 v = ld_stream<NT>(x + r * ldx + c);
         float4 s = scale ? *reinterpret_cast<const float4 *>(scale + c) : make_float4(1.f, 1.f, 1.f, 1.f);
         float4 h = shift ? *reinterpret_cast<const float4 *>(shift + c) : make_float4(0.f, 0.f, 0.f, 0.f);
         v.x = v.x * s.x + h.x; v.y = v.y * s.y + h.y; v.z = v.z * s.z + h.z; v.w = v.w * s.w + h.w;
@@ -115,7 +115,7 @@ k_scale_shift_act(const float *__restrict__ x, long long ldx, const float *__res
         }
         v.x = act_f(v.x, act, slope); v.y = act_f(v.y, act, slope);
         v.z = act_f(v.z, act, slope); v.w = act_f(v.w, act, slope);
-        *reinterpret_cast<float4 *>(y + r * ldy + c) = v;
+        st_stream<NT>(y + r * ldy + c, v);
         if (BITS) {
             // (total % 8 == 0 and the loop advances all lanes together: the eight lanes of a word are active together)
             unsigned w = ((v.x > 0.f) ? 1u : 0u) | ((v.y > 0.f) ? 2u : 0u) | ((v.z > 0.f) ? 4u : 0u) | ((v.w > 0.f) ? 8u : 0u);
@@ -163,6 +163,7 @@ k_maxpool2(const float *__restrict__ x, float *__restrict__ y, int B, int H, int
 
 // BatchNorm + activation + 2x2/2 max pool in one pass over the raw conv output (training path of the VGG trunks):
 // y[b][oh][ow][c] = max over the window of act(raw*scale[c] + shift[c]); the full-resolution activation is never stored.
+template <bool NT>
 __global__ void __launch_bounds__(TPB)
 k_maxpool2_affine(const float *__restrict__ x, const float *__restrict__ scale, const float *__restrict__ shift, int act,
                   float slope, float *__restrict__ y, int B, int H, int W, int C) {
@@ -178,7 +179,7 @@ k_maxpool2_affine(const float *__restrict__ x, const float *__restrict__ scale, 
         float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float4 v = *reinterpret_cast<const float4 *>(p + offs[q]);
+            const float4 v = ld_stream<NT>(p + offs[q]);
             m.x = fmaxf(m.x, act_f(v.x * sc.x + sf.x, act, slope)); m.y = fmaxf(m.y, act_f(v.y * sc.y + sf.y, act, slope));
             m.z = fmaxf(m.z, act_f(v.z * sc.z + sf.z, act, slope)); m.w = fmaxf(m.w, act_f(v.w * sc.w + sf.w, act, slope));
         }
@@ -308,9 +309,12 @@ extern "C" int efgh_scale_shift_act(const float *x, int64_t ldx, const float *sc
     EFGH_CHECK_ARG(x && y && M > 0 && C > 0);
     bool vec = (C % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && (!res || ldr % 4 == 0) &&
                ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)res) | ((uintptr_t)scale) | ((uintptr_t)shift)) & 15) == 0;
-    if (vec)
-        k_scale_shift_act<false><<<grid_for(M * (C / 4)), TPB, 0, (hipStream_t)stream>>>(x, ldx, scale, shift, res, ldr,
-                                                                                      y, ldy, M, C, act, slope, nullptr);
+    if (vec && efgh_stream_nt(M * C * 4ll))
+        k_scale_shift_act<false, true><<<grid_for(M * (C / 4)), TPB, 0, (hipStream_t)stream>>>(x, ldx, scale, shift, res, ldr,
+                                                                                            y, ldy, M, C, act, slope, nullptr);
+    else if (vec)
+        k_scale_shift_act<false, false><<<grid_for(M * (C / 4)), TPB, 0, (hipStream_t)stream>>>(x, ldx, scale, shift, res, ldr,
+                                                                                             y, ldy, M, C, act, slope, nullptr);
     else
         k_scale_shift_act1<<<grid_for(M * C), TPB, 0, (hipStream_t)stream>>>(x, ldx, scale, shift, res, ldr, y,
                                                                            ldy, M, C, act, slope);
@@ -325,8 +329,12 @@ extern "C" int efgh_scale_shift_act_bits(const float *x, int64_t ldx, const floa
     EFGH_CHECK_ARG(x && y && bits && M > 0 && C > 0 && C % 32 == 0);
     EFGH_CHECK_ARG((ldx % 4 == 0) && (ldy % 4 == 0) && (!res || ldr % 4 == 0) &&
                    ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)res) | ((uintptr_t)scale) | ((uintptr_t)shift)) & 15) == 0);
-    k_scale_shift_act<true><<<grid_for(M * (C / 4)), TPB, 0, (hipStream_t)stream>>>(x, ldx, scale, shift, res, ldr, y, ldy, M, C,
-                                                                                 act, slope, bits);
+    if (efgh_stream_nt(M * C * 4ll))
+        k_scale_shift_act<true, true><<<grid_for(M * (C / 4)), TPB, 0, (hipStream_t)stream>>>(x, ldx, scale, shift, res, ldr, y, ldy, M,
+                                                                                           C, act, slope, bits);
+    else
+        k_scale_shift_act<true, false><<<grid_for(M * (C / 4)), TPB, 0, (hipStream_t)stream>>>(x, ldx, scale, shift, res, ldr, y, ldy,
+                                                                                            M, C, act, slope, bits);
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
 }
@@ -341,7 +349,11 @@ extern "C" int efgh_maxpool2(const float *x, float *y, int32_t B, int32_t H, int
 extern "C" int efgh_maxpool2_affine(const float *x, const float *scale, const float *shift, int32_t act, float slope,
                                     float *y, int32_t B, int32_t H, int32_t W, int32_t C, void *stream) {
     EFGH_CHECK_ARG(x && scale && shift && y && B > 0 && H >= 2 && W >= 2 && C % 4 == 0);
-    k_maxpool2_affine<<<grid_for((long long)B * (H / 2) * (W / 2) * (C / 4)), TPB, 0, (hipStream_t)stream>>>(x, scale, shift, act,
+    if (efgh_stream_nt((long long)B * H * W * C * 4))
+        k_maxpool2_affine<true><<<grid_for((long long)B * (H / 2) * (W / 2) * (C / 4)), TPB, 0, (hipStream_t)stream>>>(x, scale, shift, act,
+                                                                                                          slope, y, B, H, W, C);
+    else
+        k_maxpool2_affine<false><<<grid_for((long long)B * (H / 2) * (W / 2) * (C / 4)), TPB, 0, (hipStream_t)stream>>>(x, scale, shift, act,
                                                                                                           slope, y, B, H, W, C);
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;

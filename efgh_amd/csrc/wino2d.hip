@@ -101,11 +101,33 @@ __device__ __forceinline__ void g46(const vec_t g[4], vec_t u[6]) {
 #undef E5
 }
 
+// 8-byte streaming accesses of the 2.25x-sized Winograd-domain tensors (see ld_stream / st_stream in common.h)
+template <bool NT>
+__device__ __forceinline__ vec_t ld2(const float *p) {
+    if (NT) {
+        typedef float v2f __attribute__((ext_vector_type(2)));
+        const v2f v = __builtin_nontemporal_load(reinterpret_cast<const v2f *>(__builtin_assume_aligned(p, 8)));
+        return make_float2(v.x, v.y);
+    }
+    return *reinterpret_cast<const vec_t *>(__builtin_assume_aligned(p, 8));
+}
+template <bool NT>
+__device__ __forceinline__ void st2(float *p, const vec_t &v) {
+    if (NT) {
+        typedef float v2f __attribute__((ext_vector_type(2)));
+        v2f w; w.x = v.x; w.y = v.y;
+        __builtin_nontemporal_store(w, reinterpret_cast<v2f *>(__builtin_assume_aligned(p, 8)));
+    } else {
+        *reinterpret_cast<vec_t *>(p) = v;
+    }
+}
+
 __device__ __forceinline__ void axpy4(vec_t &a, float s, const vec_t &v) {
     a.x += s * v.x; a.y += s * v.y;
 }
 
 // ---- input transform: thread = (tile, channel pair); 36 x 8-byte loads (pixels outside the image are zero), 36 stores
+template <bool NT>
 __global__ void __launch_bounds__(TPB)
 k_w2_input(const float *__restrict__ A, long long lda, int C, const TileGeo g, float *__restrict__ V) {
     const int q4n = C / VW, sh = ilog2(q4n);
@@ -158,10 +180,11 @@ k_w2_input(const float *__restrict__ A, long long lda, int C, const TileGeo g, f
 #pragma unroll
     for (int i = 0; i < 6; ++i)
 #pragma unroll
-        for (int j = 0; j < 6; ++j) *reinterpret_cast<vec_t *>(vp + (long long)(6 * i + j) * as) = acc[i][j];
+        for (int j = 0; j < 6; ++j) st2<NT>(vp + (long long)(6 * i + j) * as, acc[i][j]);
 }
 
 // ---- gradient-side transform of the weight gradient: Gy_a[tile][n] = (G4 dy G4^T)_a, dy outside the image is zero
+template <bool NT>
 __global__ void __launch_bounds__(TPB)
 k_w2_dy(const float *__restrict__ G, long long ldg, int N, const TileGeo g, float *__restrict__ Gy) {
     const int q4n = N / VW, sh = ilog2(q4n);
@@ -182,7 +205,7 @@ k_w2_dy(const float *__restrict__ G, long long ldg, int N, const TileGeo g, floa
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int x = x0 + c;
-            const vec_t v = *reinterpret_cast<const vec_t *>(__builtin_assume_aligned(row + (long long)min(x, g.W - 1) * ldg, 8));
+            const vec_t v = ld2<NT>(row + (long long)min(x, g.W - 1) * ldg);
             d[r][c] = (rok && x < g.W) ? v : zero;
         }
     }
@@ -203,7 +226,7 @@ k_w2_dy(const float *__restrict__ G, long long ldg, int N, const TileGeo g, floa
 #pragma unroll
     for (int i = 0; i < 6; ++i)
 #pragma unroll
-        for (int j = 0; j < 6; ++j) *reinterpret_cast<vec_t *>(vp + (long long)(6 * i + j) * as) = acc[i][j];
+        for (int j = 0; j < 6; ++j) st2<NT>(vp + (long long)(6 * i + j) * as, acc[i][j]);
 }
 
 // ---- output transform + the k_gather_gemm epilogue.  Thread = (tile column, channel pair); a workgroup walks ROWS_PER_BLOCK
@@ -218,6 +241,7 @@ struct W2OutArgs {
 
 constexpr int ROWS_PER_BLOCK = 1;              // rows of tiles per workgroup of k_w2_output (one statistics row per workgroup)
 
+template <bool NT>
 __global__ void __launch_bounds__(TPB, 4)          // (four workgroups per CU: <= 128 VGPRs - the pass is bound by bytes in flight)
 k_w2_output(const W2OutArgs p) {
     __shared__ float red[2][TPB][VW];
@@ -248,7 +272,7 @@ k_w2_output(const W2OutArgs p) {
         {
             vec_t m0[6], w0[4];
 #pragma unroll
-            for (int j = 0; j < 6; ++j) m0[j] = *reinterpret_cast<const vec_t *>(mp + (long long)j * as);
+            for (int j = 0; j < 6; ++j) m0[j] = ld2<NT>(mp + (long long)j * as);
             at4(m0, w0);
 #pragma unroll
             for (int x = 0; x < 4; ++x) Y[0][x] = w0[x];
@@ -260,8 +284,8 @@ k_w2_output(const W2OutArgs p) {
             vec_t ma[6], mb[6], wa[4], wb[4];
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
-                ma[j] = *reinterpret_cast<const vec_t *>(mp + (long long)(6 * (1 + 2 * pr) + j) * as);
-                mb[j] = *reinterpret_cast<const vec_t *>(mp + (long long)(6 * (2 + 2 * pr) + j) * as);
+                ma[j] = ld2<NT>(mp + (long long)(6 * (1 + 2 * pr) + j) * as);
+                mb[j] = ld2<NT>(mp + (long long)(6 * (2 + 2 * pr) + j) * as);
             }
             at4(ma, wa);
             at4(mb, wb);
@@ -286,7 +310,7 @@ k_w2_output(const W2OutArgs p) {
         {
             vec_t m5[6], w5[4];
 #pragma unroll
-            for (int j = 0; j < 6; ++j) m5[j] = *reinterpret_cast<const vec_t *>(mp + (long long)(30 + j) * as);
+            for (int j = 0; j < 6; ++j) m5[j] = ld2<NT>(mp + (long long)(30 + j) * as);
             at4(m5, w5);
 #pragma unroll
             for (int x = 0; x < 4; ++x) { Y[3][x].x += w5[x].x; Y[3][x].y += w5[x].y; }
@@ -314,7 +338,7 @@ k_w2_output(const W2OutArgs p) {
                 }
                 if (p.act == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); }
                 else if (p.act == 2) { v.x = v.x > 0.f ? v.x : v.x * p.slope; v.y = v.y > 0.f ? v.y : v.y * p.slope; }
-                *reinterpret_cast<vec_t *>(ob + po * ldo_i) = v;
+                st2<NT>(ob + po * ldo_i, v);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -436,7 +460,8 @@ extern "C" int efgh_wino2d_input(const float *A, int64_t lda, int32_t C, int32_t
     EFGH_CHECK_ARG((((uintptr_t)A) & 15) == 0 && (((uintptr_t)V) & 15) == 0);
     const TileGeo g = geo(B, H, W);
     EFGH_CHECK_ARG(pow2(C / VW) && (long long)B * g.TH < 65536);
-    k_w2_input<<<row_grid(g, C / VW, 1), TPB, 0, (hipStream_t)stream_>>>(A, lda, C, g, V);
+    if (efgh_stream_nt(g.T * 36ll * C * 4)) k_w2_input<true><<<row_grid(g, C / VW, 1), TPB, 0, (hipStream_t)stream_>>>(A, lda, C, g, V);
+    else k_w2_input<false><<<row_grid(g, C / VW, 1), TPB, 0, (hipStream_t)stream_>>>(A, lda, C, g, V);
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
 }
@@ -447,7 +472,8 @@ extern "C" int efgh_wino2d_dy(const float *G, int64_t ldg, int32_t N, int32_t B,
     EFGH_CHECK_ARG((((uintptr_t)G) & 15) == 0 && (((uintptr_t)Gy) & 15) == 0);
     const TileGeo g = geo(B, H, W);
     EFGH_CHECK_ARG(pow2(N / VW) && (long long)B * g.TH < 65536);
-    k_w2_dy<<<row_grid(g, N / VW, 1), TPB, 0, (hipStream_t)stream_>>>(G, ldg, N, g, Gy);
+    if (efgh_stream_nt(g.T * 36ll * N * 4)) k_w2_dy<true><<<row_grid(g, N / VW, 1), TPB, 0, (hipStream_t)stream_>>>(G, ldg, N, g, Gy);
+    else k_w2_dy<false><<<row_grid(g, N / VW, 1), TPB, 0, (hipStream_t)stream_>>>(G, ldg, N, g, Gy);
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
 }
@@ -460,7 +486,8 @@ extern "C" int efgh_wino2d_output(const float *M, const efgh_gemm_desc *d, void 
     a.M = M; a.N = d->N; a.g = geo(d->B, d->Hin, d->Win);
     a.bias = d->bias; a.scale = d->scale; a.shift = d->shift; a.residual = d->residual; a.ldr = d->ldr;
     a.act = d->act; a.slope = d->slope; a.out = d->out; a.ldo = d->ldo; a.stats = d->stats;
-    k_w2_output<<<row_grid(a.g, d->N / VW, ROWS_PER_BLOCK), TPB, 0, (hipStream_t)stream_>>>(a);
+    if (efgh_stream_nt(a.g.T * 36ll * d->N * 4)) k_w2_output<true><<<row_grid(a.g, d->N / VW, ROWS_PER_BLOCK), TPB, 0, (hipStream_t)stream_>>>(a);
+    else k_w2_output<false><<<row_grid(a.g, d->N / VW, ROWS_PER_BLOCK), TPB, 0, (hipStream_t)stream_>>>(a);
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
 }
