@@ -69,3 +69,16 @@ static inline bool efgh_stream_nt(long long bytes) {
     }
     return bytes >= thr;
 }
+
+// output stores of the MFMA kernels' epilogues (4-byte, one 128-B row segment per half-wave).  -DEFGH_MFMA_NT_OUT=1 gives them the
+// non-temporal hint (an experiment switch: see DESIGN 7 for the measurement)
+#ifndef EFGH_MFMA_NT_OUT
+#define EFGH_MFMA_NT_OUT 0
+#endif
+__device__ __forceinline__ void st_out(float *p, float v) {
+#if EFGH_MFMA_NT_OUT
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}

@@ -439,7 +439,7 @@ k_gather_gemm(const KArgs p_in) {
                     v = v * sc[j] + sf[j];
                     if (RES) v += rv[j];
                     v = act_neg(v, neg);
-                    if (FULL || cok[j]) op[j * 32] = v;
+                    if (FULL || cok[j]) st_out(op + j * 32, v);
                 }
             }
         }
@@ -454,7 +454,7 @@ k_gather_gemm(const KArgs p_in) {
                 const int rl = (wm * MI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 float *op = p.out + rowout[rl] * p.ldo + colb;
 #pragma unroll
-                for (int j = 0; j < NI; ++j) op[j * 32] = acc[i][j][r];
+                for (int j = 0; j < NI; ++j) st_out(op + j * 32, acc[i][j][r]);
             }
         }
     } else if (p.residual) {

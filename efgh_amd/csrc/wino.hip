@@ -249,7 +249,7 @@ __global__ void __launch_bounds__(256, 2) k_wino43(const WinoArgs p) {
                 v = v * sc + sf;
                 if (RES) v += rv[i];
                 v = act_neg(v, neg);
-                op[i * p.ldo] = v;
+                st_out(op + i * p.ldo, v);
                 if (bnm) {
                     const float rw = p.bn_raw[(opix + i) * p.bn_ldraw + col];
                     const float yy = p.bn_y ? p.bn_y[(opix + i) * p.bn_ldy + col] : rw * b_psc + b_psh;
