@@ -152,7 +152,7 @@ def traffic_source(workload):
 
 
 # the PMC passes the `traffic` fields are read from (tools/collect_round_evidence.sh writes them, profiles/README.md)
-TRAFFIC_FILE = {'train': 'r03_hbm_traffic_train.json', 'fwd': 'r03_hbm_traffic_fwd.json'}
+TRAFFIC_FILE = {'train': 'r04_hbm_traffic_train.json', 'fwd': 'r04_hbm_traffic_fwd.json'}
 
 
 def mfma_step_utilisation(prof, steps, ms_per_step):
@@ -160,7 +160,7 @@ def mfma_step_utilisation(prof, steps, ms_per_step):
     counted at the products they execute, half / a quarter of the direct form) / wall time of a step / dense fp32 MFMA peak"""
     fl = 0.0
     for name, lst in prof.items():
-        if name in ('bcl', 'wino2d') or not lst:        # 'wino2d' = whole layers in direct-form FLOP: its GEMM launches are 'wino2d_gemm'
+        if name in ('bcl', 'wino2d', 'hbm_convs') or not lst:   # 'wino2d' = whole layers in direct-form FLOP: its GEMM launches are 'wino2d_gemm'
             continue
         f = sum(p[2] for p in lst)
         fl += f / 2 if name in ('wino', 'wino_wgrad') else f
@@ -180,7 +180,7 @@ def gemm_roofline(prof, steps, kernel):
     ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     return {'bound': 'mfma', 'kernel': kernel, 'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
             'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
-            'traffic_unit': 'HBM-side bytes per launch (committed rocprofv3 PMC passes of this bench command, profiles/r03_hbm_traffic_*.json)',
+            'traffic_unit': 'HBM-side bytes per launch (committed rocprofv3 PMC passes of this bench command, profiles/r04_hbm_traffic_*.json)',
             'launches_per_step': n / max(1, steps),
             'avg_launch_ms': ms / max(1, n), 'algorithmic_gflop_per_launch': fl / max(1, n) / 1e9,
             'kernel_ms_per_step': ms / max(1, steps)}
@@ -203,8 +203,9 @@ def rooflines(prof, steps, workload='train'):
     rl = {}
     bcl = prof.get('bcl')
     w2 = prof.get('wino2d')
+    hb = prof.get('hbm_convs')
     for name, lst in prof.items():
-        if name in ('bcl', 'wino2d'):
+        if name in ('bcl', 'wino2d', 'hbm_convs'):
             continue
         if lst:
             r = gemm_roofline(lst, steps, KERNELS[name])
@@ -220,6 +221,11 @@ def rooflines(prof, steps, workload='train'):
     if not rl:
         return {}
     top = max(rl, key=lambda k: rl[k]['kernel_ms_per_step'])
+    # `roofline` = the dominant KERNEL.  The 2-D Winograd family is two kernels (k_gather_gemm<0> for forward / data gradient,
+    # k_gather_wgrad<0> for the weight gradient) whose summed time is within a few per cent of k_wino43's: without this the
+    # object flips between the two families from run to run
+    if 'wino' in rl and rl['wino']['kernel_ms_per_step'] >= 0.7 * rl[top]['kernel_ms_per_step']:
+        top = 'wino'
     out = {'roofline': rl[top]}
     if bcl:     # the HBM-bound side of the path: lattice build + BCL splat, SURVEY 8d algorithmic bytes / event time
         ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in bcl)
@@ -235,7 +241,7 @@ def rooflines(prof, steps, workload='train'):
                                + (' + splat adjoint' if any(k.endswith('bwd') for k in parts) else ''),
                                'achieved': ach, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': ach / PEAK_HBM_GBS,
                                'traffic': None,
-                               'traffic_unit': 'HBM-side bytes per STEP, all lattice.hip + bcl.hip launches (profiles/r03_hbm_traffic_*.json)',
+                               'traffic_unit': 'HBM-side bytes per STEP, all lattice.hip + bcl.hip launches (profiles/r04_hbm_traffic_*.json)',
                                'launches_per_step': len(bcl) / max(1, steps), 'kernel_ms_per_step': ms / max(1, steps),
                                'algorithmic_mb_per_step': by / max(1, steps) / 1e6,
                                'parts': {k: {'ms_per_step': v[0] / max(1, steps), 'algorithmic_mb_per_step': v[1] / max(1, steps) / 1e6,
@@ -249,6 +255,16 @@ def rooflines(prof, steps, workload='train'):
         if k != top:
             out['roofline_' + k] = v
     out['traffic_source'] = traffic_source(workload)
+    if hb:      # contractions below the ridge of the two rooflines (1x1 layers, narrow heads, thin kernels): bytes, not FLOP
+        ms = sum(p[0].elapsed_time(p[1]) for p in hb)
+        by = sum(p[2] for p in hb)
+        ach = by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        out['roofline_hbm_convs'] = {'bound': 'hbm', 'kernel': 'contractions with < %g FLOP per algorithmic byte (1x1 and 4-channel layers, narrow '
+                                     'heads, the point branch\'s 32-channel layers; forward, data and weight gradients): thin / small-channel '
+                                     'kernels and the generic tile' % 30.0,
+                                     'achieved': ach, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': ach / PEAK_HBM_GBS, 'traffic': None,
+                                     'launches_per_step': len(hb) / max(1, steps), 'kernel_ms_per_step': ms / max(1, steps),
+                                     'algorithmic_mb_per_step': by / max(1, steps) / 1e6}
     if w2:      # whole F(4x4,3x3) layers (input transform + batched GEMM + output transform), direct-form FLOPs
         ms = sum(p[0].elapsed_time(p[1]) for p in w2)
         fl = sum(p[2] for p in w2)
@@ -345,7 +361,7 @@ def main():
             fn()
         barrier()
         ops.PROFILE, ops.PROFILE_WGRAD, ops.PROFILE_WINO, ops.PROFILE_WINO_WGRAD, ops.PROFILE_BCL = [], [], [], [], []
-        ops.PROFILE_WINO2D, ops.PROFILE_WINO2D_GEMM = [], []
+        ops.PROFILE_WINO2D, ops.PROFILE_WINO2D_GEMM, ops.PROFILE_THIN = [], [], []
         lattice.PROFILE = ops.PROFILE_BCL
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -354,7 +370,8 @@ def main():
         dt = max_over_ranks(time.perf_counter() - t0)
         prof = {'gemm': ops.PROFILE, 'wgrad': ops.PROFILE_WGRAD, 'wino': ops.PROFILE_WINO,
                 'wino_wgrad': ops.PROFILE_WINO_WGRAD, 'bcl': ops.PROFILE_BCL, 'wino2d': ops.PROFILE_WINO2D,
-                'wino2d_gemm': ops.PROFILE_WINO2D_GEMM}
+                'wino2d_gemm': ops.PROFILE_WINO2D_GEMM, 'hbm_convs': ops.PROFILE_THIN}
+        ops.PROFILE_THIN = None
         ops.PROFILE = ops.PROFILE_WGRAD = ops.PROFILE_WINO = ops.PROFILE_WINO_WGRAD = ops.PROFILE_BCL = lattice.PROFILE = None
         ops.PROFILE_WINO2D = ops.PROFILE_WINO2D_GEMM = None
         return dt, prof

@@ -378,6 +378,21 @@ def thin_eligible(mode, C, N, T):
     return N == 4 and T * C * 16 <= 60 * 1024
 
 
+def conv_bytes(M, N, T, C):
+    """algorithmic bytes of one contraction launch: the input rows and the output rows once, the weights once"""
+    return 4.0 * (float(M) * (C + N) + float(N) * T * C)
+
+
+RIDGE_FLOP_PER_BYTE = 30.0      # 157 TFLOP/s fp32 MFMA over the ~5 TB/s a streaming pass reaches
+
+
+def hbm_bound(M, N, T, C):
+    """a contraction whose arithmetic intensity lies below the ridge of the fp32 MFMA / HBM rooflines is bound by its bytes (the
+    1x1 layers, the narrow heads, the point branch's 32-channel layers): bench.py prices it against the HBM roofline
+    (`roofline_hbm_convs`), not in the MFMA families"""
+    return 2.0 * M * N * T * C / conv_bytes(M, N, T, C) < RIDGE_FLOP_PER_BYTE
+
+
 TRACE_THIN = None       # tests set this to a list: efgh_thin_supported's answer per thin launch
 PROFILE_WINO = None     # launches served by the Winograd kernel (else they are listed in PROFILE)
 PROFILE = None          # bench.py sets this to a list: (start_event, end_event, algorithmic_flops) per launch
@@ -485,10 +500,10 @@ def gather_gemm(A, lda, C, T, Wp, N, M, out, ldo, mode=0, geom=None, table=None,
         _C.check(_L().efgh_gather_gemm_bf16x6(ctypes.byref(d), ptr(hi), ptr(mid), ptr(lo), _st()))
     else:
         _C.check(_L().efgh_gather_gemm(ctypes.byref(d), _st()))
-    if PROFILE is not None and thin:
+    if PROFILE is not None and (thin or (not wino and batch is None and hbm_bound(M, N, T, C))):
         e1.record()
         if PROFILE_THIN is not None:
-            PROFILE_THIN.append((e0, e1, float(flops) if flops is not None else 2.0 * M * N * T * C, (mode, M, N, T, C)))
+            PROFILE_THIN.append((e0, e1, conv_bytes(M, N, T, C), (mode, M, N, T, C)))
     elif PROFILE is not None:
         e1.record()
         rec = (e0, e1, float(flops) if flops is not None else 2.0 * M * N * T * C, (mode, M, N, T, C))
@@ -1025,10 +1040,10 @@ def gather_wgrad(A, lda, C, T, N, M, G, ldg, dWp, mode=0, geom=None, table=None)
     else:
         _C.check(_L().efgh_gather_wgrad(ctypes.byref(d), ptr(G), c_int64(ldg), ptr(dWp),
                                         ptr(_scratch(_L().efgh_gather_wgrad_workspace(ctypes.byref(d)), dWp.device)), _st()))
-    if PROFILE_WGRAD is not None and thin:
+    if PROFILE_WGRAD is not None and (thin or (not wino and hbm_bound(M, N, T, C))):
         e1.record()
         if PROFILE_THIN is not None:
-            PROFILE_THIN.append((e0, e1, 2.0 * M * N * T * C, (mode, M, N, T, C)))
+            PROFILE_THIN.append((e0, e1, conv_bytes(M, N, T, C), (mode, M, N, T, C)))
     elif PROFILE_WGRAD is not None:
         e1.record()
         rec = (e0, e1, 2.0 * M * N * T * C, (mode, M, N, T, C))
