@@ -255,6 +255,15 @@ def rooflines(prof, steps, workload='train'):
         if k != top:
             out['roofline_' + k] = v
     out['traffic_source'] = traffic_source(workload)
+    if hb and os.environ.get('EFGH_BENCH_SHAPES'):
+        agg = {}
+        for e0, e1, by_, key in hb:
+            a_ = agg.setdefault(key, [0, 0.0, 0.0])
+            a_[0] += 1; a_[1] += e0.elapsed_time(e1); a_[2] += by_
+        with open(os.environ['EFGH_BENCH_SHAPES'], 'a') as fh:
+            fh.write('hbm_convs: mode M N T C | calls ms GB/s\n')
+            for key, (n_, ms_, by_) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
+                fh.write('%s | %d %.2f %.0f\n' % (' '.join(map(str, key)), n_, ms_, by_ / (ms_ * 1e-3) / 1e9 if ms_ > 0 else 0))
     if hb:      # contractions below the ridge of the two rooflines (1x1 layers, narrow heads, thin kernels): bytes, not FLOP
         ms = sum(p[0].elapsed_time(p[1]) for p in hb)
         by = sum(p[2] for p in hb)

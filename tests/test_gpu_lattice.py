@@ -267,3 +267,28 @@ def test_partitioned_build_long_vertex_lists(n, spread):
     idx = np.repeat(np.arange(H), sa[:, 1])
     within = np.arange(idx.size) - np.repeat(np.cumsum(sa[:, 1]) - sa[:, 1], sa[:, 1])
     assert np.array_equal(la[sa[idx, 0] + within], lb[sb_[idx, 0] + within])
+
+
+def test_escalations_expire_after_clean_builds(monkeypatch):
+    """an outlier frame must not pin a signature to the slow plans for the rest of the process: an escalated level (big-bucket
+    kernel, then the hash build) is taken back one step after ESCALATION_DECAY clean speculative builds; every plan gives the
+    same lattice, and STATS counts the paths"""
+    from efgh_amd import lattice
+    pc = torch.from_numpy(np.stack([syn.lidar_sweep(4096, 0), syn.lidar_sweep(4096, 7)])).cuda()
+    lattice._SIZES.clear()
+    ref = lattice.build_pyramid_batched(pc, SCALES)                          # level by level; sizes known from here on
+    key = next(iter(lattice._SIZES))
+    monkeypatch.setattr(lattice, 'ESCALATION_DECAY', 2)
+    lattice._HASH_LEVELS[key] = {1}
+    lattice._BIG_LEVELS[key] = {0}
+    lattice._CLEAN[key] = 0
+    before = dict(lattice.STATS)
+    seen = []
+    for _ in range(7):
+        lv = lattice.build_pyramid_batched(pc, SCALES)
+        seen.append((sorted(lattice._HASH_LEVELS[key]), sorted(lattice._BIG_LEVELS[key]), [d._mode[0] if d._mode else None for d in lv]))
+        for u, v in zip(ref, lv):
+            assert u.H == v.H and torch.equal(u.nbr, v.nbr) and torch.equal(u.off, v.off) and torch.equal(u.bary, v.bary)
+    # hash level 1 -> big after two clean builds, then the big levels go one by one
+    assert seen[0][:2] == ([1], [0]) and seen[1][:2] == ([], [0, 1]) and seen[3][:2] == ([], [0]) and seen[5][:2] == ([], [])
+    assert lattice.STATS['speculative'] - before['speculative'] == 7 and lattice.STATS['reenqueued'] == before['reenqueued']
