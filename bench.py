@@ -441,19 +441,6 @@ def main():
         fwd.update(rooflines(prof, a.steps, 'fwd'))
         fwd['mfma_step_utilisation'] = mfma_step_utilisation(prof, a.steps, fwd['ms_per_step'])
         attach_serialized(fwd, fstep, 'fwd')
-        # opt-in fast math (NOT the default; `value` above is exact fp32 MFMA): split MFMA with fp32 accumulation.
-        #   f16x3 : x = hi + lo*2^-11 in fp16, 3 fp16 MFMAs per fp32 product, ~2^-22 per product (fp32-equivalent,
-        #           |x| < 65504);  bf16x3: x = hi + lo in bf16, ~2^-17 per product.  Both keep the pose logits
-        #           within 1e-4 (tests/test_gpu_forward.py::test_split_math_forward_logits_within_1e4).
-        fwd['fast_math'] = {}
-        for mode in ('f16x3', 'bf16x3'):
-            old_math, ops.MATH = ops.MATH, mode
-            dt3, prof3 = timed(fstep, a.steps, a.warmup)
-            ops.MATH = old_math
-            fwd['fast_math'][mode] = {
-                'value': world * Bf * a.steps / dt3, 'unit': 'frame-pairs/s', 'ms_per_step': dt3 / a.steps * 1e3,
-                'algorithmic_fp32_tflops': gemm_roofline(prof3['gemm'] + prof3['wino'], a.steps, 'k_gather_gemm<MATH>')['achieved'],
-                'note': 'EFGH_MATH=%s' % mode}
         del fsets
     if a.mode == 'train':
         Bt = a.batch or 8

@@ -7,6 +7,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get('EFGH_LIB') or os.path.join(_HERE, 'lib', 'libefgh_hip.so')      # EFGH_LIB: A/B runs of two builds
 _lib = None
+ABI_VERSION = 2          # EFGH_ABI_VERSION of include/efgh_hip.h this binding was written against
 
 c_void_p, c_int, c_int32, c_int64, c_float = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int32,
                                               ctypes.c_int64, ctypes.c_float)
@@ -47,6 +48,11 @@ def lib():
         import torch  # noqa: F401  (load torch's HIP runtime first so both share one runtime)
         _lib = ctypes.CDLL(SO_PATH)
         _lib.efgh_last_error.restype = ctypes.c_char_p
+        _lib.efgh_version.restype = c_int
+        if _lib.efgh_version() != ABI_VERSION:
+            got, _lib = _lib.efgh_version(), None
+            raise EfghError(f'{SO_PATH} has ABI version {got}, this package binds version {ABI_VERSION} of include/efgh_hip.h: '
+                            f'rebuild it (`python -m efgh_amd.build`)')
         _lib.efgh_wino2d_tiles.restype = c_int64
         _lib.efgh_gather_wgrad_workspace.restype = c_int64
         _lib.efgh_wino_wgrad_workspace.restype = c_int64

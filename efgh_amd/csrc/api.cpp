@@ -11,4 +11,4 @@ void efgh_set_error(const char *fmt, ...) {
 }
 
 extern "C" const char *efgh_last_error(void) { return g_err; }
-extern "C" int efgh_version(void) { return 1; }
+extern "C" int efgh_version(void) { return EFGH_ABI_VERSION; }

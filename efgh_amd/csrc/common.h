@@ -5,6 +5,7 @@
 #include <stdlib.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <atomic>
 
 #include "../../include/efgh_hip.h"
 
@@ -61,13 +62,25 @@ __device__ __forceinline__ void st_stream(float *p, const float4 &v) {
 }
 // tensors of at least this many bytes stream past the caches (EFGH_STREAM_NT_MB in the environment overrides; 0 = never)
 static inline bool efgh_stream_nt(long long bytes) {
-    static long long thr = -1;
-    if (thr < 0) {
+    // (a C++11 magic static: initialised once, thread-safe - the library is called from several host threads)
+    static const long long thr = [] {
         const char *e = getenv("EFGH_STREAM_NT_MB");
-        thr = e ? atoll(e) * (1ll << 20) : 384ll << 20;
-        if (thr == 0) thr = 1ll << 62;
-    }
+        const long long t = e ? atoll(e) * (1ll << 20) : 384ll << 20;
+        return t == 0 ? 1ll << 62 : t;
+    }();
     return bytes >= thr;
+}
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE setting: one flag bit per device ordinal, set after the first
+// successful call on that device (two host threads racing here both make the same idempotent call)
+static inline bool efgh_raise_lds_once(std::atomic<unsigned long long> &done, const void *fn, int bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return true;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return false;
+    done.fetch_or(bit, std::memory_order_release);
+    return true;
 }
 
 // output stores of the MFMA kernels' epilogues (4-byte, one 128-B row segment per half-wave).  -DEFGH_MFMA_NT_OUT=1 gives them the

@@ -23,52 +23,8 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-constexpr float F16_LO_SCALE = 2048.0f;      // lo terms are stored x 2^11 so that they stay normal fp16 numbers
-
 constexpr int BK = 32;
 constexpr int LDS_LD = BK + 4;       // fp32 path: floats per LDS row
-constexpr int LDH = BK + 8;          // split-bf16 path: bf16 per LDS row (80 B: conflict-free b128 reads)
-
-// x = hi + mid + lo (+ O(2^-25 |x|)): three bf16 terms carry the full fp32 significand
-__device__ __forceinline__ void split4x3(const float4 v, bf16x4 &hi, bf16x4 &mid, bf16x4 &lo) {
-    const float f[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        __bf16 h = (__bf16)f[q];
-        float r = f[q] - (float)h;
-        __bf16 m = (__bf16)r;
-        hi[q] = h; mid[q] = m;
-        lo[q] = (__bf16)(r - (float)m);
-    }
-}
-
-// x = hi + lo/2^11 (+ O(2^-22 |x|)) with hi, lo in fp16; |x| must stay below 65504 (saturates otherwise)
-__device__ __forceinline__ void split4_f16(const float4 v, f16x4 &hi, f16x4 &lo) {
-    const float f[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        float x = fminf(fmaxf(f[q], -65504.f), 65504.f);
-        _Float16 h = (_Float16)x;
-        hi[q] = h;
-        lo[q] = (_Float16)((x - (float)h) * F16_LO_SCALE);
-    }
-}
-
-// x = hi + lo (+ O(2^-17 |x|)) with hi, lo in bf16
-__device__ __forceinline__ void split4(const float4 v, bf16x4 &hi, bf16x4 &lo) {
-    const float f[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        __bf16 h = (__bf16)f[q];
-        hi[q] = h;
-        lo[q] = (__bf16)(f[q] - (float)h);
-    }
-}
-
 struct KArgs {
     const float *A; int64_t lda;
     int C, T, K;
@@ -78,7 +34,6 @@ struct KArgs {
     int Ho, Wo, osh, osw, oh0, ow0;
     const int *table;
     const float *W; int N;
-    const __bf16 *Wh, *Wm, *Wl;     // split-bf16 paths: packed weights as bf16 hi / (mid) / lo, [N][K]
     long long M; const int *M_dev;
     const float *bias, *scale, *shift, *residual; int64_t ldr;
     int act; float slope;
@@ -91,31 +46,20 @@ struct KArgs {
     int tam;                   // mode 2: taps marked in column 15 of the table row read zeros
 };
 
-// MATH 0: exact fp32 MFMA (v_mfma_f32_32x32x2_f32).
-// MATH 1: split-bf16: every fp32 operand is hi+lo in bf16 and a*b ~= ah*bh + ah*bl + al*bh on
-//         v_mfma_f32_32x32x16_bf16 with fp32 accumulation (per-product relative error ~2^-17).
-// MATH 2: three-term bf16 split, six products (fp32-equivalent).
-// MATH 3: split-fp16: x = hi + lo/2^11 in fp16 (22 significand bits), ah*bh in one accumulator and
-//         ah*bl' + al'*bh in a second one that is folded in with 2^-11 at the end (error ~2^-22/product).
-template <int MODE, int BM, int BN, int WM, int WN, int MATH>
-__global__ void __launch_bounds__(256, (MATH == 2 || MATH == 3) ? 2 : 3)
+// exact fp32 MFMA (v_mfma_f32_32x32x2_f32): fp32 operands, products and accumulation
+template <int MODE, int BM, int BN, int WM, int WN>
+__global__ void __launch_bounds__(256, 3)
 k_gather_gemm(const KArgs p_in) {
     constexpr int MI = BM / WM / 32, NI = BN / WN / 32;
     constexpr int NA = BM / 32, NB = BN / 32;
-    // LDS in floats: fp32 rows of 36 | 2 (MATH 1) or 3 (MATH 2) bf16 arrays with rows of 40
-    constexpr int A_ELEMS = MATH == 0 ? BM * LDS_LD : (MATH == 2 ? BM * LDH * 3 / 2 : BM * LDH);
-    constexpr int B_ELEMS = MATH == 0 ? BN * LDS_LD : (MATH == 2 ? BN * LDH * 3 / 2 : BN * LDH);
-    __shared__ __attribute__((aligned(16))) float As[A_ELEMS];
-    __shared__ __attribute__((aligned(16))) float Bs[B_ELEMS];
-    __bf16 *Ah = reinterpret_cast<__bf16 *>(As), *Al = Ah + BM * LDH, *Am = Al + BM * LDH;
-    __bf16 *Bh = reinterpret_cast<__bf16 *>(Bs), *Bl = Bh + BN * LDH, *Bm = Bl + BN * LDH;
+    __shared__ __attribute__((aligned(16))) float As[BM * LDS_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[BN * LDS_LD];
     __shared__ long long rowout[BM];          // output row (pixel) index per tile row, -1 = masked
 
     KArgs p = p_in;
     if (blockIdx.y) {              // batched launch: shift the operand pointers to problem blockIdx.y
         p.A += blockIdx.y * p.bsA; p.W += blockIdx.y * p.bsW; p.out += blockIdx.y * p.bsO;
         if (MODE == 2) p.table += blockIdx.y * p.bsT;
-        if (MATH != 0) { p.Wh += blockIdx.y * p.bsW; p.Wl += blockIdx.y * p.bsW; if (MATH == 2) p.Wm += blockIdx.y * p.bsW; }
     }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -190,7 +134,6 @@ k_gather_gemm(const KArgs p_in) {
     }
 
     float4 ra[NA], rb[NB];
-    float2 rbm[NB];            // MATH 2: mid term of the weights
     auto load_chunk = [&](int k0) {
         const int kk = k0 + kv;
         const bool kin = kk < p.K;
@@ -233,167 +176,54 @@ k_gather_gemm(const KArgs p_in) {
 #pragma unroll
         for (int q = 0; q < NB; ++q) {
             const bool ok = bval[q] && kin;
-            if (MATH == 0) {
-                float4 v = *reinterpret_cast<const float4 *>(p.W + (ok ? bbase[q] + kk : 0));
-                rb[q] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-            } else {                      // rb[q] = {hi(4 x bf16), lo(4 x bf16)} as raw bits
-                const long long o = ok ? bbase[q] + kk : 0;
-                float2 h = *reinterpret_cast<const float2 *>(p.Wh + o), l = *reinterpret_cast<const float2 *>(p.Wl + o);
-                rb[q] = ok ? make_float4(h.x, h.y, l.x, l.y) : make_float4(0.f, 0.f, 0.f, 0.f);
-                if (MATH == 2) {
-                    float2 m = *reinterpret_cast<const float2 *>(p.Wm + o);
-                    rbm[q] = ok ? m : make_float2(0.f, 0.f);
-                }
-            }
+            float4 v = *reinterpret_cast<const float4 *>(p.W + (ok ? bbase[q] + kk : 0));
+            rb[q] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
 
     f32x16 acc[MI][NI];
-    f32x16 acs[MATH == 3 ? MI : 1][MATH == 3 ? NI : 1];      // MATH 3: the 2^-11-scaled cross terms
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                acc[i][j][r] = 0.f;
-                if (MATH == 3) acs[i][j][r] = 0.f;
-            }
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nchunks = (p.K + BK - 1) / BK;
     load_chunk(0);
     for (int ch = 0; ch < nchunks; ++ch) {
-        if (MATH == 0) {
 #pragma unroll
-            for (int q = 0; q < NA; ++q)
-                *reinterpret_cast<float4 *>(&As[(q * 32 + arow) * LDS_LD + kv]) = ra[q];
+        for (int q = 0; q < NA; ++q)
+            *reinterpret_cast<float4 *>(&As[(q * 32 + arow) * LDS_LD + kv]) = ra[q];
 #pragma unroll
-            for (int q = 0; q < NB; ++q)
-                *reinterpret_cast<float4 *>(&Bs[(q * 32 + arow) * LDS_LD + kv]) = rb[q];
-        } else {
-#pragma unroll
-            for (int q = 0; q < NA; ++q) {
-                if (MATH == 3) {
-                    f16x4 h16, l16;
-                    split4_f16(ra[q], h16, l16);
-                    *reinterpret_cast<f16x4 *>(&Ah[(q * 32 + arow) * LDH + kv]) = h16;
-                    *reinterpret_cast<f16x4 *>(&Al[(q * 32 + arow) * LDH + kv]) = l16;
-                    continue;
-                }
-                bf16x4 hi, mid, lo;
-                if (MATH == 1) split4(ra[q], hi, lo);
-                else {
-                    split4x3(ra[q], hi, mid, lo);
-                    *reinterpret_cast<bf16x4 *>(&Am[(q * 32 + arow) * LDH + kv]) = mid;
-                }
-                *reinterpret_cast<bf16x4 *>(&Ah[(q * 32 + arow) * LDH + kv]) = hi;
-                *reinterpret_cast<bf16x4 *>(&Al[(q * 32 + arow) * LDH + kv]) = lo;
-            }
-#pragma unroll
-            for (int q = 0; q < NB; ++q) {
-                *reinterpret_cast<float2 *>(&Bh[(q * 32 + arow) * LDH + kv]) = make_float2(rb[q].x, rb[q].y);
-                *reinterpret_cast<float2 *>(&Bl[(q * 32 + arow) * LDH + kv]) = make_float2(rb[q].z, rb[q].w);
-                if (MATH == 2) *reinterpret_cast<float2 *>(&Bm[(q * 32 + arow) * LDH + kv]) = rbm[q];
-            }
-        }
+        for (int q = 0; q < NB; ++q)
+            *reinterpret_cast<float4 *>(&Bs[(q * 32 + arow) * LDS_LD + kv]) = rb[q];
         __syncthreads();
         if (ch + 1 < nchunks) load_chunk((ch + 1) * BK);
-        if (MATH == 0) {
-            const int kleft = p.K - ch * BK;          // a ragged last chunk (K = 36 for the 4-channel input convs) skips its
-#pragma unroll                                        // all-zero groups of 8
-            for (int g = 0; g < 4; ++g) {
-                if (g * 8 >= kleft) continue;
-                float4 a[MI], b[NI];
+        const int kleft = p.K - ch * BK;          // a ragged last chunk (K = 36 for the 4-channel input convs) skips its
+#pragma unroll                                    // all-zero groups of 8
+        for (int g = 0; g < 4; ++g) {
+            if (g * 8 >= kleft) continue;
+            float4 a[MI], b[NI];
 #pragma unroll
-                for (int i = 0; i < MI; ++i)
-                    a[i] = *reinterpret_cast<const float4 *>(
-                        &As[((wm * MI + i) * 32 + l31) * LDS_LD + g * 8 + lh * 4]);
-#pragma unroll
-                for (int j = 0; j < NI; ++j)
-                    b[j] = *reinterpret_cast<const float4 *>(
-                        &Bs[((wn * NI + j) * 32 + l31) * LDS_LD + g * 8 + lh * 4]);
-#pragma unroll
-                for (int i = 0; i < MI; ++i)
-#pragma unroll
-                    for (int j = 0; j < NI; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
-                    }
-            }
-        } else if (MATH == 3) {
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                f16x8 ah[MI], al[MI], bh[NI], bl[NI];
-#pragma unroll
-                for (int i = 0; i < MI; ++i) {
-                    const int o = ((wm * MI + i) * 32 + l31) * LDH + ks * 16 + lh * 8;
-                    ah[i] = *reinterpret_cast<const f16x8 *>(&Ah[o]);
-                    al[i] = *reinterpret_cast<const f16x8 *>(&Al[o]);
-                }
-#pragma unroll
-                for (int j = 0; j < NI; ++j) {
-                    const int o = ((wn * NI + j) * 32 + l31) * LDH + ks * 16 + lh * 8;
-                    bh[j] = *reinterpret_cast<const f16x8 *>(&Bh[o]);
-                    bl[j] = *reinterpret_cast<const f16x8 *>(&Bl[o]);
-                }
-#pragma unroll
-                for (int i = 0; i < MI; ++i)
-#pragma unroll
-                    for (int j = 0; j < NI; ++j) {
-                        acs[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acs[i][j], 0, 0, 0);
-                        acs[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acs[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-                    }
-            }
-        } else {
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {       // two k-steps of 16; lane holds k = 8*lh + j of the step
-                bf16x8 ah[MI], am[MI], al[MI], bh[NI], bm[NI], bl[NI];
-#pragma unroll
-                for (int i = 0; i < MI; ++i) {
-                    const int o = ((wm * MI + i) * 32 + l31) * LDH + ks * 16 + lh * 8;
-                    ah[i] = *reinterpret_cast<const bf16x8 *>(&Ah[o]);
-                    al[i] = *reinterpret_cast<const bf16x8 *>(&Al[o]);
-                    if (MATH == 2) am[i] = *reinterpret_cast<const bf16x8 *>(&Am[o]);
-                }
-#pragma unroll
-                for (int j = 0; j < NI; ++j) {
-                    const int o = ((wn * NI + j) * 32 + l31) * LDH + ks * 16 + lh * 8;
-                    bh[j] = *reinterpret_cast<const bf16x8 *>(&Bh[o]);
-                    bl[j] = *reinterpret_cast<const bf16x8 *>(&Bl[o]);
-                    if (MATH == 2) bm[j] = *reinterpret_cast<const bf16x8 *>(&Bm[o]);
-                }
-#pragma unroll
-                for (int i = 0; i < MI; ++i)
-#pragma unroll
-                    for (int j = 0; j < NI; ++j) {
-                        if (MATH == 1) {     // smallest terms first
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-                        } else {             // h/m/l x h/m/l, every term >= 2^-16 of the product kept
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bm[j], acc[i][j], 0, 0, 0);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bh[j], acc[i][j], 0, 0, 0);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bm[j], acc[i][j], 0, 0, 0);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-                        }
-                    }
-            }
-        }
-        __syncthreads();
-    }
-
-    if (MATH == 3) {
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
+            for (int i = 0; i < MI; ++i)
+                a[i] = *reinterpret_cast<const float4 *>(
+                    &As[((wm * MI + i) * 32 + l31) * LDS_LD + g * 8 + lh * 4]);
 #pragma unroll
             for (int j = 0; j < NI; ++j)
+                b[j] = *reinterpret_cast<const float4 *>(
+                    &Bs[((wn * NI + j) * 32 + l31) * LDS_LD + g * 8 + lh * 4]);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] += acs[i][j][r] * (1.0f / F16_LO_SCALE);
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+        __syncthreads();
     }
 
     // ---- epilogue -----------------------------------------------------------------------
@@ -558,41 +388,19 @@ __global__ void k_pad_vec(const float *__restrict__ v, int n, float *__restrict_
     if (i < np) out[i] = i < n ? v[i] : fill;
 }
 
-__global__ void k_split_f16(const float *__restrict__ w, _Float16 *__restrict__ hi, _Float16 *__restrict__ lo, long long n) {
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        float v = fminf(fmaxf(w[i], -65504.f), 65504.f);
-        _Float16 h = (_Float16)v;
-        hi[i] = h;
-        lo[i] = (_Float16)((v - (float)h) * F16_LO_SCALE);
-    }
-}
-
-template <int MODE, int BM, int BN, int WM, int WN, int MATH>
+template <int MODE, int BM, int BN, int WM, int WN>
 void launch(const KArgs &a0, hipStream_t st) {
     KArgs a = a0;
     a.nbx = (unsigned)((a.N + BN - 1) / BN);
     const long long nby = (a.M + BM - 1) / BM;
-    k_gather_gemm<MODE, BM, BN, WM, WN, MATH><<<dim3((unsigned)(a.nbx * nby), a.nbatch), 256, 0, st>>>(a);
+    k_gather_gemm<MODE, BM, BN, WM, WN><<<dim3((unsigned)(a.nbx * nby), a.nbatch), 256, 0, st>>>(a);
 }
 
-template <int MODE, int MATH>
+template <int MODE>
 void dispatch(const KArgs &a, hipStream_t st) {
-    if (a.N > 64) launch<MODE, 128, 128, 2, 2, MATH>(a, st);
-    else if (a.N > 32) launch<MODE, 128, 64, 2, 2, MATH>(a, st);
-    else launch<MODE, 256, 32, 4, 1, MATH>(a, st);
-}
-
-// hi/lo bf16 split of a packed fp32 weight matrix
-__global__ void k_split_bf16(const float *__restrict__ w, __bf16 *__restrict__ hi, __bf16 *__restrict__ mid,
-                             __bf16 *__restrict__ lo, long long n) {
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        float v = w[i];
-        __bf16 h = (__bf16)v;
-        hi[i] = h;
-        float r = v - (float)h;
-        if (mid) { __bf16 m = (__bf16)r; mid[i] = m; r -= (float)m; }
-        lo[i] = (__bf16)r;
-    }
+    if (a.N > 64) launch<MODE, 128, 128, 2, 2>(a, st);
+    else if (a.N > 32) launch<MODE, 128, 64, 2, 2>(a, st);
+    else launch<MODE, 256, 32, 4, 1>(a, st);
 }
 
 int tile_m(int N) { return N > 32 ? 128 : 256; }
@@ -625,7 +433,6 @@ static int fill_args(const efgh_gemm_desc *d, KArgs &a) {
     a.table = d->table; a.W = d->W; a.N = d->N; a.M = d->M; a.M_dev = d->M_dev;
     a.bias = d->bias; a.scale = d->scale; a.shift = d->shift; a.residual = d->residual; a.ldr = d->ldr;
     a.act = d->act; a.slope = d->slope; a.out = d->out; a.ldo = d->ldo; a.stats = d->stats;
-    a.Wh = a.Wm = a.Wl = nullptr;
     a.nbatch = d->nbatch > 1 ? (unsigned)d->nbatch : 1u;
     a.bsA = d->batch_stride_a; a.bsW = d->batch_stride_w; a.bsO = d->batch_stride_out; a.bsT = d->batch_stride_table;
     a.tam = d->mode == 2 ? d->table_alias_mask : 0;
@@ -646,74 +453,10 @@ extern "C" int efgh_gather_gemm(const efgh_gemm_desc *d, void *stream_) {
     KArgs a;
     int rc = fill_args(d, a);
     if (rc != EFGH_OK) return rc;
-    if (d->mode == 0) dispatch<0, 0>(a, st);
-    else if (d->mode == 1) dispatch<1, 0>(a, st);
-    else if (d->mode == 2) dispatch<2, 0>(a, st);
-    else dispatch<3, 0>(a, st);
-    EFGH_CHECK_LAUNCH();
-    return EFGH_OK;
-}
-
-extern "C" int efgh_gather_gemm_bf16x3(const efgh_gemm_desc *d, const void *W_hi, const void *W_lo, void *stream_) {
-    hipStream_t st = (hipStream_t)stream_;
-    KArgs a;
-    int rc = fill_args(d, a);
-    if (rc != EFGH_OK) return rc;
-    EFGH_CHECK_ARG(W_hi && W_lo && (((uintptr_t)W_hi) & 7) == 0 && (((uintptr_t)W_lo) & 7) == 0);
-    a.Wh = (const __bf16 *)W_hi; a.Wl = (const __bf16 *)W_lo;
-    if (d->mode == 0) dispatch<0, 1>(a, st);
-    else if (d->mode == 1) dispatch<1, 1>(a, st);
-    else if (d->mode == 2) dispatch<2, 1>(a, st);
-    else dispatch<3, 1>(a, st);
-    EFGH_CHECK_LAUNCH();
-    return EFGH_OK;
-}
-
-extern "C" int efgh_gather_gemm_bf16x6(const efgh_gemm_desc *d, const void *W_hi, const void *W_mid, const void *W_lo,
-                                       void *stream_) {
-    hipStream_t st = (hipStream_t)stream_;
-    KArgs a;
-    int rc = fill_args(d, a);
-    if (rc != EFGH_OK) return rc;
-    EFGH_CHECK_ARG(W_hi && W_mid && W_lo);
-    EFGH_CHECK_ARG(((((uintptr_t)W_hi) | ((uintptr_t)W_mid) | ((uintptr_t)W_lo)) & 7) == 0);
-    a.Wh = (const __bf16 *)W_hi; a.Wm = (const __bf16 *)W_mid; a.Wl = (const __bf16 *)W_lo;
-    if (d->mode == 0) dispatch<0, 2>(a, st);
-    else if (d->mode == 1) dispatch<1, 2>(a, st);
-    else if (d->mode == 2) dispatch<2, 2>(a, st);
-    else dispatch<3, 2>(a, st);
-    EFGH_CHECK_LAUNCH();
-    return EFGH_OK;
-}
-
-extern "C" int efgh_gather_gemm_f16x3(const efgh_gemm_desc *d, const void *W_hi, const void *W_lo, void *stream_) {
-    hipStream_t st = (hipStream_t)stream_;
-    KArgs a;
-    int rc = fill_args(d, a);
-    if (rc != EFGH_OK) return rc;
-    EFGH_CHECK_ARG(W_hi && W_lo && (((uintptr_t)W_hi) & 7) == 0 && (((uintptr_t)W_lo) & 7) == 0);
-    a.Wh = (const __bf16 *)W_hi; a.Wl = (const __bf16 *)W_lo;       // raw 16-bit storage, fp16 in this mode
-    if (d->mode == 0) dispatch<0, 3>(a, st);
-    else if (d->mode == 1) dispatch<1, 3>(a, st);
-    else if (d->mode == 2) dispatch<2, 3>(a, st);
-    else dispatch<3, 3>(a, st);
-    EFGH_CHECK_LAUNCH();
-    return EFGH_OK;
-}
-
-extern "C" int efgh_split_f16(const float *w, void *hi, void *lo, int64_t n, void *stream_) {
-    EFGH_CHECK_ARG(w && hi && lo && n > 0);
-    long long g = (n + 255) / 256;
-    k_split_f16<<<(int)(g > 8192 ? 8192 : g), 256, 0, (hipStream_t)stream_>>>(w, (_Float16 *)hi, (_Float16 *)lo, n);
-    EFGH_CHECK_LAUNCH();
-    return EFGH_OK;
-}
-
-extern "C" int efgh_split_bf16(const float *w, void *hi, void *mid, void *lo, int64_t n, void *stream_) {
-    EFGH_CHECK_ARG(w && hi && lo && n > 0);
-    long long g = (n + 255) / 256;
-    k_split_bf16<<<(int)(g > 8192 ? 8192 : g), 256, 0, (hipStream_t)stream_>>>(w, (__bf16 *)hi, (__bf16 *)mid,
-                                                                             (__bf16 *)lo, n);
+    if (d->mode == 0) dispatch<0>(a, st);
+    else if (d->mode == 1) dispatch<1>(a, st);
+    else if (d->mode == 2) dispatch<2>(a, st);
+    else dispatch<3>(a, st);
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
 }

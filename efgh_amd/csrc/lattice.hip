@@ -1624,39 +1624,27 @@ extern "C" int efgh_lattice_part_build(const float *pts, int64_t pts_cstride, co
         k_lat_scatter<2><<<w.ntiles, STP, 0, st>>>(pts, pts_cstride, n_dev, n_cap, scale32, std32, mm, sid, pps, nsamples, P, info);
     if (P.maxe == 2048) {           // (512 threads per bucket measured the same as 256: 259 vs 261 us at level 0)
         const size_t lds = (size_t)slots * 20 + (size_t)2048 * 14;          // 68 KB with slots = 2048: above the 64 KB a launch gets by default
-        static bool raised_small = false;
-        if (!raised_small && lds > 64 * 1024) {
-            if (hipFuncSetAttribute((const void *)k_lat_bucket<2048, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 20 * SMAX + 14 * 2048)
-                != hipSuccess) {
-                efgh_set_error("%s:%d: cannot raise the dynamic LDS limit of k_lat_bucket", __FILE__, __LINE__);
-                return EFGH_E_LAUNCH;
-            }
-            raised_small = true;
+        static std::atomic<unsigned long long> raised_small{0};
+        if (lds > 64 * 1024 && !efgh_raise_lds_once(raised_small, (const void *)k_lat_bucket<2048, 256>, 20 * SMAX + 14 * 2048)) {
+            efgh_set_error("%s:%d: cannot raise the dynamic LDS limit of k_lat_bucket", __FILE__, __LINE__);
+            return EFGH_E_LAUNCH;
         }
         k_lat_bucket<2048, 256><<<nbuckets, 256, lds, st>>>(P, n_dev, n_cap, list, info);
     } else {
         const size_t lds = (size_t)slots * 20 + (size_t)4096 * 14;          // up to 98 KB: above the 64 KB a launch gets by default
-        static bool raised = false;
-        if (!raised) {
-            if (hipFuncSetAttribute((const void *)k_lat_bucket<4096, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 20 * SMAX + 14 * 4096)
-                != hipSuccess) {
-                efgh_set_error("%s:%d: cannot raise the dynamic LDS limit of k_lat_bucket", __FILE__, __LINE__);
-                return EFGH_E_LAUNCH;
-            }
-            raised = true;
+        static std::atomic<unsigned long long> raised{0};
+        if (!efgh_raise_lds_once(raised, (const void *)k_lat_bucket<4096, 512>, 20 * SMAX + 14 * 4096)) {
+            efgh_set_error("%s:%d: cannot raise the dynamic LDS limit of k_lat_bucket", __FILE__, __LINE__);
+            return EFGH_E_LAUNCH;
         }
         k_lat_bucket<4096, 512><<<nbuckets, 512, lds, st>>>(P, n_dev, n_cap, list, info);
     }
     if (big_buckets) {
         const size_t lds = (size_t)slots * 20 + (size_t)MAXE_BIG * 14;      // 121-155 KB: above the 64 KB a launch gets by default
-        static bool raised_big = false;
-        if (!raised_big) {
-            if (hipFuncSetAttribute((const void *)k_lat_bucket_big, hipFuncAttributeMaxDynamicSharedMemorySize, 20 * SMAX + 14 * MAXE_BIG)
-                != hipSuccess) {
-                efgh_set_error("%s:%d: cannot raise the dynamic LDS limit of k_lat_bucket_big", __FILE__, __LINE__);
-                return EFGH_E_LAUNCH;
-            }
-            raised_big = true;
+        static std::atomic<unsigned long long> raised_big{0};
+        if (!efgh_raise_lds_once(raised_big, (const void *)k_lat_bucket_big, 20 * SMAX + 14 * MAXE_BIG)) {
+            efgh_set_error("%s:%d: cannot raise the dynamic LDS limit of k_lat_bucket_big", __FILE__, __LINE__);
+            return EFGH_E_LAUNCH;
         }
         k_lat_bucket_big<<<256, 1024, lds, st>>>(P, n_dev, n_cap, list, info);         // (one 152-KB workgroup per CU)
     }

@@ -54,6 +54,21 @@ class EFGHBackbone(nn.Module):
             setattr(self, name, cls(args))
         self.device = args['DEVICE']
 
+    def _epoch_holders(self):
+        """the distinct content-epoch owners (ops.Epoch) among this model's parameters, cached until a parameter changes owner"""
+        ps = list(self.parameters())
+        sig = tuple(id(ops.epoch_of(p)) for p in ps)
+        ent = self.__dict__.get('_efgh_holders')
+        if ent is None or ent[0] != sig:
+            seen, out = set(), []
+            for p in ps:
+                h = ops.epoch_of(p)
+                if id(h) not in seen:
+                    seen.add(id(h))
+                    out.append(h)
+            ent = self.__dict__['_efgh_holders'] = (sig, out)
+        return ent[1]
+
     def forward(self, pc, img, calib, A, check=False, keep=None):
         if getattr(self, '_is_replica', False):
             # torch.nn.DataParallel over more than one device (main.py:127 with several GPUs visible): its replicas are shallow
@@ -69,8 +84,10 @@ class EFGHBackbone(nn.Module):
         ops._C.require_f32(pc, img, calib, A)
         # packed weights that went stale with the last optimizer step are rewritten in place by ONE launch; every branch below
         # reads them, so that launch goes out here, on the current stream, before the streams fork
-        holder = ops.epoch_of(next(self.parameters()))
-        ops.repack_stale(pc.device, holder)
+        # (every distinct owner: with frozen sub-networks the frozen parameters stay with GLOBAL_EPOCH while the trainable ones carry
+        # their FlatParams' epoch - the first parameter alone would name only one of them)
+        for holder in self._epoch_holders():
+            ops.repack_stale(pc.device, holder)
         ops.TLS.train_step = bool(self.training and torch.is_grad_enabled())   # (GemmLayerFn carries it over to its backward)
         if self.training:
             ops.w2v_clear()

@@ -4,6 +4,8 @@ Conv1d) through the HIP gather-GEMM.  Activations are channels-last [B][H][W][C]
 The nn.Module objects only hold parameters/buffers (so that state_dict keys and shapes equal the
 reference's); their own forward() is never called.
 """
+import itertools
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -412,6 +414,9 @@ def _bn_cat(bns, grad):
     return bn
 
 
+_HEADS_GEN = itertools.count(1)
+
+
 def convt_heads_fusable(seq_d, seq_m):
     try:
         ct_d, ct_m, cv_d, cv_m = seq_d[0], seq_m[0], seq_d[3], seq_m[3]
@@ -457,6 +462,10 @@ def _heads_modules(ctx, seq_d, seq_m):
             store = seq_d.__dict__.setdefault('_efgh_heads_pack', {'ct': {}, 'cv': {}})
             ct.weight.__dict__['_efgh_cache'] = store['ct']
             cv.weight.__dict__['_efgh_cache'] = store['cv']
+            # every step's tensor is a NEW content generation of that shared store: a fresh torch.cat output has version 0, no
+            # optimizer epoch of its own, and - once the previous step's graph has been freed - usually the previous step's
+            # address, so without the stamp ops._ver() would equal last step's key and the step-1 packing would be served forever
+            ct.weight._efgh_gen = cv.weight._efgh_gen = next(_HEADS_GEN)
         else:
             ct.weight = build_ct(ct_d.weight.detach(), ct_m.weight.detach())
             cv.weight = build_cv(cv_d.weight.detach(), cv_m.weight.detach())

@@ -227,7 +227,7 @@ USE_WINO = _os.environ.get('EFGH_WINO', '1') != '0'   # Winograd F(4,3) kernel f
 
 def wino_eligible(mode, C, N, geom, T=None):
     """the layers efgh_wino_conv3x3 serves (mirror of efgh_wino_supported): 3x3, stride 1, pad 1, C%16 == N%64 == 0"""
-    if not USE_WINO or MATH != 'f32' or mode != 1 or geom is None or C % 16 or N % 64:
+    if not USE_WINO or mode != 1 or geom is None or C % 16 or N % 64:
         return False
     (B, Hin, Win, Hv, Wv, sh, sw, dh, dw, Ho, Wo, osh, osw, oh0, ow0) = geom
     return (len(dh) == 9 and (sh, sw, osh, osw, oh0, ow0) == (1, 1, 1, 1, 0, 0) and Hv == Hin == Ho and Wv == Win == Wo
@@ -294,7 +294,7 @@ def sc_eligible(mode, C, N, geom, wgrad=False):
     """the layers efgh_sc_conv3x3 / efgh_sc_wgrad serve (mirror of efgh_sc_supported): stride 1, "same" size; 3x3 / pad 1 with C and N in
     {16, 32}, or 1x1 with (C, N) = (64, 32) / (32, 64).  The 32 -> 32 forward / data-gradient launch keeps 144 weight registers per
     lane, which only pays on large maps (tools/bench_smallc.py: 0.092 vs 0.075 ms at 8 x 94 x 322 pixels, 0.244 vs 0.270 at 8 x 190 x 637)"""
-    if not USE_SMALLC or mode != 1 or geom is None or MATH != 'f32':
+    if not USE_SMALLC or mode != 1 or geom is None:
         return False
     (B, Hin, Win, Hv, Wv, sh, sw, dh, dw, Ho, Wo, osh, osw, oh0, ow0) = geom
     if not ((sh, sw, osh, osw, oh0, ow0) == (1, 1, 1, 1, 0, 0) and Hv == Hin == Ho and Wv == Win == Wo):
@@ -341,31 +341,6 @@ def wino_weight(Wp, N, C):
 
 
 USE_THIN = True
-MATH = _os.environ.get('EFGH_MATH', 'f32')   # 'f32': exact fp32 MFMA | 'bf16x3': split-bf16 MFMA (3 products, fp32 accumulate)
-
-
-def split_weight(Wp, terms=2):
-    """(hi, [mid,] lo) bf16 split of a packed fp32 weight, cached on the packed tensor"""
-    def make():
-        n = Wp.numel()
-        hi = torch.empty(n, dtype=torch.bfloat16, device=Wp.device)
-        lo = torch.empty(n, dtype=torch.bfloat16, device=Wp.device)
-        mid = torch.empty(n, dtype=torch.bfloat16, device=Wp.device) if terms == 3 else None
-        _C.check(_L().efgh_split_bf16(ptr(Wp), ptr(hi), ptr(mid), ptr(lo), c_int64(n), _st()))
-        return hi, mid, lo
-    return _cached(Wp, ('split', terms), _ver(Wp), make)
-
-
-def split_weight_f16(Wp):
-    def make():
-        n = Wp.numel()
-        hi = torch.empty(n, dtype=torch.float16, device=Wp.device)
-        lo = torch.empty(n, dtype=torch.float16, device=Wp.device)
-        _C.check(_L().efgh_split_f16(ptr(Wp), ptr(hi), ptr(lo), c_int64(n), _st()))
-        return hi, lo
-    return _cached(Wp, ('split_f16',), _ver(Wp), make)
-
-
 
 def thin_eligible(mode, C, N, T):
     """shapes served by the VALU "thin" kernels (thin.hip) instead of the MFMA tile"""
@@ -430,7 +405,7 @@ def gather_gemm(A, lda, C, T, Wp, N, M, out, ldo, mode=0, geom=None, table=None,
     kernel serving the launch supports it (Winograd F(4,3)) the column sums of that layer's BatchNorm backward are taken in the
     epilogue and the [rows][2][N] partials are RETURNED (else None: the layer runs its own reduction pass)."""
     if (KSPLIT_MAX_ROWS and mode == 2 and M <= KSPLIT_MAX_ROWS and T == 15 and N % 4 == 0 and T * C >= 1024 and batch is None
-            and scale is None and shift is None and residual is None and stats is None and M_dev is None and MATH == 'f32'
+            and scale is None and shift is None and residual is None and stats is None and M_dev is None
             and (bias is None or bias.numel() == N)):
         return _blur_gemm_ksplit(A, lda, C, Wp, N, M, out, ldo, table, bias, act, slope, a_off, out_off, flops, alias_mask)
     if PROFILE is not None:
@@ -489,15 +464,6 @@ def gather_gemm(A, lda, C, T, Wp, N, M, out, ldo, mode=0, geom=None, table=None,
             d.bn_mean, d.bn_invstd = bn_bwd.mean.data_ptr(), bn_bwd.invstd.data_ptr()
             d.bn_act, d.bn_slope = bn_bwd.act, bn_bwd.slope
         _C.check(_L().efgh_wino_conv3x3(ctypes.byref(d), ptr(wino_weight(Wp, N, C)), _st()))
-    elif MATH == 'bf16x3':
-        hi, _, lo = split_weight(Wp, 2)
-        _C.check(_L().efgh_gather_gemm_bf16x3(ctypes.byref(d), ptr(hi), ptr(lo), _st()))
-    elif MATH == 'f16x3':
-        hi, lo = split_weight_f16(Wp)
-        _C.check(_L().efgh_gather_gemm_f16x3(ctypes.byref(d), ptr(hi), ptr(lo), _st()))
-    elif MATH == 'bf16x6':
-        hi, mid, lo = split_weight(Wp, 3)
-        _C.check(_L().efgh_gather_gemm_bf16x6(ctypes.byref(d), ptr(hi), ptr(mid), ptr(lo), _st()))
     else:
         _C.check(_L().efgh_gather_gemm(ctypes.byref(d), _st()))
     if PROFILE is not None and (thin or (not wino and batch is None and hbm_bound(M, N, T, C))):

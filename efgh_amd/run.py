@@ -24,6 +24,24 @@ ranks share a GPU) and runs the unmodified script with three names rebound for t
     GLOBAL batch is what the config says - what DataParallel's scatter does;
   * `torch.save` on ranks > 0 is a no-op (rank 0 writes the checkpoints, as device 0's replica does under DataParallel).
 BatchNorm statistics stay per rank, as per replica under DataParallel.
+
+What makes the reference's REAL main.py safe under N processes (round 5; every rank runs the whole script):
+  * only the loader the script asked to SHUFFLE - the training loader, main.py:84-91 - is sharded; validation / test loaders
+    (`shuffle=False`, main.py:98-121) stay whole on every rank, so `is_val_best` and every printed metric are computed from all
+    of the data, as under DataParallel;
+  * rank 0 goes through the script's pre-model section FIRST (the ckpt_dir prompt, wipe and config copy, main.py:45-75): the
+    other ranks wait on the process group's store until rank 0 reaches its `DataParallel(model)` call, then run the same lines
+    with `input()` answering yes and every file operation under `ckpt_dir` turned into a no-op - so nobody races on
+    `os.path.exists(ckpt_dir)`, prompts on the shared stdin or deletes what rank 0 just wrote;
+  * on ranks > 0 `shutil.copyfile/copy/copy2/move/rmtree` and `os.remove/unlink/rmdir` skip paths under the config's `ckpt_dir`
+    (`save_checkpoint`, common/helper.py:40-61, copies and prunes checkpoint files that only rank 0 writes) and
+    `tensorboardX.SummaryWriter` is a null writer;
+  * a `test:` configuration is refused with `--gpus N` (test.py writes ONE prediction CSV / prints metrics over its own loader:
+    that is a single-process job);
+  * the parent polls its children: the first non-zero exit terminates the siblings and becomes the exit code, and the process
+    group has a timeout (`EFGH_RUN_TIMEOUT_S`, default 1800 s), so a rank that skips a step's `optimizer.step()` - the
+    reference's "CUDA out of memory: continue" path, iterater.py:108-116, taken on one rank only - ends the job with an error
+    instead of hanging it: a skipped step must be skipped on ALL ranks.
 """
 import os
 import runpy
@@ -62,6 +80,19 @@ def install_aliases():
     return out
 
 
+def install_loop_rebinds():
+    """`torch.cuda.empty_cache()` at the end of EVERY iteration (iterater.py:106, valid.py:57, test.py:81,161) becomes a no-op for
+    the duration of the run.  On the reference's eager path it papers over fragmentation; here a training step keeps ~10 GB of
+    activations per sample in the caching allocator's pool on purpose (sized for 288 GB) and handing them back to
+    hipFree / hipMalloc every step costs more than the step's own enqueue time (`bench.py` -> `config_r`: measured both ways).
+    `EFGH_RUN_KEEP_EMPTY_CACHE=1` leaves the call alone.  The out-of-memory handlers (iterater.py:108-116) call it too: an OOM
+    under this launcher is a real capacity limit, not fragmentation - the batch is skipped as in the reference."""
+    if os.environ.get('EFGH_RUN_KEEP_EMPTY_CACHE', '0') == '1':
+        return
+    import torch
+    torch.cuda.empty_cache = lambda: None
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # --gpus N: one process per GPU behind the reference's DataParallel call
 # ---------------------------------------------------------------------------------------------------------------------
@@ -84,6 +115,8 @@ def _process_data_parallel_class():
             self.device_ids, self.output_device, self.dim = [0], 0, dim
             self.world = dist.get_world_size() if dist.is_initialized() else 1
             if self.world > 1:
+                if dist.get_rank() == 0:
+                    _premodel_done()          # the ranks waiting in child_setup() may run the script's pre-model section now
                 with torch.no_grad():
                     for t in list(module.parameters()) + list(module.buffers()):
                         dist.broadcast(t.data, 0)
@@ -121,7 +154,7 @@ def _process_data_parallel_class():
     return ProcessDataParallel
 
 
-def install_process_parallel(rank, world):
+def install_process_parallel(rank, world, protected=()):
     """rebinds DataParallel / DataLoader / torch.save for a rank of a `--gpus N` run (see the module docstring)"""
     import torch
     import torch.utils.data as tud
@@ -140,7 +173,8 @@ def install_process_parallel(rank, world):
 
     class ShardedLoader(RealLoader):
         def __init__(self, dataset, batch_size=1, shuffle=None, sampler=None, batch_sampler=None, **kw):
-            if world > 1 and sampler is None and batch_sampler is None and not isinstance(dataset, tud.IterableDataset):
+            # (only the loader the script asked to shuffle is the training loader, main.py:84-91; evaluation loaders stay whole)
+            if world > 1 and shuffle and sampler is None and batch_sampler is None and not isinstance(dataset, tud.IterableDataset):
                 sampler = _EpochSampler(dataset, num_replicas=world, rank=rank, shuffle=bool(shuffle), seed=0, drop_last=False)
                 shuffle = None
                 if batch_size is not None:
@@ -151,7 +185,87 @@ def install_process_parallel(rank, world):
     torch.utils.data.DataLoader = ShardedLoader
     if rank != 0:
         torch.save = lambda *a, **k: None
+        _guard_file_ops(protected)
+        _null_summary_writer()
+        import builtins
+        builtins.input = lambda *a, **k: 'y'          # (query_yes_no, common/helper.py:63-93: rank 0 asked the user already)
     return PDP
+
+
+_PREMODEL_KEY = 'efgh_run/premodel_done'
+
+
+def _premodel_done():
+    import torch.distributed as dist
+    try:
+        dist.distributed_c10d._get_default_store().set(_PREMODEL_KEY, '1')
+    except Exception as e:                            # (a store without set/wait: nothing waits on it either)
+        sys.stderr.write('efgh_amd.run: could not signal the waiting ranks: %r\n' % (e,))
+
+
+def _wait_for_rank0_premodel(timeout_s):
+    import datetime
+    import torch.distributed as dist
+    dist.distributed_c10d._get_default_store().wait([_PREMODEL_KEY], datetime.timedelta(seconds=timeout_s))
+
+
+def _inside(path, roots):
+    try:
+        a = os.path.abspath(os.fspath(path))
+    except TypeError:
+        return False
+    return any(a == r or a.startswith(r + os.sep) for r in roots)
+
+
+def _guard_file_ops(protected):
+    """ranks > 0: file operations whose TARGET lies under a protected directory (the config's ckpt_dir) do nothing - rank 0 is the
+    only writer there (save_checkpoint's copies and pruning, common/helper.py:40-61; the ckpt_dir wipe, main.py:45-70)"""
+    import shutil
+    roots = [os.path.abspath(p) for p in protected if p]
+    if not roots:
+        return
+
+    def skip_on(fn, which):
+        def guarded(*a, **k):
+            tgt = a[which] if len(a) > which else None
+            if tgt is not None and _inside(tgt, roots):
+                return tgt if which == 1 else None
+            return fn(*a, **k)
+        guarded.__name__ = getattr(fn, '__name__', 'guarded')
+        return guarded
+    for name in ('copyfile', 'copy', 'copy2', 'move'):
+        setattr(shutil, name, skip_on(getattr(shutil, name), 1))        # (src, dst): the destination decides
+    shutil.rmtree = skip_on(shutil.rmtree, 0)
+    for name in ('remove', 'unlink', 'rmdir'):
+        setattr(os, name, skip_on(getattr(os, name), 0))
+
+
+def _null_summary_writer():
+    try:
+        import tensorboardX
+    except Exception:
+        return
+
+    class NullWriter:
+        def __init__(self, *a, **k):
+            pass
+
+        def __getattr__(self, name):
+            return lambda *a, **k: None
+    tensorboardX.SummaryWriter = NullWriter
+
+
+def script_config(rest):
+    """the reference passes ONE yaml file as the script's first argument (main.py:31-32): {} when that is not what `rest` holds"""
+    if not rest or not str(rest[0]).lower().endswith(('.yaml', '.yml')) or not os.path.isfile(rest[0]):
+        return {}
+    try:
+        import yaml
+        with open(rest[0]) as f:
+            cfg = yaml.safe_load(f)
+        return cfg if isinstance(cfg, dict) else {}
+    except Exception:
+        return {}
 
 
 def spawn(gpus, argv_tail):
@@ -179,13 +293,31 @@ def spawn(gpus, argv_tail):
         env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')          # dmabuf IPC only on this pool (RCCL needs it)
         env.setdefault('OMP_NUM_THREADS', '8')
         procs.append(subprocess.Popen([sys.executable, '-m', 'efgh_amd.run'] + argv_tail, env=env))
-    rc = 0
-    for p in procs:
-        rc = p.wait() or rc
+    # poll: a rank that dies (an exception, sys.exit(1) in the script's loop) leaves the others blocked in a collective - the
+    # first non-zero exit ends the job with that code
+    import time
+    rc, live = 0, list(procs)
+    while live:
+        time.sleep(0.2)
+        for p in list(live):
+            r = p.poll()
+            if r is None:
+                continue
+            live.remove(p)
+            if r != 0 and rc == 0:
+                rc = r
+                for q in live:
+                    q.terminate()
+                deadline = time.time() + 10.0
+                for q in live:
+                    try:
+                        q.wait(max(0.1, deadline - time.time()))
+                    except subprocess.TimeoutExpired:
+                        q.kill()
     return rc
 
 
-def child_setup():
+def child_setup(rest=()):
     """a rank of a `--gpus N` run: pin the device, join the group, rebind the three names.  Returns (rank, world)"""
     rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
     import torch
@@ -193,11 +325,18 @@ def child_setup():
     # (the parent made this rank's device the only visible one; more ranks than devices = ranks share GPUs, a plumbing run)
     shared = os.environ.get('EFGH_RUN_SHARED') == '1' or not os.environ.get('HIP_VISIBLE_DEVICES')
     backend = os.environ.get('EFGH_DIST_BACKEND', 'gloo' if shared else 'nccl')
+    import datetime
+    timeout = datetime.timedelta(seconds=float(os.environ.get('EFGH_RUN_TIMEOUT_S', '1800')))
     if backend == 'nccl':
-        dist.init_process_group('nccl', device_id=torch.device('cuda', 0))
+        dist.init_process_group('nccl', device_id=torch.device('cuda', 0), timeout=timeout)
     else:
-        dist.init_process_group(backend)
-    install_process_parallel(rank, world)
+        dist.init_process_group(backend, timeout=timeout)
+    cfg = script_config(rest)
+    install_process_parallel(rank, world, protected=[cfg.get('ckpt_dir')] if isinstance(cfg.get('ckpt_dir'), str) else [])
+    if rank != 0 and world > 1:
+        # rank 0 first through the script's pre-model section (prompt, ckpt_dir wipe, config copy: main.py:45-75); released by its
+        # DataParallel(model) call.  The wait covers a user thinking about the prompt; rank 0 dying ends the job from the parent.
+        _wait_for_rank0_premodel(float(os.environ.get('EFGH_RUN_PREMODEL_WAIT_S', '86400')))
     return rank, world
 
 
@@ -238,12 +377,16 @@ def main(argv=None):
         raise SystemExit('efgh_amd.run: no such script: %s' % script)
     child = os.environ.get('EFGH_RUN_CHILD') == '1' and 'RANK' in os.environ
     if gpus > 1 and not child:
+        if script_config(rest).get('test', False) not in (False, None):
+            raise SystemExit('efgh_amd.run: --gpus %d with a `test:` configuration: evaluation (test.py:13-167) writes one prediction '
+                             'CSV and prints metrics over its own loader - run it as a single process (drop --gpus)' % gpus)
         raise SystemExit(spawn(gpus, argv))
     if child:
-        child_setup()
+        child_setup(rest)
     elif pin:
         pin_one_device(device)
     install_aliases()
+    install_loop_rebinds()
     script = os.path.abspath(script)
     sys.argv = [script] + list(rest)
     sys.path.insert(0, os.path.dirname(script))
@@ -253,6 +396,8 @@ def main(argv=None):
         if child:
             import torch.distributed as dist
             if dist.is_initialized():
+                if dist.get_rank() == 0:
+                    _premodel_done()          # (a script that never wrapped a model: release the ranks that waited for it)
                 dist.destroy_process_group()
 
 

@@ -27,6 +27,16 @@ extern "C" {
 #define EFGH_E_LAUNCH (-2)    /* hip launch error */
 
 const char *efgh_last_error(void);
+
+/* ABI version of this header; efgh_version() returns the one the library was built from.  A caller compiled against another
+ * value must not call into the library (the Python binding refuses to load it).
+ *   1  rounds 1-4.  NOTE: round 4 added the caller-owned `workspace` argument to efgh_thin_wgrad / efgh_c4_wgrad and a
+ *      16-byte alignment requirement on their dWp without moving this number; out-of-tree callers of those two built
+ *      against a round-3 header pass their stream as the workspace.
+ *   2  round 5: that signature change is recorded here; efgh_plane_gemm / efgh_plane_wgrad (LDS-DMA staged batched plain GEMMs),
+ *      the per-sample fused small-level lattice build, the split-precision entry points (efgh_gather_gemm_{bf16x3,bf16x6,f16x3},
+ *      efgh_split_{bf16,f16}) removed. */
+#define EFGH_ABI_VERSION 2
 int efgh_version(void);
 
 /* ------------------------------------------------------------------ lattice (K1, K2) ------
@@ -458,23 +468,6 @@ int efgh_c4_conv3x3(const efgh_gemm_desc *d, void *stream);
 int efgh_c4_wgrad_supported(const efgh_gemm_desc *d);
 int64_t efgh_c4_wgrad_workspace(const efgh_gemm_desc *d);
 int efgh_c4_wgrad(const efgh_gemm_desc *d, const float *G, int64_t ldg, float *dWp, float *workspace, void *stream);
-
-/* split-bf16 variant of efgh_gather_gemm: every fp32 operand x is used as hi+lo (two bf16 numbers,
- * |x-hi-lo| <= 2^-17|x|) and each product as ah*bh + ah*bl + al*bh on v_mfma_f32_32x32x16_bf16 with fp32
- * accumulation: 3 bf16 MFMAs of K=16 replace 8 fp32 MFMAs of K=2.  Activations are split on the fly
- * in the staging pass; W_hi / W_lo are the packed weights [N][K] as bf16 (efgh_split_bf16).     */
-int efgh_gather_gemm_bf16x3(const efgh_gemm_desc *d, const void *W_hi, const void *W_lo, void *stream);
-/* three-term split x = hi+mid+lo (all 24 significand bits) and the six products >= 2^-16 of a*b:
- * fp32-equivalent accuracy (dropped terms <= 2^-24) on bf16 MFMAs: 6 x K=16 instead of 8 x K=2.  */
-int efgh_gather_gemm_bf16x6(const efgh_gemm_desc *d, const void *W_hi, const void *W_mid, const void *W_lo,
-                            void *stream);
-/* split-fp16: x = hi + lo*2^-11 with hi, lo in fp16 (22 significand bits, |x| < 65504); the cross terms
- * ah*bl + al*bh are summed in a second accumulator and folded in with 2^-11: ~2^-22 per product at the
- * cost of three fp16 MFMAs (intended for inference; gradients would need loss scaling).             */
-int efgh_gather_gemm_f16x3(const efgh_gemm_desc *d, const void *W_hi, const void *W_lo, void *stream);
-int efgh_split_f16(const float *w, void *hi, void *lo, int64_t n, void *stream);
-/* w[i] -> hi[i] (+ mid[i], optional: NULL for the two-term split) + lo[i], each bf16 */
-int efgh_split_bf16(const float *w, void *hi, void *mid, void *lo, int64_t n, void *stream);
 
 /* stride-2 3x3 transposed conv with <= 4 output channels (G's depth / mask heads, gnet.py:56-68) as
  * ONE gather-GEMM over the input pixels (Y [B*Hin*Win][ldy], column (kh*3+kw)*O+o) + this fold:

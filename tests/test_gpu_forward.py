@@ -129,39 +129,6 @@ def test_cpu_tensors_are_refused(manifest):
         m(inp[0], inp[1].to(torch.uint8), *inp[2:])
 
 
-@pytest.mark.parametrize('math', ['bf16x3', 'f16x3'])
-def test_split_math_forward_logits_within_1e4(golden_dir, manifest, math):
-    """the opt-in fast math modes (EFGH_MATH=bf16x3 | f16x3) keep the north-star tolerance on the pose
-    logits (stage-wise teacher-forced, eval mode)"""
-    from efgh_amd import ops
-    from oracle import efgh_oracle as O
-    old = ops.MATH
-    ops.MATH = math
-    try:
-        m = _model(manifest, False)
-        b, inp = _inputs()
-        P = syn.synthetic_state_dict(manifest['state_dict'], 1)
-        args = syn.default_args(RAW, 'cpu')
-        cpu = [t.cpu() for t in inp]
-        with torch.no_grad():
-            rete, reth = O.enet(P, cpu[0], False), O.hnet(P, cpu[1], False)
-            r = dict(rete); r.update(reth); r['network'] = 'EH'
-            r['eh_cam_T_velo'] = O.compute_cam_T_velo(r['intrinsic_sensor2'], r['sensor2_T_sensor1'], cpu[2], cpu[3])
-            rf = O.fnet(P, cpu[0], r, args, False)
-            rf['efh_cam_T_velo'] = O.compute_cam_T_velo(rf['intrinsic_sensor2'], rf['sensor2_T_sensor1'], cpu[2], cpu[3])
-            rg = O.gnet(P, cpu[0], cpu[1], rf, args, False)
-            dev = lambda d: {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in d.items()}
-            e, h = m.E(inp[0]), m.H(inp[1])
-            f = m.F(inp[0], dev(r))
-            g = m.G(inp[0], inp[1], dev(rf))
-        for got, ref, keys in ((e, rete, ('e_gn_sgn', 'e_gn_abs')), (h, reth, ('h_hrzn_sgn', 'h_hrzn_abs')),
-                               (f, rf, ('f_score',)), (g, rg, ('g_trs',))):
-            for k in keys:
-                assert _rel(got[k].cpu().numpy(), ref[k].numpy()) < 1e-4, k
-    finally:
-        ops.MATH = old
-
-
 def test_odd_point_count_and_strided_inputs_vs_oracle(manifest):
     """a sweep whose point count is neither a multiple of 4 nor of 64 (2 045 of the 2 048 points), handed over as a
     non-contiguous slice of a larger buffer, and an image that is a strided view: E / H logits and the E rasters against the

@@ -262,29 +262,6 @@ def test_corr_head():
         assert _rel(score[b].cpu(), torch.sigmoid(ref)) < 2e-5
 
 
-@pytest.mark.parametrize('math,tol', [('bf16x3', 3e-5), ('bf16x6', 6e-6), ('f16x3', 6e-6)])
-def test_split_bf16_math_modes(L, math, tol):
-    """opt-in split MFMA paths (x = hi+lo / hi+mid+lo in bf16, or hi + lo*2^-11 in fp16; fp32 accumulation)
-    vs the exact fp32-MFMA path and vs torch fp32: 2^-17 per product (bf16x3) / fp32-equivalent (bf16x6, f16x3)."""
-    from efgh_amd import ops
-    torch.manual_seed(7)
-    old = ops.MATH
-    try:
-        with torch.no_grad():
-            for (ci, co, k, s_, hw) in [(64, 64, 3, 1, (24, 40)), (128, 256, 3, 2, (17, 23)), (512, 96, 1, 1, (6, 10))]:
-                conv = nn.Conv2d(ci, co, k, s_, k // 2, bias=True).cuda()
-                x = torch.randn(2, *hw, ci, device='cuda')
-                ops.MATH = 'f32'
-                ref = L.conv2d(L.Ctx(False), x, conv, None, L.ACT_LEAKY, 0.2)
-                ops.MATH = math
-                got = L.conv2d(L.Ctx(False), x, conv, None, L.ACT_LEAKY, 0.2)
-                cpu = F.leaky_relu(conv.cpu()(x.cpu().permute(0, 3, 1, 2)), 0.2)
-                assert _rel(got, ref) < tol, (ci, co, _rel(got, ref))
-                assert _rel(got.permute(0, 3, 1, 2).cpu(), cpu) < tol
-    finally:
-        ops.MATH = old
-
-
 @pytest.mark.parametrize('cin,cout,hw,B', [(64, 64, (24, 40), 2), (128, 256, (9, 13), 2), (256, 128, (5, 3), 1),
                                            (64, 192, (17, 262), 1), (512, 512, (6, 10), 3)])
 def test_winograd_conv3x3_vs_direct_and_fp64(L, cin, cout, hw, B):

@@ -406,7 +406,8 @@ def test_gradients_are_reproducible_run_to_run(manifest):
         ops.DETERMINISTIC = old
 
 
-def test_repack_is_ordered_before_the_stream_fork(manifest):
+@pytest.mark.parametrize('freeze_first', [False, True])
+def test_repack_is_ordered_before_the_stream_fork(manifest, freeze_first):
     """after FusedAdam every packed weight is re-packed in place by ONE launch; H, G's image part and E / F start on three streams
     and all read those buffers, so the launch has to sit on the current stream BEFORE the fork (ops.repack_stale).  No host sync
     between steps, the H stream stalled at the start of every step (where the repack used to be enqueued): the losses of step 3
@@ -424,6 +425,12 @@ def test_repack_is_ordered_before_the_stream_fork(manifest):
     def run(side):
         m = EFGHBackbone(args)
         m.load_state_dict(sd)
+        if freeze_first:
+            # the reference's `grad_false_keys` (main.py:162-176) freezing the FIRST sub-network: the model's first parameter then
+            # belongs to GLOBAL_EPOCH while the trainable weights carry the FlatParams' epoch - the repack before the fork has to
+            # cover every owner, not the first parameter's (round-4 advisor finding)
+            for q in m.E.parameters():
+                q.requires_grad_(False)
         tr = Trainer(m.cuda(), EFGHCriterion(args), lr=1e-3)
         out = []
         for _ in range(3):
@@ -549,3 +556,45 @@ def test_two_threads_two_models_equal_the_serial_results(manifest):
         assert serial[i][0] == threaded[i][0], (i, serial[i][0], threaded[i][0])
         assert torch.equal(serial[i][1], threaded[i][1]) and torch.equal(serial[i][2], threaded[i][2]), i
     assert serial[0][0] != serial[1][0]
+
+
+def test_fused_heads_packed_weights_follow_the_optimizer_when_outputs_are_dropped(manifest):
+    """G's fused depth / mask heads (layers._heads_modules) pack per-step torch.cat outputs into persistent buffers shared across steps.
+    A fresh cat output has version 0, no optimizer epoch and - when the caller drops the step's result, so that the previous graph is
+    freed before the next forward - the previous step's ADDRESS: the cache key must still change every step, or the step-1 packing
+    is served forever while the optimizer moves the real weights (round-4 advisor finding).  Four steps with discarded outputs, then
+    every packed layout of the store is compared with a fresh packing of the CURRENT concatenated weights."""
+    import torch.nn.functional as F
+    from efgh_amd import ops
+    from efgh_amd.losses import EFGHCriterion
+    from efgh_amd.nets import EFGHBackbone
+    from efgh_amd.train import Trainer
+    args = syn.default_args(RAW, 'cuda')
+    m = EFGHBackbone(args)
+    m.load_state_dict(syn.synthetic_state_dict(manifest['state_dict'], 1))
+    tr = Trainer(m.cuda(), EFGHCriterion(args), lr=1e-2)
+    b = syn.make_batch(RAW, NPTS, 2)
+    inp = [torch.from_numpy(b[k]).cuda() for k in ('pc', 'img', 'calib', 'A')]
+    gt = {k: torch.from_numpy(v) for k, v in b['gt'].items()}
+    w0 = m.G.convt_dimg[0].weight.detach().clone()
+    for _ in range(4):
+        tr.step(*inp, gt)                        # result dropped: the graph (and the fused tensors' storage) dies here
+    assert not torch.equal(w0, m.G.convt_dimg[0].weight.detach())
+    tr.base_lr = 0.0
+    w4 = tr.flat.w.detach().clone()
+    tr.step(*inp, gt)                            # forward AND backward layouts are packed from the current weights; Adam with lr 0
+    assert torch.equal(w4, tr.flat.w)            # leaves them where they are
+    store = m.G.convt_dimg.__dict__['_efgh_heads_pack']
+    ct_d, ct_m, cv_d, cv_m = m.G.convt_dimg[0], m.G.convt_mask[0], m.G.convt_dimg[3], m.G.convt_mask[3]
+    od, om = ct_d.out_channels, ct_m.out_channels
+    cur = {'ct': torch.cat([ct_d.weight.detach(), ct_m.weight.detach()], 1).contiguous(),
+           'cv': torch.cat([F.pad(cv_d.weight.detach(), (0, 0, 0, 0, 0, om)), F.pad(cv_m.weight.detach(), (0, 0, 0, 0, od, 0))], 0).contiguous()}
+    checked = 0
+    for name in ('ct', 'cv'):
+        assert store[name], name
+        for key, (ver, buf) in store[name].items():
+            fresh = torch.empty_like(buf)
+            ops._pack_one(cur[name], fresh, buf._efgh_pack)
+            assert torch.equal(fresh, buf), (name, key)
+            checked += 1
+    assert checked >= 3          # forward layouts of both convolutions + at least one data-gradient layout
