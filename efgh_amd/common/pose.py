@@ -13,7 +13,8 @@ import torch
 from .. import _C
 
 _CONST = {}
-USE_KERNELS = os.environ.get('EFGH_POSE_KERNELS', '1') != '0'    # fused heads (csrc/pose.hip) whenever autograd is off
+USE_KERNELS = True      # the heads are csrc/pose.hip kernels.  False (set by tests/test_gpu_pose.py only): the same formulas as batched tensor
+                        # expressions - the independent reference the kernels and their hand-written backward are held to, not a product path
 
 
 def _fused():

@@ -476,13 +476,9 @@ int grid_for(long long total) {
 
 // rows per partial-sum block: 512, grown for huge tensors so that the finalize pass folds at most 4096 partial rows
 static long long bwd_rows_per_block(long long M) {
-    // partial rows a reduction leaves for k_bwd_finalize (EFGH_BWD_GROUPS: tuning knob; a thread-safe magic static).
-    // (4096 until round 4: the fold of 4 096 rows cost 14 us per layer; tools/bench_elementwise.py: 0.358 -> 0.326 ms at 1 GB)
-    static const long long groups = [] {
-        const char *e = getenv("EFGH_BWD_GROUPS");
-        const long long g = e ? atoll(e) : 1024;
-        return g < 64 ? 64ll : g;
-    }();
+    // partial rows a reduction leaves for k_bwd_finalize (4096 until round 4: the fold of 4 096 rows cost 14 us per layer;
+    // tools/bench_elementwise.py: 0.358 -> 0.326 ms at 1 GB)
+    const long long groups = 1024;
     long long rows = (M + groups - 1) / groups;
     rows = (rows + 63) / 64 * 64;
     return rows < 512 ? 512 : rows;

@@ -60,16 +60,8 @@ __device__ __forceinline__ void st_stream(float *p, const float4 &v) {
         *reinterpret_cast<float4 *>(p) = v;
     }
 }
-// tensors of at least this many bytes stream past the caches (EFGH_STREAM_NT_MB in the environment overrides; 0 = never)
-static inline bool efgh_stream_nt(long long bytes) {
-    // (a C++11 magic static: initialised once, thread-safe - the library is called from several host threads)
-    static const long long thr = [] {
-        const char *e = getenv("EFGH_STREAM_NT_MB");
-        const long long t = e ? atoll(e) * (1ll << 20) : 384ll << 20;
-        return t == 0 ? 1ll << 62 : t;
-    }();
-    return bytes >= thr;
-}
+// tensors of at least this many bytes stream past the caches (384 MB: beyond the 256-MB MALL with room for the other operand)
+static inline bool efgh_stream_nt(long long bytes) { return bytes >= (384ll << 20); }
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE setting: one flag bit per device ordinal, set after the first
 // successful call on that device (two host threads racing here both make the same idempotent call)

@@ -301,7 +301,7 @@ __global__ void k_wino_pack(const float *__restrict__ Wp, float *__restrict__ U,
 //     S_alpha[n][kh][c] = sum_tiles (G4 dy)_alpha[tile][n] * (B^T x)_alpha[tile][kh][c]
 // six GEMMs contracted over the tiles (18 instead of 36 products per tile, tap row and channel pair).  One
 // workgroup = 64 n x 64 (kh, c) columns x all six alpha; the tiles are split over gridDim.z and the partial
-// S blocks combined with fp32 atomics; k_wino_wgrad_finish applies A3^T and writes the packed [N][9][C] layout.
+// S blocks left as one partial per unit (folded in a fixed order); k_wino_wgrad_finish3 writes the packed [N][9][C] layout.
 constexpr int TT = 16;            // tiles per contraction step
 
 struct WinoWArgs {
@@ -309,157 +309,17 @@ struct WinoWArgs {
     const float *G; long long ldg; int N;
     int B, H, W, TW;
     long long Mt; long long tchunk;
-    float *S;                      // [zs][6][N][3C]: one partial per tile range (plain stores; folded by k_wino_wgrad_finish)
+    float *S;                      // [units][3][N][3C]: one partial per unit (plain stores; folded in unit order, then k_wino_wgrad_finish3)
     unsigned kt, nt;               // column / row blocks of S
 };
 
-__global__ void __launch_bounds__(256, 2) k_wino_wgrad(const WinoWArgs p) {
-    __shared__ __attribute__((aligned(16))) float Gs[6 * TT * 64];
-    __shared__ __attribute__((aligned(16))) float Vs[6 * TT * 64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wn = wave >> 1, wc = wave & 1, l31 = lane & 31, lh = lane >> 5;
-    // XCD-aware order: consecutive workgroups are dealt round-robin over the 8 XCDs; give every XCD one contiguous band of
-    // tile ranges and run all (n, kh, c) blocks of a range back to back on it, so that the x / dy rows they share are
-    // fetched from HBM once (measured before: 4.3 GB fetched per launch for ~0.9 GB of operands)
-    const unsigned nblk = gridDim.x, q8 = nblk >> 3, r8 = nblk & 7, xcd = blockIdx.x & 7, within = blockIdx.x >> 3;
-    const unsigned lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + within;
-    const unsigned per_z = p.kt * p.nt, bz = lin / per_z, rem = lin - bz * per_z;
-    const unsigned by = rem / p.kt, bx = rem - by * p.kt;
-    const int k0 = bx * 64;                           // column block inside [3][C]
-    const int kh = k0 / p.C, c0 = k0 - kh * p.C;
-    const int n0 = by * 64;
-    const long long tbeg = (long long)bz * p.tchunk;
-    long long tend = tbeg + p.tchunk;
-    if (tend > p.Mt) tend = p.Mt;
-    if (tbeg >= tend) return;
-
-    // staging: thread = (tile ts of the step, channel quad q)
-    const int ts = tid >> 4, q4 = (tid & 15) * 4;
-    int xt, y; long long b;
-    {
-        const long long t = tbeg + ts;
-        xt = (int)(t % p.TW); const long long r = t / p.TW;
-        y = (int)(r % p.H); b = r / p.H;
-    }
-    float4 rx0, rx1, rx2, rx3, rx4, rx5, rg0, rg1, rg2, rg3;
-    // addresses of the next step once per step; the ten loads are then issued between the MFMA groups (see k_wino43)
-    const float *zpage = g_zero_page;
-    const float *xrow = p.A, *grow = p.G;
-    bool rok = false, tv = false;
-    int x0 = 0, xg = 0;
-#define EFGH_STEP_ADDR(t0)                                                                            \
-    {                                                                                                \
-        tv = (t0) + ts < tend;                                                                       \
-        const long long rowb = b * p.H + y;                                                          \
-        x0 = 4 * xt - 1; xg = 4 * xt;                                                                \
-        rok = tv && (unsigned)(y + kh - 1) < (unsigned)p.H;                                          \
-        xrow = p.A + (((rowb + (kh - 1)) * p.W + x0) * p.lda + c0 + q4);                             \
-        grow = p.G + ((rowb * p.W + xg) * p.ldg + n0 + q4);                                          \
-        xt += TT;                                                                                    \
-        while (xt >= p.TW) { xt -= p.TW; ++y; }                                                      \
-        while (y >= p.H) { y -= p.H; ++b; }                                                          \
-    }
-#define EFGH_LDX(q, dst)                                                                              \
-    dst = *reinterpret_cast<const float4 *>((rok && (unsigned)(x0 + q) < (unsigned)p.W) ? xrow + (long long)q * p.lda : zpage);
-#define EFGH_LDG(i, dst)                                                                              \
-    dst = *reinterpret_cast<const float4 *>((tv && (xg + i) < p.W) ? grow + (long long)i * p.ldg : zpage);
-
-    f32x16 acc[6];
-#pragma unroll
-    for (int a = 0; a < 6; ++a)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
-
-    EFGH_STEP_ADDR(tbeg)
-    EFGH_LDX(0, rx0) EFGH_LDX(1, rx1) EFGH_LDX(2, rx2) EFGH_LDX(3, rx3) EFGH_LDX(4, rx4) EFGH_LDX(5, rx5)
-    EFGH_LDG(0, rg0) EFGH_LDG(1, rg1) EFGH_LDG(2, rg2) EFGH_LDG(3, rg3)
-    for (long long t0 = tbeg; t0 < tend; t0 += TT) {
-        {
-            float4 v0, v1, v2, v3, v4, v5, u0, u1, u2, u3, u4, u5;
-#define EFGH_TR(e)                                                                                    \
-            {                                                                                        \
-                const float d0 = rx0.e, d1 = rx1.e, d2 = rx2.e, d3 = rx3.e, d4 = rx4.e, d5 = rx5.e;    \
-                const float p42 = d4 - 4.f * d2, p31 = d3 - 4.f * d1;                                \
-                const float q42 = d4 - d2, q31 = 2.f * (d3 - d1);                                    \
-                v0.e = 4.f * d0 - 5.f * d2 + d4;                                                     \
-                v1.e = p42 + p31; v2.e = p42 - p31; v3.e = q42 + q31; v4.e = q42 - q31;              \
-                v5.e = 4.f * d1 - 5.f * d3 + d5;                                                     \
-                const float g0 = rg0.e, g1 = rg1.e, g2 = rg2.e, g3 = rg3.e;                          \
-                const float ev = g0 + g2, od = g1 + g3, e2 = g0 + 4.f * g2, o2 = 2.f * g1 + 8.f * g3; \
-                u0.e = 0.25f * g0;                                                                   \
-                u1.e = (ev + od) * (-1.f / 6.f); u2.e = (ev - od) * (-1.f / 6.f);                    \
-                u3.e = (e2 + o2) * (1.f / 24.f); u4.e = (e2 - o2) * (1.f / 24.f);                    \
-                u5.e = g3;                                                                           \
-            }
-            EFGH_TR(x) EFGH_TR(y) EFGH_TR(z) EFGH_TR(w)
-#undef EFGH_TR
-#define EFGH_STW(a, vv, uu)                                                                           \
-            *reinterpret_cast<float4 *>(&Vs[(a * TT + ts) * 64 + q4]) = vv;                          \
-            *reinterpret_cast<float4 *>(&Gs[(a * TT + ts) * 64 + q4]) = uu;
-            EFGH_STW(0, v0, u0) EFGH_STW(1, v1, u1) EFGH_STW(2, v2, u2) EFGH_STW(3, v3, u3) EFGH_STW(4, v4, u4) EFGH_STW(5, v5, u5)
-#undef EFGH_STW
-        }
-        __syncthreads();
-        const bool more = t0 + TT < tend;
-        if (more) EFGH_STEP_ADDR(t0 + TT)
-        {   // contraction index = tile: lane half lh takes tile 2s + lh; operands are single dwords of the images
-            const float *gp = &Gs[lh * 64 + wn * 32 + l31];
-            const float *vp = &Vs[lh * 64 + wc * 32 + l31];
-            float fg[2][8], fv[2][8];
-#pragma unroll
-            for (int s8 = 0; s8 < 8; ++s8) { fg[0][s8] = gp[s8 * 128]; fv[0][s8] = vp[s8 * 128]; }
-#pragma unroll
-            for (int a = 0; a < 6; ++a) {
-                const int cur = a & 1, nxt = cur ^ 1;
-                if (a < 5) {
-#pragma unroll
-                    for (int s8 = 0; s8 < 8; ++s8) {
-                        fg[nxt][s8] = gp[(a + 1) * TT * 64 + s8 * 128];
-                        fv[nxt][s8] = vp[(a + 1) * TT * 64 + s8 * 128];
-                    }
-                }
-                if (more) {
-                    if (a == 0) { EFGH_LDX(0, rx0) EFGH_LDG(0, rg0) }
-                    if (a == 1) { EFGH_LDX(1, rx1) EFGH_LDG(1, rg1) }
-                    if (a == 2) { EFGH_LDX(2, rx2) EFGH_LDG(2, rg2) }
-                    if (a == 3) { EFGH_LDX(3, rx3) EFGH_LDG(3, rg3) }
-                    if (a == 4) { EFGH_LDX(4, rx4) }
-                    if (a == 5) { EFGH_LDX(5, rx5) }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int s8 = 0; s8 < 8; ++s8)
-                    acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(fg[cur][s8], fv[cur][s8], acc[a], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        __syncthreads();
-    }
-#undef EFGH_STEP_ADDR
-#undef EFGH_LDX
-#undef EFGH_LDG
-    // D[row = n][col = c]: lanes run along c (contiguous in S)
-    const long long K3 = 3LL * p.C;
-#pragma unroll
-    for (int a = 0; a < 6; ++a) {
-        float *sa = p.S + (((long long)bz * 6 + a) * p.N + n0 + wn * 32) * K3 + k0 + wc * 32 + l31;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int nl = (r & 3) + 8 * (r >> 2) + 4 * lh;
-            sa[nl * K3] = acc[a][r];
-        }
-    }
-}
-
-// dWp[n][kh*3 + kw][c] = sum_alpha A3^T[kw][alpha] * S[alpha][n][kh*C + c]
-// ---- the same contraction with every operand row read ONCE.  k_wino_wgrad gives each (n, kh, c) block its own workgroup: the three
-// kernel rows kh of a tile range are three workgroups that each read the gradient tiles and their own input row y + kh - 1 (measured:
-// 3.9 GB from HBM per launch for 2.0 GB of operands - the ranges of the resident workgroups, 27 MB per XCD, do not live in a 4 MB L2
-// long enough to be shared).  Here ONE workgroup of 12 waves owns a strip of 16 tiles (64 pixels) and walks DOWN the image rows:
+// ---- every operand row is read ONCE.  (Rounds 1-2 gave each (n, kh, c) block its own workgroup: the three kernel rows kh of a
+// tile range were three workgroups that each read the gradient tiles and their own input row y + kh - 1 - 3.9 GB from HBM per
+// launch for 2.0 GB of operands; that kernel, k_wino_wgrad, was removed in round 5.)  ONE workgroup of 12 waves owns a strip of 16 tiles (64 pixels) and walks DOWN the image rows:
 // per row it transforms one gradient tile row (G4 dy) and one new input row (B^T x) into LDS; the transformed input rows stay in a
 // ring of three, so the row staged for y + 1 is kernel row 2 of this step, row 1 of the next and row 0 of the one after.  Wave group
 // kh (4 waves, 32 n x 32 c x 6 alpha each, as before) contracts the gradient image with ring slot y + kh - 1.  Per step the workgroup
-// loads 40 KB for 3 x the MFMA work of a k_wino_wgrad step.
+// loads 40 KB for 3 x the MFMA work of one kernel row's contraction step.
 constexpr int WR_WAVES = 12;
 
 __global__ void __launch_bounds__(64 * WR_WAVES, 1) k_wino_wgrad_rows(const WinoWArgs p, int strips, int chunks, int rh, int ct) {
@@ -601,23 +461,6 @@ __global__ void k_wino_wgrad_finish3(const float *__restrict__ S, float *__restr
     }
 }
 
-__global__ void k_wino_wgrad_finish(const float *__restrict__ S, int zs, float *__restrict__ dWp, int N, int C) {
-    const long long K3 = 3LL * C, total = (long long)N * K3, plane = total;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int kc = (int)(i % K3); const long long n = i / K3;
-        const int kh = kc / C, c = kc - kh * C;
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f;
-        for (int z = 0; z < zs; ++z) {                  // the tile ranges in order: a fixed summation order
-            const float *Sz = S + (long long)z * 6 * plane + i;
-            s0 += Sz[0]; s1 += Sz[plane]; s2 += Sz[2 * plane]; s3 += Sz[3 * plane]; s4 += Sz[4 * plane]; s5 += Sz[5 * plane];
-        }
-        float *o = dWp + (n * 9 + kh * 3) * C + c;
-        o[0] = s0 + s1 + s2 + s3 + s4;
-        o[C] = (s1 - s2) + 2.f * (s3 - s4);
-        o[2 * (long long)C] = (s1 + s2) + 4.f * (s3 + s4) + s5;
-    }
-}
-
 bool supported(const efgh_gemm_desc *d) {
     if (!d || d->mode != 1 || d->T != 9 || d->C % KC || d->N % TN || d->M_dev || d->nbatch > 1) return false;
     if (d->sh != 1 || d->sw != 1 || d->osh != 1 || d->osw != 1 || d->oh0 || d->ow0) return false;
@@ -672,25 +515,8 @@ extern "C" int efgh_wino_wgrad_supported(const efgh_gemm_desc *d) {
     return (supported(d) && d->C % 64 == 0) ? 1 : 0;
 }
 
-static long long wino_wgrad_ranges(const efgh_gemm_desc *d, long long *chunk_out) {
-    const long long Mt = (long long)d->B * d->Hin * ((d->Win + 3) / 4);
-    const int kt = 3 * d->C / 64, nt = d->N / 64;
-    long long want = 1024 / (kt * nt);                 // 2 rounds of 512 resident workgroups; each range costs one partial S
-    if (want < 1) want = 1;
-    long long chunk = (Mt + want - 1) / want;
-    chunk = (chunk + TT - 1) / TT * TT;
-    if (chunk < 8 * TT) chunk = 8 * TT;
-    if (chunk_out) *chunk_out = chunk;
-    return (Mt + chunk - 1) / chunk;
-}
-
 // k_wino_wgrad_rows: units = samples x strips of 16 tiles x row chunks; one 12-wave workgroup per CU, so the number of row chunks is
 // the one (<= 8, >= 8 rows each) that fills whole rounds of 256 workgroups best
-static bool wino_wgrad_rows_enabled() {
-    static const int on = [] { const char *e = getenv("EFGH_WINO_WGRAD_ROWS"); return (e && e[0] == '0') ? 0 : 1; }();
-    return on != 0;
-}
-
 static long long wino_wgrad_row_units(const efgh_gemm_desc *d, int *strips_out, int *chunks_out, int *rh_out) {
     const int strips = ((d->Win + 3) / 4 + TT - 1) / TT, blocks = (d->C / 64) * (d->N / 64);
     int best = 1; double beste = -1.0;
@@ -711,8 +537,7 @@ static long long wino_wgrad_row_units(const efgh_gemm_desc *d, int *strips_out, 
 /* floats of scratch `S` efgh_wino_wgrad needs: one [6][N][3C] partial per tile range */
 extern "C" int64_t efgh_wino_wgrad_workspace(const efgh_gemm_desc *d) {
     if (!supported(d) || d->C % 64 != 0 || d->B <= 0) return 0;
-    if (wino_wgrad_rows_enabled()) return wino_wgrad_row_units(d, nullptr, nullptr, nullptr) * 3 * (int64_t)d->N * 3 * d->C;
-    return wino_wgrad_ranges(d, nullptr) * 6 * (int64_t)d->N * 3 * d->C;
+    return wino_wgrad_row_units(d, nullptr, nullptr, nullptr) * 3 * (int64_t)d->N * 3 * d->C;
 }
 
 extern "C" int efgh_wino_wgrad(const efgh_gemm_desc *d, const float *G, int64_t ldg, float *S, float *dWp,
@@ -727,28 +552,16 @@ extern "C" int efgh_wino_wgrad(const efgh_gemm_desc *d, const float *G, int64_t 
     a.Mt = (long long)d->B * d->Hin * a.TW;
     a.S = S;
     const int kt = 3 * d->C / 64, nt = d->N / 64;
-    long long zs = 0;
-    if (wino_wgrad_rows_enabled()) {
-        int strips = 0, chunks = 0, rh = 0;
-        zs = wino_wgrad_row_units(d, &strips, &chunks, &rh);
-        EFGH_CHECK_ARG(zs < 0x7fffffffLL && (long long)(d->C / 64) * nt < 65536);
-        a.tchunk = 0; a.kt = (unsigned)kt; a.nt = (unsigned)nt;
-        k_wino_wgrad_rows<<<dim3((unsigned)zs, (unsigned)((d->C / 64) * nt)), 64 * WR_WAVES, 0, st>>>(a, strips, chunks, rh, d->C / 64);
-    } else {
-        long long chunk = 0;
-        zs = wino_wgrad_ranges(d, &chunk);
-        a.tchunk = chunk;
-        EFGH_CHECK_ARG(zs * kt * nt < 0x7fffffffLL);
-        a.kt = (unsigned)kt; a.nt = (unsigned)nt;
-        k_wino_wgrad<<<(unsigned)(zs * kt * nt), 256, 0, st>>>(a);
-    }
+    int strips = 0, chunks = 0, rh = 0;
+    const long long zs = wino_wgrad_row_units(d, &strips, &chunks, &rh);
+    EFGH_CHECK_ARG(zs < 0x7fffffffLL && (long long)(d->C / 64) * nt < 65536);
+    a.tchunk = 0; a.kt = (unsigned)kt; a.nt = (unsigned)nt;
+    k_wino_wgrad_rows<<<dim3((unsigned)zs, (unsigned)((d->C / 64) * nt)), 64 * WR_WAVES, 0, st>>>(a, strips, chunks, rh, d->C / 64);
     EFGH_CHECK_LAUNCH();
-    const bool rows = wino_wgrad_rows_enabled();
-    if (zs > 1) efgh_launch_fold_splits(S, (int)zs, (rows ? 3LL : 6LL) * d->N * 3 * d->C, S, st);      // into the first partial, fixed order
+    if (zs > 1) efgh_launch_fold_splits(S, (int)zs, 3LL * d->N * 3 * d->C, S, st);      // into the first partial, fixed order
     const long long total = (long long)d->N * 3 * d->C;
     long long g = (total + 255) / 256;
-    if (rows) k_wino_wgrad_finish3<<<(int)(g > 4096 ? 4096 : g), 256, 0, st>>>(S, dWp, d->N, d->C);
-    else k_wino_wgrad_finish<<<(int)(g > 4096 ? 4096 : g), 256, 0, st>>>(S, 1, dWp, d->N, d->C);
+    k_wino_wgrad_finish3<<<(int)(g > 4096 ? 4096 : g), 256, 0, st>>>(S, dWp, d->N, d->C);
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
 }

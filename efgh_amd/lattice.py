@@ -29,7 +29,7 @@ _CLEAN = {}             # the same key -> consecutive clean speculative builds s
 # An outlier frame must not pin a signature to the slow plans for the rest of the process: after this many clean builds in a row
 # the most expensive escalation of the signature is taken back one step (hash -> big buckets -> regular) and the cheaper plan gets
 # another try (a renewed overflow costs one re-enqueue of the pyramid and resets the count)
-ESCALATION_DECAY = int(os.environ.get('EFGH_LATTICE_ESCALATION_DECAY', '64'))
+ESCALATION_DECAY = 64
 STATS = {'speculative': 0, 'level_by_level': 0, 'reenqueued': 0}      # pyramids by path (tests, bench --rotate-inputs)
 _log = logging.getLogger('efgh_amd.lattice')
 
@@ -81,8 +81,6 @@ class _SampleView:
     __slots__ = ('n_in', 'H', 'bary', 'emg', 'off', 'nbr', 'pts_next')
 
 
-PART = os.environ.get('EFGH_LATTICE_PART', '1') != '0'      # partitioned build (lattice.hip, round 3); 0 = global-hash build only
-SMALL_HASH = os.environ.get('EFGH_LATTICE_SMALL_HASH', '1') != '0'
 
 
 def _pow2ceil(v):
@@ -93,12 +91,12 @@ def _plan(L, n_cap, h_est):
     """how to build a level of n_cap points expecting ~h_est vertices (None: unknown):
     ('part', buckets, slots per bucket) - entries dealt into buckets, every bucket grouped in LDS - or, for more points than the
     partitioned build's bucket limit (~2.8 M), ('hash', slots) - the global hash insert (0 = its default table)"""
-    nb = L.efgh_lattice_part_buckets(_C.c_int32(n_cap)) if PART else 0
+    nb = L.efgh_lattice_part_buckets(_C.c_int32(n_cap))
     if nb:
         if h_est is None:
             return ('part', nb, 2048)
         return ('part', nb, min(2048, max(64, _pow2ceil(2.5 * h_est / nb + 64))))
-    if h_est is None or not SMALL_HASH:
+    if h_est is None:
         return ('hash', 0)
     # hash table sized for the expected vertex count (load <= 1/2) instead of the worst case 4 * n_cap keys
     return ('hash', max(4096, 1 << (2 * h_est - 1).bit_length()))
@@ -216,7 +214,7 @@ def build_pyramid_batched(pc, scales, need_off=True):
             hc = min(4 * nc, hp + hp // 4 + 1024)
             md = _plan(L, nc, hc)
             if l in forced and md[0] == 'part':
-                md = ('hash', max(4096, 1 << (2 * hc - 1).bit_length()) if SMALL_HASH else 0)
+                md = ('hash', max(4096, 1 << (2 * hc - 1).bit_length()))
             elif l in bigl and md[0] == 'part':
                 md = md + (True,)
             caps.append((nc, hc, md))

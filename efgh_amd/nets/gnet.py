@@ -9,7 +9,7 @@ from . import layers as L
 from .builders import conv_bn_relu, convt_bn_relu, resnet18_layers
 
 import os as _os
-HEADS_FUSED = _os.environ.get('EFGH_HEADS_FUSED', '1') != '0'    # depth + mask heads as one 3-channel pipeline (layers.run_convt_heads)
+HEADS_FUSED = True    # depth + mask heads as one 3-channel pipeline (layers.run_convt_heads)
 
 
 class Gnet(nn.Module):

@@ -83,7 +83,7 @@ def _ver(*tensors):
     return (tuple(epoch_of(t).n for t in tensors),) + tuple((t._version, t.data_ptr(), getattr(t, '_efgh_gen', 0)) for t in tensors)
 
 
-BATCH_PACK = _os.environ.get('EFGH_BATCH_PACK', '1') != '0'
+BATCH_PACK = True        # every stale packed layout of an owner in ONE launch (tests flip it to compare with per-layout packing)
 
 
 class _PackJob(ctypes.Structure):
@@ -222,7 +222,7 @@ def gemm_grid_m(M, N):
     return _L().efgh_gather_gemm_grid_m(c_int64(M), c_int32(N))
 
 
-USE_WINO = _os.environ.get('EFGH_WINO', '1') != '0'   # Winograd F(4,3) kernel for the "same" 3x3 convolutions
+USE_WINO = True  # Winograd F(4,3) kernel for the "same" 3x3 convolutions
 
 
 def wino_eligible(mode, C, N, geom, T=None):
@@ -234,15 +234,15 @@ def wino_eligible(mode, C, N, geom, T=None):
             and list(dh) == [t // 3 - 1 for t in range(9)] and list(dw) == [t % 3 - 1 for t in range(9)])
 
 
-USE_WINO2D = _os.environ.get('EFGH_WINO2D', '1') != '0'   # F(4x4,3x3) as transform / batched GEMM / transform (wino2d.hip)
-WINO2D_MIN_C = int(_os.environ.get('EFGH_WINO2D_MIN_C', '256'))            # forward / data gradient
-WINO2D_MIN_C_WGRAD = int(_os.environ.get('EFGH_WINO2D_MIN_C_WGRAD', '128'))  # weight gradient
+USE_WINO2D = True  # F(4x4,3x3) as transform / batched GEMM / transform (wino2d.hip)
+WINO2D_MIN_C = 256           # forward / data gradient
+WINO2D_MIN_C_WGRAD = 128 # weight gradient
 # forward / data gradient inside a training step (EFGHBackbone sets TLS.train_step): EFGH_WINO2D_MIN_C_TRAIN=128 moves the 128-channel
 # layers to the 2-D form there - their weight gradient is 2-D anyway and re-uses the forward's transformed input, and the extra
 # transform passes run underneath MFMA kernels of the other streams: -0.9 ms per step for +10 GB (the eval forward alone is 0.5 %
 # faster on the 1-D kernel).  Not the default: a sub-percent gain that re-rounds F's trunks, whose arg-max heads turn a 1e-6
 # difference of the logits into a different yaw bin on near-ties (tests/test_gpu_train.py::test_winograd_and_direct_kernels...)
-WINO2D_MIN_C_TRAIN = int(_os.environ.get('EFGH_WINO2D_MIN_C_TRAIN', '256'))
+WINO2D_MIN_C_TRAIN = 256
 
 
 def _pow2(v):
@@ -270,7 +270,7 @@ def wino2d_weight(Wp, N, C):
     return _cached(Wp, ('wino2d',), _ver(Wp), make)
 
 
-USE_C4 = _os.environ.get('EFGH_C4', '1') != '0'       # dedicated MFMA kernels for the 4-channel input layers (c4conv.hip)
+USE_C4 = True      # dedicated MFMA kernels for the 4-channel input layers (c4conv.hip)
 
 
 def c4_eligible(mode, C, N, geom, wgrad=False):
@@ -284,7 +284,7 @@ def c4_eligible(mode, C, N, geom, wgrad=False):
             and list(dh) == [t // 3 - 1 for t in range(9)] and list(dw) == [t % 3 - 1 for t in range(9)])
 
 
-USE_SMALLC = _os.environ.get('EFGH_SMALLC', '1') != '0'       # dedicated kernels for the 16- / 32-channel 3x3 layers (smallc.hip)
+USE_SMALLC = True      # dedicated kernels for the 16- / 32-channel 3x3 layers (smallc.hip)
 
 
 SC_MIN_PIXELS_32 = 60000        # per image, so that the choice of kernel (and with it the rounding) does not depend on the batch size
@@ -373,7 +373,7 @@ PROFILE_WINO = None     # launches served by the Winograd kernel (else they are 
 PROFILE = None          # bench.py sets this to a list: (start_event, end_event, algorithmic_flops) per launch
 
 
-KSPLIT_MAX_ROWS = int(_os.environ.get('EFGH_BLUR_KSPLIT_ROWS', '16384'))     # 0 disables
+KSPLIT_MAX_ROWS = 16384
 
 
 def _blur_gemm_ksplit(A, lda, C, Wp, N, M, out, ldo, table, bias, act, slope, a_off, out_off, flops, alias_mask=False):
@@ -501,7 +501,7 @@ def _batched_plain_gemm(A3, W3, out3, rows, C, N):
 
 
 W2V_CACHE = {}          # training: B^T x B of a layer's input, kept from the forward for the layer's weight gradient
-W2V_KEEP = _os.environ.get('EFGH_WINO2D_KEEP_V', '1') != '0'
+W2V_KEEP = True
 
 
 def w2v_clear():
@@ -667,7 +667,7 @@ def softmax2_to_nchw(x):
 # ----------------------------------------------------------------------------------------------
 # BCL splat
 # ----------------------------------------------------------------------------------------------
-SPLAT_LANES = int(_os.environ.get('EFGH_SPLAT_LANES', '0'))       # 0 = auto, 32 / 64 = forced lane mapping (tuning)
+SPLAT_LANES = 0          # 0 = the kernel picks the lane mapping from the mean list length
 PROFILE_BCL = None      # bench.py: (start_event, end_event, algorithmic_bytes, what) per BCL index/splat launch
 
 
@@ -725,7 +725,7 @@ def neighbor_gather_adjoint(lv, src, C):
 # OPT-IN: measured on a batch-8 training step it LOSES 6 ms (313.8 vs 307.8 ms, same box, alternating runs): the epilogue's 64
 # extra 4-byte loads per thread of the producer's raw output sit at the end of the kernel, behind the MFMA loop, and cost
 # k_wino43<true> more than the 1-GB read the reduction pass no longer does.
-BN_BWD_FUSED = _os.environ.get('EFGH_BN_BWD_FUSED', '0') == '1'
+BN_BWD_FUSED = False
 
 
 def bwd_finalize_f32(stats, C, count):
@@ -740,9 +740,9 @@ def bwd_finalize_f32(stats, C, count):
     return s1, s2, m1, m2
 
 
-BLUR_DGRAD_FUSED = _os.environ.get('EFGH_BLUR_DGRAD_FUSED', '1') != '0'
+BLUR_DGRAD_FUSED = True
 # residual BatchNorm layers keep the activation mask of their backward as sign bits (1/32 of re-reading the activation in both passes)
-BN_MASK_BITS = _os.environ.get('EFGH_BN_MASK_BITS', '1') != '0'
+BN_MASK_BITS = True
 
 
 def blur_dgrad(lv, draw, C0, w, C):
@@ -880,7 +880,7 @@ def corr_head(cam, rng, want_logit=False, want_aux=False):
 PROFILE_WGRAD = None
 PROFILE_WINO_WGRAD = None
 PROFILE_THIN = None
-USE_WINO_WGRAD = _os.environ.get('EFGH_WINO_WGRAD', '1') != '0'
+USE_WINO_WGRAD = True
 
 
 _SCRATCH = {}
@@ -911,7 +911,7 @@ def side_streams():
     """every side stream this package has created (branch streams of the backbone + the weight-gradient stream)"""
     from .nets import efghbackbone as bb
     return list(bb._SIDE.values())
-DETERMINISTIC = _os.environ.get('EFGH_DETERMINISTIC', '0') == '1'      # (kept for callers that set it; a no-op since round 4: see gather_wgrad)
+DETERMINISTIC = False     # (kept for callers that set it; a no-op since round 4: see gather_wgrad)
 
 
 def _scratch(nfloats, device):

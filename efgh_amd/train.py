@@ -38,7 +38,7 @@ class FlatParams:
         # autograd's AccumulateGrad (which costs an allocation, a copy and an `add` launch per parameter).  `arrived[i]` is set
         # by whichever route delivers parameter i's gradient first; later deliveries in the same step go through autograd and
         # accumulate, so shared parameters and gradient accumulation over several backward calls keep their meaning.
-        self.direct = os.environ.get('EFGH_DIRECT_GRAD', '1') != '0'
+        self.direct = True
         # BatchNorm's `num_batches_tracked` counters re-homed as views of ONE int64 vector: a training forward notes which layers
         # ran (GemmLayerFn.forward -> tick) and Trainer.step adds the whole step's counts with one launch instead of one per layer
         bns = [m for m in model.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm)

@@ -121,3 +121,41 @@ def test_launcher_runs_a_reference_shaped_script_on_two_ranks(tmp_path):
 def np_isfinite(v):
     import math
     return math.isfinite(v)
+
+
+def _two_devices():
+    import torch
+    return torch.cuda.device_count() >= 2            # (counting devices does not initialise the GPU)
+
+
+@pytest.mark.skipif(not _two_devices(), reason='needs two visible MI355X (this pool hands out 1-GPU boxes): the first multi-GPU lease runs it')
+def test_two_ranks_on_rccl_over_xgmi():
+    """the RCCL path itself, on the first box that has two devices: `bench.py --gpus 2 --small` must rendezvous on `nccl` (RCCL), one
+    rank per device, with the bucketed gradient all-reduce over xGMI inside the timed region - world size from RCCL's own
+    communicator (`rccl_ranks == 2`), bit-identical replicas after the steps, three compute streams (the fourth hardware queue is
+    the collective's), and `HSA_ENABLE_IPC_MODE_LEGACY=0` carried into the ranks (dmabuf IPC only on this pool).  The zero-edit
+    launcher takes the same route with the reference-shaped script and stock Adam."""
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT',
+                                                            'EFGH_DIST_BACKEND')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--small', '--steps', '3', '--warmup', '1',
+                        '--no-cpu-baseline'], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
+    assert out['dist_backend'] == 'nccl' and out['rccl_ranks'] == 2 and out['visible_gpus'] >= 2
+    assert out['replicas_identical'] is True and out['compute_streams'] == 3 and out['n_gpus'] == 2
+    assert out['scaling'] == 'weak' and out['value'] > 0
+
+
+@pytest.mark.skipif(not _two_devices(), reason='needs two visible MI355X')
+def test_launcher_two_ranks_on_rccl(tmp_path):
+    script = tmp_path / 'main.py'
+    script.write_text(REFERENCE_LIKE_SCRIPT)
+    out = str(tmp_path / 'out')
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT',
+                                                            'EFGH_DIST_BACKEND')}
+    env['PYTHONPATH'] = ROOT
+    r = subprocess.run([sys.executable, '-m', 'efgh_amd.run', '--gpus', '2', str(script), out], env=env, capture_output=True,
+                       text=True, timeout=900, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-3000:]
+    r0, r1 = json.load(open(out + '.r0')), json.load(open(out + '.r1'))
+    assert r0['ck'] == r1['ck'] and r0['iters'] == r1['iters'] == 2

@@ -31,6 +31,20 @@ def _rel(got, ref):
     return float(np.abs(got - ref).max() / (np.abs(ref).max() + 1e-12))
 
 
+def _rel_elem(got, ref):
+    """ELEMENT-WISE relative error max_i |got_i - ref_i| / max(|ref_i|, 1e-6 * max|ref|): the max-norm `_rel` lets a logit 100x
+    smaller than the largest be off by 1e-2 of itself and still pass at 1e-4 (round-4 verdict); this one does not.  The absolute
+    floor keeps exact zeros and denormal-sized entries from dividing by nothing."""
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    floor = 1e-6 * np.abs(ref).max() + 1e-300
+    return float((np.abs(got - ref) / np.maximum(np.abs(ref), floor)).max())
+
+
+# element-wise bound for the six pose-logit tensors (teacher-forced stages, this small configuration); the measured values are
+# printed by test_stagewise_teacher_forced (-s) and kept in profiles/r05_logit_elementwise.txt
+ELEM_TOL = {'e_gn_sgn': 1e-4, 'e_gn_abs': 1e-4, 'h_hrzn_sgn': 1e-4, 'h_hrzn_abs': 1e-4, 'f_score': 1e-4, 'g_trs': 1e-3}
+
+
 def test_eval_forward_vs_reference_golden(golden_dir, manifest):
     """whole forward, no teacher forcing, against the outputs of the unmodified reference"""
     G = np.load(os.path.join(golden_dir, 'e2e_small.npz'))
@@ -99,6 +113,18 @@ def test_stagewise_teacher_forced(golden_dir, manifest, train):
     assert _rel(g['g_trs'].cpu().numpy(), G[tag + 'g_trs']) < 1e-4
     assert _rel(g['g_depth'].cpu().numpy(), rg['g_depth'].numpy()) < 5e-4
     assert _rel(g['g_mask'].cpu().numpy(), rg['g_mask'].numpy()) < 5e-4
+    # the same six tensors ELEMENT-wise, against the oracle and against the reference's golden outputs
+    worst = {}
+    for got, ref, keys in ((e, rete, ('e_gn_sgn', 'e_gn_abs')), (h, reth, ('h_hrzn_sgn', 'h_hrzn_abs')), (f, rf, ('f_score',)),
+                           (g, rg, ('g_trs',))):
+        for k in keys:
+            a = got[k].cpu().numpy()
+            worst[k] = (_rel(a, ref[k].numpy()), _rel_elem(a, ref[k].numpy()), _rel_elem(a, G[tag + k]),
+                        float(np.abs(ref[k].numpy()).min() / np.abs(ref[k].numpy()).max()))
+    print('\nelementwise[%s]: ' % tag + '; '.join('%s max-norm %.2e elem(oracle) %.2e elem(golden) %.2e min|ref|/max|ref| %.1e'
+                                                  % ((k,) + v) for k, v in worst.items()))
+    for k, v in worst.items():
+        assert v[1] < ELEM_TOL[k] and v[2] < ELEM_TOL[k], (k, v)
     if train:
         sd = m.state_dict()
         for k in [k for k in G.files if k.startswith('train.buf.')]:

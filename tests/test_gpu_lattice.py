@@ -76,6 +76,50 @@ def test_degenerate_inputs():
             assert d['H'] == r['H'] and np.array_equal(d['off'], r['off']) and np.array_equal(d['nbr'], r['nbr'])
 
 
+DEGENERATE = ('one_point', 'coincident7', 'origin7', 'line', 'plane', 'blob_1cm', 'two_clusters_80m', 'on_vertices')
+
+
+@pytest.mark.parametrize('scene', DEGENERATE)
+def test_degenerate_scenes_bit_exact_vs_reference(golden_dir, scene):
+    """the HIP build against the REFERENCE's outputs (not only the oracle's) on the degenerate scenes of
+    tests/golden/make_golden_degenerate.py: every level's vertex count, barycentric / el_minus_gr bit patterns, lattice_offset and
+    blur_neighbors"""
+    g = np.load(os.path.join(golden_dir, 'lattice_degenerate.npz'))
+    out = _gpu(g[scene + '/pc'])
+    assert len(out) == 5
+    for l, d in enumerate(out):
+        assert d['H'] == int(g[f'{scene}/H{l}']), l
+        assert np.array_equal(d['bary'].view(np.uint32), g[f'{scene}/bary{l}'].view(np.uint32)), l
+        assert np.array_equal(d['emg'].view(np.uint32), g[f'{scene}/emg{l}'].view(np.uint32)), l
+        assert np.array_equal(d['off'], g[f'{scene}/off{l}']), l
+        assert np.array_equal(d['nbr'], g[f'{scene}/nbr{l}']), l
+
+
+def test_degenerate_scenes_batched_together(golden_dir):
+    """all eight degenerate scenes padded to one point count and built as ONE batch (the shape the training path uses): every
+    sample's lattice equals its own reference fixture - the samples' key ranges, hashes and numberings never interact.  Padding
+    repeats a scene's last point (coincident points change neither the vertex set nor its first-seen order)"""
+    from efgh_amd import lattice
+    g = np.load(os.path.join(golden_dir, 'lattice_degenerate.npz'))
+    n = max(g[s + '/pc'].shape[1] for s in DEGENERATE)
+    pcs = []
+    for s in DEGENERATE:
+        p = g[s + '/pc']
+        pcs.append(np.concatenate([p, np.repeat(p[:, -1:], n - p.shape[1], 1)], 1))
+    lv = lattice.build_pyramid_batched(torch.from_numpy(np.stack(pcs)).cuda(), SCALES)
+    for b, s in enumerate(DEGENERATE):
+        n0 = g[s + '/pc'].shape[1]
+        for l in range(5):
+            d = lv[l].sample(b)
+            assert d.H == int(g[f'{s}/H{l}']), (s, l)
+            assert np.array_equal(d.nbr.cpu().numpy()[:, :15].T.astype(np.int64), g[f'{s}/nbr{l}']), (s, l)
+            if l == 0:      # (deeper levels have the fixture's own point count; level 0 carries the padding)
+                assert np.array_equal(d.off.cpu().numpy().astype(np.int64)[:, :n0], g[f'{s}/off{l}']), (s, l)
+            else:
+                assert np.array_equal(d.off.cpu().numpy().astype(np.int64), g[f'{s}/off{l}']), (s, l)
+                assert np.array_equal(d.bary.cpu().numpy().view(np.uint32), g[f'{s}/bary{l}'].view(np.uint32)), (s, l)
+
+
 def test_batched_build_equals_per_sample():
     """the batched lattice (one launch sequence for all samples) reproduces every sample's own lattice:
     local offsets / neighbours / barycentric weights bit-exact vs the oracle"""

@@ -593,6 +593,8 @@ def test_fused_heads_packed_weights_follow_the_optimizer_when_outputs_are_droppe
     for name in ('ct', 'cv'):
         assert store[name], name
         for key, (ver, buf) in store[name].items():
+            if not hasattr(buf, '_efgh_pack'):          # (other memoised values of the fused tensor share the dictionary)
+                continue
             fresh = torch.empty_like(buf)
             ops._pack_one(cur[name], fresh, buf._efgh_pack)
             assert torch.equal(fresh, buf), (name, key)

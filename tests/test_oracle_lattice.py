@@ -61,3 +61,22 @@ def test_edge_cases():
             assert d['nbr'].min() >= -1 and d['nbr'].max() < d['H']
             assert np.array_equal(d['nbr'][0], np.arange(d['H']))      # offset 0 = the vertex itself
             assert np.allclose(d['bary'].sum(0), 1.0, atol=1e-5)
+
+
+DEGENERATE = ('one_point', 'coincident7', 'origin7', 'line', 'plane', 'blob_1cm', 'two_clusters_80m', 'on_vertices')
+
+
+@pytest.mark.parametrize('scene', DEGENERATE)
+def test_degenerate_scenes_bit_exact_vs_reference(golden_dir, scene):
+    """one point, coincident points, a line, a plane, a 1-cm blob, two clusters 80 m apart, points on lattice vertices: the
+    reference's own outputs (tests/golden/make_golden_degenerate.py) - key ranges of extent 1 and `key2int` without a range check
+    (transforms.py:62-77) are exercised here, not in the LiDAR-like fixtures"""
+    g = np.load(os.path.join(golden_dir, 'lattice_degenerate.npz'))
+    out = lattice.generate_data(g[scene + '/pc'])
+    assert len(out) == 5
+    for l, d in enumerate(out):
+        assert d['H'] == int(g[f'{scene}/H{l}']), l
+        assert np.array_equal(d['bary'].view(np.uint32), g[f'{scene}/bary{l}'].view(np.uint32)), l
+        assert np.array_equal(d['emg'].view(np.uint32), g[f'{scene}/emg{l}'].view(np.uint32)), l
+        assert np.array_equal(d['off'], g[f'{scene}/off{l}']), l
+        assert np.array_equal(d['nbr'], g[f'{scene}/nbr{l}']), l
