@@ -55,6 +55,7 @@ def lib():
                             f'rebuild it (`python -m efgh_amd.build`)')
         _lib.efgh_wino2d_tiles.restype = c_int64
         _lib.efgh_gather_wgrad_workspace.restype = c_int64
+        _lib.efgh_plane_wgrad_workspace.restype = c_int64
         _lib.efgh_wino_wgrad_workspace.restype = c_int64
         _lib.efgh_sc_wgrad_workspace.restype = c_int64
         _lib.efgh_c4n4_wgrad_workspace.restype = c_int64

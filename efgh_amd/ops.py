@@ -480,6 +480,8 @@ def gather_gemm(A, lda, C, T, Wp, N, M, out, ldo, mode=0, geom=None, table=None,
     return bn_stats
 
 
+PLANE_DMA = True                # the 36 planes of a 2-D Winograd layer on the LDS-DMA staged kernels (planes.hip); False: k_gather_gemm / k_gather_wgrad
+PLANE_DMA_NBUF = 0              # ring slots (0: the library's default; 2 or 3 for A/B runs, tools/bench_planes.py)
 PROFILE_WINO2D = None           # bench.py: whole 2-D Winograd layers (three launches), direct-form FLOPs
 PROFILE_WINO2D_GEMM = None      # bench.py: their batched GEMM launches alone, EXECUTED FLOPs (2*36*T*C*N)
 
@@ -494,7 +496,10 @@ def _batched_plain_gemm(A3, W3, out3, rows, C, N):
     if PROFILE_WINO2D_GEMM is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    _C.check(_L().efgh_gather_gemm(ctypes.byref(g), _st()))
+    if PLANE_DMA and _L().efgh_plane_gemm_supported(ctypes.byref(g)):
+        _C.check(_L().efgh_plane_gemm(ctypes.byref(g), c_int32(PLANE_DMA_NBUF), _st()))      # LDS-DMA staged (planes.hip)
+    else:
+        _C.check(_L().efgh_gather_gemm(ctypes.byref(g), _st()))
     if PROFILE_WINO2D_GEMM is not None:
         e1.record()
         PROFILE_WINO2D_GEMM.append((e0, e1, 2.0 * 36 * rows * C * N, (0, rows, N, 36, C)))
@@ -993,8 +998,13 @@ def gather_wgrad(A, lda, C, T, N, M, G, ldg, dWp, mode=0, geom=None, table=None)
         if PROFILE_WINO2D_GEMM is not None:
             f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             f0.record()
-        _C.check(_L().efgh_gather_wgrad_batched(ctypes.byref(g), ptr(Gy), c_int64(36 * N), c_int64(N), ptr(S), c_int64(N * C),
-                                                ptr(_scratch(_L().efgh_gather_wgrad_workspace(ctypes.byref(g)), dev)), _st()))
+        if PLANE_DMA and _L().efgh_plane_wgrad_supported(ctypes.byref(g), c_int64(36 * N)):
+            _C.check(_L().efgh_plane_wgrad_batched(ctypes.byref(g), ptr(Gy), c_int64(36 * N), c_int64(N), ptr(S), c_int64(N * C),
+                                                   ptr(_scratch(_L().efgh_plane_wgrad_workspace(ctypes.byref(g)), dev)),
+                                                   c_int32(PLANE_DMA_NBUF), _st()))
+        else:
+            _C.check(_L().efgh_gather_wgrad_batched(ctypes.byref(g), ptr(Gy), c_int64(36 * N), c_int64(N), ptr(S), c_int64(N * C),
+                                                    ptr(_scratch(_L().efgh_gather_wgrad_workspace(ctypes.byref(g)), dev)), _st()))
         if PROFILE_WINO2D_GEMM is not None:
             f1.record()
             PROFILE_WINO2D_GEMM.append((f0, f1, 2.0 * 36 * T2 * C * N, (0, T2, N, 36, C)))

@@ -469,6 +469,22 @@ int efgh_c4_wgrad_supported(const efgh_gemm_desc *d);
 int64_t efgh_c4_wgrad_workspace(const efgh_gemm_desc *d);
 int efgh_c4_wgrad(const efgh_gemm_desc *d, const float *G, int64_t ldg, float *dWp, float *workspace, void *stream);
 
+/* ------------------------------------------------------------------ batched plain GEMMs, LDS-DMA staged (round 5) ------
+ * The 36 alpha planes of a 2-D Winograd F(4x4,3x3) layer (every 3x3 / stride-1 convolution with >= 256 channels, weight
+ * gradient >= 128: nets/vgg.py:77, nets/resnet.py:22-30) are plain GEMMs over contiguous fp32 rows.  These entry points run
+ * them with `global_load_lds_dwordx4` staging into an NBUF-slot LDS ring (one workgroup barrier per 32-deep step, no VGPR /
+ * ds_write staging pass) instead of efgh_gather_gemm / efgh_gather_wgrad_batched (mode 0); same descriptor, same arithmetic
+ * order, bit-identical results.  nbuf: ring slots, 2 or 3 (0 = default).
+ *   efgh_plane_gemm:  out[b][m][n] = sum_k A[b][m][k] * W[b][n][k];  needs mode 0, T 1, C % 32 == 0, N % 128 == 0, no epilogue.
+ *   efgh_plane_wgrad_batched: dWp[b][n][c] = sum_m G[b][m][n] * A[b][m][c];  needs C % 128 == 0, N % 128 == 0; row chunks leave
+ *   partial planes in `workspace` (efgh_plane_wgrad_workspace floats), folded in chunk order.                              */
+int efgh_plane_gemm_supported(const efgh_gemm_desc *d);
+int efgh_plane_gemm(const efgh_gemm_desc *d, int32_t nbuf, void *stream);
+int efgh_plane_wgrad_supported(const efgh_gemm_desc *d, int64_t ldg);
+int64_t efgh_plane_wgrad_workspace(const efgh_gemm_desc *d);
+int efgh_plane_wgrad_batched(const efgh_gemm_desc *d, const float *G, int64_t ldg, int64_t batch_stride_g, float *dWp,
+                             int64_t batch_stride_dw, float *workspace, int32_t nbuf, void *stream);
+
 /* stride-2 3x3 transposed conv with <= 4 output channels (G's depth / mask heads, gnet.py:56-68) as
  * ONE gather-GEMM over the input pixels (Y [B*Hin*Win][ldy], column (kh*3+kw)*O+o) + this fold:
  * out[b][oh][ow][o] = act(scale[o]*sum_{oh=2ih-pad+kh, ow=2iw-pad+kw} Y[b][ih][iw][..] + shift[o]).

@@ -739,3 +739,78 @@ def test_nan_preactivation_stays_nan_in_the_fused_epilogues(L, cin, cout, hw, ac
     keep = torch.ones(hw, dtype=torch.bool, device=y.device)
     keep[0:12, 0:16] = False                                     # (a Winograd tile spreads the NaN over its 4 / 4x4 outputs)
     assert torch.isfinite(y[0][keep]).all() and int(keep.sum()) > 0
+
+
+@pytest.mark.parametrize('T2,C,N', [(128, 128, 128), (1000, 256, 128), (777, 128, 384), (4099, 512, 256), (37, 64, 128)])
+@pytest.mark.parametrize('nbuf', [2, 3])
+def test_plane_gemm_equals_gather_gemm(T2, C, N, nbuf):
+    """the LDS-DMA staged batched plain GEMM (planes.hip: global_load_lds into an XOR-swizzled ring, counted vmcnt + one barrier per
+    step) against k_gather_gemm<0> on the tile-major layout of the 2-D Winograd planes ([tiles][36][C] x [36][N][C] ->
+    [tiles][36][N]): same products in the same k order, so the outputs must be BIT-identical - including ragged tile counts (rows
+    past the end are re-reads of the last row and never stored) and a float64 cross-check of one plane"""
+    import ctypes
+    from efgh_amd import _C
+    from efgh_amd._C import c_int32
+    lib = _C.lib()
+    torch.manual_seed(T2 + C)
+    V = torch.randn(T2, 36, C, device='cuda')
+    U = torch.randn(36, N, C, device='cuda')
+    outs = []
+    for _ in range(2):
+        o = torch.full((T2 + 1, 36, N), 7.0, device='cuda')          # (one guard row behind the last tile)
+        g = _C.GemmDesc()
+        g.A, g.lda, g.C, g.T, g.mode = V.data_ptr(), 36 * C, C, 1, 0
+        g.W, g.N, g.M = U.data_ptr(), N, T2
+        g.out, g.ldo = o.data_ptr(), 36 * N
+        g.nbatch, g.batch_stride_a, g.batch_stride_w, g.batch_stride_out = 36, C, N * C, N
+        outs.append((o, g))
+    assert lib.efgh_plane_gemm_supported(ctypes.byref(outs[1][1])) == 1
+    _C.check(lib.efgh_gather_gemm(ctypes.byref(outs[0][1]), _C.stream_ptr()))
+    _C.check(lib.efgh_plane_gemm(ctypes.byref(outs[1][1]), c_int32(nbuf), _C.stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert bool((outs[1][0][T2] == 7.0).all())                       # nothing written past the last row
+    ref = torch.einsum('tc,nc->tn', V[:, 5].double(), U[5].double())
+    assert float((outs[1][0][:T2, 5].double() - ref).abs().max() / ref.abs().max()) < 2e-6
+
+
+def test_plane_gemm_refuses_what_it_does_not_serve():
+    import ctypes
+    from efgh_amd import _C
+    lib = _C.lib()
+    V, U, o = torch.randn(64, 96, device='cuda'), torch.randn(64, 96, device='cuda'), torch.empty(64, 64, device='cuda')
+    g = _C.GemmDesc()
+    g.A, g.lda, g.C, g.T, g.mode, g.W, g.N, g.M, g.out, g.ldo = V.data_ptr(), 96, 96, 1, 0, U.data_ptr(), 64, 64, o.data_ptr(), 64
+    assert lib.efgh_plane_gemm_supported(ctypes.byref(g)) == 0           # N % 128 != 0
+    assert lib.efgh_plane_gemm(ctypes.byref(g), 0, _C.stream_ptr()) != 0
+    assert lib.efgh_plane_wgrad_supported(ctypes.byref(g), _C.c_int64(64)) == 0
+
+
+@pytest.mark.parametrize('T2,C,N', [(256, 128, 128), (5000, 256, 128), (3333, 128, 256), (20011, 256, 256)])
+@pytest.mark.parametrize('nbuf', [2, 3])
+def test_plane_wgrad_equals_gather_wgrad(T2, C, N, nbuf):
+    """the LDS-DMA staged batched weight gradient dU_a[n][c] = sum_tile G_a[tile][n] V_a[tile][c] against k_gather_wgrad<0, 128>:
+    the same row chunks, the same per-chunk partial planes folded in chunk order - bit-identical; rows past the end of a chunk come
+    from a zero page"""
+    import ctypes
+    from efgh_amd import _C
+    from efgh_amd._C import c_int32, c_int64, ptr
+    lib = _C.lib()
+    torch.manual_seed(T2)
+    V = torch.randn(T2, 36, C, device='cuda')
+    Gy = torch.randn(T2, 36, N, device='cuda')
+    g = _C.GemmDesc()
+    g.A, g.lda, g.C, g.T, g.mode, g.N, g.M = V.data_ptr(), 36 * C, C, 1, 0, N, T2
+    g.nbatch, g.batch_stride_a = 36, C
+    assert lib.efgh_plane_wgrad_supported(ctypes.byref(g), c_int64(36 * N)) == 1
+    S0, S1 = torch.empty(36, N, C, device='cuda'), torch.full((36, N, C), 3.0, device='cuda')
+    w0 = torch.empty(max(1, lib.efgh_gather_wgrad_workspace(ctypes.byref(g))), device='cuda')
+    w1 = torch.empty(max(1, lib.efgh_plane_wgrad_workspace(ctypes.byref(g))), device='cuda')
+    _C.check(lib.efgh_gather_wgrad_batched(ctypes.byref(g), ptr(Gy), c_int64(36 * N), c_int64(N), ptr(S0), c_int64(N * C), ptr(w0),
+                                           _C.stream_ptr()))
+    _C.check(lib.efgh_plane_wgrad_batched(ctypes.byref(g), ptr(Gy), c_int64(36 * N), c_int64(N), ptr(S1), c_int64(N * C), ptr(w1),
+                                          c_int32(nbuf), _C.stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(S0, S1)
+    ref = torch.einsum('tn,tc->nc', Gy[:, 7].double(), V[:, 7].double())
+    assert float((S1[7].double() - ref).abs().max() / ref.abs().max()) < 5e-6
