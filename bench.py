@@ -42,6 +42,9 @@ def parse():
                     help='cycle this many resident batches of DIFFERENT synthetic frame-pairs through the steps (1 = the same batch '
                          'every step): every sweep has its own lattice sizes, so the speculative sizing of the pyramid (previous '
                          'sizes + 25 %%) and its fallback are part of what is timed, as in a real training loop (iterater.py:26-43)')
+    ap.add_argument('--set', action='append', default=[], metavar='MODULE.ATTR=VALUE',
+                    help='builder A/B runs: set a switch of efgh_amd (e.g. ops.PLANE_DMA=0) before anything is built; the line '
+                         'records it under "switches" (a default run has none)')
     return ap.parse_args()
 
 
@@ -311,6 +314,19 @@ def main():
     from efgh_amd.nets import EFGHBackbone
     from efgh_amd.train import Trainer
 
+    switches = {}
+    for item in a.set:
+        import ast
+        import importlib
+        name, val = item.split('=', 1)
+        mod, attr = name.rsplit('.', 1)
+        m_ = importlib.import_module('efgh_amd.' + mod)
+        if not hasattr(m_, attr):
+            sys.exit('bench.py --set: efgh_amd.%s has no attribute %s' % (mod, attr))
+        setattr(m_, attr, ast.literal_eval(val))
+        switches[name] = ast.literal_eval(val)
+    if switches:
+        ops.apply_switches()
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
@@ -500,6 +516,8 @@ def main():
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(raw, npts, a.mode)
+        if switches:
+            out['switches'] = switches            # (an A/B run of the builder: not the default configuration)
         if fwd is not None and a.mode == 'train':
             # small copies at the END of the line (a log tail keeps them): the forward-only workload, BASELINE configs[1]
             out['forward_value'] = fwd['value']

@@ -87,3 +87,23 @@ __device__ __forceinline__ void st_out(float *p, float v) {
     *p = v;
 #endif
 }
+
+// ---- LDS-DMA (global -> LDS without a VGPR round trip), used by planes.hip and the DMA-staged instances of gemm.hip ----
+// one 1-KiB piece: lane l -> LDS base + 16 l  (base wave-uniform, passed in M0).  Inline assembly on purpose: hipcc orders every
+// ds_read behind a pending `__builtin_amdgcn_global_load_lds` with `s_waitcnt vmcnt(0)` (it cannot tell the ring slots of one
+// __shared__ object apart), which drains the prefetch at the top of every step - seen in the ISA of the first version of this
+// file.  The compiler does not see these loads; the counted `s_waitcnt vmcnt` + barrier below are the only ordering, and the
+// only other vector-memory operations of the kernels are the epilogue's stores, issued after the last wait.  M0 is saved and
+// restored around the statement (the compiler owns it).
+__device__ __forceinline__ void dma16(const float *src, unsigned lds_byte_addr) {
+    unsigned keep;
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_byte_addr);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const float *p) {
+    return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) float *)p;
+}
+
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+

@@ -46,6 +46,104 @@ struct KArgs {
     int tam;                   // mode 2: taps marked in column 15 of the table row read zeros
 };
 
+// epilogue shared by the register-staged and the DMA-staged kernels: bias, BatchNorm scale / shift, residual, activation, per-tile
+// column statistics.  `scratch`: >= 2 * WM * BN floats of LDS nobody reads any more (the column statistics of the waves)
+template <int MODE, int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void gemm_epilogue(const KArgs &p, const long long M, const long long m0, const int n0, const unsigned tile_m,
+                                              f32x16 (&acc)[BM / WM / 32][BN / WN / 32], const long long *rowout, float *scratch,
+                                              const int wm, const int wn, const int l31, const int lh, const int tid) {
+    constexpr int MI = BM / WM / 32, NI = BN / WN / 32;
+    float *As = scratch;
+    // ---- epilogue -----------------------------------------------------------------------
+    // rows outside, columns inside: the output row index, its two 64-bit row addresses and the mask are formed once per row (16 MI
+    // of them per lane) instead of once per element, the per-column terms once per column block
+    float *ssum = As;            // [WM][BN] column sums, [WM][BN] sums of squares (LDS reuse)
+    float *ssq = As + WM * BN;
+    float bi[NI], sc[NI], sf[NI], s1[NI], s2[NI];
+    bool cok[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int col = n0 + (wn * NI + j) * 32 + l31;
+        cok[j] = col < p.N;
+        bi[j] = (p.bias && cok[j]) ? p.bias[col] : 0.f;
+        sc[j] = (p.scale && cok[j]) ? p.scale[col] : 1.f;
+        sf[j] = (p.shift && cok[j]) ? p.shift[col] : 0.f;
+        s1[j] = 0.f; s2[j] = 0.f;
+    }
+    const int colb = n0 + wn * NI * 32 + l31;
+    const float neg = p.act == 1 ? 0.f : (p.act == 2 ? p.slope : 1.f);      // act(v) = max(v, 0) + neg * min(v, 0)
+    // two workgroup-uniform switches pick one of four straight-line bodies: with / without a residual operand (its NI loads of a row
+    // are issued together, ahead of the arithmetic), and the whole tile inside M x N (no row mask, no per-element predicate) or not
+    auto rows = [&](auto res_c, auto full_c) {
+        constexpr bool RES = decltype(res_c)::value, FULL = decltype(full_c)::value;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rl = (wm * MI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const long long orow = rowout[rl];
+                if (!FULL && orow < 0) continue;
+                float *op = p.out + orow * p.ldo + colb;
+                float rv[NI];
+                if (RES) {
+                    const float *rp = p.residual + orow * p.ldr + colb;
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) rv[j] = (FULL || cok[j]) ? rp[j * 32] : 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    float v = acc[i][j][r] + bi[j];
+                    if (FULL || cok[j]) { s1[j] += v; s2[j] = fmaf(v, v, s2[j]); }      // (explicit fma: the rounding must not follow the vectoriser)
+                    v = v * sc[j] + sf[j];
+                    if (RES) v += rv[j];
+                    v = act_neg(v, neg);
+                    if (FULL || cok[j]) st_out(op + j * 32, v);
+                }
+            }
+        }
+    };
+    const bool fulln = n0 + BN <= p.N && m0 + BM <= M;      // the whole tile exists: no row mask, no column predicate
+    if (fulln && !p.bias && !p.scale && !p.shift && !p.residual && !p.stats && p.act == 0) {
+        // bare products (the 36 planes of a 2-D Winograd layer, the GEMM + col2im heads): one store per element
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rl = (wm * MI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                float *op = p.out + rowout[rl] * p.ldo + colb;
+#pragma unroll
+                for (int j = 0; j < NI; ++j) st_out(op + j * 32, acc[i][j][r]);
+            }
+        }
+    } else if (p.residual) {
+        if (fulln) rows(std::true_type{}, std::true_type{});
+        else rows(std::true_type{}, std::false_type{});
+    } else {
+        if (fulln) rows(std::false_type{}, std::true_type{});
+        else rows(std::false_type{}, std::false_type{});
+    }
+    if (p.stats) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int coll = (wn * NI + j) * 32 + l31;
+            s1[j] += __shfl_xor(s1[j], 32); s2[j] += __shfl_xor(s2[j], 32);
+            if (lh == 0) { ssum[wm * BN + coll] = s1[j]; ssq[wm * BN + coll] = s2[j]; }
+        }
+    }
+    if (p.stats) {
+        __syncthreads();
+        for (int c = tid; c < BN; c += 256) {
+            if (n0 + c < p.N) {
+                float a = 0.f, b = 0.f;
+#pragma unroll
+                for (int w = 0; w < WM; ++w) { a += ssum[w * BN + c]; b += ssq[w * BN + c]; }
+                p.stats[((long long)tile_m * 2 + 0) * p.N + n0 + c] = a;
+                p.stats[((long long)tile_m * 2 + 1) * p.N + n0 + c] = b;
+            }
+        }
+    }
+}
+
 // exact fp32 MFMA (v_mfma_f32_32x32x2_f32): fp32 operands, products and accumulation
 template <int MODE, int BM, int BN, int WM, int WN>
 __global__ void __launch_bounds__(256, 3)
@@ -226,94 +324,158 @@ k_gather_gemm(const KArgs p_in) {
         __syncthreads();
     }
 
-    // ---- epilogue -----------------------------------------------------------------------
-    // rows outside, columns inside: the output row index, its two 64-bit row addresses and the mask are formed once per row (16 MI
-    // of them per lane) instead of once per element, the per-column terms once per column block
-    float *ssum = As;            // [WM][BN] column sums, [WM][BN] sums of squares (LDS reuse)
-    float *ssq = As + WM * BN;
-    float bi[NI], sc[NI], sf[NI], s1[NI], s2[NI];
-    bool cok[NI];
+    gemm_epilogue<MODE, BM, BN, WM, WN>(p, M, m0, n0, tile_m, acc, rowout, As, wm, wn, l31, lh, tid);
+}
+
+// ---- the same contraction with LDS-DMA staging (round 5): BM = 128, 2 x 2 waves, modes 0 and 1 with C % 32 == 0 (a 32-deep step
+// never straddles a tap).  Staging as in planes.hip: every wave moves four 1-KiB pieces (8 rows x 128 B) of A and BN / 32 of W per
+// step with `global_load_lds_dwordx4` into a two-slot ring, the 16-B quad q of row r sits at slot q ^ ((r >> 1) & 7) (conflict-free
+// ds_read_b128 without row padding), ONE barrier per step; rows past M and taps outside the image fetch a zero page (the source
+// address is per lane).  No VGPR staging, no ds_write pass, no second barrier - the register-staged kernel spends a fifth of its
+// issue slots on them at K = 128 ... 576.  Same products in the same k order: bit-identical outputs
+// (tests/test_gpu_ops.py::test_dma_gemm_equals_register_staged).
+__device__ __attribute__((aligned(128))) float g_gemm_zero[32];
+
+constexpr int DMA_BM = 128;
+
+template <int MODE, int BN>
+__global__ void __launch_bounds__(256, 2)
+k_gather_gemm_dma(const KArgs p_in) {
+    constexpr int BM = DMA_BM, WM = 2, WN = 2, MI = 2, NI = BN / WN / 32, NBP = BN / 32;      // NBP: W pieces per wave and step
+    constexpr int STAGE = (BM + BN) * BK;
+    extern __shared__ __attribute__((aligned(1024))) float ring[];          // 2 x STAGE floats
+    __shared__ long long rowout[BM];
+
+    KArgs p = p_in;
+    if (blockIdx.y) { p.A += blockIdx.y * p.bsA; p.W += blockIdx.y * p.bsW; p.out += blockIdx.y * p.bsO; }
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN, l31 = lane & 31, lh = lane >> 5;
+    const unsigned ring_lds = lds_addr(ring);
+    const long long M = p.M;
+    const unsigned nbx = p.nbx, nblk = gridDim.x;
+    const unsigned q8 = nblk >> 3, r8 = nblk & 7, xcd = blockIdx.x & 7, within = blockIdx.x >> 3;
+    const unsigned lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + within;
+    const unsigned tile_m = lin / nbx, tile_n = lin - tile_m * nbx;
+    const long long m0 = (long long)tile_m * BM;
+    const int n0 = tile_n * BN;
+    if (m0 >= M) return;
+
+    // ---- DMA roles: wave w moves A pieces 4w .. 4w+3 and W pieces NBP w .. ; lane l -> row 8 piece + (l >> 3), slot l & 7
+    long long abase[4]; unsigned amask[4];
+    const float *srcW[NBP];
+    const int sub = lane >> 3;
 #pragma unroll
-    for (int j = 0; j < NI; ++j) {
-        const int col = n0 + (wn * NI + j) * 32 + l31;
-        cok[j] = col < p.N;
-        bi[j] = (p.bias && cok[j]) ? p.bias[col] : 0.f;
-        sc[j] = (p.scale && cok[j]) ? p.scale[col] : 1.f;
-        sf[j] = (p.shift && cok[j]) ? p.shift[col] : 0.f;
-        s1[j] = 0.f; s2[j] = 0.f;
-    }
-    const int colb = n0 + wn * NI * 32 + l31;
-    const float neg = p.act == 1 ? 0.f : (p.act == 2 ? p.slope : 1.f);      // act(v) = max(v, 0) + neg * min(v, 0)
-    // two workgroup-uniform switches pick one of four straight-line bodies: with / without a residual operand (its NI loads of a row
-    // are issued together, ahead of the arithmetic), and the whole tile inside M x N (no row mask, no per-element predicate) or not
-    auto rows = [&](auto res_c, auto full_c) {
-        constexpr bool RES = decltype(res_c)::value, FULL = decltype(full_c)::value;
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rl = (wm * MI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const long long orow = rowout[rl];
-                if (!FULL && orow < 0) continue;
-                float *op = p.out + orow * p.ldo + colb;
-                float rv[NI];
-                if (RES) {
-                    const float *rp = p.residual + orow * p.ldr + colb;
-#pragma unroll
-                    for (int j = 0; j < NI; ++j) rv[j] = (FULL || cok[j]) ? rp[j * 32] : 0.f;
+    for (int q = 0; q < 4; ++q) {
+        const int r = (wave * 4 + q) * 8 + sub;
+        const int kq = (lane & 7) ^ ((r >> 1) & 7);
+        const long long m = m0 + r;
+        abase[q] = kq * 4; amask[q] = 0;
+        if (m < M) {
+            if (MODE == 0) { abase[q] += m * p.lda; amask[q] = 1; }
+            else {
+                const int j = (int)(m % p.Wv); const long long rr = m / p.Wv;
+                const int i = (int)(rr % p.Hv); const long long b = rr / p.Hv;
+                const int ih0 = i * p.sh, iw0 = j * p.sw;
+                abase[q] += ((b * p.Hin + ih0) * p.Win + iw0) * p.lda;
+                unsigned mk = 0;
+                for (int t = 0; t < p.T; ++t) {
+                    const int ih = ih0 + (int)((p.dhpack >> (4 * t)) & 15) - 8, iw = iw0 + (int)((p.dwpack >> (4 * t)) & 15) - 8;
+                    if ((unsigned)ih < (unsigned)p.Hin && (unsigned)iw < (unsigned)p.Win) mk |= 1u << t;
                 }
+                amask[q] = mk;
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NBP; ++q) {
+        const int r = (wave * NBP + q) * 8 + sub;
+        const int kq = (lane & 7) ^ ((r >> 1) & 7);
+        int n = n0 + r;
+        if (n >= p.N) n = p.N - 1;               // (columns past N are never stored)
+        srcW[q] = p.W + (long long)n * p.K + kq * 4;
+    }
+    for (int r = tid; r < BM; r += 256) {
+        const long long m = m0 + r;
+        long long o = -1;
+        if (m < M) {
+            if (MODE == 1) {
+                const int j = (int)(m % p.Wv); const long long rr = m / p.Wv;
+                const int i = (int)(rr % p.Hv); const long long b = rr / p.Hv;
+                o = (b * p.Ho + (i * p.osh + p.oh0)) * p.Wo + (j * p.osw + p.ow0);
+            } else o = m;
+        }
+        rowout[r] = o;
+    }
+    const float *zsrc = g_gemm_zero + (lane & 7) * 4;
+    auto issue = [&](int chunk, int buf) {
+        const unsigned base = ring_lds + (unsigned)(buf * STAGE) * 4u;
+        const int k0 = chunk * BK;
+        const int t = (int)(((unsigned long long)k0 * p.magicC) >> 32);        // (uniform: C % 32 == 0, the step lies inside tap t)
+        const int c = k0 - t * p.C;
+        long long dl = c;
+        if (MODE == 1) {
+            const int dh = (int)((p.dhpack >> (4 * (t & 15))) & 15) - 8, dw = (int)((p.dwpack >> (4 * (t & 15))) & 15) - 8;
+            dl += ((long long)dh * p.Win + dw) * p.lda;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const bool ok = MODE == 0 ? amask[q] != 0 : ((amask[q] >> t) & 1u) != 0;
+            dma16(ok ? p.A + abase[q] + dl : zsrc, base + (unsigned)((wave * 4 + q) * 1024));
+        }
+#pragma unroll
+        for (int q = 0; q < NBP; ++q) dma16(srcW[q] + k0, base + (unsigned)(BM * BK * 4 + (wave * NBP + q) * 1024));
+    };
+
+    int offA[MI], offW[NI], swA[MI], swW[NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) { const int ra = (wm * MI + i) * 32 + l31; offA[i] = ra * BK; swA[i] = (ra >> 1) & 7; }
+#pragma unroll
+    for (int j = 0; j < NI; ++j) { const int rw = (wn * NI + j) * 32 + l31; offW[j] = BM * BK + rw * BK; swW[j] = (rw >> 1) & 7; }
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nch = p.K / BK;
+    issue(0, 0);
+    for (int ch = 0; ch < nch; ++ch) {
+        wait_vm<0>();
+        __builtin_amdgcn_s_barrier();            // step ch is in LDS (every wave waited for its own pieces); step ch-1's slot is free
+        asm volatile("" ::: "memory");
+        if (ch + 1 < nch) issue(ch + 1, (ch + 1) & 1);
+        const float *buf = ring + (ch & 1) * STAGE;
+        float4 a[2][MI], b[2][NI];
+        auto frag = [&](int g, float4 (&fa)[MI], float4 (&fb)[NI]) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) fa[i] = *reinterpret_cast<const float4 *>(buf + offA[i] + (((g * 2 + lh) ^ swA[i]) << 2));
+#pragma unroll
+            for (int j = 0; j < NI; ++j) fb[j] = *reinterpret_cast<const float4 *>(buf + offW[j] + (((g * 2 + lh) ^ swW[j]) << 2));
+        };
+        frag(0, a[0], b[0]);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (g < 3) frag(g + 1, a[(g + 1) & 1], b[(g + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            const float4 (&ca)[MI] = a[g & 1];
+            const float4 (&cb)[NI] = b[g & 1];
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NI; ++j) {
-                    float v = acc[i][j][r] + bi[j];
-                    if (FULL || cok[j]) { s1[j] += v; s2[j] = fmaf(v, v, s2[j]); }      // (explicit fma: the rounding must not follow the vectoriser)
-                    v = v * sc[j] + sf[j];
-                    if (RES) v += rv[j];
-                    v = act_neg(v, neg);
-                    if (FULL || cok[j]) st_out(op + j * 32, v);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[i].x, cb[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[i].y, cb[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[i].z, cb[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[i].w, cb[j].w, acc[i][j], 0, 0, 0);
                 }
-            }
-        }
-    };
-    const bool fulln = n0 + BN <= p.N && m0 + BM <= M;      // the whole tile exists: no row mask, no column predicate
-    if (fulln && !p.bias && !p.scale && !p.shift && !p.residual && !p.stats && p.act == 0) {
-        // bare products (the 36 planes of a 2-D Winograd layer, the GEMM + col2im heads): one store per element
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rl = (wm * MI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                float *op = p.out + rowout[rl] * p.ldo + colb;
-#pragma unroll
-                for (int j = 0; j < NI; ++j) st_out(op + j * 32, acc[i][j][r]);
-            }
-        }
-    } else if (p.residual) {
-        if (fulln) rows(std::true_type{}, std::true_type{});
-        else rows(std::true_type{}, std::false_type{});
-    } else {
-        if (fulln) rows(std::false_type{}, std::true_type{});
-        else rows(std::false_type{}, std::false_type{});
-    }
-    if (p.stats) {
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            const int coll = (wn * NI + j) * 32 + l31;
-            s1[j] += __shfl_xor(s1[j], 32); s2[j] += __shfl_xor(s2[j], 32);
-            if (lh == 0) { ssum[wm * BN + coll] = s1[j]; ssq[wm * BN + coll] = s2[j]; }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
-    if (p.stats) {
-        __syncthreads();
-        for (int c = tid; c < BN; c += 256) {
-            if (n0 + c < p.N) {
-                float a = 0.f, b = 0.f;
-#pragma unroll
-                for (int w = 0; w < WM; ++w) { a += ssum[w * BN + c]; b += ssq[w * BN + c]; }
-                p.stats[((long long)tile_m * 2 + 0) * p.N + n0 + c] = a;
-                p.stats[((long long)tile_m * 2 + 1) * p.N + n0 + c] = b;
-            }
-        }
-    }
+    __syncthreads();            // (the epilogue's statistics scratch is the ring: every wave is done reading it)
+    gemm_epilogue<MODE, BM, BN, WM, WN>(p, M, m0, n0, tile_m, acc, rowout, ring, wm, wn, l31, lh, tid);
 }
 
 __global__ void k_pack_weight(const float *__restrict__ W, float *__restrict__ Wp, int N, int T, int C, int Nw, int Cw,
@@ -396,11 +558,39 @@ void launch(const KArgs &a0, hipStream_t st) {
     k_gather_gemm<MODE, BM, BN, WM, WN><<<dim3((unsigned)(a.nbx * nby), a.nbatch), 256, 0, st>>>(a);
 }
 
+std::atomic<unsigned long long> g_dma_raised[4];
+bool g_use_dma = true;          // efgh_gather_gemm_set_dma (tests, A/B runs)
+
+// the launches the DMA-staged instances serve: modes 0 / 1, more than 32 outputs, every 32-deep step inside one tap, no device-side
+// row count, 16-byte aligned rows
+bool dma_ok(const KArgs &a, int mode) {
+    return g_use_dma && (mode == 0 || mode == 1) && a.N > 32 && a.C % 32 == 0 && !a.M_dev && a.lda % 4 == 0 && a.K % BK == 0
+           && (((uintptr_t)a.A) & 15) == 0 && (((uintptr_t)a.W) & 15) == 0;
+}
+
+template <int MODE, int BN>
+int launch_dma(const KArgs &a0, hipStream_t st) {
+    KArgs a = a0;
+    a.nbx = (unsigned)((a.N + BN - 1) / BN);
+    const long long nby = (a.M + DMA_BM - 1) / DMA_BM;
+    const size_t lds = (size_t)2 * (DMA_BM + BN) * BK * sizeof(float);
+    if (!efgh_raise_lds_once(g_dma_raised[MODE * 2 + (BN == 128)], (const void *)k_gather_gemm_dma<MODE, BN>, (int)lds)) {
+        efgh_set_error("%s:%d: cannot raise the dynamic LDS limit of k_gather_gemm_dma", __FILE__, __LINE__);
+        return EFGH_E_LAUNCH;
+    }
+    k_gather_gemm_dma<MODE, BN><<<dim3((unsigned)(a.nbx * nby), a.nbatch), 256, lds, st>>>(a);
+    return EFGH_OK;
+}
+
 template <int MODE>
-void dispatch(const KArgs &a, hipStream_t st) {
+int dispatch(const KArgs &a, hipStream_t st) {
+    if constexpr (MODE == 0 || MODE == 1) {
+        if (dma_ok(a, MODE)) return a.N > 64 ? launch_dma<MODE, 128>(a, st) : launch_dma<MODE, 64>(a, st);
+    }
     if (a.N > 64) launch<MODE, 128, 128, 2, 2>(a, st);
     else if (a.N > 32) launch<MODE, 128, 64, 2, 2>(a, st);
     else launch<MODE, 256, 32, 4, 1>(a, st);
+    return EFGH_OK;
 }
 
 int tile_m(int N) { return N > 32 ? 128 : 256; }
@@ -453,12 +643,21 @@ extern "C" int efgh_gather_gemm(const efgh_gemm_desc *d, void *stream_) {
     KArgs a;
     int rc = fill_args(d, a);
     if (rc != EFGH_OK) return rc;
-    if (d->mode == 0) dispatch<0>(a, st);
-    else if (d->mode == 1) dispatch<1>(a, st);
-    else if (d->mode == 2) dispatch<2>(a, st);
-    else dispatch<3>(a, st);
+    if (d->mode == 0) rc = dispatch<0>(a, st);
+    else if (d->mode == 1) rc = dispatch<1>(a, st);
+    else if (d->mode == 2) rc = dispatch<2>(a, st);
+    else rc = dispatch<3>(a, st);
+    if (rc != EFGH_OK) return rc;
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
+}
+
+/* tests / A-B runs: 0 = every launch on the register-staged kernel, 1 = eligible launches on the DMA-staged instances (default).
+ * Returns the previous setting.  Process-wide; not meant to be flipped while another thread launches. */
+extern "C" int efgh_gather_gemm_set_dma(int32_t on) {
+    const int old = g_use_dma ? 1 : 0;
+    g_use_dma = on != 0;
+    return old;
 }
 
 extern "C" int efgh_pack_weight_batched(const efgh_pack_job *jobs_dev, const int64_t *prefix_dev, int32_t njobs, int64_t total,

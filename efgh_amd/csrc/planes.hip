@@ -17,8 +17,10 @@
 // linear and the bank-conflict-free layout is obtained by permuting which SOURCE 16 bytes a lane fetches:
 //   k_plane_gemm:  image [row][32 floats] (128-B rows); the 16-B quad q of row r is stored at slot q ^ ((r >> 1) & 7) - the 16
 //                  lanes of a ds_read_b128 phase (rows r .. r+15, one quad) then cover all 16 slots of the 256-B bank row;
-//   k_plane_wgrad: image [m][128 floats]; odd rows store their halves swapped (quad ^ 8), so that the two rows a ds_read_b32
-//                  touches (lanes 0-31: row 2j, lanes 32-63: row 2j+1, same 32 columns) fall on different banks.
+//   k_plane_wgrad: image [m][128 floats], linear.  The contraction index is the ROW here, so a lane's MFMA operand is one float
+//                  of a row; a lane reads TWO adjacent floats per ds_read_b64 (256 B contiguous per half-wave: conflict free)
+//                  and feeds them to two MFMA tiles whose rows / columns interleave (tile q holds n = 2 i + q): half the LDS
+//                  instructions of a ds_read_b32 per operand, and the epilogue stores 8 bytes per lane.
 // Arithmetic: v_mfma_f32_32x32x2_f32, exact fp32 products and accumulation, the same k order as the kernels they replace
 // (bit-identical results: tests/test_gpu_ops.py::test_plane_gemm_equals_gather_gemm).
 #include "common.h"
@@ -38,24 +40,6 @@ struct PArgs {
     long long bsA, bsW, bsO;
     unsigned nbx;
 };
-
-// one 1-KiB piece: lane l -> LDS base + 16 l  (base wave-uniform, passed in M0).  Inline assembly on purpose: hipcc orders every
-// ds_read behind a pending `__builtin_amdgcn_global_load_lds` with `s_waitcnt vmcnt(0)` (it cannot tell the ring slots of one
-// __shared__ object apart), which drains the prefetch at the top of every step - seen in the ISA of the first version of this
-// file.  The compiler does not see these loads; the counted `s_waitcnt vmcnt` + barrier below are the only ordering, and the
-// only other vector-memory operations of the kernels are the epilogue's stores, issued after the last wait.  M0 is saved and
-// restored around the statement (the compiler owns it).
-__device__ __forceinline__ void dma16(const float *src, unsigned lds_byte_addr) {
-    unsigned keep;
-    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_byte_addr);
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
-}
-__device__ __forceinline__ unsigned lds_addr(const float *p) {
-    return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) float *)p;
-}
-
-template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <int NBUF>
 __global__ void __launch_bounds__(256, NBUF == 2 ? 2 : 1) k_plane_gemm(const PArgs p0) {
@@ -122,22 +106,33 @@ __global__ void __launch_bounds__(256, NBUF == 2 ? 2 : 1) k_plane_gemm(const PAr
         asm volatile("" ::: "memory");
         if (ch + NBUF - 1 < nch) issue(ch + NBUF - 1, (ch + NBUF - 1) % NBUF);
         const float *buf = ring + (ch % NBUF) * STAGE;
+        // fragments of group g+1 are fetched while the 16 MFMAs of group g run (two register sets; sched_barrier pins the order -
+        // left alone the scheduler issues the next group's reads two MFMAs before they are needed and exposes the LDS latency
+        // four times per step)
+        float4 a[2][2], b[2][2];
+        auto frag = [&](int g, float4 (&fa)[2], float4 (&fb)[2]) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const float4 *>(buf + offA[i] + (((g * 2 + lh) ^ swA[i]) << 2));
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const float4 *>(buf + offW[j] + (((g * 2 + lh) ^ swW[j]) << 2));
+        };
+        frag(0, a[0], b[0]);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            float4 a[2], b[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const float4 *>(buf + offA[i] + (((g * 2 + lh) ^ swA[i]) << 2));
-#pragma unroll
-            for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const float4 *>(buf + offW[j] + (((g * 2 + lh) ^ swW[j]) << 2));
+            if (g < 3) frag(g + 1, a[(g + 1) & 1], b[(g + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            const float4 (&ca)[2] = a[g & 1];
+            const float4 (&cb)[2] = b[g & 1];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[i].x, cb[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[i].y, cb[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[i].z, cb[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[i].w, cb[j].w, acc[i][j], 0, 0, 0);
                 }
+            __builtin_amdgcn_sched_barrier(0);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the fragment reads of this step are retired before the next barrier)
     }
@@ -209,9 +204,9 @@ __global__ void __launch_bounds__(256, NBUF == 2 ? 2 : 1) k_plane_wgrad(const PW
     p.dW += (long long)bz * p.zstride;
 
     // ---- DMA roles: wave w moves G pieces 4w .. 4w+3 (rows 8w .. 8w+7) and A pieces 4w .. 4w+3 of every step.
-    // piece = 2 rows x 512 B; lane l -> row 2 piece + (l >> 5), LDS quad (l & 31), source quad (l & 31) ^ ((l >> 5) << 3)
+    // piece = 2 rows x 512 B; lane l -> row 2 piece + (l >> 5), quad (l & 31) of that row
     const int prow = wave * 8 + (lane >> 5);                  // + 2 q
-    const int cq = ((lane & 31) ^ ((lane >> 5) << 3)) * 4;
+    const int cq = (lane & 31) * 4;
     const float *gcol = p.G + n0 + cq, *acol = p.A + k0 + cq;
     const float *zsrc = g_plane_zero + (lane & 31) * 4;
     auto issue = [&](long long ms, int buf) {
@@ -240,44 +235,48 @@ __global__ void __launch_bounds__(256, NBUF == 2 ? 2 : 1) k_plane_wgrad(const PW
 #pragma unroll
     for (int s = 0; s < NBUF - 1; ++s)
         if (s < nst) issue(mbeg + (long long)s * TM, s);
-    // fragment columns: odd rows (lh = 1) have their 32-float halves swapped
-    const int gx0 = ((wn * 2 + 0) * 32 + l31) ^ (lh << 5), gx1 = ((wn * 2 + 1) * 32 + l31) ^ (lh << 5);
-    const int ax0 = ((wk * 2 + 0) * 32 + l31) ^ (lh << 5), ax1 = ((wk * 2 + 1) * 32 + l31) ^ (lh << 5);
+    // fragment columns: lane (l31, lh) reads floats 2 l31, 2 l31 + 1 of its wave's 64-column range in row 2 mm + lh
+    const int gx = wn * 64 + 2 * l31, ax = TM * TN + wk * 64 + 2 * l31;
     for (int s = 0; s < nst; ++s) {
         if (NBUF == 2 || s + 1 >= nst) wait_vm<0>();
         else wait_vm<8>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (s + NBUF - 1 < nst) issue(mbeg + (long long)(s + NBUF - 1) * TM, (s + NBUF - 1) % NBUF);
-        const float *Gs = ring + (s % NBUF) * WSTAGE, *As = Gs + TM * TN;
+        const float *Gs = ring + (s % NBUF) * WSTAGE + lh * 128;
+        float2 g[2], a[2];
+        g[0] = *reinterpret_cast<const float2 *>(Gs + gx);
+        a[0] = *reinterpret_cast<const float2 *>(Gs + ax);
 #pragma unroll
         for (int mm = 0; mm < TM / 2; ++mm) {
-            const int ro = (mm * 2 + lh) * 128;
-            const float g0 = Gs[ro + gx0], g1 = Gs[ro + gx1], a0 = As[ro + ax0], a1 = As[ro + ax1];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(g0, a0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(g0, a1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(g1, a0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(g1, a1, acc[1][1], 0, 0, 0);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
-    // D[row = n][col = k]; lanes run along k (contiguous in dW)
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int k = k0 + (wk * 2 + j) * 32 + l31;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int n = n0 + (wn * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                p.dW[(long long)n * p.K + k] = acc[i][j][r];
+            if (mm + 1 < TM / 2) {              // the next row pair's operands while this one's four MFMAs run
+                g[(mm + 1) & 1] = *reinterpret_cast<const float2 *>(Gs + (mm + 1) * 256 + gx);
+                a[(mm + 1) & 1] = *reinterpret_cast<const float2 *>(Gs + (mm + 1) * 256 + ax);
             }
+            __builtin_amdgcn_sched_barrier(0);
+            const float2 cg = g[mm & 1], ca = a[mm & 1];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(cg.x, ca.x, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(cg.x, ca.y, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(cg.y, ca.x, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(cg.y, ca.y, acc[1][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
+    }
+    // tile (q, q'): D row i <-> n = 2 i + q, column j <-> k = 2 j + q' of the wave's 64 x 64 block; lanes run along k: 8 bytes each
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        float *dp = p.dW + (long long)(n0 + wn * 64 + q + 8 * lh) * p.K + k0 + wk * 64 + 2 * l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = (r & 3) + 8 * (r >> 2);                 // (+ 4 lh: in dp)
+            *reinterpret_cast<float2 *>(dp + (long long)(2 * i) * p.K) = make_float2(acc[q][0][r], acc[q][1][r]);
+        }
+    }
 }
 
 std::atomic<unsigned long long> g_raised[4];
 
-int plane_nbuf() { return 2; }
+int plane_nbuf() { return 2; }          // two 32-KiB slots, two workgroups per CU: 7 % / 3 % faster than a three-slot ring with one (tools/bench_planes.py)
 
 bool gemm_ok(const efgh_gemm_desc *d) {
     if (!d || d->mode != 0 || d->T != 1 || !d->A || !d->W || !d->out) return false;
@@ -330,15 +329,29 @@ extern "C" int efgh_plane_gemm(const efgh_gemm_desc *d, int32_t nbuf, void *stre
     return EFGH_OK;
 }
 
+// The rows m are cut into `zs` chunks (one partial plane each, folded in chunk order).  Two workgroups per CU are resident, 512 at
+// a time; a grid of 576 workgroups - what one chunk gives a 512 x 512-channel layer: 16 (n, c) blocks x 36 planes - runs one full
+// round and then an eighth of one (measured: 97 TFLOP/s against 125 on grids that fill their rounds).  zs is therefore chosen by a
+// small cost model: rounds of 512 workgroups (a partly filled last round costs between half and a whole one: its workgroups have
+// their CU to themselves) x rows per chunk, plus the fold's traffic (2 x zs planes at ~5 TB/s, in row-equivalents of 0.12 us).
 static long long plane_wgrad_chunks(const efgh_gemm_desc *d, int nbatch, long long *chunk_out) {
-    const long long kt = d->C / TK, nt = d->N / TN;
-    long long want = 1024 / (kt * nt * nbatch);          // (as efgh_gather_wgrad: ~1024 workgroups per launch)
-    if (want < 1) want = 1;
-    long long chunk = (d->M + want - 1) / want;
-    chunk = (chunk + TM - 1) / TM * TM;
-    if (chunk < 256) chunk = 256;
-    if (chunk_out) *chunk_out = chunk;
-    return (d->M + chunk - 1) / chunk;
+    const long long blocks = (long long)(d->C / TK) * (d->N / TN) * nbatch;
+    const double fold_rows = (double)nbatch * d->N * d->C * 1.31e-5;
+    long long best_zs = 1, best_chunk = (d->M + TM - 1) / TM * TM;
+    double best = -1.0;
+    for (long long zs = 1; zs <= 64; ++zs) {
+        long long chunk = (d->M + zs - 1) / zs;
+        chunk = (chunk + TM - 1) / TM * TM;
+        if (zs > 1 && chunk < 256) break;
+        const long long z = (d->M + chunk - 1) / chunk;              // chunks that actually hold rows
+        if (z != zs && zs > 1) continue;
+        const long long wg = z * blocks, full = wg / 512, rem = wg % 512;
+        const double rounds = (double)full + (rem ? 0.5 + 0.5 * (double)rem / 512.0 : 0.0);
+        const double cost = rounds * (double)chunk + (z > 1 ? (double)z * fold_rows : 0.0);
+        if (best < 0.0 || cost < best) { best = cost; best_zs = z; best_chunk = chunk; }
+    }
+    if (chunk_out) *chunk_out = best_chunk;
+    return best_zs;
 }
 
 static bool wgrad_ok(const efgh_gemm_desc *d, int64_t ldg) {
@@ -360,7 +373,8 @@ extern "C" int64_t efgh_plane_wgrad_workspace(const efgh_gemm_desc *d) {
 }
 
 /* dWp[b][n][c] = sum_m G[b][m][n] * A[b][m][c]: the LDS-DMA staged form of efgh_gather_wgrad_batched (same arguments, same
- * row-chunk partials folded in chunk order) for the launches efgh_plane_wgrad_supported accepts */
+ * row-chunk partials folded in chunk order; the chunks are sized to fill rounds of resident workgroups) for the launches
+ * efgh_plane_wgrad_supported accepts */
 extern "C" int efgh_plane_wgrad_batched(const efgh_gemm_desc *d, const float *G, int64_t ldg, int64_t batch_stride_g, float *dWp,
                                         int64_t batch_stride_dw, float *workspace, int32_t nbuf, void *stream_) {
     hipStream_t st = (hipStream_t)stream_;

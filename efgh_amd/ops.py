@@ -480,6 +480,14 @@ def gather_gemm(A, lda, C, T, Wp, N, M, out, ldo, mode=0, geom=None, table=None,
     return bn_stats
 
 
+GEMM_DMA = True                 # eligible efgh_gather_gemm launches on the LDS-DMA staged instances (a process-wide switch of the library)
+
+
+def apply_switches():
+    """push the switches that live inside the library (bench.py --set, tools): call after changing GEMM_DMA"""
+    _L().efgh_gather_gemm_set_dma(c_int32(1 if GEMM_DMA else 0))
+
+
 PLANE_DMA = True                # the 36 planes of a 2-D Winograd layer on the LDS-DMA staged kernels (planes.hip); False: k_gather_gemm / k_gather_wgrad
 PLANE_DMA_NBUF = 0              # ring slots (0: the library's default; 2 or 3 for A/B runs, tools/bench_planes.py)
 PROFILE_WINO2D = None           # bench.py: whole 2-D Winograd layers (three launches), direct-form FLOPs

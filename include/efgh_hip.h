@@ -469,6 +469,12 @@ int efgh_c4_wgrad_supported(const efgh_gemm_desc *d);
 int64_t efgh_c4_wgrad_workspace(const efgh_gemm_desc *d);
 int efgh_c4_wgrad(const efgh_gemm_desc *d, const float *G, int64_t ldg, float *dWp, float *workspace, void *stream);
 
+/* efgh_gather_gemm serves modes 0 / 1 with more than 32 outputs and C % 32 == 0 on LDS-DMA staged instances of its kernel since
+ * round 5 (`global_load_lds_dwordx4` into a two-slot XOR-swizzled ring, one barrier per 32-deep step; same products, same k
+ * order, same epilogue: bit-identical outputs).  This switch exists for tests and A/B timing: 0 = register-staged kernel for
+ * every launch, 1 = default.  Returns the previous setting; process-wide. */
+int efgh_gather_gemm_set_dma(int32_t on);
+
 /* ------------------------------------------------------------------ batched plain GEMMs, LDS-DMA staged (round 5) ------
  * The 36 alpha planes of a 2-D Winograd F(4x4,3x3) layer (every 3x3 / stride-1 convolution with >= 256 channels, weight
  * gradient >= 128: nets/vgg.py:77, nets/resnet.py:22-30) are plain GEMMs over contiguous fp32 rows.  These entry points run
