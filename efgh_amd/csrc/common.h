@@ -107,3 +107,37 @@ __device__ __forceinline__ unsigned lds_addr(const float *p) {
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+
+// ---- row chunks of a weight-gradient launch (the contraction runs over the rows m and is cut into `zs` chunks, one partial plane
+// each, folded in chunk order).  `wg_per_cu` workgroups are resident per CU, 256 * wg_per_cu at a time; a grid that is a round and
+// an eighth runs the eighth alone on its CUs (measured on the 512 x 512-channel planes: 97 TFLOP/s against 125 on grids that fill
+// their rounds).  zs is chosen by a small cost model: rounds of resident workgroups (a partly filled last round costs between half
+// and a whole one: its workgroups have their CU to themselves) x rows per chunk, plus the fold's traffic (2 x zs planes at ~5 TB/s)
+// in row-equivalents.  `blocks`: workgroups per chunk, `plane_elems`: floats of one partial plane set, `unit`: row granularity.
+static inline long long efgh_round_chunks(long long M, long long blocks, int wg_per_cu, int unit, long long min_chunk,
+                                          double plane_elems, long long *chunk_out) {
+    const long long slots = 256LL * wg_per_cu;
+    const double fold_rows = plane_elems * 1.31e-5 * 2.0 / wg_per_cu;
+    long long best_zs = 1, best_chunk = (M + unit - 1) / unit * unit;
+    double best = -1.0;
+    auto consider = [&](long long zs) {
+        if (zs < 1) return;
+        long long chunk = (M + zs - 1) / zs;
+        chunk = (chunk + unit - 1) / unit * unit;
+        if (zs > 1 && chunk < min_chunk) return;
+        const long long z = (M + chunk - 1) / chunk;              // chunks that actually hold rows
+        const long long wg = z * blocks, full = wg / slots, rem = wg % slots;
+        const double rounds = (double)full + (rem ? 0.5 + 0.5 * (double)rem / (double)slots : 0.0);
+        const double cost = rounds * (double)chunk + (z > 1 ? (double)z * fold_rows : 0.0);
+        if (best < 0.0 || cost < best) { best = cost; best_zs = z; best_chunk = chunk; }
+    };
+    // candidates: one chunk, and the chunk counts that just fill 1 .. 8 rounds (and their neighbours: the rounding of the chunk to
+    // `unit` rows can drop one) - a dozen evaluations per launch, this runs on the host for every weight-gradient launch
+    consider(1);
+    for (int r = 1; r <= 8; ++r) {
+        const long long zs = r * slots / blocks;
+        consider(zs); consider(zs - 1); consider(zs + 1);
+    }
+    if (chunk_out) *chunk_out = best_chunk;
+    return best_zs;
+}

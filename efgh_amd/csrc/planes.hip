@@ -329,29 +329,11 @@ extern "C" int efgh_plane_gemm(const efgh_gemm_desc *d, int32_t nbuf, void *stre
     return EFGH_OK;
 }
 
-// The rows m are cut into `zs` chunks (one partial plane each, folded in chunk order).  Two workgroups per CU are resident, 512 at
-// a time; a grid of 576 workgroups - what one chunk gives a 512 x 512-channel layer: 16 (n, c) blocks x 36 planes - runs one full
-// round and then an eighth of one (measured: 97 TFLOP/s against 125 on grids that fill their rounds).  zs is therefore chosen by a
-// small cost model: rounds of 512 workgroups (a partly filled last round costs between half and a whole one: its workgroups have
-// their CU to themselves) x rows per chunk, plus the fold's traffic (2 x zs planes at ~5 TB/s, in row-equivalents of 0.12 us).
+// row chunks that fill rounds of the 512 resident workgroups (efgh_round_chunks, common.h): a 512 x 512-channel layer has 16 (n, c)
+// blocks x 36 planes = 576 workgroups per chunk - one chunk alone runs a round and an eighth
 static long long plane_wgrad_chunks(const efgh_gemm_desc *d, int nbatch, long long *chunk_out) {
     const long long blocks = (long long)(d->C / TK) * (d->N / TN) * nbatch;
-    const double fold_rows = (double)nbatch * d->N * d->C * 1.31e-5;
-    long long best_zs = 1, best_chunk = (d->M + TM - 1) / TM * TM;
-    double best = -1.0;
-    for (long long zs = 1; zs <= 64; ++zs) {
-        long long chunk = (d->M + zs - 1) / zs;
-        chunk = (chunk + TM - 1) / TM * TM;
-        if (zs > 1 && chunk < 256) break;
-        const long long z = (d->M + chunk - 1) / chunk;              // chunks that actually hold rows
-        if (z != zs && zs > 1) continue;
-        const long long wg = z * blocks, full = wg / 512, rem = wg % 512;
-        const double rounds = (double)full + (rem ? 0.5 + 0.5 * (double)rem / 512.0 : 0.0);
-        const double cost = rounds * (double)chunk + (z > 1 ? (double)z * fold_rows : 0.0);
-        if (best < 0.0 || cost < best) { best = cost; best_zs = z; best_chunk = chunk; }
-    }
-    if (chunk_out) *chunk_out = best_chunk;
-    return best_zs;
+    return efgh_round_chunks(d->M, blocks, 2, TM, 256, (double)nbatch * d->N * d->C, chunk_out);
 }
 
 static bool wgrad_ok(const efgh_gemm_desc *d, int64_t ldg) {

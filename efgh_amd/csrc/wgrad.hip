@@ -18,9 +18,6 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int TK = 128, TM = 32, LD = 128;
-#ifndef WGRAD_TARGET_BLOCKS
-#define WGRAD_TARGET_BLOCKS 1024      // workgroups a launch is cut into along the rows (each row chunk costs one partial plane)
-#endif
 
 struct WArgs {
     const float *A; int64_t lda;
@@ -276,18 +273,15 @@ void efgh_launch_fold_splits(const float *part, int zs, long long total, float *
 static int gather_wgrad_impl(const efgh_gemm_desc *d, const float *G, int64_t ldg, float *dWp, float *workspace, int nbatch,
                              int64_t bsG, int64_t bsD, void *stream_);
 
-// the rows m are cut into `zs` chunks so that the grid has ~2048+ workgroups; chunks are multiples of TM
+// the rows m are cut into `zs` chunks that fill whole rounds of resident workgroups (efgh_round_chunks, common.h; round 5 - rounds
+// 1-4 aimed at ~1024 workgroups whatever the occupancy: three workgroups of the 128-wide instance fit a CU, 768 at a time, so a
+// grid of 1020 ran a round and a third).  Chunks are multiples of TM.
 static long long wgrad_chunks(const efgh_gemm_desc *d, int nbatch, long long *chunk_out) {
     const int K = d->T * d->C;
     const int TN = d->N <= 64 ? 64 : 128;
     const long long kt = (K + TK - 1) / TK, nt = (d->N + TN - 1) / TN;
-    long long want = WGRAD_TARGET_BLOCKS / (kt * nt * nbatch);
-    if (want < 1) want = 1;
-    long long chunk = (d->M + want - 1) / want;
-    chunk = (chunk + TM - 1) / TM * TM;
-    if (chunk < 256) chunk = 256;
-    if (chunk_out) *chunk_out = chunk;
-    return (d->M + chunk - 1) / chunk;
+    // registers: 160 (TN = 128) / 128 (TN = 64) per lane -> 3 / 4 workgroups per CU
+    return efgh_round_chunks(d->M, kt * nt * nbatch, TN == 128 ? 3 : 4, TM, 256, (double)nbatch * d->N * K, chunk_out);
 }
 
 /* floats of scratch efgh_gather_wgrad(_batched) needs for this problem (0: a single row chunk writes dWp directly) */
