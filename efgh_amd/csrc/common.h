@@ -128,16 +128,29 @@ static inline long long efgh_round_chunks(long long M, long long blocks, int wg_
         const long long z = (M + chunk - 1) / chunk;              // chunks that actually hold rows
         const long long wg = z * blocks, full = wg / slots, rem = wg % slots;
         const double rounds = (double)full + (rem ? 0.5 + 0.5 * (double)rem / (double)slots : 0.0);
-        const double cost = rounds * (double)chunk + (z > 1 ? (double)z * fold_rows : 0.0);
-        if (best < 0.0 || cost < best) { best = cost; best_zs = z; best_chunk = chunk; }
+        // (+ a workgroup's fixed part - row iterators, the 64-KB partial tile it stores - priced at 128 rows: without it the model
+        // liked eight rounds of 25-step workgroups as much as one round of 200-step ones, and lost 30 % on k_gather_wgrad)
+        const double cost = rounds * ((double)chunk + 128.0) + (z > 1 ? (double)z * fold_rows : 0.0);
+        if (best < 0.0 || cost < best * 0.995) { best = cost; best_zs = z; best_chunk = chunk; }
     };
-    // candidates: one chunk, and the chunk counts that just fill 1 .. 8 rounds (and their neighbours: the rounding of the chunk to
+    // candidates: one chunk, and the chunk counts that just fill 1 .. 4 rounds (and their neighbours: the rounding of the chunk to
     // `unit` rows can drop one) - a dozen evaluations per launch, this runs on the host for every weight-gradient launch
+    const long long zmax = M / min_chunk > 1 ? M / min_chunk : 1;        // the most chunks the minimum chunk size allows
+    auto clamp = [&](long long z) { return z < 1 ? 1 : (z > zmax ? zmax : z); };
     consider(1);
-    for (int r = 1; r <= 8; ++r) {
+    for (int r = 1; r <= 4; ++r) {
         const long long zs = r * slots / blocks;
-        consider(zs); consider(zs - 1); consider(zs + 1);
+        consider(clamp(zs)); consider(clamp(zs - 1)); consider(clamp(zs + 1));
     }
+    consider(zmax); consider(clamp(zmax - 1)); consider(clamp(zmax / 2));
     if (chunk_out) *chunk_out = best_chunk;
     return best_zs;
+}
+
+// resident workgroups per CU of a kernel, asked of the runtime once per instance (register and LDS allocation decide it; reading
+// it off the code object's register counts by hand was wrong once: round 5)
+static inline int efgh_wg_per_cu(const void *kernel, int threads, size_t dyn_lds) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, threads, dyn_lds) != hipSuccess || n < 1) n = 1;
+    return n;
 }

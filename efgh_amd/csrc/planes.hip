@@ -333,7 +333,8 @@ extern "C" int efgh_plane_gemm(const efgh_gemm_desc *d, int32_t nbuf, void *stre
 // blocks x 36 planes = 576 workgroups per chunk - one chunk alone runs a round and an eighth
 static long long plane_wgrad_chunks(const efgh_gemm_desc *d, int nbatch, long long *chunk_out) {
     const long long blocks = (long long)(d->C / TK) * (d->N / TN) * nbatch;
-    return efgh_round_chunks(d->M, blocks, 2, TM, 256, (double)nbatch * d->N * d->C, chunk_out);
+    static const int occ = efgh_wg_per_cu((const void *)k_plane_wgrad<2>, 256, (size_t)2 * WSTAGE * sizeof(float));
+    return efgh_round_chunks(d->M, blocks, occ, TM, 256, (double)nbatch * d->N * d->C, chunk_out);
 }
 
 static bool wgrad_ok(const efgh_gemm_desc *d, int64_t ldg) {

@@ -274,14 +274,17 @@ static int gather_wgrad_impl(const efgh_gemm_desc *d, const float *G, int64_t ld
                              int64_t bsG, int64_t bsD, void *stream_);
 
 // the rows m are cut into `zs` chunks that fill whole rounds of resident workgroups (efgh_round_chunks, common.h; round 5 - rounds
-// 1-4 aimed at ~1024 workgroups whatever the occupancy: three workgroups of the 128-wide instance fit a CU, 768 at a time, so a
-// grid of 1020 ran a round and a third).  Chunks are multiples of TM.
+// 1-4 aimed at ~1024 workgroups whatever the layer).  The occupancy is asked of the runtime.  Chunks are multiples of TM.
 static long long wgrad_chunks(const efgh_gemm_desc *d, int nbatch, long long *chunk_out) {
     const int K = d->T * d->C;
     const int TN = d->N <= 64 ? 64 : 128;
     const long long kt = (K + TK - 1) / TK, nt = (d->N + TN - 1) / TN;
-    // registers: 160 (TN = 128) / 128 (TN = 64) per lane -> 3 / 4 workgroups per CU
-    return efgh_round_chunks(d->M, kt * nt * nbatch, TN == 128 ? 3 : 4, TM, 256, (double)nbatch * d->N * K, chunk_out);
+    static const int occ128[3] = {efgh_wg_per_cu((const void *)k_gather_wgrad<0, 128>, 256, 0), efgh_wg_per_cu((const void *)k_gather_wgrad<1, 128>, 256, 0),
+                                  efgh_wg_per_cu((const void *)k_gather_wgrad<2, 128>, 256, 0)};
+    static const int occ64[3] = {efgh_wg_per_cu((const void *)k_gather_wgrad<0, 64>, 256, 0), efgh_wg_per_cu((const void *)k_gather_wgrad<1, 64>, 256, 0),
+                                 efgh_wg_per_cu((const void *)k_gather_wgrad<2, 64>, 256, 0)};
+    const int mode = d->mode >= 0 && d->mode <= 2 ? d->mode : 0;
+    return efgh_round_chunks(d->M, kt * nt * nbatch, TN == 128 ? occ128[mode] : occ64[mode], TM, 256, (double)nbatch * d->N * K, chunk_out);
 }
 
 /* floats of scratch efgh_gather_wgrad(_batched) needs for this problem (0: a single row chunk writes dWp directly) */
@@ -385,5 +388,15 @@ extern "C" int efgh_table_scatter_add(const float *src, const int32_t *table, in
     long long g = (total + 255) / 256;
     k_table_scatter_add<<<(int)(g > 16384 ? 16384 : g), 256, 0, (hipStream_t)stream_>>>(src, table, M, T, C, dst);
     EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}
+
+/* debugging aid (tools/probes/occupancy.py): the occupancy figures the chunking uses, as text */
+extern "C" int efgh_debug_occupancy(char *out, int32_t cap) {
+    EFGH_CHECK_ARG(out && cap > 64);
+    snprintf(out, cap, "k_gather_wgrad<0,128> %d  <1,128> %d  <2,128> %d  <0,64> %d  <1,64> %d  <2,64> %d workgroups per CU",
+             efgh_wg_per_cu((const void *)k_gather_wgrad<0, 128>, 256, 0), efgh_wg_per_cu((const void *)k_gather_wgrad<1, 128>, 256, 0),
+             efgh_wg_per_cu((const void *)k_gather_wgrad<2, 128>, 256, 0), efgh_wg_per_cu((const void *)k_gather_wgrad<0, 64>, 256, 0),
+             efgh_wg_per_cu((const void *)k_gather_wgrad<1, 64>, 256, 0), efgh_wg_per_cu((const void *)k_gather_wgrad<2, 64>, 256, 0));
     return EFGH_OK;
 }

@@ -469,6 +469,9 @@ int efgh_c4_wgrad_supported(const efgh_gemm_desc *d);
 int64_t efgh_c4_wgrad_workspace(const efgh_gemm_desc *d);
 int efgh_c4_wgrad(const efgh_gemm_desc *d, const float *G, int64_t ldg, float *dWp, float *workspace, void *stream);
 
+/* debugging aid: the resident-workgroups-per-CU figures the weight-gradient chunking uses, as text */
+int efgh_debug_occupancy(char *out, int32_t cap);
+
 /* efgh_gather_gemm serves modes 0 / 1 with more than 32 outputs and C % 32 == 0 on LDS-DMA staged instances of its kernel since
  * round 5 (`global_load_lds_dwordx4` into a two-slot XOR-swizzled ring, one barrier per 32-deep step; same products, same k
  * order, same epilogue: bit-identical outputs).  This switch exists for tests and A/B timing: 0 = register-staged kernel for
