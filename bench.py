@@ -38,6 +38,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-forward-section', action='store_true')
     ap.add_argument('--small', action='store_true', help='debug: 128x256 / 2048 points')
+    ap.add_argument('--no-config-r', action='store_true', help='skip the batch-1 reference-loop section (config_r)')
     ap.add_argument('--rotate-inputs', type=int, default=4,
                     help='cycle this many resident batches of DIFFERENT synthetic frame-pairs through the steps (1 = the same batch '
                          'every step): every sweep has its own lattice sizes, so the speculative sizing of the pyramid (previous '
@@ -286,6 +287,97 @@ def rooflines(prof, steps, workload='train'):
     return out
 
 
+def config_r(iters=6, warm=3):
+    """BASELINE configs[0], the reference's OWN configuration and loop shape (configs/train_rellis.yaml:19-29: raw 900x1600, 65 536
+    points, batch 1; iterater.py:25-46,106): per iteration `.to(DEVICE).float()` of the four inputs from host memory, `model(...)`,
+    `criterion.compute_loss`, `optimizer.zero_grad / backward / step` with STOCK torch.optim.Adam (main.py:181-183), `lss.update`
+    = one `.item()` per loss term (helper.py:123-126), `err.update` = two `.cpu()` pose reads (helper.py:142-145), and
+    `torch.cuda.empty_cache()`.  Timed three ways per iteration: host wall-clock of the loop body, host time until everything up to
+    `optimizer.step()` is ENQUEUED (the forward's one lattice read-back included), and the GPU interval between two events around
+    the same span.  The loop runs twice: with the real `empty_cache()` as the reference calls it, and with the no-op that
+    `python -m efgh_amd.run` rebinds it to (efgh_amd/run.py:install_loop_rebinds); eval forward the same way (valid.py:21-41)."""
+    import time
+    import numpy as np
+    import torch
+    from efgh_amd import synthetic as syn
+    from efgh_amd.losses import EFGHCriterion
+    from efgh_amd.nets import EFGHBackbone
+    raw, npts = (900, 1600), 65536
+    args = syn.default_args(raw, 'cuda')
+    torch.manual_seed(0)
+    model = EFGHBackbone(args).cuda()
+    model = torch.nn.DataParallel(model, device_ids=[0])            # main.py:127 on a one-GPU process: calls the module directly
+    criterion = EFGHCriterion(args)
+    optimizer = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-4, weight_decay=0)
+    pairs = [syn.make_batch(raw, npts, 1, first_seed=i) for i in range(4)]          # four different frame-pairs, cycled
+    host = [([torch.from_numpy(b[k]).pin_memory() for k in ('pc', 'img', 'calib', 'A')],
+             {k: torch.from_numpy(v) for k, v in b['gt'].items()}) for b in pairs]
+    real_empty = torch.cuda.empty_cache
+
+    def train_iter(i, empty):
+        (pcd, img, calib, A), gt = host[i % len(host)]
+        t0 = time.perf_counter()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        pcd, img, calib, A = (t.to('cuda').float() for t in (pcd, img, calib, A))
+        e0.record()
+        pred = model(pcd, img, calib, A, False)
+        losses, gt2 = criterion.compute_loss(pcd, img, calib, A, dict(gt), pred)
+        optimizer.zero_grad()
+        losses['total'].backward()
+        optimizer.step()
+        e1.record()
+        t1 = time.perf_counter()
+        vals = [losses[k].item() for k in list(losses.keys())]                       # Lss.update
+        _ = gt2['sensor2_T_sensor1'].cpu().detach().numpy()[0], pred['sensor2_T_sensor1'].cpu().detach().numpy()[0]      # Err.update
+        del pcd, img, gt2
+        empty()
+        t2 = time.perf_counter()
+        return (t2 - t0) * 1e3, (t1 - t0) * 1e3, e0.elapsed_time(e1), len(vals)
+
+    def eval_iter(i, empty):
+        (pcd, img, calib, A), gt = host[i % len(host)]
+        t0 = time.perf_counter()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        pcd, img, calib, A = (t.to('cuda').float() for t in (pcd, img, calib, A))
+        e0.record()
+        with torch.no_grad():
+            pred = model(pcd, img, calib, A)
+        e1.record()
+        t1 = time.perf_counter()
+        _ = pred['sensor2_T_sensor1'].cpu().numpy()[0]                               # test.py:46-53: the 3x4 pose goes to the CSV
+        empty()
+        t2 = time.perf_counter()
+        return (t2 - t0) * 1e3, (t1 - t0) * 1e3, e0.elapsed_time(e1), 0
+
+    def run(fn, empty):
+        for i in range(warm):
+            fn(i, empty)
+        torch.cuda.synchronize()
+        rows = [fn(warm + i, empty) for i in range(iters)]
+        torch.cuda.synchronize()
+        med = lambda j: float(np.median([r[j] for r in rows]))
+        return {'loop_ms': med(0), 'enqueue_ms': med(1), 'gpu_ms': med(2)}
+    out = {'workload': 'BASELINE.json configs[0]: the shipped RELLIS configuration (raw 900x1600, 65 536 points), batch 1, the '
+                       'reference\'s loop shape (iterater.py:25-46,106) with stock torch.optim.Adam; medians of %d iterations over 4 '
+                       'rotating synthetic frame-pairs' % iters}
+    model.train()
+    out['train_reference_loop'] = run(train_iter, real_empty)
+    out['train'] = run(train_iter, lambda: None)
+    losses_n = train_iter(0, lambda: None)[3]
+    model.eval()
+    out['eval_reference_loop'] = run(eval_iter, real_empty)
+    out['eval'] = run(eval_iter, lambda: None)
+    out['train_ms'], out['fwd_ms'] = out['train']['loop_ms'], out['eval']['loop_ms']
+    out['host_syncs_per_train_iteration'] = losses_n + 2 + 1
+    out['note'] = ('loop_ms: host wall-clock of one loop body (what the user waits for); enqueue_ms: host time until optimizer.step() '
+                   '(eval: the forward) has been enqueued; gpu_ms: GPU interval between events around the same span - enqueue_ms '
+                   '>= gpu_ms means the host, not the GPU, sets the pace.  *_reference_loop: torch.cuda.empty_cache() really called '
+                   'every iteration (iterater.py:106); train / eval: the no-op `python -m efgh_amd.run` rebinds it to')
+    del model, optimizer
+    real_empty()
+    return out
+
+
 def spawn_ranks(a):
     """`python bench.py --gpus N` outside a launcher: start `torch.distributed.run` with N ranks as a CHILD process and hand its
     exit code on.  Nothing in this process has touched the GPU (no torch import yet), so no initialised process is replaced."""
@@ -516,6 +608,16 @@ def main():
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(raw, npts, a.mode)
+        if world == 1 and not a.small and not a.no_config_r:
+            # the reference's own configuration and loop (batch 1): everything of the main measurement is released first
+            fsets = tsets = trainer = model = None
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+            try:
+                out['config_r'] = config_r()
+            except Exception as e:          # noqa: BLE001  (a side measurement must not take the headline line down)
+                out['config_r'] = {'error': repr(e)}
         if switches:
             out['switches'] = switches            # (an A/B run of the builder: not the default configuration)
         if fwd is not None and a.mode == 'train':

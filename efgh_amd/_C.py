@@ -86,9 +86,22 @@ def ptr(t):
     return c_void_p(0 if t is None else t.data_ptr())
 
 
+_raw_stream = None
+
+
 def stream_ptr():
+    """the current HIP stream of the current device as a raw pointer.  `torch.cuda.current_stream().cuda_stream` builds a Python
+    Stream object per call (device-index resolution, `os.environ` look-ups: 2 us x ~600 launches of a batch-1 forward = 15 % of
+    its host time, tools/host_profile.py); the private raw getter is the same value without the object"""
+    global _raw_stream
     import torch
-    return c_void_p(torch.cuda.current_stream().cuda_stream)
+    if _raw_stream is None:
+        get, dev = getattr(torch._C, '_cuda_getCurrentRawStream', None), getattr(torch._C, '_cuda_getDevice', None)
+        if get is not None and dev is not None:
+            _raw_stream = lambda: get(dev())
+        else:                                   # (a torch without the private getters)
+            _raw_stream = lambda: torch.cuda.current_stream().cuda_stream
+    return c_void_p(_raw_stream())
 
 
 def require_cuda(*tensors):

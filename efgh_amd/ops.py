@@ -52,6 +52,7 @@ class Epoch:
         self.repacked_at = {}    # device index -> n of the last batched repack enqueued by repack_stale
 
 
+HOLDER_GEN = [0]                 # bumped whenever parameters change owner (train.FlatParams): caches of "the owners of this model" key on it
 GLOBAL_EPOCH = Epoch()           # weights without an owner (no FlatParams: stock torch optimizers bump the version counters)
 _LOCK = threading.RLock()        # guards the Python-side job tables (the kernels themselves are ordered by their streams)
 
@@ -100,6 +101,11 @@ def _pack_one(w, buf, prm):
     buf._efgh_gen = getattr(buf, '_efgh_gen', 0) + 1
 
 
+def _same_storage(a, b):
+    """two _ver() keys of the same tensors that differ at most in the optimizer epoch and the version counters"""
+    return len(a) == len(b) and all(x[1:] == y[1:] for x, y in zip(a[1:], b[1:]))
+
+
 def _repack_all(device, holder):
     """ONE launch re-packs every registered layout of every live weight of `holder` on `device` whose cache entry is stale only
     because the optimizer stepped (train.FusedAdam bumps the owner's Epoch): 279 launches of 5 us per training step otherwise"""
@@ -114,7 +120,10 @@ def _repack_all(device, holder):
             if ent is None or not w.is_cuda or w.device != device:
                 continue
             cur = _ver(w)
-            if ent[0] != cur and ent[0][1:] == cur[1:]:
+            # stale, and the buffers are the ones the job table was built for: the optimizer epoch moved (FusedAdam) and / or the
+            # version counter did (a stock torch optimizer's in-place update).  A re-allocated weight (another data_ptr) or a
+            # re-generated one falls through to pack_weight's own path
+            if ent[0] != cur and _same_storage(ent[0], cur):
                 jobs.append((w, key, ent[1], cur))
         holder.jobs[:] = live
         if not jobs:
@@ -152,9 +161,28 @@ def repack_stale(device, holder=None):
     if not BATCH_PACK or device is None or device.type != 'cuda':
         return
     if holder.repacked_at.get(device.index) == holder.n:
-        return
+        if holder is not GLOBAL_EPOCH or not _sentinel_stale(holder, device):
+            return
     holder.repacked_at[device.index] = holder.n
     _repack_all(device, holder)
+
+
+def _sentinel_stale(holder, device):
+    """weights without an owner are updated by stock torch optimizers, which move version counters, not the holder's epoch: one
+    registered layout stands for all (an optimizer step rewrites every parameter) - if its key is stale, the whole set is
+    re-packed by the one batched launch instead of layer by layer (145 launches per step of the reference's own loop)"""
+    jobs = holder.jobs
+    for i in sorted({0, len(jobs) // 3, 2 * len(jobs) // 3, len(jobs) - 1}):      # (a few: frozen sub-networks never go stale)
+        if i < 0 or i >= len(jobs):
+            continue
+        ref, key = jobs[i]
+        w = ref()
+        if w is None or not w.is_cuda or w.device != device or epoch_of(w) is not holder:
+            continue
+        ent = w.__dict__.get('_efgh_cache', {}).get(key)
+        if ent is not None and ent[0] != _ver(w):
+            return True
+    return False
 
 
 def pack_weight(w, N, T, C, sn, sc, st, taps=None, Np=None, Cp=None, key=None):
@@ -188,7 +216,7 @@ def pack_weight(w, N, T, C, sn, sc, st, taps=None, Np=None, Cp=None, key=None):
                 jl[:] = [j for j in jl if j[0]() is not None]
             jl.append((weakref.ref(w), key))
         return buf
-    if BATCH_PACK and ent[0][1:] == cur[1:]:          # only the optimizer epoch moved: everything else is stale the same way
+    if BATCH_PACK and _same_storage(ent[0], cur):     # the optimizer stepped: everything else is stale the same way
         _repack_all(wd.device, epoch_of(w))
         ent = store[key]
         if ent[0] == cur:
@@ -933,7 +961,7 @@ def _scratch(nfloats, device):
     nfloats = int(nfloats)
     if nfloats <= 0:
         return None
-    key = (str(device), torch.cuda.current_stream().cuda_stream, threading.get_ident())      # (autograd's device thread is its own)
+    key = (device.index, _C.stream_ptr().value, threading.get_ident())      # (autograd's device thread is its own)
     t = _SCRATCH.get(key)
     if t is None or t.numel() < nfloats:
         t = _SCRATCH[key] = torch.empty(max(nfloats, 1 << 22), dtype=torch.float32, device=device)

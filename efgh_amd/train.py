@@ -59,6 +59,7 @@ class FlatParams:
         # content epoch of the flat weight buffer (FusedAdam rewrites it through raw pointers): the packed-weight / folded-BN caches
         # of THESE parameters key on it, and their batched repack is registered on it (ops.Epoch)
         self.epoch = ops.Epoch()
+        ops.HOLDER_GEN[0] += 1
         for i, p in enumerate(ps):
             p._efgh_flat = (self, i)
             p._efgh_epoch = self.epoch

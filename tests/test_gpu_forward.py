@@ -42,7 +42,11 @@ def _rel_elem(got, ref):
 
 # element-wise bound for the six pose-logit tensors (teacher-forced stages, this small configuration); the measured values are
 # printed by test_stagewise_teacher_forced (-s) and kept in profiles/r05_logit_elementwise.txt
-ELEM_TOL = {'e_gn_sgn': 1e-4, 'e_gn_abs': 1e-4, 'h_hrzn_sgn': 1e-4, 'h_hrzn_abs': 1e-4, 'f_score': 1e-4, 'g_trs': 1e-3}
+# Measured (round 5, MI355X): 1e-6 or better on every tensor in eval mode and on five of the six in train mode; `h_hrzn_sgn` in
+# TRAIN mode has one logit of 0.037 x the largest that is off by 2.9e-4 of itself (1.8e-5 in the max-norm): H's head normalises
+# 32 positions per channel with batch statistics at this image size, which amplifies the rounding of the trunk
+ELEM_TOL = {'e_gn_sgn': 1e-4, 'e_gn_abs': 1e-4, 'h_hrzn_sgn': 1e-4, 'h_hrzn_abs': 1e-4, 'f_score': 1e-4, 'g_trs': 1e-4}
+ELEM_TOL_TRAIN = dict(ELEM_TOL, h_hrzn_sgn=1e-3)
 
 
 def test_eval_forward_vs_reference_golden(golden_dir, manifest):
@@ -124,7 +128,8 @@ def test_stagewise_teacher_forced(golden_dir, manifest, train):
     print('\nelementwise[%s]: ' % tag + '; '.join('%s max-norm %.2e elem(oracle) %.2e elem(golden) %.2e min|ref|/max|ref| %.1e'
                                                   % ((k,) + v) for k, v in worst.items()))
     for k, v in worst.items():
-        assert v[1] < ELEM_TOL[k] and v[2] < ELEM_TOL[k], (k, v)
+        tol = (ELEM_TOL_TRAIN if train else ELEM_TOL)[k]
+        assert v[1] < tol and v[2] < tol, (k, v)
     if train:
         sd = m.state_dict()
         for k in [k for k in G.files if k.startswith('train.buf.')]:
