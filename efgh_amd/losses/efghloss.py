@@ -122,6 +122,27 @@ class EFGHCriterion(nn.Module):
         j = torch.arange(width, device=axis.device)[None, :]
         return (torch.remainder(j - xmin[:, None], width) < self.positive_num).float()
 
+    dp_exact = True       # weight the masked depth mean by the ranks' valid-pixel counts under data parallelism (see below)
+
+    def _dp_weight_masked_mean(self, l_dep, n_valid):
+        """`torch.nn.DataParallel` (main.py:127) gathers the replicas' outputs and computes ONE loss over the global batch
+        (iterater.py:35-42).  Every term of efghloss is a plain batch mean - so the mean over ranks of the per-rank terms IS the
+        global term - except `g_depth`, a mean over the VALID pixels of the whole batch (loss_utils.py:186-190: sum of squares of
+        all samples / valid pixels of all samples): the mean of the ranks' own masked means weights rank r by 1 / n_r instead of
+        1 / mean(n).  With a process group of more than one rank the per-rank term is therefore rescaled by n_r / mean_r(n_r)
+        (one 4-byte all-reduce, issued here in the forward, before any gradient bucket): the all-reduced mean of the ranks' losses
+        and gradients then equals the single global loss EXACTLY, whatever the samples' valid-pixel counts
+        (tests/test_gpu_dp.py::test_two_ranks_equal_dataparallel_on_the_real_net measures both forms).  The F term selects the same
+        number of scores per sample (positive_num * (1 + neg_ratio), loss_utils.py:96-115), so its mean needs no weight."""
+        import torch.distributed as dist
+        if not (self.dp_exact and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            return l_dep
+        n_mean = n_valid.detach().clone().reshape(1)
+        dist.all_reduce(n_mean, op=dist.ReduceOp.SUM)
+        n_mean = n_mean / dist.get_world_size()
+        scale = torch.where(n_mean > 0, n_valid.reshape(1) / n_mean.clamp_min(1.0), torch.ones_like(n_mean))
+        return l_dep * scale.reshape(()).detach()
+
     def compute_loss(self, pc, img, calib, A, gt, pred):
         if not pose.USE_KERNELS:
             return self._compute_loss_expressions(pc, img, calib, A, gt, pred)
@@ -137,7 +158,8 @@ class EFGHCriterion(nn.Module):
         gt['img_mask'] = torch.as_tensor(gt['img_mask']).to(dev)
         imask = gt['img_mask'].to(torch.uint8).contiguous()
         # masked L2 on the depth image + BCE on the mask image: one HIP sweep forward, one backward (loss_utils.py:186-199)
-        l_dep, l_msk_mean, gt['g_depth'], gt['g_mask'] = FN.GImageLossFn.apply(pred['g_depth'], pred['g_mask'], gdep, imask)
+        l_dep, l_msk_mean, gt['g_depth'], gt['g_mask'], n_valid = FN.GImageLossFn.apply(pred['g_depth'], pred['g_mask'], gdep, imask)
+        l_dep = self._dp_weight_masked_mean(l_dep, n_valid)
         cfg = (self.lam, self.positive_num, self.neg_ratio)
         Lv, gtbuf, gtcls, gtfs = PoseLossFn.apply(pred['e_gn_abs'], pred['e_gn_sgn'], pred['h_hrzn_abs'], pred['h_hrzn_sgn'],
                                                   pred['f_score'], pred['g_trs'], pred['e_l'], pred['f_l'], l_dep, l_msk_mean,
@@ -169,7 +191,8 @@ class EFGHCriterion(nn.Module):
         gt['img_mask'] = torch.as_tensor(gt['img_mask']).to(dev)
         imask = gt['img_mask'].to(torch.uint8).contiguous()
         # masked L2 on the depth image + BCE on the mask image: one HIP sweep forward, one backward (loss_utils.py:186-199)
-        l_dep, l_msk_mean, gt['g_depth'], gt['g_mask'] = FN.GImageLossFn.apply(pred['g_depth'], pred['g_mask'], gdep, imask)
+        l_dep, l_msk_mean, gt['g_depth'], gt['g_mask'], n_valid = FN.GImageLossFn.apply(pred['g_depth'], pred['g_mask'], gdep, imask)
+        l_dep = self._dp_weight_masked_mean(l_dep, n_valid)
         l_msk = l_msk_mean * lam['g_mask']
         L['g_depth'] = l_dep * lam['g_depth']
         L['g_mask'] = l_msk * lam['g_depth']

@@ -594,11 +594,12 @@ class GImageLossFn(torch.autograd.Function):
         pred_depth, pred_mask = pred_depth.contiguous(), pred_mask.contiguous()
         out3, gt_depth, gt_mask = ops.gimg_loss_fwd(pred_depth, pred_mask, gdep4, img_mask)
         ctx.save_for_backward(pred_depth, pred_mask, gt_depth, img_mask, out3)
-        ctx.mark_non_differentiable(gt_depth, gt_mask)
-        return out3[0], out3[1], gt_depth, gt_mask
+        n_valid = out3[2].detach().clone()             # pixels the masked depth mean was taken over (data-parallel weighting)
+        ctx.mark_non_differentiable(gt_depth, gt_mask, n_valid)
+        return out3[0], out3[1], gt_depth, gt_mask, n_valid
 
     @staticmethod
-    def backward(ctx, g_dep, g_msk, _a, _b):
+    def backward(ctx, g_dep, g_msk, _a, _b, _c):
         pred_depth, pred_mask, gt_depth, img_mask, out3 = ctx.saved_tensors
         d_depth, d_mask = ops.gimg_loss_bwd(pred_depth, pred_mask, gt_depth, img_mask, out3,
                                             g_dep.reshape(1).float().contiguous(), g_msk.reshape(1).float().contiguous())

@@ -330,10 +330,10 @@ def test_g_image_losses_vs_torch_autograd():
     gdep4 = torch.zeros(B, H, W, 4)
     gdep4[..., 3] = gd[:, 0]
     pdg, pmg = pd.detach().cuda().requires_grad_(True), pm.detach().cuda().requires_grad_(True)
-    a, b, gtd, gtm = FN.GImageLossFn.apply(pdg, pmg, gdep4.cuda(), im.cuda())
+    a, b, gtd, gtm, nval = FN.GImageLossFn.apply(pdg, pmg, gdep4.cuda(), im.cuda())
     (3.0 * a + 0.5 * b).backward()
     assert abs(float(a) - float(l_dep)) < 1e-5 * float(l_dep) and abs(float(b) - float(l_msk)) < 1e-5 * float(l_msk)
-    assert torch.equal(gtd.cpu(), gd) and torch.equal(gtm.cpu(), (gd > 0).float())
+    assert torch.equal(gtd.cpu(), gd) and torch.equal(gtm.cpu(), (gd > 0).float()) and float(nval) == float(valid.sum())
     assert _relerr(pdg.grad.cpu(), pd.grad) < 1e-5 and _relerr(pmg.grad.cpu(), pm.grad) < 1e-5
 
 
