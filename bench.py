@@ -156,7 +156,7 @@ def traffic_source(workload):
 
 
 # the PMC passes the `traffic` fields are read from (tools/collect_round_evidence.sh writes them, profiles/README.md)
-TRAFFIC_FILE = {'train': 'r04_hbm_traffic_train.json', 'fwd': 'r04_hbm_traffic_fwd.json'}
+TRAFFIC_FILE = {'train': 'r05_hbm_traffic_train.json', 'fwd': 'r05_hbm_traffic_fwd.json'}
 
 
 def mfma_step_utilisation(prof, steps, ms_per_step):
@@ -184,16 +184,16 @@ def gemm_roofline(prof, steps, kernel):
     ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     return {'bound': 'mfma', 'kernel': kernel, 'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
             'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
-            'traffic_unit': 'HBM-side bytes per launch (committed rocprofv3 PMC passes of this bench command, profiles/r04_hbm_traffic_*.json)',
+            'traffic_unit': 'HBM-side bytes per launch (committed rocprofv3 PMC passes of this bench command, profiles/r05_hbm_traffic_*.json)',
             'launches_per_step': n / max(1, steps),
             'avg_launch_ms': ms / max(1, n), 'algorithmic_gflop_per_launch': fl / max(1, n) / 1e9,
             'kernel_ms_per_step': ms / max(1, steps)}
 
 
 KERNELS = {
-    'wino2d_gemm': 'k_gather_gemm<0> / k_gather_wgrad<0>, batched over the 36 planes of Winograd F(4x4,3x3): the 3x3 / stride-1 '
+    'wino2d_gemm': 'k_plane_gemm / k_plane_wgrad (LDS-DMA staged), batched over the 36 planes of Winograd F(4x4,3x3): the 3x3 / stride-1 '
                    'convolutions with >= 256 channels, their data gradients and (>= 128 channels) weight gradients',
-    'gemm': 'k_gather_gemm (fp32 MFMA implicit GEMM: every contraction that is not a "same" 3x3 convolution)',
+    'gemm': 'k_gather_gemm / k_gather_gemm_dma (fp32 MFMA implicit GEMM: every contraction that is not a "same" 3x3 convolution)',
     'wino': 'k_wino43 (Winograd F(4,3) on fp32 MFMA: the 3x3 / stride-1 convolutions and their data gradients)',
     'wgrad': 'k_gather_wgrad (fp32 MFMA weight gradient)',
     'wino_wgrad': 'k_wino_wgrad_rows (Winograd F(3,4) weight gradient of the 3x3 / stride-1 convolutions, fp32 MFMA)',
@@ -245,7 +245,7 @@ def rooflines(prof, steps, workload='train'):
                                + (' + splat adjoint' if any(k.endswith('bwd') for k in parts) else ''),
                                'achieved': ach, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': ach / PEAK_HBM_GBS,
                                'traffic': None,
-                               'traffic_unit': 'HBM-side bytes per STEP, all lattice.hip + bcl.hip launches (profiles/r04_hbm_traffic_*.json)',
+                               'traffic_unit': 'HBM-side bytes per STEP, all lattice.hip + bcl.hip launches (profiles/r05_hbm_traffic_*.json)',
                                'launches_per_step': len(bcl) / max(1, steps), 'kernel_ms_per_step': ms / max(1, steps),
                                'algorithmic_mb_per_step': by / max(1, steps) / 1e6,
                                'parts': {k: {'ms_per_step': v[0] / max(1, steps), 'algorithmic_mb_per_step': v[1] / max(1, steps) / 1e6,
@@ -272,12 +272,32 @@ def rooflines(prof, steps, workload='train'):
         ms = sum(p[0].elapsed_time(p[1]) for p in hb)
         by = sum(p[2] for p in hb)
         ach = by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        ded = [p for p in hb if len(p) > 4 and p[4]]
+        ded_by, ded_ms = sum(p[2] for p in ded), sum(p[0].elapsed_time(p[1]) for p in ded)
         out['roofline_hbm_convs'] = {'bound': 'hbm', 'kernel': 'contractions with < %g FLOP per algorithmic byte (1x1 and 4-channel layers, narrow '
                                      'heads, the point branch\'s 32-channel layers; forward, data and weight gradients): thin / small-channel '
                                      'kernels and the generic tile' % 30.0,
                                      'achieved': ach, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': ach / PEAK_HBM_GBS, 'traffic': None,
                                      'launches_per_step': len(hb) / max(1, steps), 'kernel_ms_per_step': ms / max(1, steps),
                                      'algorithmic_mb_per_step': by / max(1, steps) / 1e6}
+        # counter traffic exists for the launches the DEDICATED kernels served (thin / 4-channel / small-channel: a PMC fold goes by
+        # kernel name, and the generic tile's HBM-bound launches share their name with its MFMA-bound ones)
+        rh = out['roofline_hbm_convs']
+        rh['dedicated'] = {'launches_per_step': len(ded) / max(1, steps), 'kernel_ms_per_step': ded_ms / max(1, steps),
+                           'algorithmic_mb_per_step': ded_by / max(1, steps) / 1e6,
+                           'achieved': ded_by / (ded_ms * 1e-3) / 1e9 if ded_ms > 0 else 0.0,
+                           'note': 'the launches served by thin.hip / c4conv.hip / smallc.hip kernels; `traffic` covers exactly these'}
+        rh['traffic_unit'] = 'HBM-side bytes per STEP of the dedicated kernels (rocprofv3 PMC fold, profiles/' + TRAFFIC_FILE[workload] + ')'
+        try:
+            ent = json.loads(open(os.path.join(ROOT, 'profiles', TRAFFIC_FILE[workload])).read())['per_launch']['hbm_convs']
+            if abs(ent.get('launches_per_step', -1) - rh['dedicated']['launches_per_step']) < 1e-6:
+                rh['traffic'] = ent['traffic_bytes']
+                rh['traffic_over_algorithmic'] = ent['traffic_bytes'] / max(1.0, ded_by / max(1, steps))
+            else:
+                rh['traffic_error'] = 'STALE: the committed fold saw %s dedicated launches per step, this run made %s' % (
+                    ent.get('launches_per_step'), rh['dedicated']['launches_per_step'])
+        except Exception as e:          # noqa: BLE001
+            rh['traffic_error'] = 'no committed PMC fold for this family (%s)' % type(e).__name__
     if w2:      # whole F(4x4,3x3) layers (input transform + batched GEMM + output transform), direct-form FLOPs
         ms = sum(p[0].elapsed_time(p[1]) for p in w2)
         fl = sum(p[2] for p in w2)
@@ -529,6 +549,66 @@ def main():
         if 'winograd2d_layers' in ser:
             dst['winograd2d_layers'] = ser['winograd2d_layers']
 
+    def resnet_branch(inp, gt, train):
+        """north star: ">= 60 % MFMA for the ResNet branch".  G = two ResNet-18 trunks + the decoder + the depth / mask heads
+        (nets/gnet.py:31-36,82-87,103-124; 60 % of the forward FLOPs of the path) run ALONE on one stream on the upstream outputs
+        of a full forward (detached): forward - and in training the three G loss terms and the backward through G - between two
+        HIP events.  `achieved` = MFMA FLOP the contraction kernels of that span EXECUTE (Winograd kernels at the products they
+        run) / the whole span's GPU time - BatchNorm passes, Winograd transforms, pooling, the rasteriser, the loss sweep and every
+        small launch included - / 157.3 TFLOP/s: the branch-level figure next to the per-kernel fractions."""
+        from efgh_amd.nets import efghbackbone as bb
+        keep = (bb.SIDE_STREAM, ops.WGRAD_SIDE)
+        bb.SIDE_STREAM, ops.WGRAD_SIDE = False, False
+        try:
+            model.train(train)
+            with torch.set_grad_enabled(train):
+                full = model(*inp)
+            ret = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in full.items()
+                   if not k.startswith('g_') and k not in ('efgh_cam_T_velo', 'cam_T_velo')}
+            ret['network'] = 'EHF'
+            ret['sensor2_T_sensor1'] = torch.bmm(ret['f_l'], ret['e_l'])
+            del full
+            crit = EFGHCriterion(args)
+
+            def once():
+                with torch.set_grad_enabled(train):
+                    pg = model.G(inp[0], inp[1], dict(ret))
+                    if train:
+                        Lg, _ = crit.compute_loss(inp[0], inp[1], inp[2], inp[3], gt, pg)
+                        (Lg['g_trs'] + Lg['g_depth'] + Lg['g_mask']).backward()
+                        for p_ in model.parameters():
+                            p_.grad = None
+            once()
+            torch.cuda.synchronize()
+            ops.PROFILE, ops.PROFILE_WGRAD, ops.PROFILE_WINO, ops.PROFILE_WINO_WGRAD = [], [], [], []
+            ops.PROFILE_WINO2D, ops.PROFILE_WINO2D_GEMM, ops.PROFILE_THIN = [], [], []
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            n = 2
+            e0.record()
+            for _ in range(n):
+                once()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / n
+            fl = (sum(p[2] for p in ops.PROFILE) + sum(p[2] for p in ops.PROFILE_WGRAD) + sum(p[2] for p in ops.PROFILE_WINO2D_GEMM)
+                  + 0.5 * (sum(p[2] for p in ops.PROFILE_WINO) + sum(p[2] for p in ops.PROFILE_WINO_WGRAD))) / n
+            mfma_ms = sum(p[0].elapsed_time(p[1]) for lst in (ops.PROFILE, ops.PROFILE_WGRAD, ops.PROFILE_WINO, ops.PROFILE_WINO_WGRAD,
+                                                             ops.PROFILE_WINO2D_GEMM) for p in lst) / n
+            tf = fl / (ms * 1e-3) / 1e12
+            return {'bound': 'mfma', 'kernel': 'everything G launches (%s), one stream, upstream outputs detached: contraction kernels, '
+                                               'BatchNorm / activation passes, Winograd transforms, depth rasteriser, loss sweep'
+                                               % ('forward + G loss terms + backward' if train else 'eval forward'),
+                    'achieved': tf, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': tf / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
+                    'span_ms': ms, 'executed_mfma_tflop': fl / 1e12, 'mfma_kernel_ms': mfma_ms,
+                    'mfma_kernels_alone': {'achieved': fl / (mfma_ms * 1e-3) / 1e12 if mfma_ms > 0 else 0.0,
+                                           'frac': fl / (mfma_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS if mfma_ms > 0 else 0.0},
+                    'non_mfma_ms': ms - mfma_ms, 'batch': int(inp[0].shape[0])}
+        finally:
+            ops.PROFILE_THIN = None
+            ops.PROFILE = ops.PROFILE_WGRAD = ops.PROFILE_WINO = ops.PROFILE_WINO_WGRAD = None
+            ops.PROFILE_WINO2D = ops.PROFILE_WINO2D_GEMM = None
+            bb.SIDE_STREAM, ops.WGRAD_SIDE = keep
+
     out = None
     fwd = None
     if a.mode == 'fwd' or not a.no_forward_section:
@@ -549,6 +629,7 @@ def main():
         fwd.update(rooflines(prof, a.steps, 'fwd'))
         fwd['mfma_step_utilisation'] = mfma_step_utilisation(prof, a.steps, fwd['ms_per_step'])
         attach_serialized(fwd, fstep, 'fwd')
+        fwd['roofline_resnet_branch'] = resnet_branch(fsets[0][0], None, False)
         del fsets
     if a.mode == 'train':
         Bt = a.batch or 8
@@ -595,6 +676,8 @@ def main():
                 out['replicas_identical'] = bool(torch.equal(hi, lo))
                 out['compute_streams'] = 1 + len(ops.side_streams())
         attach_serialized(out, tstep, 'train')
+        if rank == 0:
+            out['roofline_resnet_branch'] = resnet_branch(tsets[0][0], tsets[0][1], True)
     elif rank == 0:
         out = {'metric': fwd['metric'], 'value': fwd['value'], 'unit': 'frame-pairs/s', 'n_gpus': world,
                'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': fwd['ms_per_step'], 'higher_is_better': True,

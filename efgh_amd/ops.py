@@ -464,7 +464,7 @@ def gather_gemm(A, lda, C, T, Wp, N, M, out, ldo, mode=0, geom=None, table=None,
         d.batch_stride_table = batch[4] if len(batch) > 4 else 0
     d.table_alias_mask = 1 if (alias_mask and mode == 2) else 0
     thin = stats is None and M_dev is None and thin_eligible(mode, C, N, T)
-    wino = False
+    wino = sc = False
     if thin:
         if TRACE_THIN is not None:
             TRACE_THIN.append(int(_L().efgh_thin_supported(ctypes.byref(d))))      # (tests: which form serves the launch)
@@ -474,6 +474,7 @@ def gather_gemm(A, lda, C, T, Wp, N, M, out, ldo, mode=0, geom=None, table=None,
         thin = True             # (for the profile lists: an HBM-bound launch, not part of the MFMA GEMM family)
         _C.check(_L().efgh_c4_conv3x3(ctypes.byref(d), _st()))
     elif M_dev is None and batch is None and sc_eligible(mode, C, N, geom) and _sc_aligned(d, lda, ldo, residual, ldr, stats):
+        sc = True
         _C.check(_L().efgh_sc_conv3x3(ctypes.byref(d), _st()))
     elif M_dev is None and batch is None and wino2d_eligible(mode, C, N, geom):
         wino = '2d'
@@ -496,8 +497,8 @@ def gather_gemm(A, lda, C, T, Wp, N, M, out, ldo, mode=0, geom=None, table=None,
         _C.check(_L().efgh_gather_gemm(ctypes.byref(d), _st()))
     if PROFILE is not None and (thin or (not wino and batch is None and hbm_bound(M, N, T, C))):
         e1.record()
-        if PROFILE_THIN is not None:
-            PROFILE_THIN.append((e0, e1, conv_bytes(M, N, T, C), (mode, M, N, T, C)))
+        if PROFILE_THIN is not None:       # (last field: served by a dedicated HBM-bound kernel - thin / 4-channel / small-channel - not the generic tile)
+            PROFILE_THIN.append((e0, e1, conv_bytes(M, N, T, C), (mode, M, N, T, C), bool(thin or sc)))
     elif PROFILE is not None:
         e1.record()
         rec = (e0, e1, float(flops) if flops is not None else 2.0 * M * N * T * C, (mode, M, N, T, C))
@@ -986,7 +987,7 @@ def gather_wgrad(A, lda, C, T, N, M, G, ldg, dWp, mode=0, geom=None, table=None)
     # training step are bit-reproducible run to run by default, and EFGH_DETERMINISTIC has nothing left to switch)
     nq = N // 4
     thin = thin_eligible(mode, C, N, T) and (N == 4 or (T in (1, 2, 4, 9) and nq & (nq - 1) == 0))
-    wino = False
+    wino = sc = False
     if (C == 4 and N == 4 and T == 9 and mode == 1 and lda % 4 == 0 and ldg % 4 == 0 and dWp.data_ptr() % 16 == 0
             and _L().efgh_c4n4_supported(ctypes.byref(d))):
         # the 1- / 2-channel 3x3 convolutions behind G's transposed heads: column-walking stencil, per-workgroup partial planes folded
@@ -1009,6 +1010,7 @@ def gather_wgrad(A, lda, C, T, N, M, G, ldg, dWp, mode=0, geom=None, table=None)
         _C.check(_L().efgh_c4_wgrad(ctypes.byref(d), ptr(G), c_int64(ldg), ptr(dWp),
                                     ptr(_scratch(_L().efgh_c4_wgrad_workspace(ctypes.byref(d)), dWp.device)), _st()))
     elif sc_eligible(mode, C, N, geom, wgrad=True) and lda % 4 == 0 and ldg % 4 == 0 and d.A % 16 == 0 and G.data_ptr() % 16 == 0:
+        sc = True
         _C.check(_L().efgh_sc_wgrad(ctypes.byref(d), ptr(G), c_int64(ldg), ptr(dWp),
                                     ptr(_scratch(_L().efgh_sc_wgrad_workspace(ctypes.byref(d)), dWp.device)), _st()))
     elif USE_WINO_WGRAD and wino2d_eligible(mode, C, N, geom, wgrad=True):
@@ -1055,7 +1057,7 @@ def gather_wgrad(A, lda, C, T, N, M, G, ldg, dWp, mode=0, geom=None, table=None)
     if PROFILE_WGRAD is not None and (thin or (not wino and hbm_bound(M, N, T, C))):
         e1.record()
         if PROFILE_THIN is not None:
-            PROFILE_THIN.append((e0, e1, conv_bytes(M, N, T, C), (mode, M, N, T, C)))
+            PROFILE_THIN.append((e0, e1, conv_bytes(M, N, T, C), (mode, M, N, T, C), bool(thin or sc)))
     elif PROFILE_WGRAD is not None:
         e1.record()
         rec = (e0, e1, 2.0 * M * N * T * C, (mode, M, N, T, C))

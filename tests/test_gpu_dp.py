@@ -167,7 +167,8 @@ def test_two_ranks_equal_dataparallel_on_the_real_net(capsys):
     for k in ref:
         assert abs(t[k] - ref[k]) <= 2e-5 * abs(ref[k]) + 1e-7, (k, t[k], ref[k])
     g = res['grad_rel_True']
-    assert g['E'] < 1e-3 and g['H'] < 1e-3 and g['F'] < 5e-2 and g['G'] < 5e-2, g
+    assert all(v < 1e-5 for v in g.values()), g          # measured 2.7e-8 on every sub-network (round 5)
+    assert res['grad_rel_False']['G'] > 10 * g['G']        # (the weighting is what closes G's gap: 6.7e-3 without it)
     # the unweighted form is what rounds 1-4 did: the same except for g_depth
     u = res['terms_False']
     for k in ref:

@@ -10,17 +10,21 @@ The `bcl` family (every kernel of lattice.hip and bcl.hip) is reported per STEP,
 import collections, csv, glob, json, sys
 
 FAMILIES = {
-    'gemm': ['k_gather_gemm<1,', 'k_gather_gemm<2,', 'k_gather_gemm<3,', 'k_gather_gemm<0, 256', 'k_gather_gemm<0, 128, 64'],
+    'gemm': ['k_gather_gemm<', 'k_gather_gemm_dma<'],
     'wino': ['k_wino43<'],
-    'wgrad': ['k_gather_wgrad<1,', 'k_gather_wgrad<2,', 'k_gather_wgrad<0, 64'],
-    'wino_wgrad': ['k_wino_wgrad(', 'k_wino_wgrad_rows('],
-    'wino2d_gemm': ['k_gather_gemm<0, 128, 128', 'k_gather_wgrad<0, 128'],
+    'wgrad': ['k_gather_wgrad<'],
+    'wino_wgrad': ['k_wino_wgrad_rows('],
+    'wino2d_gemm': ['k_plane_gemm<', 'k_plane_wgrad<'],
     'wino2d_transforms': ['k_w2_input', 'k_w2_output', 'k_w2_dy'],
+    # the dedicated HBM-bound contraction kernels (thin.hip, c4conv.hip, smallc.hip): reported per STEP, like `bcl`; bench.py sets
+    # it against the algorithmic bytes of the launches these kernels served (roofline_hbm_convs.dedicated)
+    'hbm_convs': ['k_thin_', 'k_c4_conv<', 'k_c4_wgrad<', 'k_sc_conv<', 'k_sc_wgrad<', 'k_c4n4_', 'k_n4_conv3x3_c64'],
     'bcl': ['k_lat_keys', 'k_lat_minmax', 'k_lat_scatter', 'k_lat_bucket', 'k_lat_rank', 'k_lat_number', 'k_lat_nbr', 'k_blur_dgrad_alias',
             'k_level_init', 'k_point_keys', 'k_minmax_finalize', 'k_insert', 'k_seg_count', 'k_seg_scan', 'k_seg_assign', 'k_place',
             'k_sortmin', 'k_flag_count', 'k_scan_sums', 'k_assign', 'k_offsets', 'k_neighbors', 'k_splat_gather', 'k_splat_bwd',
-            'k_table_gather_t', 'k_table_alias_add'],
+            'k_table_gather_t', 'k_table_alias_add', 'k_lat_small'],
 }
+PER_STEP = ('bcl', 'hbm_convs')
 
 
 BENCH_JSON = sys.argv[5] if len(sys.argv) > 5 and sys.argv[5].endswith('.json') else None
@@ -52,12 +56,13 @@ out = {'workload': sys.argv[4], 'steps_in_trace': steps,
                'FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B)', 'per_launch': {}}
 for fam in FAMILIES:
     if nf[fam]:
-        div = steps if fam == 'bcl' else nf[fam]
-        divw = steps if fam == 'bcl' else max(1, nw[fam])
+        div = steps if fam in PER_STEP else nf[fam]
+        divw = steps if fam in PER_STEP else max(1, nw[fam])
         fb, wb = fetch[fam] / div, write[fam] / divw
         out['per_launch'][fam] = {'fetch_bytes_reported': fb, 'fetch_bytes_corrected_x2': 2 * fb, 'write_bytes': wb,
                                   'launches': nf[fam], 'traffic_bytes': 2 * fb + wb,
-                                  'unit': 'bytes per step (all launches of the family)' if fam == 'bcl' else 'bytes per launch'}
+                                  'launches_per_step': nf[fam] / steps,
+                                  'unit': 'bytes per step (all launches of the family)' if fam in PER_STEP else 'bytes per launch'}
 if BENCH_JSON:
     def census(doc):
         c = {}
