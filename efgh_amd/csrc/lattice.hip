@@ -1368,6 +1368,325 @@ k_lat_nbr(LatPart P, LatGeom G, const int *__restrict__ mm, int *__restrict__ in
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The TAIL of the pyramid as ONE launch (round 5).  The lattices of different samples never interact - own key extrema, own
+// keys, own first-seen numbering - so once a sample's level fits one workgroup's LDS (<= 8 192 points: levels 3 and 4 of the
+// bench scene, every level of a small cloud) the whole level is built by ONE workgroup with __syncthreads() only: keys +
+// extrema, an open-addressing table int64 key -> (first-seen position, count) in LDS, first-seen numbering as a prefix
+// popcount over one bit per flat position, vertex records, lattice_offset, the ascending entry lists and the 15 neighbour probes
+// against the same LDS table.  The level's vertices ARE the sample's points of the next level, so the workgroup walks down the
+// remaining levels itself.  The only thing that crosses samples is the sample-major vertex base (an exclusive prefix of B
+// counts): the B co-resident workgroups meet once per level on a ticket in the level's zeroed info block (B <= 64, one
+// workgroup per CU: co-residency is guaranteed on 256 CUs whatever else runs).  Replaces 7 launches per level, each at its
+// 5-12 us floor (profiles/r04_bcl_timeline.txt): 21 launches -> 1 for levels 2-4 worth of floors.
+// Anything it cannot hold (a sample with more points, more vertices than 0.9 S slots, a list longer than TAIL_MAX_LIST) sets bit 2
+// of the level's ERR word: efgh_amd/lattice.py then rebuilds the pyramid with the per-level kernels.
+constexpr int TAIL_THREADS = 1024;
+constexpr int TAIL_NMAX = 8192;           // points of one sample and level (32 768 flat positions = 1 024 bitmap words)
+constexpr int TAIL_MAX_LIST = 2048;       // entries of one vertex (the rank sort below is quadratic in it)
+constexpr int TAIL_MAX_LEVELS = 5;
+
+struct TailLevel {
+    float scale32, div32; int h_cap, alias_cap;
+    float4 *bary, *emg; int4 *off; int *list; int2 *vseg; int *nbr; float *pts_next; int *vsid; int *info; int2 *alist;
+};
+struct TailArgs {
+    TailLevel lv[TAIL_MAX_LEVELS];
+    int nlevels, nsamples, S, pps;        // pps: points per sample when the first tail level is level 0 (info_prev == NULL)
+    const float *pts; int64_t cstride; const int *info_prev; int prev_h_cap; float std32;
+};
+
+// exclusive prefix of one value per thread over the workgroup (1 024 threads); every thread gets the total
+__device__ __forceinline__ int tail_scan(int v, int *wsum, int &total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+    __syncthreads();                       // (wsum may still be read from a previous call)
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < TAIL_THREADS / 64; ++w) { const int x = wsum[w]; tot += x; if (w < wave) base += x; }
+    total = tot;
+    return base + inc - v;
+}
+
+__device__ __forceinline__ int tail_probe(const unsigned long long *tkey, int S, long long ki) {
+    int s = (int)(mix64((uint64_t)ki) >> 20) & (S - 1);
+    for (int probe = 0; probe < S; ++probe) {
+        const unsigned long long cur = tkey[s];
+        if (cur == (unsigned long long)ki) return s;
+        if (cur == EMPTY) return -1;
+        s = (s + 1) & (S - 1);
+    }
+    return -1;
+}
+
+__global__ void __launch_bounds__(TAIL_THREADS, 1) k_lat_tail(const TailArgs A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char tail_smem[];
+    const int S = A.S, tid = threadIdx.x, lane = tid & 63, b = blockIdx.x, B = A.nsamples;
+    unsigned long long *tkey = reinterpret_cast<unsigned long long *>(tail_smem);      // [S] key integer of the slot
+    int *tmin = reinterpret_cast<int *>(tkey + S);       // [S] smallest local flat position of the key (its first-seen entry)
+    int *tcnt = tmin + S;                                // [S] entries of the key; later the placement cursor
+    int *tnum = tcnt + S;                                // [S] local vertex number of the slot
+    int *vfirst = tnum + S;                              // [S] by local vertex number: first-seen local flat position
+    int *vcnt = vfirst + S;                              // [S] by local vertex number: entries
+    int *vstart = vcnt + S;                              // [S + 1] by local vertex number: list start (exclusive scan); first the word prefix
+    unsigned *bits = reinterpret_cast<unsigned *>(vstart + S + 4);      // [1024] one bit per local flat position: first-seen entries
+    int *mm = reinterpret_cast<int *>(bits + 1024);      // [8] key extrema of the sample
+    int *wsum = mm + 8;                                  // [16]
+    int *misc = wsum + 16;                               // [0] overflow, [1] base, [2] total, [3] longest list
+
+    const float *pts = A.pts;
+    int64_t cs = A.cstride;
+    int p0, n;
+    if (A.info_prev) {
+        const int hp = min(A.info_prev[EFGH_LATTICE_INFO_H], A.prev_h_cap);
+        p0 = A.info_prev[EFGH_LATTICE_INFO_SEG + b];
+        const int e = b + 1 < B ? A.info_prev[EFGH_LATTICE_INFO_SEG + b + 1] : hp;
+        n = e - p0;
+        if ((A.info_prev[EFGH_LATTICE_INFO_ERR] & 5) || n < 0) n = 0;       // (the level above is garbage: flagged there)
+    } else { p0 = b * A.pps; n = A.pps; }
+
+    for (int l = 0; l < A.nlevels; ++l) {
+        const TailLevel &L = A.lv[l];
+        const bool fit_in = n <= TAIL_NMAX;
+        const int nn = fit_in ? n : 0;                   // points this workgroup really processes
+        // ---- 0: clear
+        for (int i = tid; i < S; i += TAIL_THREADS) { tkey[i] = EMPTY; tmin[i] = INT32_MAX; tcnt[i] = 0; }
+        bits[tid] = 0u;
+        if (tid < 8) mm[tid] = tid < 4 ? INT32_MAX : INT32_MIN;
+        if (tid < 4) misc[tid] = 0;
+        __syncthreads();
+        if (!fit_in && tid == 0) misc[0] = 1;
+        // ---- 1: barycentric weights, el_minus_gr, key extrema
+        {
+            int kmin[4] = {INT32_MAX, INT32_MAX, INT32_MAX, INT32_MAX}, kmax[4] = {INT32_MIN, INT32_MIN, INT32_MIN, INT32_MIN};
+            for (int i = tid; i < nn; i += TAIL_THREADS) {
+                const int p = p0 + i;
+                PointKeys pk;
+                point_keys(pts[p], pts[cs + p], pts[2 * cs + p], L.scale32, A.std32, pk);
+                L.bary[p] = make_float4(pk.bary[0], pk.bary[1], pk.bary[2], pk.bary[3]);
+                L.emg[p] = make_float4(pk.emg[0], pk.emg[1], pk.emg[2], pk.emg[3]);
+#pragma unroll
+                for (int rem = 0; rem < 4; ++rem) {
+                    int k[4];
+                    entry_key(pk, rem, k);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) { kmin[c] = min(kmin[c], k[c]); kmax[c] = max(kmax[c], k[c]); }
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) { kmin[c] = min(kmin[c], __shfl_xor(kmin[c], o)); kmax[c] = max(kmax[c], __shfl_xor(kmax[c], o)); }
+            }
+            if (lane == 0 && nn > 0) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { atomicMin(&mm[c], kmin[c]); atomicMax(&mm[4 + c], kmax[c]); }
+            }
+        }
+        __syncthreads();
+        // ---- 2: insert (key integer -> slot; smallest flat position and count per slot)
+        for (int i = tid; i < nn; i += TAIL_THREADS) {
+            const int p = p0 + i;
+            PointKeys pk;
+            point_keys(pts[p], pts[cs + p], pts[2 * cs + p], L.scale32, A.std32, pk);
+#pragma unroll
+            for (int rem = 0; rem < 4; ++rem) {
+                int k[4];
+                entry_key(pk, rem, k);
+                const unsigned long long ki = (unsigned long long)key2int(k, mm);
+                int s = (int)(mix64(ki) >> 20) & (S - 1), probe = 0;
+                for (; probe < S; ++probe) {
+                    unsigned long long cur = tkey[s];
+                    if (cur == EMPTY) cur = atomicCAS(&tkey[s], EMPTY, ki);
+                    if (cur == EMPTY || cur == ki) break;
+                    s = (s + 1) & (S - 1);
+                }
+                if (probe >= S) { misc[0] = 1; continue; }
+                atomicMin(&tmin[s], 4 * i + rem);
+                atomicAdd(&tcnt[s], 1);
+            }
+        }
+        __syncthreads();
+        // ---- 3: first-seen numbering = number of first-seen bits in front of the vertex's own
+        for (int s = tid; s < S; s += TAIL_THREADS)
+            if (tkey[s] != EMPTY) { const int f = tmin[s]; atomicOr(&bits[f >> 5], 1u << (f & 31)); atomicMax(&misc[3], tcnt[s]); }
+        __syncthreads();
+        int Hb;
+        {
+            const int pre = tail_scan(__popc(bits[tid]), wsum, Hb);
+            vstart[tid] = pre;                           // (word prefix, S >= 1024)
+        }
+        __syncthreads();
+        if (tid == 0 && (Hb * 10 > S * 9 || misc[3] > TAIL_MAX_LIST)) misc[0] = 1;
+        for (int s = tid; s < S; s += TAIL_THREADS)
+            if (tkey[s] != EMPTY) {
+                const int f = tmin[s];
+                const int num = vstart[f >> 5] + __popc(bits[f >> 5] & ((1u << (f & 31)) - 1u));
+                tnum[s] = num; vfirst[num] = f; vcnt[num] = tcnt[s];
+            }
+        __syncthreads();
+        const bool over = misc[0] != 0;
+        if (over) Hb = 0;
+        // ---- 4: the sample-major vertex base: the B workgroups of the launch meet on the level's ticket
+        if (tid == 0) {
+            int *slot = L.info + EFGH_LATTICE_INFO_SEG + B + 1;
+            __hip_atomic_store(&slot[b], Hb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __threadfence();
+            __hip_atomic_fetch_add(&L.info[EFGH_LATTICE_INFO_SEG + B], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            while (__hip_atomic_load(&L.info[EFGH_LATTICE_INFO_SEG + B], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < B) __builtin_amdgcn_s_sleep(2);
+            __threadfence();
+            int base = 0, tot = 0;
+            for (int q = 0; q < B; ++q) {
+                const int h = __hip_atomic_load(&slot[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (q < b) base += h;
+                tot += h;
+            }
+            misc[1] = base; misc[2] = tot;
+            L.info[EFGH_LATTICE_INFO_SEG + b] = base;
+            if (over) atomicOr(&L.info[EFGH_LATTICE_INFO_ERR], 4);
+            if (b == 0) {
+                L.info[EFGH_LATTICE_INFO_H] = tot;
+                if (tot > L.h_cap) atomicOr(&L.info[EFGH_LATTICE_INFO_ERR], 1);
+            }
+        }
+        __syncthreads();
+        const int base = misc[1], Htot = misc[2];
+        const bool ok = !over && Htot <= L.h_cap;        // (else nothing vertex-indexed is written; the level is flagged)
+        // ---- 5: list starts (exclusive scan of the counts in vertex order), vertex records
+        {
+            constexpr int IT = 4;                        // S <= 4096: four consecutive vertices per thread
+            int c[IT], sum = 0;
+#pragma unroll
+            for (int q = 0; q < IT; ++q) { const int v = tid * IT + q; c[q] = (v < Hb && v < S) ? vcnt[v] : 0; sum += c[q]; }
+            int tot;
+            int pre = tail_scan(sum, wsum, tot);
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < IT; ++q) { const int v = tid * IT + q; if (v <= Hb && v < S + 1) vstart[v] = pre; pre += c[q]; }
+        }
+        __syncthreads();
+        if (ok) {
+            for (int v = tid; v < Hb; v += TAIL_THREADS) {
+                const int f = vfirst[v], p = p0 + (f >> 2), rem = f & 3;
+                PointKeys pk;
+                point_keys(pts[p], pts[cs + p], pts[2 * cs + p], L.scale32, A.std32, pk);
+                int k[4];
+                entry_key(pk, rem, k);
+                const int h = base + v;
+                L.vseg[h] = make_int2(4 * p0 + vstart[v], vcnt[v]);
+                L.vsid[h] = b;
+                const float kf[4] = {__fdiv_rn((float)k[0], L.div32), __fdiv_rn((float)k[1], L.div32),
+                                     __fdiv_rn((float)k[2], L.div32), __fdiv_rn((float)k[3], L.div32)};
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    float acc = __fmul_rn(elev(0, q), kf[0]);
+                    acc = __fmaf_rn(elev(1, q), kf[1], acc);
+                    acc = __fmaf_rn(elev(2, q), kf[2], acc);
+                    acc = __fmaf_rn(elev(3, q), kf[3], acc);
+                    L.pts_next[(int64_t)q * L.h_cap + h] = acc;
+                }
+            }
+        }
+        // ---- 6: lattice_offset per point; every entry into its vertex's list (arrival order), then a rank sort per entry
+        for (int s = tid; s < S; s += TAIL_THREADS) tcnt[s] = 0;          // (placement cursors)
+        __syncthreads();
+        int ef[TAIL_NMAX / TAIL_THREADS][4], ev[TAIL_NMAX / TAIL_THREADS][4];
+#pragma unroll
+        for (int it = 0; it < TAIL_NMAX / TAIL_THREADS; ++it) {
+            const int i = it * TAIL_THREADS + tid;
+#pragma unroll
+            for (int rem = 0; rem < 4; ++rem) { ef[it][rem] = -1; ev[it][rem] = 0; }
+            if (i < nn && ok) {
+                const int p = p0 + i;
+                PointKeys pk;
+                point_keys(pts[p], pts[cs + p], pts[2 * cs + p], L.scale32, A.std32, pk);
+                int o[4];
+#pragma unroll
+                for (int rem = 0; rem < 4; ++rem) {
+                    int k[4];
+                    entry_key(pk, rem, k);
+                    const int s = tail_probe(tkey, S, key2int(k, mm));
+                    const int v = s >= 0 ? tnum[s] : 0;
+                    o[rem] = base + v;
+                    if (s >= 0) {
+                        const int pos = vstart[v] + atomicAdd(&tcnt[s], 1);
+                        L.list[4 * p0 + pos] = 4 * p + rem;
+                        ef[it][rem] = 4 * p + rem; ev[it][rem] = v;
+                    }
+                }
+                if (L.off) L.off[p] = make_int4(o[0], o[1], o[2], o[3]);
+            }
+        }
+        __threadfence();
+        __syncthreads();
+        __threadfence();
+#pragma unroll
+        for (int it = 0; it < TAIL_NMAX / TAIL_THREADS; ++it)
+#pragma unroll
+            for (int rem = 0; rem < 4; ++rem) {
+                const int f = ef[it][rem];
+                if (f < 0) continue;
+                const int v = ev[it][rem], j0 = 4 * p0 + vstart[v], j1 = 4 * p0 + vstart[v + 1];
+                int r = 0;
+                for (int j = j0; j < j1; ++j) r += L.list[j] < f ? 1 : 0;
+                ev[it][rem] = j0 + r;                    // (its sorted place)
+            }
+        __syncthreads();                                 // every entry has been read
+#pragma unroll
+        for (int it = 0; it < TAIL_NMAX / TAIL_THREADS; ++it)
+#pragma unroll
+            for (int rem = 0; rem < 4; ++rem)
+                if (ef[it][rem] >= 0) L.list[ev[it][rem]] = ef[it][rem];
+        // ---- 7: the 15 blur neighbours per vertex (16 lanes per vertex; key2int without a range check, aliased hits recorded)
+        if (ok) {
+            for (int g0 = 0; g0 < Hb * 16; g0 += TAIL_THREADS) {
+                const int g = g0 + tid, v = g >> 4, t = g & 15;
+                int k0[4] = {0, 0, 0, 0};
+                if (v < Hb && t == 0) {
+                    const int f = vfirst[v], p = p0 + (f >> 2);
+                    PointKeys pk;
+                    point_keys(pts[p], pts[cs + p], pts[2 * cs + p], L.scale32, A.std32, pk);
+                    entry_key(pk, f & 3, k0);
+                }
+                const int src = lane & 48;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) k0[c] = __shfl(k0[c], src);
+                int res = -1;
+                bool aliased = false;
+                if (v < Hb && t == 0) res = base + v;
+                if (v < Hb && t > 0 && t < 15) {
+                    const int k[4] = {k0[0] + c_nbr[t][0], k0[1] + c_nbr[t][1], k0[2] + c_nbr[t][2], k0[3] + c_nbr[t][3]};
+                    const int64_t ki = key2int(k, mm);
+                    if (ki >= 0) { const int s = tail_probe(tkey, S, ki); if (s >= 0) res = base + tnum[s]; }
+                    aliased = res >= 0 && (k[1] < mm[1] || k[1] > mm[5] || k[2] < mm[2] || k[2] > mm[6] || k[3] < mm[3] || k[3] > mm[7]);
+                }
+                const unsigned long long am = __ballot(aliased);
+                const int64_t gg = (int64_t)(base + v) * 16 + t;
+                if (v < Hb) L.nbr[gg] = t < 15 ? res : (int)((am >> (lane & 48)) & 0x7FFFu);
+                if (am) {
+                    int ab = 0;
+                    if (lane == 0) ab = atomicAdd(&L.info[EFGH_LATTICE_INFO_ALIAS], __popcll(am));
+                    ab = __shfl(ab, 0);
+                    if (aliased) {
+                        const int k_ = ab + __popcll(am & ((1ULL << lane) - 1ULL));
+                        if (k_ < L.alias_cap) L.alist[k_] = make_int2((int)gg, res);
+                        else atomicOr(&L.info[EFGH_LATTICE_INFO_ERR], 2);
+                    }
+                }
+            }
+        }
+        // ---- the level's vertices are this sample's points of the next level
+        __threadfence();
+        __syncthreads();
+        __threadfence();
+        pts = L.pts_next; cs = L.h_cap; p0 = base; n = ok ? Hb : 0;
+    }
+}
+
 int64_t align256(int64_t x) { return (x + 255) / 256 * 256; }
 
 struct WsLayout {
@@ -1676,6 +1995,41 @@ extern "C" int efgh_lattice_part_neighbors(const void *workspace, const float *p
     if (gv > 2048) gv = 2048;
     k_lat_nbr<<<gn + go + gv, TPB, 0, st>>>(P, G, (const int *)(ws + w.mm), info, h_cap, nbr, nsamples, (int2 *)alist, alias_cap, gn, go,
                                             n_dev, n_cap, (int4 *)off, (int2 *)vseg, pts_next, h_cap_build, vsid);
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}
+
+/* ---- the tail of the pyramid in one launch (k_lat_tail): see include/efgh_hip.h efgh_lattice_tail_build ---- */
+extern "C" int64_t efgh_lattice_tail_lds_bytes(int32_t slots) {
+    return (int64_t)slots * 8 + (int64_t)slots * 4 * 6 + 16 + 1024 * 4 + (8 + 16 + 4) * 4 + 64;
+}
+
+extern "C" int32_t efgh_lattice_tail_max_points(void) { return TAIL_NMAX; }
+
+extern "C" int efgh_lattice_tail_build(const efgh_lattice_tail_desc *d, void *stream_) {
+    hipStream_t st = (hipStream_t)stream_;
+    EFGH_CHECK_ARG(d && d->nlevels >= 1 && d->nlevels <= TAIL_MAX_LEVELS && d->nsamples >= 1 && d->nsamples <= 64 && d->pts);
+    EFGH_CHECK_ARG(d->slots >= 1024 && d->slots <= 4096 && (d->slots & (d->slots - 1)) == 0);
+    EFGH_CHECK_ARG(d->info_prev ? d->prev_h_cap > 0 : (d->pts_per_sample > 0 && d->pts_per_sample <= TAIL_NMAX));
+    TailArgs a;
+    memset(&a, 0, sizeof(a));
+    a.nlevels = d->nlevels; a.nsamples = d->nsamples; a.S = d->slots; a.pps = d->pts_per_sample;
+    a.pts = d->pts; a.cstride = d->pts_cstride; a.info_prev = d->info_prev; a.prev_h_cap = d->prev_h_cap; a.std32 = part_std32();
+    for (int l = 0; l < d->nlevels; ++l) {
+        const efgh_lattice_tail_level &s = d->levels[l];
+        EFGH_CHECK_ARG(s.bary && s.emg && s.list && s.vseg && s.nbr && s.pts_next && s.vsid && s.info && s.alist && s.h_cap > 0 && s.alias_cap > 0);
+        TailLevel &t = a.lv[l];
+        t.scale32 = s.scale32; t.div32 = s.div32; t.h_cap = s.h_cap; t.alias_cap = s.alias_cap;
+        t.bary = (float4 *)s.bary; t.emg = (float4 *)s.emg; t.off = (int4 *)s.off; t.list = s.list; t.vseg = (int2 *)s.vseg; t.nbr = s.nbr;
+        t.pts_next = s.pts_next; t.vsid = s.vsid; t.info = s.info; t.alist = (int2 *)s.alist;
+    }
+    const size_t lds = (size_t)efgh_lattice_tail_lds_bytes(d->slots);
+    static std::atomic<unsigned long long> raised{0};
+    if (!efgh_raise_lds_once(raised, (const void *)k_lat_tail, 160 * 1024)) {
+        efgh_set_error("%s:%d: cannot raise the dynamic LDS limit of k_lat_tail", __FILE__, __LINE__);
+        return EFGH_E_LAUNCH;
+    }
+    k_lat_tail<<<d->nsamples, TAIL_THREADS, lds, st>>>(a);
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
 }

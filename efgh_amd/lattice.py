@@ -12,6 +12,8 @@ import math
 
 import os
 
+import ctypes
+
 import numpy as np
 import torch
 
@@ -23,6 +25,9 @@ INFO_H, INFO_ERR, INFO_ALIAS, INFO_SEG = 0, 1, 2, 4          # include/efgh_hip.
 
 PROFILE = None          # bench.py: list of (start_event, end_event, algorithmic_bytes, 'lattice build') per pyramid
 _SIZES = {}             # (device, B, N, scales) -> vertex counts of the last build with that signature
+_PER_SAMPLE = {}        # the same key -> (largest per-sample point count, largest per-sample vertex count) per level of that build
+_NO_TAIL = {}           # the same key -> levels the one-launch tail build overflowed on: they keep the per-level kernels
+TAIL = True             # levels whose samples fit one workgroup's LDS are built by ONE launch (lattice.hip k_lat_tail)
 _BIG_LEVELS = {}        # the same key -> levels where a bucket of the partitioned build overflowed: built with the big-bucket kernel from then on
 _HASH_LEVELS = {}       # the same key -> levels where that overflowed as well: they take the hash build
 _CLEAN = {}             # the same key -> consecutive clean speculative builds since the last change of the escalation sets
@@ -102,9 +107,43 @@ def _plan(L, n_cap, h_est):
     return ('hash', max(4096, 1 << (2 * h_est - 1).bit_length()))
 
 
+class _TailLevel(ctypes.Structure):
+    """mirror of efgh_lattice_tail_level (include/efgh_hip.h)"""
+    _fields_ = [('scale32', ctypes.c_float), ('div32', ctypes.c_float), ('h_cap', ctypes.c_int32), ('alias_cap', ctypes.c_int32),
+                ('bary', ctypes.c_void_p), ('emg', ctypes.c_void_p), ('off', ctypes.c_void_p), ('list', ctypes.c_void_p),
+                ('vseg', ctypes.c_void_p), ('nbr', ctypes.c_void_p), ('pts_next', ctypes.c_void_p), ('vsid', ctypes.c_void_p),
+                ('info', ctypes.c_void_p), ('alist', ctypes.c_void_p)]
+
+
+class _TailDesc(ctypes.Structure):
+    """mirror of efgh_lattice_tail_desc"""
+    _fields_ = [('nlevels', ctypes.c_int32), ('nsamples', ctypes.c_int32), ('slots', ctypes.c_int32), ('pts_per_sample', ctypes.c_int32),
+                ('pts', ctypes.c_void_p), ('pts_cstride', ctypes.c_int64), ('info_prev', ctypes.c_void_p), ('prev_h_cap', ctypes.c_int32),
+                ('pad', ctypes.c_int32), ('levels', _TailLevel * 5)]
+
+
+def _tail_plan(L, key, B, N, nlev):
+    """(first tail level, table slots) or None: the levels [l0, nlev) of this signature whose largest sample had, in the previous
+    build, few enough points and vertices (with 25 % headroom) for one workgroup's LDS"""
+    ps = _PER_SAMPLE.get(key)
+    if not TAIL or ps is None or B > 64:
+        return None
+    nmax = L.efgh_lattice_tail_max_points()
+    bad = _NO_TAIL.get(key, set())
+    l0, slots = nlev, 1024
+    for l in range(nlev - 1, -1, -1):
+        mn, mh = ps[l]
+        need = _pow2ceil(max(1024, int(2.5 * (mh + mh // 4 + 64))))
+        if l in bad or mn + mn // 4 + 64 > nmax or need > 4096:
+            break
+        l0, slots = l, max(slots, need)
+    return (l0, slots) if l0 < nlev else None
+
+
 def _ctrl_bytes(L, n_cap, B, mode):
-    """bytes of the zero-initialised control block of a level: info, and for the partitioned build its `zeroed` area"""
-    info_b = (4 * (INFO_SEG + B) + 255) // 256 * 256
+    """bytes of the zero-initialised control block of a level: info (+ the tail build's ticket and per-sample counts behind the
+    sample bases), and for the partitioned build its `zeroed` area"""
+    info_b = (4 * (INFO_SEG + 2 * B + 2) + 255) // 256 * 256
     return info_b, (L.efgh_lattice_part_zeroed_bytes(_C.c_int32(n_cap)) if mode[0] == 'part' else 0)
 
 
@@ -115,10 +154,13 @@ def _level_arrays(L, dev, n_cap, h_cap, B, mode=('hash', 0), ctrl=None, need_off
     lv._mode = mode
     lv.bary_pm = torch.empty((n_cap, 4), dtype=torch.float32, device=dev)
     lv.emg_pm = torch.empty((n_cap, 4), dtype=torch.float32, device=dev)
-    lv.off_pm = torch.empty((n_cap, 4), dtype=torch.int32, device=dev) if (need_off or mode[0] != 'part') else None
+    lv.off_pm = torch.empty((n_cap, 4), dtype=torch.int32, device=dev) if (need_off or mode[0] == 'hash') else None
     if mode[0] == 'part':       # every bucket owns a fixed window of the list array
         lv.list = torch.empty(L.efgh_lattice_part_list_len(n_cap, mode[1]), dtype=torch.int32, device=dev)
         ws_bytes = L.efgh_lattice_part_workspace_bytes(n_cap, h_cap, B, mode[1], mode[2])
+    elif mode[0] == 'tail':     # everything else lives in the workgroups' LDS
+        lv.list = torch.empty(4 * n_cap, dtype=torch.int32, device=dev)
+        ws_bytes = 0
     else:
         lv.list = torch.empty(4 * n_cap, dtype=torch.int32, device=dev)
         ws_bytes = L.efgh_lattice_workspace_bytes(n_cap, h_cap, B)
@@ -210,10 +252,15 @@ def build_pyramid_batched(pc, scales, need_off=True):
         # and the pyramid is enqueued once more; a vertex count beyond its capacity (bit 0) sends the batch to the
         # level-by-level path below
         caps, nc = [], n_cap
+        tail = _tail_plan(L, key, B, N, len(prev))
+        if tail is not None and any(l in forced or l in bigl for l in range(tail[0], len(prev))):
+            tail = None
         for l, hp in enumerate(prev):
             hc = min(4 * nc, hp + hp // 4 + 1024)
             md = _plan(L, nc, hc)
-            if l in forced and md[0] == 'part':
+            if tail is not None and l >= tail[0]:
+                md = ('tail', tail[1])
+            elif l in forced and md[0] == 'part':
                 md = ('hash', max(4096, 1 << (2 * hc - 1).bit_length()))
             elif l in bigl and md[0] == 'part':
                 md = md + (True,)
@@ -222,13 +269,37 @@ def build_pyramid_batched(pc, scales, need_off=True):
         sizes = [_ctrl_bytes(L, nc_, B, md) for nc_, _, md in caps]
         ctrl = torch.zeros(sum(a + b for a, b in sizes), dtype=torch.uint8, device=dev)
         coff = 0
+        tail_lvs = []
         for s, (n_cap, h_cap, mode), (ib, zb) in zip(scales, caps, sizes):
             lv = _level_arrays(L, dev, n_cap, h_cap, B, mode, ctrl[coff:coff + ib + zb], need_off)
             coff += ib + zb
+            if mode[0] == 'tail':
+                lv.nbr = torch.empty((h_cap, 16), dtype=torch.int32, device=dev)
+                tail_lvs.append((lv, s))
+                lvs.append(lv)
+                continue
             _launch_build(L, lv, pts, cstride, n_dev, sid, N, B, s, st)
             _launch_neighbors(L, lv, B, h_cap, st)
             lvs.append(lv)
             pts, cstride, n_dev, sid, n_cap = lv.pts_next_buf, h_cap, lv.info[INFO_H:], lv.vsid, h_cap
+        if tail_lvs:
+            # the remaining levels in ONE launch: one workgroup per sample walks down them in LDS
+            d = _TailDesc()
+            d.nlevels, d.nsamples, d.slots = len(tail_lvs), B, tail_lvs[0][0]._mode[1]
+            first = len(lvs) - len(tail_lvs)
+            d.pts, d.pts_cstride = pts.data_ptr(), cstride
+            if first == 0:
+                d.pts_per_sample, d.info_prev, d.prev_h_cap = N, 0, 0
+            else:
+                d.pts_per_sample, d.info_prev, d.prev_h_cap = 0, lvs[first - 1].info.data_ptr(), lvs[first - 1]._caps[1]
+            for i, (lv, s) in enumerate(tail_lvs):
+                t = d.levels[i]
+                t.scale32, t.div32 = float(np.float32(s)), float(np.float32(EXPECTED_STD * s))
+                t.h_cap, t.alias_cap = lv._caps[1], ALIAS_CAP
+                t.bary, t.emg, t.off = lv.bary_pm.data_ptr(), lv.emg_pm.data_ptr(), (0 if lv.off_pm is None else lv.off_pm.data_ptr())
+                t.list, t.vseg, t.nbr = lv.list.data_ptr(), lv.vseg.data_ptr(), lv.nbr.data_ptr()
+                t.pts_next, t.vsid, t.info, t.alist = lv.pts_next_buf.data_ptr(), lv.vsid.data_ptr(), lv.info.data_ptr(), lv.alist.data_ptr()
+            _C.check(L.efgh_lattice_tail_build(ctypes.byref(d), st))
         if PROFILE is not None:
             e1.record()              # (before the read-back: the events bracket the launches only)
         host = torch.stack([lv.info for lv in lvs]).cpu().tolist()           # the one host sync of the pyramid
@@ -252,6 +323,16 @@ def build_pyramid_batched(pc, scales, need_off=True):
                     bigl.discard(l)
                     _log.info('lattice %s: level %d back to the regular partitioned build after %d clean builds', key, l, ESCALATION_DECAY)
             break
+        tail_over = [l for l, (h, lv) in enumerate(zip(host, lvs)) if h[INFO_ERR] & 4 and lv._mode[0] == 'tail']
+        if tail_over and not any(h[INFO_ERR] & 4 and lv._mode[0] == 'part' for h, lv in zip(host, lvs)) \
+                and not any(h[INFO_ERR] & 1 for h, lv in zip(host, lvs) if lv._mode[0] != 'tail'):
+            # a sample did not fit a workgroup's LDS on that level (points, vertices, a very long list): the level keeps the
+            # per-level kernels for this signature from now on; the pyramid is enqueued once more
+            _NO_TAIL.setdefault(key, set()).add(tail_over[0])
+            STATS['reenqueued'] += 1
+            _log.warning('lattice %s: level %d does not fit the one-launch tail build; per-level kernels from now on, pyramid re-enqueued',
+                         key, tail_over[0])
+            continue
         over = [l for l, (h, lv) in enumerate(zip(host, lvs)) if h[INFO_ERR] & 4 and lv._mode[0] == 'part']
         if not over or any(h[INFO_ERR] & 1 for h in host):
             break
@@ -296,6 +377,8 @@ def build_pyramid_batched(pc, scales, need_off=True):
             out.append(lv)
             pts, cstride, sid, n, seg_in = lv.pts_next_buf, 4 * n, lv.vsid, H, lv.seg
     _SIZES[key] = [lv.H for lv in out]
+    _PER_SAMPLE[key] = [(max(b - a for a, b in zip(lv.seg_in[:-1], lv.seg_in[1:])), max(b - a for a, b in zip(lv.seg[:-1], lv.seg[1:])))
+                        for lv in out]
     if PROFILE is not None:
         if prev is None or out is not lvs:
             e1.record()

@@ -101,6 +101,33 @@ int efgh_lattice_level_neighbors(const void *workspace, int32_t n_cap, int32_t h
                                  int32_t *info, const int32_t *vsid, int32_t h_cap, int32_t *nbr, int32_t *alist,
                                  int32_t alias_cap, int64_t hash_slots, void *stream);
 
+/* The TAIL of a pyramid in ONE launch (round 5): from the first level whose samples have at most efgh_lattice_tail_max_points()
+ * points each, one workgroup per sample builds that level and every level below it entirely in LDS (the lattices of different
+ * samples never interact; the level's vertices are the sample's points of the next level) - keys, extrema, an open-addressing
+ * table of `slots` entries, first-seen numbering, vertex records, lattice_offset, ascending lists, the 15 neighbour probes -
+ * and the workgroups meet once per level on a ticket to exchange the sample-major vertex bases.  Same arrays and meaning as
+ * efgh_lattice_level_build / _neighbors per level, with the list of sample b's vertices inside [4 * first point of b, ...).
+ * Input of the first tail level: the level above (pts = its pts_next, pts_cstride = prev_h_cap = its h_cap, info_prev = its
+ * info: vertex count and per-sample bases), or - when the tail starts at level 0 - the cloud itself (info_prev NULL,
+ * pts_per_sample points per sample).  Every level's info block must be zeroed and have EFGH_LATTICE_INFO_SEG + 2 * nsamples + 1
+ * ints (the ticket and the per-sample counts live behind the bases).  A sample that does not fit (points, 0.9 * slots
+ * vertices, a list of more than 2 048 entries) sets bit 2 of that level's ERR word: rebuild with the per-level entry points.
+ * nsamples <= 64 (the workgroups of the launch wait for each other).                                                        */
+typedef struct efgh_lattice_tail_level {
+    float scale32, div32;              /* as efgh_lattice_level_build */
+    int32_t h_cap, alias_cap;
+    float *bary, *emg; int32_t *off;   /* off may be NULL (inference) */
+    int32_t *list, *vseg, *nbr; float *pts_next; int32_t *vsid, *info, *alist;
+} efgh_lattice_tail_level;
+typedef struct efgh_lattice_tail_desc {
+    int32_t nlevels, nsamples, slots, pts_per_sample;
+    const float *pts; int64_t pts_cstride; const int32_t *info_prev; int32_t prev_h_cap, pad;
+    efgh_lattice_tail_level levels[5];
+} efgh_lattice_tail_desc;
+int32_t efgh_lattice_tail_max_points(void);
+int64_t efgh_lattice_tail_lds_bytes(int32_t slots);
+int efgh_lattice_tail_build(const efgh_lattice_tail_desc *d, void *stream);
+
 /* The same level WITHOUT a global hash insert (round 3; the default of efgh_amd/lattice.py): every (point, corner) entry is
  * bucket-sorted inside its tile of points (bucket = top bits of a bijective mix of its key integer), one workgroup per bucket
  * gathers its runs and groups them in LDS, the first-seen numbering is a prefix count over one bit per entry, the neighbour

@@ -336,3 +336,69 @@ def test_escalations_expire_after_clean_builds(monkeypatch):
     # hash level 1 -> big after two clean builds, then the big levels go one by one
     assert seen[0][:2] == ([1], [0]) and seen[1][:2] == ([], [0, 1]) and seen[3][:2] == ([], [0]) and seen[5][:2] == ([], [])
     assert lattice.STATS['speculative'] - before['speculative'] == 7 and lattice.STATS['reenqueued'] == before['reenqueued']
+
+
+def _same_levels(a, b):
+    for l, (x, y) in enumerate(zip(a, b)):
+        assert x.H == y.H and x.seg == y.seg, l
+        for name in ('bary_pm', 'emg_pm', 'off_pm'):
+            assert torch.equal(getattr(x, name)[:x.n_in], getattr(y, name)[:y.n_in]), (l, name)
+        assert torch.equal(x.nbr[:x.H], y.nbr[:y.H]), l
+        assert torch.equal(x.pts_next, y.pts_next) and torch.equal(x.vsid[:x.H], y.vsid[:y.H]), l
+        # the lists: same vertices, same ascending entries (the windows they live in differ between the builds)
+        vx, vy = x.vseg[:x.H].cpu().numpy(), y.vseg[:y.H].cpu().numpy()
+        assert np.array_equal(vx[:, 1], vy[:, 1]), l
+        lx, ly = x.list.cpu().numpy(), y.list.cpu().numpy()
+        for h in list(range(0, x.H, max(1, x.H // 97))) + [x.H - 1]:
+            assert np.array_equal(lx[vx[h, 0]:vx[h, 0] + vx[h, 1]], ly[vy[h, 0]:vy[h, 0] + vy[h, 1]]), (l, h)
+        al = lambda v: sorted(map(tuple, v.alist[:v.n_alias].cpu().tolist()))
+        assert x.n_alias == y.n_alias and al(x) == al(y), l
+
+
+@pytest.mark.parametrize('B,N,seeds', [(3, 4096, (0, 7, 11)), (8, 2048, tuple(range(8))), (2, 20000, (3, 4)), (1, 131072, (0,))])
+def test_one_launch_tail_equals_the_per_level_kernels(B, N, seeds):
+    """levels whose samples fit one workgroup's LDS are built by ONE launch (k_lat_tail: one workgroup per sample walks down the
+    remaining levels, the workgroups exchange their vertex counts once per level) - against the per-level kernels array by array,
+    on clouds where the tail starts at level 0 (small N), at level 1-3 (the bench sizes), with several samples per batch"""
+    from efgh_amd import lattice
+    pcs = [syn.lidar_sweep(N, s) if s % 2 == 0 else (np.random.RandomState(s).randn(3, N) * np.array([[15.], [15.], [1.5]])).astype(np.float32)
+           for s in seeds]
+    pc = torch.from_numpy(np.stack(pcs)).cuda()
+    old = lattice.TAIL
+    try:
+        lattice.TAIL = False
+        lattice._SIZES.clear(); lattice._PER_SAMPLE.clear(); lattice._NO_TAIL.clear()
+        lattice.build_pyramid_batched(pc, SCALES)
+        ref = lattice.build_pyramid_batched(pc, SCALES)                 # speculative, per-level kernels
+        lattice.TAIL = True
+        before = dict(lattice.STATS)
+        got = lattice.build_pyramid_batched(pc, SCALES)                 # speculative, tail in one launch
+        assert lattice.STATS['speculative'] == before['speculative'] + 1 and lattice.STATS['reenqueued'] == before['reenqueued']
+        modes = [lv._mode[0] for lv in got]
+        assert modes[-1] == 'tail' and modes.count('tail') >= 2, modes
+        _same_levels(got, ref)
+    finally:
+        lattice.TAIL = old
+
+
+def test_tail_overflow_falls_back_to_the_per_level_kernels():
+    """a vertex with more entries than the tail kernel's rank sort takes (3 000 coincident points: one list of 3 000) flags the level;
+    the pyramid is re-enqueued with the per-level kernels for that level and the result is still the oracle's"""
+    from efgh_amd import lattice
+    from oracle import lattice as olat
+    rs = np.random.RandomState(5)
+    pc = (rs.randn(3, 6000) * np.array([[10.], [10.], [1.]])).astype(np.float32)
+    pc[:, 3000:] = pc[:, 2999:3000]
+    t = torch.from_numpy(pc[None]).cuda()
+    lattice._SIZES.clear(); lattice._PER_SAMPLE.clear(); lattice._NO_TAIL.clear()
+    lattice.build_pyramid_batched(t, SCALES)
+    before = dict(lattice.STATS)
+    lv = lattice.build_pyramid_batched(t, SCALES)
+    assert lattice.STATS['reenqueued'] > before['reenqueued']
+    assert any(lattice._NO_TAIL.values())
+    ref = olat.generate_data(pc)
+    for l, r in enumerate(ref):
+        d = lv[l].sample(0)
+        assert d.H == r['H'], l
+        assert np.array_equal(d.off.cpu().numpy().astype(np.int64), r['off']), l
+        assert np.array_equal(d.nbr.cpu().numpy()[:, :15].T.astype(np.int64), r['nbr']), l
