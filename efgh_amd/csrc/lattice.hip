@@ -1379,7 +1379,7 @@ k_lat_nbr(LatPart P, LatGeom G, const int *__restrict__ mm, int *__restrict__ in
 // counts): the B co-resident workgroups meet once per level on a ticket in the level's zeroed info block (B <= 64, one
 // workgroup per CU: co-residency is guaranteed on 256 CUs whatever else runs).  Replaces 7 launches per level, each at its
 // 5-12 us floor (profiles/r04_bcl_timeline.txt): 21 launches -> 1 for levels 2-4 worth of floors.
-// Anything it cannot hold (a sample with more points, more vertices than 0.9 S slots, a list longer than TAIL_MAX_LIST) sets bit 2
+// Anything it cannot hold (a sample with more points, more vertices than 0.8 S slots, a list longer than TAIL_MAX_LIST) sets bit 2
 // of the level's ERR word: efgh_amd/lattice.py then rebuilds the pyramid with the per-level kernels.
 constexpr int TAIL_THREADS = 1024;
 constexpr int TAIL_NMAX = 8192;           // points of one sample and level (32 768 flat positions = 1 024 bitmap words)
@@ -1432,11 +1432,12 @@ __global__ void __launch_bounds__(TAIL_THREADS, 1) k_lat_tail(const TailArgs A) 
     int *tnum = tcnt + S;                                // [S] local vertex number of the slot
     int *vfirst = tnum + S;                              // [S] by local vertex number: first-seen local flat position
     int *vcnt = vfirst + S;                              // [S] by local vertex number: entries
-    int *vstart = vcnt + S;                              // [S + 1] by local vertex number: list start (exclusive scan); first the word prefix
+    int *vstart = vcnt + S;                              // [S + 4] by local vertex number: list start (exclusive scan); first the word prefix
     unsigned *bits = reinterpret_cast<unsigned *>(vstart + S + 4);      // [1024] one bit per local flat position: first-seen entries
     int *mm = reinterpret_cast<int *>(bits + 1024);      // [8] key extrema of the sample
     int *wsum = mm + 8;                                  // [16]
     int *misc = wsum + 16;                               // [0] overflow, [1] base, [2] total, [3] longest list
+    unsigned short *stage = reinterpret_cast<unsigned short *>(misc + 4);      // [4 * TAIL_NMAX] the lists in arrival order (local flat positions)
 
     const float *pts = A.pts;
     int64_t cs = A.cstride;
@@ -1521,7 +1522,7 @@ __global__ void __launch_bounds__(TAIL_THREADS, 1) k_lat_tail(const TailArgs A) 
             vstart[tid] = pre;                           // (word prefix, S >= 1024)
         }
         __syncthreads();
-        if (tid == 0 && (Hb * 10 > S * 9 || misc[3] > TAIL_MAX_LIST)) misc[0] = 1;
+        if (tid == 0 && (Hb * 10 > S * 8 || misc[3] > TAIL_MAX_LIST)) misc[0] = 1;
         for (int s = tid; s < S; s += TAIL_THREADS)
             if (tkey[s] != EMPTY) {
                 const int f = tmin[s];
@@ -1614,33 +1615,26 @@ __global__ void __launch_bounds__(TAIL_THREADS, 1) k_lat_tail(const TailArgs A) 
                     o[rem] = base + v;
                     if (s >= 0) {
                         const int pos = vstart[v] + atomicAdd(&tcnt[s], 1);
-                        L.list[4 * p0 + pos] = 4 * p + rem;
-                        ef[it][rem] = 4 * p + rem; ev[it][rem] = v;
+                        stage[pos] = (unsigned short)(4 * i + rem);
+                        ef[it][rem] = 4 * i + rem; ev[it][rem] = v;
                     }
                 }
                 if (L.off) L.off[p] = make_int4(o[0], o[1], o[2], o[3]);
             }
         }
-        __threadfence();
         __syncthreads();
-        __threadfence();
+        // rank of every entry inside its vertex's list (lists are short: counting in LDS), then ONE store to its sorted place
 #pragma unroll
         for (int it = 0; it < TAIL_NMAX / TAIL_THREADS; ++it)
 #pragma unroll
             for (int rem = 0; rem < 4; ++rem) {
                 const int f = ef[it][rem];
                 if (f < 0) continue;
-                const int v = ev[it][rem], j0 = 4 * p0 + vstart[v], j1 = 4 * p0 + vstart[v + 1];
+                const int v = ev[it][rem], j0 = vstart[v], j1 = vstart[v + 1];
                 int r = 0;
-                for (int j = j0; j < j1; ++j) r += L.list[j] < f ? 1 : 0;
-                ev[it][rem] = j0 + r;                    // (its sorted place)
+                for (int j = j0; j < j1; ++j) r += (int)stage[j] < f ? 1 : 0;
+                L.list[4 * p0 + j0 + r] = 4 * p0 + f;
             }
-        __syncthreads();                                 // every entry has been read
-#pragma unroll
-        for (int it = 0; it < TAIL_NMAX / TAIL_THREADS; ++it)
-#pragma unroll
-            for (int rem = 0; rem < 4; ++rem)
-                if (ef[it][rem] >= 0) L.list[ev[it][rem]] = ef[it][rem];
         // ---- 7: the 15 blur neighbours per vertex (16 lanes per vertex; key2int without a range check, aliased hits recorded)
         if (ok) {
             for (int g0 = 0; g0 < Hb * 16; g0 += TAIL_THREADS) {
@@ -2001,7 +1995,7 @@ extern "C" int efgh_lattice_part_neighbors(const void *workspace, const float *p
 
 /* ---- the tail of the pyramid in one launch (k_lat_tail): see include/efgh_hip.h efgh_lattice_tail_build ---- */
 extern "C" int64_t efgh_lattice_tail_lds_bytes(int32_t slots) {
-    return (int64_t)slots * 8 + (int64_t)slots * 4 * 6 + 16 + 1024 * 4 + (8 + 16 + 4) * 4 + 64;
+    return (int64_t)slots * 8 + (int64_t)slots * 4 * 6 + 16 + 1024 * 4 + (8 + 16 + 4) * 4 + (int64_t)4 * TAIL_NMAX * 2 + 64;
 }
 
 extern "C" int32_t efgh_lattice_tail_max_points(void) { return TAIL_NMAX; }
@@ -2009,7 +2003,7 @@ extern "C" int32_t efgh_lattice_tail_max_points(void) { return TAIL_NMAX; }
 extern "C" int efgh_lattice_tail_build(const efgh_lattice_tail_desc *d, void *stream_) {
     hipStream_t st = (hipStream_t)stream_;
     EFGH_CHECK_ARG(d && d->nlevels >= 1 && d->nlevels <= TAIL_MAX_LEVELS && d->nsamples >= 1 && d->nsamples <= 64 && d->pts);
-    EFGH_CHECK_ARG(d->slots >= 1024 && d->slots <= 4096 && (d->slots & (d->slots - 1)) == 0);
+    EFGH_CHECK_ARG(d->slots >= 1024 && d->slots <= 2048 && (d->slots & (d->slots - 1)) == 0);
     EFGH_CHECK_ARG(d->info_prev ? d->prev_h_cap > 0 : (d->pts_per_sample > 0 && d->pts_per_sample <= TAIL_NMAX));
     TailArgs a;
     memset(&a, 0, sizeof(a));

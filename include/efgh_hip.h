@@ -110,8 +110,8 @@ int efgh_lattice_level_neighbors(const void *workspace, int32_t n_cap, int32_t h
  * Input of the first tail level: the level above (pts = its pts_next, pts_cstride = prev_h_cap = its h_cap, info_prev = its
  * info: vertex count and per-sample bases), or - when the tail starts at level 0 - the cloud itself (info_prev NULL,
  * pts_per_sample points per sample).  Every level's info block must be zeroed and have EFGH_LATTICE_INFO_SEG + 2 * nsamples + 1
- * ints (the ticket and the per-sample counts live behind the bases).  A sample that does not fit (points, 0.9 * slots
- * vertices, a list of more than 2 048 entries) sets bit 2 of that level's ERR word: rebuild with the per-level entry points.
+ * ints (the ticket and the per-sample counts live behind the bases).  A sample that does not fit (points, 0.8 * slots
+ * vertices with slots <= 2 048, a list of more than 2 048 entries) sets bit 2 of that level's ERR word: rebuild with the per-level entry points.
  * nsamples <= 64 (the workgroups of the launch wait for each other).                                                        */
 typedef struct efgh_lattice_tail_level {
     float scale32, div32;              /* as efgh_lattice_level_build */
