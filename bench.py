@@ -569,6 +569,7 @@ def main():
             ret['sensor2_T_sensor1'] = torch.bmm(ret['f_l'], ret['e_l'])
             del full
             crit = EFGHCriterion(args)
+            crit.dp_exact = False            # (rank 0 alone runs this span: no collective inside it)
 
             def once():
                 with torch.set_grad_enabled(train):

@@ -263,14 +263,13 @@ def wino_eligible(mode, C, N, geom, T=None):
 
 
 USE_WINO2D = True  # F(4x4,3x3) as transform / batched GEMM / transform (wino2d.hip)
-WINO2D_MIN_C = 256           # forward / data gradient
-WINO2D_MIN_C_WGRAD = 128 # weight gradient
-# forward / data gradient inside a training step (EFGHBackbone sets TLS.train_step): EFGH_WINO2D_MIN_C_TRAIN=128 moves the 128-channel
-# layers to the 2-D form there - their weight gradient is 2-D anyway and re-uses the forward's transformed input, and the extra
-# transform passes run underneath MFMA kernels of the other streams: -0.9 ms per step for +10 GB (the eval forward alone is 0.5 %
-# faster on the 1-D kernel).  Not the default: a sub-percent gain that re-rounds F's trunks, whose arg-max heads turn a 1e-6
-# difference of the logits into a different yaw bin on near-ties (tests/test_gpu_train.py::test_winograd_and_direct_kernels...)
-WINO2D_MIN_C_TRAIN = 256
+# channel threshold of the 2-D form.  Rounds 2-4: 256 (forward / data gradient), 128 only for the weight gradient - the 128-channel
+# layers were break-even on k_gather_gemm<0>'s planes.  Round 5: with the LDS-DMA staged planes (planes.hip, +8-16 %) the 128-channel
+# layers win too - training step 269.8 -> 263.9 ms (+10 GB of kept transformed inputs: 96 GB peak at batch 8), eval forward 41.0 ->
+# 39.7 ms per batch of 4 (gpurun_out/r5_ac_*, r5_ad_*; alternating runs on one box).  The full GPU suite is green at 128.
+WINO2D_MIN_C = 128           # forward / data gradient
+WINO2D_MIN_C_WGRAD = 128     # weight gradient
+WINO2D_MIN_C_TRAIN = 128     # forward / data gradient inside a training step (kept separate for A/B runs)
 
 
 def _pow2(v):
