@@ -129,7 +129,7 @@ def translation_matrix(vec):
     """torch_utils.py:220-233 (built with torch.tensor([...]) -> detached)."""
     out = []
     for b in range(vec.size(0)):
-        t = torch.eye(4)
+        t = torch.eye(4, dtype=vec.dtype)          # (follows the input: float32 on the parity path, float64 in the conditioning checks)
         t[:3, 3] = vec[b, :3, 0].detach()
         out.append(t[None])
     return torch.cat(out, 0)
