@@ -39,6 +39,7 @@ def parse():
     ap.add_argument('--no-forward-section', action='store_true')
     ap.add_argument('--small', action='store_true', help='debug: 128x256 / 2048 points')
     ap.add_argument('--no-config-r', action='store_true', help='skip the batch-1 reference-loop section (config_r)')
+    ap.add_argument('--no-branch-section', action='store_true', help='skip roofline_resnet_branch (profiler passes: its G-only spans would count as launches of the steps)')
     ap.add_argument('--rotate-inputs', type=int, default=4,
                     help='cycle this many resident batches of DIFFERENT synthetic frame-pairs through the steps (1 = the same batch '
                          'every step): every sweep has its own lattice sizes, so the speculative sizing of the pyramid (previous '
@@ -164,7 +165,7 @@ def mfma_step_utilisation(prof, steps, ms_per_step):
     counted at the products they execute, half / a quarter of the direct form) / wall time of a step / dense fp32 MFMA peak"""
     fl = 0.0
     for name, lst in prof.items():
-        if name in ('bcl', 'wino2d', 'hbm_convs') or not lst:   # 'wino2d' = whole layers in direct-form FLOP: its GEMM launches are 'wino2d_gemm'
+        if name in ('bcl', 'wino2d', 'hbm_convs', 'dedicated') or not lst:   # 'wino2d' = whole layers in direct-form FLOP: its GEMM launches are 'wino2d_gemm'
             continue
         f = sum(p[2] for p in lst)
         fl += f / 2 if name in ('wino', 'wino_wgrad') else f
@@ -209,7 +210,7 @@ def rooflines(prof, steps, workload='train'):
     w2 = prof.get('wino2d')
     hb = prof.get('hbm_convs')
     for name, lst in prof.items():
-        if name in ('bcl', 'wino2d', 'hbm_convs'):
+        if name in ('bcl', 'wino2d', 'hbm_convs', 'dedicated'):
             continue
         if lst:
             r = gemm_roofline(lst, steps, KERNELS[name])
@@ -272,7 +273,7 @@ def rooflines(prof, steps, workload='train'):
         ms = sum(p[0].elapsed_time(p[1]) for p in hb)
         by = sum(p[2] for p in hb)
         ach = by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        ded = [p for p in hb if len(p) > 4 and p[4]]
+        ded = prof.get('dedicated') or []
         ded_by, ded_ms = sum(p[2] for p in ded), sum(p[0].elapsed_time(p[1]) for p in ded)
         out['roofline_hbm_convs'] = {'bound': 'hbm', 'kernel': 'contractions with < %g FLOP per algorithmic byte (1x1 and 4-channel layers, narrow '
                                      'heads, the point branch\'s 32-channel layers; forward, data and weight gradients): thin / small-channel '
@@ -286,7 +287,7 @@ def rooflines(prof, steps, workload='train'):
         rh['dedicated'] = {'launches_per_step': len(ded) / max(1, steps), 'kernel_ms_per_step': ded_ms / max(1, steps),
                            'algorithmic_mb_per_step': ded_by / max(1, steps) / 1e6,
                            'achieved': ded_by / (ded_ms * 1e-3) / 1e9 if ded_ms > 0 else 0.0,
-                           'note': 'the launches served by thin.hip / c4conv.hip / smallc.hip kernels; `traffic` covers exactly these'}
+                           'note': 'EVERY launch served by a thin.hip / c4conv.hip / smallc.hip kernel (also the 16- / 32-channel 3x3 layers, which sit at the ridge and are listed under roofline_gemm); `traffic` covers exactly these kernels'}
         rh['traffic_unit'] = 'HBM-side bytes per STEP of the dedicated kernels (rocprofv3 PMC fold, profiles/' + TRAFFIC_FILE[workload] + ')'
         try:
             ent = json.loads(open(os.path.join(ROOT, 'profiles', TRAFFIC_FILE[workload])).read())['per_launch']['hbm_convs']
@@ -498,7 +499,7 @@ def main():
             fn()
         barrier()
         ops.PROFILE, ops.PROFILE_WGRAD, ops.PROFILE_WINO, ops.PROFILE_WINO_WGRAD, ops.PROFILE_BCL = [], [], [], [], []
-        ops.PROFILE_WINO2D, ops.PROFILE_WINO2D_GEMM, ops.PROFILE_THIN = [], [], []
+        ops.PROFILE_WINO2D, ops.PROFILE_WINO2D_GEMM, ops.PROFILE_THIN, ops.PROFILE_DED = [], [], [], []
         lattice.PROFILE = ops.PROFILE_BCL
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -507,8 +508,8 @@ def main():
         dt = max_over_ranks(time.perf_counter() - t0)
         prof = {'gemm': ops.PROFILE, 'wgrad': ops.PROFILE_WGRAD, 'wino': ops.PROFILE_WINO,
                 'wino_wgrad': ops.PROFILE_WINO_WGRAD, 'bcl': ops.PROFILE_BCL, 'wino2d': ops.PROFILE_WINO2D,
-                'wino2d_gemm': ops.PROFILE_WINO2D_GEMM, 'hbm_convs': ops.PROFILE_THIN}
-        ops.PROFILE_THIN = None
+                'wino2d_gemm': ops.PROFILE_WINO2D_GEMM, 'hbm_convs': ops.PROFILE_THIN, 'dedicated': ops.PROFILE_DED}
+        ops.PROFILE_THIN = ops.PROFILE_DED = None
         ops.PROFILE = ops.PROFILE_WGRAD = ops.PROFILE_WINO = ops.PROFILE_WINO_WGRAD = ops.PROFILE_BCL = lattice.PROFILE = None
         ops.PROFILE_WINO2D = ops.PROFILE_WINO2D_GEMM = None
         return dt, prof
@@ -630,7 +631,8 @@ def main():
         fwd.update(rooflines(prof, a.steps, 'fwd'))
         fwd['mfma_step_utilisation'] = mfma_step_utilisation(prof, a.steps, fwd['ms_per_step'])
         attach_serialized(fwd, fstep, 'fwd')
-        fwd['roofline_resnet_branch'] = resnet_branch(fsets[0][0], None, False)
+        if not a.no_branch_section:
+            fwd['roofline_resnet_branch'] = resnet_branch(fsets[0][0], None, False)
         del fsets
     if a.mode == 'train':
         Bt = a.batch or 8
@@ -677,7 +679,7 @@ def main():
                 out['replicas_identical'] = bool(torch.equal(hi, lo))
                 out['compute_streams'] = 1 + len(ops.side_streams())
         attach_serialized(out, tstep, 'train')
-        if rank == 0:
+        if rank == 0 and not a.no_branch_section:
             out['roofline_resnet_branch'] = resnet_branch(tsets[0][0], tsets[0][1], True)
     elif rank == 0:
         out = {'metric': fwd['metric'], 'value': fwd['value'], 'unit': 'frame-pairs/s', 'n_gpus': world,

@@ -395,6 +395,7 @@ def hbm_bound(M, N, T, C):
     return 2.0 * M * N * T * C / conv_bytes(M, N, T, C) < RIDGE_FLOP_PER_BYTE
 
 
+PROFILE_DED = None      # bench.py: every launch served by a dedicated small-channel kernel (thin.hip / c4conv.hip / smallc.hip), with its bytes
 TRACE_THIN = None       # tests set this to a list: efgh_thin_supported's answer per thin launch
 PROFILE_WINO = None     # launches served by the Winograd kernel (else they are listed in PROFILE)
 PROFILE = None          # bench.py sets this to a list: (start_event, end_event, algorithmic_flops) per launch
@@ -496,10 +497,14 @@ def gather_gemm(A, lda, C, T, Wp, N, M, out, ldo, mode=0, geom=None, table=None,
         _C.check(_L().efgh_gather_gemm(ctypes.byref(d), _st()))
     if PROFILE is not None and (thin or (not wino and batch is None and hbm_bound(M, N, T, C))):
         e1.record()
-        if PROFILE_THIN is not None:       # (last field: served by a dedicated HBM-bound kernel - thin / 4-channel / small-channel - not the generic tile)
-            PROFILE_THIN.append((e0, e1, conv_bytes(M, N, T, C), (mode, M, N, T, C), bool(thin or sc)))
+        if PROFILE_THIN is not None:
+            PROFILE_THIN.append((e0, e1, conv_bytes(M, N, T, C), (mode, M, N, T, C)))
+        if PROFILE_DED is not None and (thin or sc):      # every launch a dedicated kernel (thin / 4-channel / small-channel) served
+            PROFILE_DED.append((e0, e1, conv_bytes(M, N, T, C), (mode, M, N, T, C)))
     elif PROFILE is not None:
         e1.record()
+        if PROFILE_DED is not None and sc:
+            PROFILE_DED.append((e0, e1, conv_bytes(M, N, T, C), (mode, M, N, T, C)))
         rec = (e0, e1, float(flops) if flops is not None else 2.0 * M * N * T * C, (mode, M, N, T, C))
         if wino == '2d' and PROFILE_WINO2D is not None:
             PROFILE_WINO2D.append(rec)
@@ -1056,9 +1061,13 @@ def gather_wgrad(A, lda, C, T, N, M, G, ldg, dWp, mode=0, geom=None, table=None)
     if PROFILE_WGRAD is not None and (thin or (not wino and hbm_bound(M, N, T, C))):
         e1.record()
         if PROFILE_THIN is not None:
-            PROFILE_THIN.append((e0, e1, conv_bytes(M, N, T, C), (mode, M, N, T, C), bool(thin or sc)))
+            PROFILE_THIN.append((e0, e1, conv_bytes(M, N, T, C), (mode, M, N, T, C)))
+        if PROFILE_DED is not None and (thin or sc):
+            PROFILE_DED.append((e0, e1, conv_bytes(M, N, T, C), (mode, M, N, T, C)))
     elif PROFILE_WGRAD is not None:
         e1.record()
+        if PROFILE_DED is not None and sc:
+            PROFILE_DED.append((e0, e1, conv_bytes(M, N, T, C), (mode, M, N, T, C)))
         rec = (e0, e1, 2.0 * M * N * T * C, (mode, M, N, T, C))
         if wino == '2d' and PROFILE_WINO2D is not None:
             PROFILE_WINO2D.append(rec)
