@@ -535,11 +535,11 @@ def main():
         if dst is None:
             return
         mine = {v['kernel']: (k, v) for k, v in dst.items() if k.startswith('roofline') and isinstance(v, dict)}
-        keep = ('achieved', 'frac', 'avg_launch_ms', 'kernel_ms_per_step', 'algorithmic_tflops', 'parts')
+        keep = ('achieved', 'frac', 'avg_launch_ms', 'kernel_ms_per_step', 'algorithmic_tflops', 'parts', 'dedicated')
         for k, v in rooflines(prof2, nser, workload).items():
             if k.startswith('roofline') and isinstance(v, dict) and v.get('kernel') in mine:
                 key, cur = mine[v['kernel']]
-                conc = {f: cur[f] for f in keep if f in cur and f != 'parts'}
+                conc = {f: cur[f] for f in keep if f in cur and f not in ('parts', 'dedicated')}
                 conc['note'] = 'the same launches inside the timed region, sharing the GPU with the other streams'
                 for f in keep:
                     if f in v:
