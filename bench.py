@@ -597,11 +597,18 @@ def main():
             mfma_ms = sum(p[0].elapsed_time(p[1]) for lst in (ops.PROFILE, ops.PROFILE_WGRAD, ops.PROFILE_WINO, ops.PROFILE_WINO_WGRAD,
                                                              ops.PROFILE_WINO2D_GEMM) for p in lst) / n
             tf = fl / (ms * 1e-3) / 1e12
+            # the same span in DIRECT-form FLOP (what a kernel without Winograd would have to execute): the 2-D layers in full
+            alg = (sum(p[2] for p in ops.PROFILE) + sum(p[2] for p in ops.PROFILE_WGRAD) + sum(p[2] for p in ops.PROFILE_WINO)
+                   + sum(p[2] for p in ops.PROFILE_WINO_WGRAD) + sum(p[2] for p in ops.PROFILE_WINO2D)) / n
             return {'bound': 'mfma', 'kernel': 'everything G launches (%s), one stream, upstream outputs detached: contraction kernels, '
                                                'BatchNorm / activation passes, Winograd transforms, depth rasteriser, loss sweep'
                                                % ('forward + G loss terms + backward' if train else 'eval forward'),
                     'achieved': tf, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': tf / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
                     'span_ms': ms, 'executed_mfma_tflop': fl / 1e12, 'mfma_kernel_ms': mfma_ms,
+                    'algorithmic_tflops': alg / (ms * 1e-3) / 1e12,
+                    'note': 'frac counts the MFMA FLOP the kernels EXECUTE: moving a layer from the 1-D to the 2-D Winograd form halves '
+                            'them and lowers frac while the span gets shorter (round 5: the 128-channel layers); algorithmic_tflops is '
+                            'the direct-form rate of the same span',
                     'mfma_kernels_alone': {'achieved': fl / (mfma_ms * 1e-3) / 1e12 if mfma_ms > 0 else 0.0,
                                            'frac': fl / (mfma_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS if mfma_ms > 0 else 0.0},
                     'non_mfma_ms': ms - mfma_ms, 'batch': int(inp[0].shape[0])}
