@@ -308,7 +308,7 @@ def rooflines(prof, steps, workload='train'):
     return out
 
 
-def config_r(iters=6, warm=3):
+def config_r(iters=10, warm=3):
     """BASELINE configs[0], the reference's OWN configuration and loop shape (configs/train_rellis.yaml:19-29: raw 900x1600, 65 536
     points, batch 1; iterater.py:25-46,106): per iteration `.to(DEVICE).float()` of the four inputs from host memory, `model(...)`,
     `criterion.compute_loss`, `optimizer.zero_grad / backward / step` with STOCK torch.optim.Adam (main.py:181-183), `lss.update`

@@ -474,16 +474,18 @@ int grid_for(long long total) {
 }
 }  // namespace
 
-// rows per partial-sum block: M / 1024 (the finalize pass folds at most 1 024 partial rows), at least 64.  (Until round 5 at least
+// rows per partial-sum block: M / 1024 (the finalize pass folds at most 1 024 partial rows), at least 16.  (Until round 5 at least
 // 512: a batch-1 layer of 5 700 positions x 512 channels then ran as 24 workgroups whose threads walked 128 rows each - 50 us for
 // 23 MB; the reference's own configuration is batch 1.)
 static long long bwd_rows_per_block(long long M) {
     // partial rows a reduction leaves for k_bwd_finalize (4096 until round 4: the fold of 4 096 rows cost 14 us per layer;
     // tools/bench_elementwise.py: 0.358 -> 0.326 ms at 1 GB)
+    // (multiples of 16 rows, at least 16 - until the end of round 5 multiples of 64: the batch-1 layers of the reference's own
+    // configuration, 1 400-22 600 positions, then ran as 22-350 workgroups walking 16 dependent trips each, 60-70 us for 11 MB)
     const long long groups = 1024;
     long long rows = (M + groups - 1) / groups;
-    rows = (rows + 63) / 64 * 64;
-    return rows < 64 ? 64 : rows;
+    rows = (rows + 15) / 16 * 16;
+    return rows < 16 ? 16 : rows;
 }
 
 extern "C" int32_t efgh_bwd_groups(int64_t M) {

@@ -154,3 +154,39 @@ static inline int efgh_wg_per_cu(const void *kernel, int threads, size_t dyn_lds
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, threads, dyn_lds) != hipSuccess || n < 1) n = 1;
     return n;
 }
+
+// ---- Winograd weight transforms, one work item per call (k_wino_pack / k_w2_pack and the batched form k_wino_pack_batched) ----
+// 1-D F(4,3), item i in [0, 3*C*N): U[(cc*3 + kh)*6 + a][n][ci] = sum_kw G[a][kw] * Wp[n][kh*3 + kw][cc*16 + ci]
+__device__ __forceinline__ void wino_pack_item(const float *__restrict__ Wp, float *__restrict__ U, int N, int C, long long i) {
+    const double G[6][3] = {{0.25, 0., 0.}, {-1. / 6, -1. / 6, -1. / 6}, {-1. / 6, 1. / 6, -1. / 6},
+                            {1. / 24, 1. / 12, 1. / 6}, {1. / 24, -1. / 12, 1. / 6}, {0., 0., 1.}};
+    const int ci = (int)(i % 16); long long r = i / 16;
+    const int n = (int)(r % N); const int ch = (int)(r / N);
+    const int cc = ch / 3, kh = ch - cc * 3, c = cc * 16 + ci;
+    const float *w = Wp + ((long long)n * 9 + kh * 3) * C + c;
+    const double w0 = w[0], w1 = w[C], w2 = w[2 * (long long)C];
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+        U[(((long long)ch * 6 + a) * N + n) * 16 + ci] = (float)(G[a][0] * w0 + G[a][1] * w1 + G[a][2] * w2);
+}
+
+// 2-D F(4x4,3x3), points 0, +-3/4, +-3/2, inf (wino2d.hip), item i in [0, N*C): U[6i + j][n][c] = sum_{kh,kw} G[i][kh] G[j][kw] Wp[n][kh*3 + kw][c]
+__device__ __forceinline__ void w2_pack_item(const float *__restrict__ Wp, float *__restrict__ U, int N, int C, long long i) {
+    const double a = 0.75, b = 1.5, f0 = a * a * b * b, fa = 2 * a * a * (a * a - b * b), fb = 2 * b * b * (b * b - a * a);
+    const double G[6][3] = {{1 / f0, 0., 0.}, {1 / fa, a / fa, a * a / fa}, {1 / fa, -a / fa, a * a / fa},
+                            {1 / fb, b / fb, b * b / fb}, {1 / fb, -b / fb, b * b / fb}, {0., 0., 1.}};
+    const int c = (int)(i % C); const long long n = i / C;
+    double w[3][3];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) w[t / 3][t % 3] = Wp[(n * 9 + t) * C + c];
+    double gw[6][3];
+#pragma unroll
+    for (int p = 0; p < 6; ++p)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) gw[p][kw] = G[p][0] * w[0][kw] + G[p][1] * w[1][kw] + G[p][2] * w[2][kw];
+#pragma unroll
+    for (int p = 0; p < 6; ++p)
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+            U[((long long)(6 * p + q) * N + n) * C + c] = (float)(gw[p][0] * G[q][0] + gw[p][1] * G[q][1] + gw[p][2] * G[q][2]);
+}

@@ -280,19 +280,9 @@ __global__ void __launch_bounds__(256, 2) k_wino43(const WinoArgs p) {
 
 // U[(cc*3 + kh)*6 + a][n][ci] = sum_kw G[a][kw] * Wp[n][kh*3 + kw][cc*16 + ci]      (Wp: packed [N][9][C])
 __global__ void k_wino_pack(const float *__restrict__ Wp, float *__restrict__ U, int N, int C) {
-    const double G[6][3] = {{0.25, 0., 0.}, {-1. / 6, -1. / 6, -1. / 6}, {-1. / 6, 1. / 6, -1. / 6},
-                            {1. / 24, 1. / 12, 1. / 6}, {1. / 24, -1. / 12, 1. / 6}, {0., 0., 1.}};
-    const long long total = 3LL * C * N;        // (ch, n, ci) triples, six outputs each
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int ci = (int)(i % KC); long long r = i / KC;
-        const int n = (int)(r % N); const int ch = (int)(r / N);
-        const int cc = ch / 3, kh = ch - cc * 3, c = cc * KC + ci;
-        const float *w = Wp + ((long long)n * 9 + kh * 3) * C + c;
-        const double w0 = w[0], w1 = w[C], w2 = w[2 * (long long)C];
-#pragma unroll
-        for (int a = 0; a < 6; ++a)
-            U[(((long long)ch * 6 + a) * N + n) * KC + ci] = (float)(G[a][0] * w0 + G[a][1] * w1 + G[a][2] * w2);
-    }
+    const long long total = 3LL * C * N;        // (ch, n, ci) triples, six outputs each (wino_pack_item, common.h)
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
+        wino_pack_item(Wp, U, N, C, i);
 }
 
 // ---------------------------------------------------------------------------------------------------------

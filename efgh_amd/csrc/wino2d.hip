@@ -363,26 +363,26 @@ k_w2_output(const W2OutArgs p) {
 
 // U[6i + j][n][c] = sum_{kh,kw} G[i][kh] G[j][kw] Wp[n][kh*3 + kw][c]        (Wp: packed [N][9][C])
 __global__ void k_w2_pack(const float *__restrict__ Wp, float *__restrict__ U, int N, int C) {
-    const double a = 0.75, b = 1.5, f0 = a * a * b * b, fa = 2 * a * a * (a * a - b * b), fb = 2 * b * b * (b * b - a * a);
-    const double G[6][3] = {{1 / f0, 0., 0.}, {1 / fa, a / fa, a * a / fa}, {1 / fa, -a / fa, a * a / fa},
-                            {1 / fb, b / fb, b * b / fb}, {1 / fb, -b / fb, b * b / fb}, {0., 0., 1.}};
     const long long total = (long long)N * C;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C); const long long n = i / C;
-        double w[3][3];
-#pragma unroll
-        for (int t = 0; t < 9; ++t) w[t / 3][t % 3] = Wp[(n * 9 + t) * C + c];
-        double gw[6][3];
-#pragma unroll
-        for (int a = 0; a < 6; ++a)
-#pragma unroll
-            for (int kw = 0; kw < 3; ++kw) gw[a][kw] = G[a][0] * w[0][kw] + G[a][1] * w[1][kw] + G[a][2] * w[2][kw];
-#pragma unroll
-        for (int a = 0; a < 6; ++a)
-#pragma unroll
-            for (int b = 0; b < 6; ++b)
-                U[((long long)(6 * a + b) * N + n) * C + c] = (float)(gw[a][0] * G[b][0] + gw[a][1] * G[b][1] + gw[a][2] * G[b][2]);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
+        w2_pack_item(Wp, U, N, C, i);
+}
+
+// every Winograd-domain weight of a model in ONE launch (after an optimizer step all of them are stale, like the packed layouts they
+// are made from: 96 launches of 5-12 us per training step otherwise).  Job j owns the workgroups [first_block[j], first_block[j+1]):
+// 256 work items each, no workgroup straddles two jobs.
+__global__ void __launch_bounds__(256) k_wino_pack_batched(const efgh_wino_pack_job *__restrict__ jobs, int njobs) {
+    __shared__ int job_s;
+    if (threadIdx.x == 0) {
+        int lo = 0, hi = njobs - 1;                      // largest j with first_block[j] <= blockIdx.x
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (jobs[mid].first_block <= (long long)blockIdx.x) lo = mid; else hi = mid - 1; }
+        job_s = lo;
     }
+    __syncthreads();
+    const efgh_wino_pack_job j = jobs[job_s];
+    const long long i = ((long long)blockIdx.x - j.first_block) * 256 + threadIdx.x;
+    if (j.kind == 0) { if (i < 3LL * j.C * j.N) wino_pack_item(j.Wp, j.U, j.N, j.C, i); }
+    else if (i < (long long)j.N * j.C) w2_pack_item(j.Wp, j.U, j.N, j.C, i);
 }
 
 // dWp[n][kh*3 + kw][c] = sum_{i,j} A3T[kh][i] A3T[kw][j] S[6i + j][n][c]
@@ -450,6 +450,13 @@ extern "C" int efgh_wino2d_pack(const float *Wp, float *U, int32_t N, int32_t C,
     const long long total = (long long)N * C;
     long long g = (total + 255) / 256;
     k_w2_pack<<<(int)(g > 8192 ? 8192 : g), 256, 0, (hipStream_t)stream_>>>(Wp, U, N, C);
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}
+
+extern "C" int efgh_wino_pack_batched(const efgh_wino_pack_job *jobs_dev, int32_t njobs, int64_t nblocks, void *stream_) {
+    EFGH_CHECK_ARG(jobs_dev && njobs > 0 && nblocks > 0 && nblocks < 0x7fffffffLL);
+    k_wino_pack_batched<<<(unsigned)nblocks, 256, 0, (hipStream_t)stream_>>>(jobs_dev, njobs);
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
 }

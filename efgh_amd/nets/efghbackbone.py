@@ -66,6 +66,15 @@ class EFGHBackbone(nn.Module):
         return ent[1]
 
     def forward(self, pc, img, calib, A, check=False, keep=None):
+        # BatchNorm's `num_batches_tracked += 1` of every layer that runs in training mode: one multi-tensor add per forward
+        own = self.training and ops.nbt_collect()
+        try:
+            return self._forward(pc, img, calib, A, check, keep)
+        finally:
+            if own:
+                ops.nbt_flush()
+
+    def _forward(self, pc, img, calib, A, check=False, keep=None):
         if getattr(self, '_is_replica', False):
             # torch.nn.DataParallel over more than one device (main.py:127 with several GPUs visible): its replicas are shallow
             # per-forward copies whose parameters are broadcast outputs, driven by one Python thread per device.  This path is

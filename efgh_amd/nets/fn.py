@@ -164,11 +164,7 @@ class GemmLayerFn(torch.autograd.Function):
             if need_stats and thin:
                 stats, _ = ops.col_stats(out, M, Np, Np)
             if need_stats:
-                slot = getattr(bn, '_efgh_nbt', None)          # (train.FlatParams, index): counted once per step there
-                if slot is not None and slot[0].collect_ticks:
-                    slot[0].tick(slot[1])
-                else:
-                    bn.num_batches_tracked += 1
+                ops.bn_tick(bn)          # num_batches_tracked += 1, batched per forward / per step
                 momentum = bn.momentum if bn.momentum is not None else 0.1
                 g_, b_ = ops.pad_vec(gamma.detach(), Np), ops.pad_vec(beta.detach(), Np)
                 if Np == N:
@@ -317,9 +313,10 @@ class GemmLayerFn(torch.autograd.Function):
                                       invstd if has_bn else None, M, Np, spec.act, spec.slope, part, s1, s2, m1, m2,
                                       pscale=psc, pshift=psh)
             if has_bn and gs1 is None:
-                dbeta, dgamma = s1[:N].clone(), s2[:N].clone()
+                # (s1 / s2 are this backward's own tensors: handed to autograd as they are when there is no padding to cut off)
+                dbeta, dgamma = (s1, s2) if Np == N else (s1[:N].clone(), s2[:N].clone())
             if has_bias and not has_bn and gs1 is None:
-                dbias = s1[:N].clone()
+                dbias = s1 if Np == N else s1[:N].clone()
             draw = torch.empty(tuple(spec.out_shape) + (Np,), dtype=torch.float32, device=dev)
             if has_res:
                 dres = torch.empty(tuple(spec.out_shape) + (Np,), dtype=torch.float32, device=dev)

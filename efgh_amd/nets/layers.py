@@ -51,7 +51,7 @@ def _bias_vec(bias, Np):
 def _bn_train(ctx, bn, stats, G, Np, count):
     """finalize batch statistics -> (scale, shift); updates running stats in place."""
     N = bn.num_features
-    bn.num_batches_tracked += 1
+    ops.bn_tick(bn)
     momentum = bn.momentum if bn.momentum is not None else 0.1
     if Np == N:
         scale, shift, _, _ = ops.bn_finalize(stats, G, N, count, bn.weight.detach(), bn.bias.detach(),
@@ -344,11 +344,8 @@ class _NbtPair:
 
     def __iadd__(self, k):
         for b in self.bns:
-            slot = getattr(b, '_efgh_nbt', None)
-            if slot is not None and slot[0].collect_ticks:
-                slot[0].tick(slot[1])
-            elif b.num_batches_tracked is not None:
-                b.num_batches_tracked += k
+            for _ in range(int(k)):
+                ops.bn_tick(b)
         return self
 
 

@@ -74,9 +74,53 @@ class _ThreadState(threading.local):
     def __init__(self):
         self.train_step = False
         self.w2v_wanted = False
+        self.nbt_pending = None        # see bn_tick
 
 
 TLS = _ThreadState()
+
+
+def bn_tick(bn):
+    """`bn.num_batches_tracked += 1` of a training forward (nn.BatchNorm2d.forward does it per layer: 93 one-element launches per
+    EFGHNet forward).  Inside a train.FlatParams step the layer's slot is counted on the host and added once per step; inside an
+    EFGHBackbone forward (any optimizer: the reference's own loop) the counters are collected and bumped by ONE multi-tensor add
+    when that forward returns (nbt_flush); a sub-network called on its own bumps its counter at once, as before."""
+    slot = getattr(bn, '_efgh_nbt', None)          # (train.FlatParams, index)
+    if slot is not None and slot[0].collect_ticks:
+        slot[0].tick(slot[1])
+        return
+    t = bn.num_batches_tracked
+    if t is None:
+        return
+    pend = TLS.nbt_pending
+    if pend is None or not torch.is_tensor(t):
+        bn.num_batches_tracked += 1                # (layers._NbtPair forwards `+=` to its parts, which come back here)
+    else:
+        ent = pend.get(id(t))
+        if ent is None:
+            pend[id(t)] = [t, 1]
+        else:
+            ent[1] += 1
+
+
+def nbt_collect():
+    """start collecting bn_tick() calls of this thread; -> True when the caller owns the collection (and has to nbt_flush())"""
+    if TLS.nbt_pending is not None:
+        return False
+    TLS.nbt_pending = {}
+    return True
+
+
+def nbt_flush():
+    pend, TLS.nbt_pending = TLS.nbt_pending, None
+    if not pend:
+        return
+    by_count = {}
+    for t, k in pend.values():
+        by_count.setdefault((k, t.device, t.dtype), []).append(t)
+    with torch.no_grad():
+        for (k, _, _), ts in by_count.items():
+            torch._foreach_add_(ts, k)
 
 
 def _ver(*tensors):
@@ -149,6 +193,49 @@ def _repack_all(device, holder):
         for w, key, buf, cur in jobs:
             buf._efgh_gen = getattr(buf, '_efgh_gen', 0) + 1
             w.__dict__['_efgh_cache'][key] = (cur, buf)
+        _rewino_all(device, holder, [buf for _, _, buf, _ in jobs])
+
+
+class _WinoJob(ctypes.Structure):
+    """mirror of efgh_wino_pack_job (include/efgh_hip.h)"""
+    _fields_ = [('Wp', ctypes.c_void_p), ('U', ctypes.c_void_p), ('N', c_int32), ('C', c_int32), ('kind', c_int32), ('pad', c_int32),
+                ('first_block', c_int64)]
+
+
+BATCH_WINO = True        # the Winograd-domain weights of the re-packed layouts in one launch as well (tests flip it)
+
+
+def _rewino_all(device, holder, bufs):
+    """the Winograd-domain images (wino_weight / wino2d_weight) of the packed layouts `bufs`, which were just rewritten in place,
+    recomputed IN PLACE by one launch (48 + 48 launches and as many allocations per training step otherwise); called under _LOCK"""
+    if not BATCH_WINO:
+        return
+    derived = []
+    for buf in bufs:
+        store = buf.__dict__.get('_efgh_cache')
+        if not store:
+            continue
+        for kind, key in ((0, ('wino',)), (1, ('wino2d',))):
+            ent = store.get(key)
+            if ent is not None and ent[1].device == device:
+                derived.append((buf, key, kind, ent[1]))
+    if not derived:
+        return
+    sig = tuple((buf.data_ptr(), U.data_ptr(), kind) for buf, _, kind, U in derived)
+    tab = holder.tables.get(('wino', device.index))
+    if tab is None or tab[0] != sig:
+        arr = (_WinoJob * len(derived))()
+        nb = 0
+        for i, (buf, _, kind, U) in enumerate(derived):
+            N, C = (U.shape[2], U.shape[0] // 3 * 16) if kind == 0 else (U.shape[1], U.shape[2])
+            j = arr[i]
+            j.Wp, j.U, j.N, j.C, j.kind, j.first_block = buf.data_ptr(), U.data_ptr(), N, C, kind, nb
+            nb += ((3 * C * N if kind == 0 else N * C) + 255) // 256
+        raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
+        tab = holder.tables[('wino', device.index)] = (sig, raw, nb)
+    _C.check(_L().efgh_wino_pack_batched(ptr(tab[1]), c_int32(len(derived)), c_int64(tab[2]), _st()))
+    for buf, key, _, U in derived:
+        buf.__dict__['_efgh_cache'][key] = (_ver(buf), U)
 
 
 def repack_stale(device, holder=None):

@@ -386,6 +386,16 @@ int efgh_wino2d_supported(const efgh_gemm_desc *d);
 int64_t efgh_wino2d_tiles(int32_t B, int32_t H, int32_t W);
 int32_t efgh_wino2d_stats_rows(int32_t B, int32_t H, int32_t W, int32_t N);
 int efgh_wino2d_pack(const float *Wp, float *U, int32_t N, int32_t C, void *stream);          /* U = G w G^T of packed [N][9][C] */
+/* every Winograd-domain weight of a model in one launch: kind 0 = efgh_wino_pack (1-D F(4,3), C % 16 == 0), kind 1 =
+ * efgh_wino2d_pack; jobs_dev: DEVICE array sorted by first_block, job j owns the workgroups [first_block[j], first_block[j+1]) of
+ * 256 work items each (3*C*N items for kind 0, N*C for kind 1), nblocks = their total */
+typedef struct efgh_wino_pack_job {
+    const float *Wp;
+    float *U;
+    int32_t N, C, kind, pad_;
+    int64_t first_block;
+} efgh_wino_pack_job;
+int efgh_wino_pack_batched(const efgh_wino_pack_job *jobs_dev, int32_t njobs, int64_t nblocks, void *stream);
 int efgh_wino2d_input(const float *A, int64_t lda, int32_t C, int32_t B, int32_t H, int32_t W, float *V, void *stream);
 int efgh_wino2d_output(const float *M, const efgh_gemm_desc *d, void *stream);
 int efgh_wino2d_dy(const float *G, int64_t ldg, int32_t N, int32_t B, int32_t H, int32_t W, float *Gy, void *stream);

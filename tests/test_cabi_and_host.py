@@ -137,6 +137,24 @@ def test_flat_params_shared_parameter_and_rebound_counter_cpu():
     assert int(m[1].num_batches_tracked) == 2 and int(f.nbt[0]) == 2 and int(m[2].num_batches_tracked) == 1
 
 
+def test_bn_tick_collects_one_add_per_forward():
+    """ops.bn_tick: inside a collection (EFGHBackbone.forward) the counters are bumped together at flush time, a layer that
+    ran twice counts twice; outside of one the counter moves at once (a sub-network called on its own)"""
+    from efgh_amd import ops
+    a, b = torch.nn.BatchNorm1d(4), torch.nn.BatchNorm1d(4)
+    ops.bn_tick(a)
+    assert int(a.num_batches_tracked) == 1
+    assert ops.nbt_collect() is True and ops.nbt_collect() is False          # (a nested forward does not own the collection)
+    ops.bn_tick(a); ops.bn_tick(b); ops.bn_tick(b)
+    assert int(a.num_batches_tracked) == 1 and int(b.num_batches_tracked) == 0
+    va = a.num_batches_tracked._version
+    ops.nbt_flush()
+    assert int(a.num_batches_tracked) == 2 and int(b.num_batches_tracked) == 2
+    assert a.num_batches_tracked._version > va            # (layers._bn_eval_affine keys its cache on the version)
+    assert ops.TLS.nbt_pending is None
+    ops.bn_tick(torch.nn.BatchNorm1d(4, track_running_stats=False))           # no counter: nothing to do
+
+
 def test_header_is_plain_c():
     """the boundary is a C ABI: include/efgh_hip.h must compile as C99 (no C++ or torch types in the signatures)"""
     import os

@@ -855,3 +855,48 @@ def test_dma_gemm_equals_register_staged(L, cin, cout, k, stride, hw, B):
         assert torch.equal(a, b)
     ref = F.leaky_relu(conv(x.permute(0, 3, 1, 2)), 0.2).permute(0, 2, 3, 1)
     assert _rel(outs[1][0], ref.detach()) < 2e-5
+
+
+def test_batched_winograd_weight_transforms_follow_the_batched_repack():
+    """after an in-place weight update the batched repack (ops.repack_stale) rewrites the packed layouts AND their Winograd-domain
+    images (wino_weight: 1-D F(4,3), wino2d_weight: F(4x4,3x3)) in place, one launch each: same buffers, bit-identical to the
+    per-layer transforms of the new weights; with BATCH_WINO off the images are re-made lazily as before"""
+    from efgh_amd import _C, ops
+    from efgh_amd._C import c_int32, ptr
+    torch.manual_seed(3)
+    shapes = [(64, 64), (128, 64), (256, 128), (16, 32)]
+    ws = [torch.randn(n, c, 3, 3, device='cuda') for n, c in shapes]
+
+    def packed(w):
+        n, c = w.shape[:2]
+        return ops.pack_weight(w, n, 9, c, c * 9, 9, 1, list(range(9)), key=('t', n, c))
+    bufs = [packed(w) for w in ws]
+    U1 = [ops.wino_weight(b, *s) for b, s in zip(bufs, shapes)]
+    U2 = [ops.wino2d_weight(b, *s) for b, s in zip(bufs[:3], shapes[:3])]
+    for old_flag in (True, False):
+        ops.BATCH_WINO = old_flag
+        try:
+            with torch.no_grad():
+                for w in ws:
+                    w.add_(torch.randn_like(w))                  # what a stock optimizer does: version counters move
+            ops.repack_stale(torch.device('cuda', torch.cuda.current_device()))
+            new_bufs = [packed(w) for w in ws]
+            assert all(a is b for a, b in zip(bufs, new_bufs))       # persistent buffers, rewritten in place
+            V1 = [ops.wino_weight(b, *s) for b, s in zip(bufs, shapes)]
+            V2 = [ops.wino2d_weight(b, *s) for b, s in zip(bufs[:3], shapes[:3])]
+            if old_flag:
+                assert all(a is b for a, b in zip(U1 + U2, V1 + V2))  # and so are their Winograd images
+            for b, (n, c), v in zip(bufs, shapes, V1):
+                fresh = torch.empty_like(v)
+                _C.check(_C.lib().efgh_wino_pack(ptr(b), ptr(fresh), c_int32(n), c_int32(c), _C.stream_ptr()))
+                assert torch.equal(fresh, v)
+            for b, (n, c), v in zip(bufs[:3], shapes[:3], V2):
+                fresh = torch.empty_like(v)
+                _C.check(_C.lib().efgh_wino2d_pack(ptr(b), ptr(fresh), c_int32(n), c_int32(c), _C.stream_ptr()))
+                assert torch.equal(fresh, v)
+                # and the packed layout itself is the new weight
+            for w, b in zip(ws, bufs):
+                assert torch.equal(b, w.permute(0, 2, 3, 1).reshape(w.shape[0], 9, w.shape[1]))
+            U1, U2 = V1, V2
+        finally:
+            ops.BATCH_WINO = True

@@ -161,6 +161,29 @@ def test_overfitting_one_small_batch_reduces_every_loss_group(manifest):
     assert int(m.H.vgg.features[1].num_batches_tracked) == 20
 
 
+def test_stock_loop_counts_batches_once_per_forward(manifest):
+    """the reference's loop (no Trainer): every BatchNorm that ran in training mode has counted each forward exactly once (the
+    per-layer `num_batches_tracked += 1` launches are collected into one multi-tensor add, ops.bn_tick), eval forwards count nothing"""
+    from efgh_amd.nets import EFGHBackbone
+    args = syn.default_args(RAW, 'cuda')
+    m = EFGHBackbone(args)
+    m.load_state_dict(syn.synthetic_state_dict(manifest['state_dict'], 1))
+    m = m.cuda()
+    b = syn.make_batch(RAW, NPTS, 2)
+    inp = [torch.from_numpy(b[k]).cuda() for k in ('pc', 'img', 'calib', 'A')]
+    bns = [mod for mod in m.modules() if isinstance(mod, torch.nn.modules.batchnorm._BatchNorm)]
+    m.train()
+    m(*inp)
+    first = [int(x.num_batches_tracked) for x in bns]
+    assert max(first) == 1 and sum(first) >= 80, (sum(first), len(bns))
+    m(*inp)
+    assert [int(x.num_batches_tracked) for x in bns] == [2 * c for c in first]
+    m.eval()
+    with torch.no_grad():
+        m(*inp)
+    assert [int(x.num_batches_tracked) for x in bns] == [2 * c for c in first]
+
+
 def test_dataparallel_wrapper_single_device(manifest):
     """main.py:127 wraps the model in nn.DataParallel; on one device that must be a transparent wrapper (same outputs, 'module.'-
     prefixed state_dict that the checkpoint helpers accept)"""
