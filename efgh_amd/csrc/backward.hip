@@ -477,6 +477,9 @@ int grid_for(long long total) {
 // rows per partial-sum block: M / 1024 (the finalize pass folds at most 1 024 partial rows), at least 16.  (Until round 5 at least
 // 512: a batch-1 layer of 5 700 positions x 512 channels then ran as 24 workgroups whose threads walked 128 rows each - 50 us for
 // 23 MB; the reference's own configuration is batch 1.)
+#ifndef EFGH_BWD_ROW_GRAN
+#define EFGH_BWD_ROW_GRAN 16
+#endif
 static long long bwd_rows_per_block(long long M) {
     // partial rows a reduction leaves for k_bwd_finalize (4096 until round 4: the fold of 4 096 rows cost 14 us per layer;
     // tools/bench_elementwise.py: 0.358 -> 0.326 ms at 1 GB)
@@ -484,8 +487,8 @@ static long long bwd_rows_per_block(long long M) {
     // configuration, 1 400-22 600 positions, then ran as 22-350 workgroups walking 16 dependent trips each, 60-70 us for 11 MB)
     const long long groups = 1024;
     long long rows = (M + groups - 1) / groups;
-    rows = (rows + 15) / 16 * 16;
-    return rows < 16 ? 16 : rows;
+    rows = (rows + EFGH_BWD_ROW_GRAN - 1) / EFGH_BWD_ROW_GRAN * EFGH_BWD_ROW_GRAN;
+    return rows < EFGH_BWD_ROW_GRAN ? EFGH_BWD_ROW_GRAN : rows;
 }
 
 extern "C" int32_t efgh_bwd_groups(int64_t M) {

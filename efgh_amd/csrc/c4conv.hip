@@ -212,6 +212,133 @@ __global__ void __launch_bounds__(64 * WAVES, 2) k_c4_conv(const C4Args p) {
     }
 }
 
+// ---- the same layer followed by MaxPool2d(2,2) (inference path of the VGG trunks, nets/vgg.py:69-83) ----------------------------
+// unit = 32 output pixels of a ROW PAIR (2 ip, 2 ip + 1): four input rows in the wave's LDS slice, both rows' accumulators in
+// registers (2 x NT x 16), the window maximum of act((v + bias) * scale + shift) taken vertically in the accumulator layout and
+// horizontally on the way out of the transpose tile - 16 pooled pixels x 32 channels leave per tile, the full-resolution map
+// (4 GB at 15.7 M pixels x 64 channels) is neither written nor read back by a pooling pass.  Stride 1 only; same MFMA order as
+// k_c4_conv, so the result is bit-identical to k_c4_conv followed by efgh_maxpool2.
+constexpr int LW1 = TP + 2;
+__device__ __forceinline__ float4 load_px4(const C4Args &p, int idx, int ip, long long b, int j0) {
+    const int kh = idx / LW1, x = idx - kh * LW1;
+    const int yin = 2 * ip - 1 + kh, xin = j0 - 1 + x;
+    if (kh < 4 && (unsigned)yin < (unsigned)p.Hin && (unsigned)xin < (unsigned)p.Win)
+        return *reinterpret_cast<const float4 *>(p.A + ((b * p.Hin + yin) * p.Win + xin) * p.lda);
+    return make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+template <int NT>
+__global__ void __launch_bounds__(64 * WAVES, 2) k_c4_conv_pool(const C4Args p) {
+    __shared__ float2 Pw[WAVES][4][2][LW1 + 1];
+    constexpr int TPITCH = 40;
+    __shared__ __attribute__((aligned(16))) float Tw[WAVES][32 * TPITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    float2 (*P)[2][LW1 + 1] = Pw[wave];
+    float *T = Tw[wave];
+    const int Hp = p.Ho >> 1, Wp = p.Wo >> 1;
+
+    float2 bw[9][NT];
+    float bi[NT], sc[NT], sf[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int n = 32 * j + r;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) bw[t][j] = *reinterpret_cast<const float2 *>(p.W + ((long long)n * 9 + t) * 4 + 2 * h);
+        bi[j] = p.bias ? p.bias[n] : 0.f;
+        sc[j] = p.scale ? p.scale[n] : 1.f;
+        sf[j] = p.shift ? p.shift[n] : 0.f;
+    }
+    const float neg = p.act == 1 ? 0.f : (p.act == 2 ? p.slope : 1.f);
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) asm volatile("" ::"v"(bw[t][j].x), "v"(bw[t][j].y));
+
+    const long long nwaves = (long long)gridDim.x * WAVES;
+    long long unit = (long long)blockIdx.x * WAVES + wave;
+    long long rowp = 0, b = 0; int ip = 0, j0 = 0;   // coordinates of the unit whose pixels are in pf0..2 (rowp = b * Hp + ip)
+    long long crow = 0; int cj0 = 0;                 // ... of the unit staged in LDS
+    float4 pf0, pf1, pf2;                            // 4 x 34 staged pixels = 136 <= 192
+#define EFGH_FETCH(u)                                                                    \
+    {                                                                                   \
+        const int jb = (int)((u) % p.jblocks);                                          \
+        rowp = (u) / p.jblocks; ip = (int)(rowp % Hp); b = rowp / Hp; j0 = jb * TP;     \
+        pf0 = load_px4(p, lane, ip, b, j0); pf1 = load_px4(p, lane + 64, ip, b, j0);    \
+        pf2 = load_px4(p, lane + 128, ip, b, j0);                                       \
+    }
+#define EFGH_PUT(q, v)                                                                   \
+    {                                                                                   \
+        const int idx = lane + 64 * q;                                                  \
+        if (idx < 4 * LW1) {                                                            \
+            const int kh = idx / LW1, x = idx - kh * LW1;                               \
+            P[kh][0][x] = make_float2(v.x, v.y); P[kh][1][x] = make_float2(v.z, v.w);   \
+        }                                                                               \
+    }
+#define EFGH_STAGE()                                                                     \
+    {                                                                                   \
+        crow = rowp; cj0 = j0;                                                          \
+        EFGH_PUT(0, pf0) EFGH_PUT(1, pf1) EFGH_PUT(2, pf2)                              \
+    }
+    if (unit < p.units) {
+        EFGH_FETCH(unit)
+        EFGH_STAGE()
+        if (unit + nwaves < p.units) EFGH_FETCH(unit + nwaves)
+    }
+    for (; unit < p.units; unit += nwaves) {
+        const long long orow0 = crow; const int oj0 = cj0;
+        wave_lds_sync();
+        f32x16 acc[2][NT];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[half][j][q] = 0.f;
+            float2 af[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) af[t] = P[t / 3 + half][h][r + t % 3];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    acc[half][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[t].x, bw[t][j].x, acc[half][j], 0, 0, 0);
+                    acc[half][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[t].y, bw[t][j].y, acc[half][j], 0, 0, 0);
+                }
+            }
+        }
+        wave_lds_sync();
+        if (unit + nwaves < p.units) {
+            EFGH_STAGE()
+            if (unit + 2 * nwaves < p.units) EFGH_FETCH(unit + 2 * nwaves)
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            wave_lds_sync();                         // the tile's previous readers are done
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int pl = (q & 3) + 8 * (q >> 2) + 4 * h;
+                const float v0 = act_neg(fmaf(acc[0][j][q] + bi[j], sc[j], sf[j]), neg);
+                const float v1 = act_neg(fmaf(acc[1][j][q] + bi[j], sc[j], sf[j]), neg);
+                T[pl * TPITCH + r] = fmaxf(v0, v1);
+            }
+            wave_lds_sync();
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {
+                const int item = 64 * pass + lane, pp = item >> 3, c4 = (item & 7) * 4;
+                const float4 a = *reinterpret_cast<const float4 *>(&T[(2 * pp) * TPITCH + c4]);
+                const float4 c = *reinterpret_cast<const float4 *>(&T[(2 * pp + 1) * TPITCH + c4]);
+                float4 v;
+                v.x = fmaxf(a.x, c.x); v.y = fmaxf(a.y, c.y); v.z = fmaxf(a.z, c.z); v.w = fmaxf(a.w, c.w);
+                if ((oj0 >> 1) + pp < Wp)
+                    *reinterpret_cast<float4 *>(p.out + (orow0 * Wp + (oj0 >> 1) + pp) * p.ldo + 32 * j + c4) = v;
+            }
+        }
+    }
+#undef EFGH_FETCH
+#undef EFGH_PUT
+#undef EFGH_STAGE
+}
+
 // ---- weight gradient ---------------------------------------------------------------------------------------------
 // unit = 32 output (= gradient) pixels of one image row, taken by one wave in 8 groups of 4 (the k of
 // v_mfma_f32_16x16x4_f32).  A operand: G[pixel k][n] (16 outputs of an n-tile), B operand: X[pixel k + tap][c] for column
@@ -349,6 +476,25 @@ extern "C" int efgh_c4_conv3x3(const efgh_gemm_desc *d, void *stream_) {
     }
     if (d->N == 32) EFGH_GO(1) else if (d->N == 64) EFGH_GO(2) else EFGH_GO(4)
 #undef EFGH_GO
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}
+
+extern "C" int efgh_c4_pooled_supported(const efgh_gemm_desc *d) {
+    return (efgh_c4_supported(d) && d->sh == 1 && !d->residual && !d->stats && d->Ho >= 2 && d->Wo >= 2) ? 1 : 0;
+}
+
+extern "C" int efgh_c4_conv3x3_pooled(const efgh_gemm_desc *d, void *stream_) {
+    hipStream_t st = (hipStream_t)stream_;
+    EFGH_CHECK_ARG(efgh_c4_pooled_supported(d) && d->W && d->out && (((uintptr_t)d->W) & 7) == 0);
+    EFGH_CHECK_ARG(d->ldo % 4 == 0 && (((uintptr_t)d->out) & 15) == 0);
+    C4Args a;
+    fill(a, d);
+    a.units = (long long)d->B * (d->Ho / 2) * a.jblocks;          // row pairs x 32-pixel blocks
+    const int grid = grid_of(a.units);
+    if (d->N == 32) k_c4_conv_pool<1><<<grid, 64 * WAVES, 0, st>>>(a);
+    else if (d->N == 64) k_c4_conv_pool<2><<<grid, 64 * WAVES, 0, st>>>(a);
+    else k_c4_conv_pool<4><<<grid, 64 * WAVES, 0, st>>>(a);
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
 }

@@ -156,6 +156,9 @@ static inline int efgh_wg_per_cu(const void *kernel, int threads, size_t dyn_lds
 }
 
 // ---- Winograd weight transforms, one work item per call (k_wino_pack / k_w2_pack and the batched form k_wino_pack_batched) ----
+// float64 with the contraction order WRITTEN OUT (explicit fma): every kernel that inlines these produces the same bits - left to
+// -ffp-contract the two instantiations differed in the last bit of ~0.4 % of the entries, enough to flip near-tie max-pool windows
+// downstream (tests/test_gpu_fullsize.py: H's gradient error against the fp32 oracle moved between 1.6e-3 and 1.0e-2)
 // 1-D F(4,3), item i in [0, 3*C*N): U[(cc*3 + kh)*6 + a][n][ci] = sum_kw G[a][kw] * Wp[n][kh*3 + kw][cc*16 + ci]
 __device__ __forceinline__ void wino_pack_item(const float *__restrict__ Wp, float *__restrict__ U, int N, int C, long long i) {
     const double G[6][3] = {{0.25, 0., 0.}, {-1. / 6, -1. / 6, -1. / 6}, {-1. / 6, 1. / 6, -1. / 6},
@@ -167,7 +170,7 @@ __device__ __forceinline__ void wino_pack_item(const float *__restrict__ Wp, flo
     const double w0 = w[0], w1 = w[C], w2 = w[2 * (long long)C];
 #pragma unroll
     for (int a = 0; a < 6; ++a)
-        U[(((long long)ch * 6 + a) * N + n) * 16 + ci] = (float)(G[a][0] * w0 + G[a][1] * w1 + G[a][2] * w2);
+        U[(((long long)ch * 6 + a) * N + n) * 16 + ci] = (float)fma(G[a][2], w2, fma(G[a][1], w1, G[a][0] * w0));
 }
 
 // 2-D F(4x4,3x3), points 0, +-3/4, +-3/2, inf (wino2d.hip), item i in [0, N*C): U[6i + j][n][c] = sum_{kh,kw} G[i][kh] G[j][kw] Wp[n][kh*3 + kw][c]
@@ -183,10 +186,10 @@ __device__ __forceinline__ void w2_pack_item(const float *__restrict__ Wp, float
 #pragma unroll
     for (int p = 0; p < 6; ++p)
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw) gw[p][kw] = G[p][0] * w[0][kw] + G[p][1] * w[1][kw] + G[p][2] * w[2][kw];
+        for (int kw = 0; kw < 3; ++kw) gw[p][kw] = fma(G[p][2], w[2][kw], fma(G[p][1], w[1][kw], G[p][0] * w[0][kw]));
 #pragma unroll
     for (int p = 0; p < 6; ++p)
 #pragma unroll
         for (int q = 0; q < 6; ++q)
-            U[((long long)(6 * p + q) * N + n) * C + c] = (float)(gw[p][0] * G[q][0] + gw[p][1] * G[q][1] + gw[p][2] * G[q][2]);
+            U[((long long)(6 * p + q) * N + n) * C + c] = (float)fma(gw[p][2], G[q][2], fma(gw[p][1], G[q][1], gw[p][0] * G[q][0]));
 }

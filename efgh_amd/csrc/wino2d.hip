@@ -71,9 +71,11 @@ __device__ __forceinline__ void bt6(const vec_t d[6], vec_t v[6]) {
 // A^T (6 -> 4)
 __device__ __forceinline__ void at4(const vec_t m[6], vec_t y[4]) {
 #define E0(e) (m[0].e + (m[1].e + m[2].e) + (m[3].e + m[4].e))
-#define E1(e) (W2_A * (m[1].e - m[2].e) + W2_B * (m[3].e - m[4].e))
-#define E2(e) (W2_A2 * (m[1].e + m[2].e) + W2_B2 * (m[3].e + m[4].e))
-#define E3(e) (W2_A3 * (m[1].e - m[2].e) + W2_B3 * (m[3].e - m[4].e) + m[5].e)
+// (the contraction order of the a*b + c*d forms is WRITTEN OUT: the pooled and the plain instantiation of k_w2_output, left to
+// -ffp-contract, differed in the last bit of a third of their outputs)
+#define E1(e) fmaf(W2_A, m[1].e - m[2].e, W2_B * (m[3].e - m[4].e))
+#define E2(e) fmaf(W2_A2, m[1].e + m[2].e, W2_B2 * (m[3].e + m[4].e))
+#define E3(e) (fmaf(W2_A3, m[1].e - m[2].e, W2_B3 * (m[3].e - m[4].e)) + m[5].e)
     F4OP(y[0], E0) F4OP(y[1], E1) F4OP(y[2], E2) F4OP(y[3], E3)
 #undef E0
 #undef E1
@@ -241,7 +243,10 @@ struct W2OutArgs {
 
 constexpr int ROWS_PER_BLOCK = 1;              // rows of tiles per workgroup of k_w2_output (one statistics row per workgroup)
 
-template <bool NT>
+// POOL: the layer is followed by MaxPool2d(2,2) (inference path of the VGG trunks, nets/vgg.py:69-83): a 4x4 output tile holds four
+// whole pooling windows (tiles start at multiples of 4), so the epilogue writes max over each window of act(v*scale + shift) into
+// the POOLED map [B][H/2][W/2][N] - the full-resolution activation is neither written nor read back by a pooling pass.
+template <bool NT, bool POOL>
 __global__ void __launch_bounds__(TPB, 4)          // (four workgroups per CU: <= 128 VGPRs - the pass is bound by bytes in flight)
 k_w2_output(const W2OutArgs p) {
     __shared__ float red[2][TPB][VW];
@@ -314,6 +319,31 @@ k_w2_output(const W2OutArgs p) {
             at4(m5, w5);
 #pragma unroll
             for (int x = 0; x < 4; ++x) { Y[3][x].x += w5[x].x; Y[3][x].y += w5[x].y; }
+        }
+        if (POOL) {
+            const int Hp = p.g.H >> 1, Wp = p.g.W >> 1;
+            float *ob = p.out + ((b * Hp + (y0 >> 1)) * Wp + (x0 >> 1)) * p.ldo + col;
+            const int ldo_i = (int)p.ldo;
+#pragma unroll
+            for (int pa = 0; pa < 2; ++pa) {
+                if ((y0 >> 1) + pa >= Hp) continue;            // (floor mode: an odd last row / column belongs to no window)
+#pragma unroll
+                for (int px = 0; px < 2; ++px) {
+                    if ((x0 >> 1) + px >= Wp) continue;
+                    vec_t best = zero;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        vec_t v = Y[2 * pa + (e >> 1)][2 * px + (e & 1)];
+                        v.x = (v.x + bi.x) * sc.x + sf.x; v.y = (v.y + bi.y) * sc.y + sf.y;
+                        if (p.act == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); }
+                        else if (p.act == 2) { v.x = v.x > 0.f ? v.x : v.x * p.slope; v.y = v.y > 0.f ? v.y : v.y * p.slope; }
+                        if (e == 0) best = v;
+                        else { best.x = fmaxf(best.x, v.x); best.y = fmaxf(best.y, v.y); }
+                    }
+                    st2<NT>(ob + (pa * Wp + px) * ldo_i, best);
+                }
+            }
+            continue;
         }
         // one 64-bit base per operand, 32-bit element offsets inside the tile (4 rows x 4 pixels: far below 2^31 elements)
         const long long pix0 = (b * p.g.H + y0) * p.g.W + x0;
@@ -493,8 +523,22 @@ extern "C" int efgh_wino2d_output(const float *M, const efgh_gemm_desc *d, void 
     a.M = M; a.N = d->N; a.g = geo(d->B, d->Hin, d->Win);
     a.bias = d->bias; a.scale = d->scale; a.shift = d->shift; a.residual = d->residual; a.ldr = d->ldr;
     a.act = d->act; a.slope = d->slope; a.out = d->out; a.ldo = d->ldo; a.stats = d->stats;
-    if (efgh_stream_nt(a.g.T * 36ll * d->N * 4)) k_w2_output<true><<<row_grid(a.g, d->N / VW, ROWS_PER_BLOCK), TPB, 0, (hipStream_t)stream_>>>(a);
-    else k_w2_output<false><<<row_grid(a.g, d->N / VW, ROWS_PER_BLOCK), TPB, 0, (hipStream_t)stream_>>>(a);
+    if (efgh_stream_nt(a.g.T * 36ll * d->N * 4)) k_w2_output<true, false><<<row_grid(a.g, d->N / VW, ROWS_PER_BLOCK), TPB, 0, (hipStream_t)stream_>>>(a);
+    else k_w2_output<false, false><<<row_grid(a.g, d->N / VW, ROWS_PER_BLOCK), TPB, 0, (hipStream_t)stream_>>>(a);
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}
+
+extern "C" int efgh_wino2d_output_pooled(const float *M, const efgh_gemm_desc *d, void *stream_) {
+    EFGH_CHECK_ARG(M && supported(d) && d->out && d->B > 0 && d->Hin >= 2 && d->Win >= 2);
+    EFGH_CHECK_ARG((((uintptr_t)M) & 15) == 0 && (((uintptr_t)d->out) & 15) == 0 && d->ldo % 4 == 0);
+    EFGH_CHECK_ARG(!d->residual && !d->stats);          // (an inference epilogue: bias, folded BatchNorm affine, activation)
+    W2OutArgs a;
+    a.M = M; a.N = d->N; a.g = geo(d->B, d->Hin, d->Win);
+    a.bias = d->bias; a.scale = d->scale; a.shift = d->shift; a.residual = nullptr; a.ldr = 0;
+    a.act = d->act; a.slope = d->slope; a.out = d->out; a.ldo = d->ldo; a.stats = nullptr;
+    if (efgh_stream_nt(a.g.T * 36ll * d->N * 4)) k_w2_output<true, true><<<row_grid(a.g, d->N / VW, ROWS_PER_BLOCK), TPB, 0, (hipStream_t)stream_>>>(a);
+    else k_w2_output<false, true><<<row_grid(a.g, d->N / VW, ROWS_PER_BLOCK), TPB, 0, (hipStream_t)stream_>>>(a);
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
 }

@@ -92,7 +92,7 @@ def _alloc_out(x, shape_rows, N, out):
 
 
 def _run(ctx, x, lda, C, T, Wp, N, M, mode, geoms, out_t, ldo, coff, bias, bn, act, slope, residual=None,
-         res_ld=0, res_off=0, table=None, a_off=0, count=None, c_real=None):
+         res_ld=0, res_off=0, table=None, a_off=0, count=None, c_real=None, pool=False):
     """One logical layer = one or more GEMM launches (`geoms`: list of (geom, Wp, M_launch)), then the
     BatchNorm finalize/apply pass when batch statistics are needed."""
     Np = N if N % 4 == 0 else ceil4(N)
@@ -105,8 +105,9 @@ def _run(ctx, x, lda, C, T, Wp, N, M, mode, geoms, out_t, ldo, coff, bias, bn, a
         for geom, wp, m in geoms:
             ops.gather_gemm(x, lda, C, T if geom is None else len(geom[7]), wp, Np, m, out_t, ldo, mode=mode,
                             geom=geom, table=table, bias=b, scale=sc, shift=sh, residual=residual, ldr=res_ld,
-                            act=act, slope=slope, a_off=a_off, out_off=coff, res_off=res_off, flops=fl(geom, m))
+                            act=act, slope=slope, a_off=a_off, out_off=coff, res_off=res_off, flops=fl(geom, m), pool=pool)
         return
+    assert not pool
     # train-mode BatchNorm: raw conv output + per-block column statistics, then normalise in place
     thin = all(ops.thin_eligible(mode, C, Np, T if geom is None else len(geom[7])) for geom, _, _ in geoms)
     if thin:       # VALU kernels carry no statistics epilogue: one extra streaming pass over the (small) output
@@ -154,6 +155,13 @@ def conv2d(ctx, x, conv, bn=None, act=ACT_NONE, slope=0.0, residual=None, out=No
         xs = x if in_ch is None else x[..., a_off:a_off + Cx]
         return _conv2d_grad(ctx, xs, conv, bn, act, slope, residual, geom, (B, H, W, Ho, Wo), Cp, passthrough=skip_out, pool=pool,
                             out=out)
+    if pool:
+        # inference: the following MaxPool2d(2,2) rides in the layer's output transform (run_vgg asks pool_fusable first)
+        assert out is None and residual is None and not ctx.train
+        out_t, ldo, coff = _alloc_out(x, (B, Ho // 2, Wo // 2), O, None)
+        _run(ctx, x, ldx, Cp, T, Wp, O, M, 1, [(geom, Wp, M)], out_t, ldo, coff, conv.bias, bn, act, slope, a_off=a_off, c_real=Cw,
+             pool=True)
+        return out_t
     out_t, ldo, coff = _alloc_out(x, (B, Ho, Wo), O, out)
     res_ld = residual.shape[-1] if residual is not None else 0
     _run(ctx, x, ldx, Cp, T, Wp, O, M, 1, [(geom, Wp, M)], out_t, ldo, coff, conv.bias, bn, act, slope,
@@ -282,6 +290,17 @@ def maxpool2(ctx, x):
 
 
 # ----------------------------------------------------------------------------------------------
+def _pool_fusable_eval(x, conv):
+    """inference: can the MaxPool2d(2,2) behind this 3x3 / stride-1 / pad-1 convolution ride in its epilogue (ops.pool_fusable)?"""
+    if conv.kernel_size != (3, 3) or conv.stride != (1, 1) or conv.padding != (1, 1):
+        return False
+    B, H, W, ldx = x.shape
+    if ldx != ceil4(conv.in_channels):
+        return False
+    geom = (B, H, W, H, W, 1, 1, [t // 3 - 1 for t in range(9)], [t % 3 - 1 for t in range(9)], H, W, 1, 1, 0, 0)
+    return ops.pool_fusable(1, ldx, ceil4(conv.out_channels), geom)
+
+
 def run_vgg(ctx, features, x):
     """nets/vgg.py:69-83: [Conv2d, BatchNorm2d, ReLU]* with 'M' = MaxPool2d(2,2)."""
     mods = list(features.children())
@@ -293,8 +312,10 @@ def run_vgg(ctx, features, x):
             i += 1
         else:
             assert isinstance(m, nn.Conv2d) and isinstance(mods[i + 1], nn.BatchNorm2d)
-            # training path: a following MaxPool2d is folded into the layer (BatchNorm + ReLU + pool in one pass over raw)
-            fuse = ctx.grad and i + 3 < len(mods) and isinstance(mods[i + 3], nn.MaxPool2d) and m.out_channels % 4 == 0
+            # training path: a following MaxPool2d is folded into the layer (BatchNorm + ReLU + pool in one pass over raw);
+            # inference: into the output transform of the 2-D Winograd layers (the pooled map is all that is ever written)
+            pooled = i + 3 < len(mods) and isinstance(mods[i + 3], nn.MaxPool2d) and m.out_channels % 4 == 0
+            fuse = pooled and (ctx.grad or (not ctx.train and _pool_fusable_eval(x, m)))
             x = conv2d(ctx, x, m, mods[i + 1], ACT_RELU, pool=fuse)
             i += 4 if fuse else 3
     return x

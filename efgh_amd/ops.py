@@ -514,8 +514,9 @@ def _blur_gemm_ksplit(A, lda, C, Wp, N, M, out, ldo, table, bias, act, slope, a_
 
 def gather_gemm(A, lda, C, T, Wp, N, M, out, ldo, mode=0, geom=None, table=None, bias=None, scale=None,
                 shift=None, residual=None, ldr=0, act=ACT_NONE, slope=0.0, stats=None, a_off=0, out_off=0,
-                res_off=0, M_dev=None, flops=None, batch=None, alias_mask=False, bn_bwd=None):
+                res_off=0, M_dev=None, flops=None, batch=None, alias_mask=False, bn_bwd=None, pool=False):
     """See efgh_gemm_desc.  A/out/residual may be addressed with an element offset (channel slices).
+    pool: `out` is the 2x2 max-pooled map [B][Ho/2][Wo/2][ldo] (only for launches pool_fusable() accepts: the 2-D Winograd path).
     bn_bwd: a BnSrc (nets/fn.py) - the BatchNorm layer that produced the tensor whose GRADIENT this launch writes; when the
     kernel serving the launch supports it (Winograd F(4,3)) the column sums of that layer's BatchNorm backward are taken in the
     epilogue and the [rows][2][N] partials are RETURNED (else None: the layer runs its own reduction pass)."""
@@ -559,13 +560,18 @@ def gather_gemm(A, lda, C, T, Wp, N, M, out, ldo, mode=0, geom=None, table=None,
     elif M_dev is None and batch is None and c4_eligible(mode, C, N, geom):
         assert lda % 4 == 0
         thin = True             # (for the profile lists: an HBM-bound launch, not part of the MFMA GEMM family)
-        _C.check(_L().efgh_c4_conv3x3(ctypes.byref(d), _st()))
+        if pool:
+            _C.check(_L().efgh_c4_conv3x3_pooled(ctypes.byref(d), _st()))
+            pool = False
+        else:
+            _C.check(_L().efgh_c4_conv3x3(ctypes.byref(d), _st()))
     elif M_dev is None and batch is None and sc_eligible(mode, C, N, geom) and _sc_aligned(d, lda, ldo, residual, ldr, stats):
         sc = True
         _C.check(_L().efgh_sc_conv3x3(ctypes.byref(d), _st()))
     elif M_dev is None and batch is None and wino2d_eligible(mode, C, N, geom):
         wino = '2d'
-        _wino2d_forward(d, A, a_off, lda, C, N, geom, Wp)
+        _wino2d_forward(d, A, a_off, lda, C, N, geom, Wp, pool=pool)
+        pool = False
     elif M_dev is None and batch is None and wino_eligible(mode, C, N, geom):
         wino = True
         if bn_bwd is not None and stats is None and BN_BWD_FUSED and out_off == 0 and bn_bwd.fits(M, N):
@@ -582,6 +588,8 @@ def gather_gemm(A, lda, C, T, Wp, N, M, out, ldo, mode=0, geom=None, table=None,
         _C.check(_L().efgh_wino_conv3x3(ctypes.byref(d), ptr(wino_weight(Wp, N, C)), _st()))
     else:
         _C.check(_L().efgh_gather_gemm(ctypes.byref(d), _st()))
+    if pool:
+        raise _C.EfghError('gather_gemm(pool=True) on a launch no pooling epilogue serves (ask pool_fusable() first)')
     if PROFILE is not None and (thin or (not wino and batch is None and hbm_bound(M, N, T, C))):
         e1.record()
         if PROFILE_THIN is not None:
@@ -648,7 +656,24 @@ def w2v_clear():
             del W2V_CACHE[k]
 
 
-def _wino2d_forward(d, A, a_off, lda, C, N, geom, Wp):
+POOL_FUSED = True               # inference: MaxPool2d(2,2) behind a 2-D Winograd layer folded into its output transform
+
+
+def pool_fusable(mode, C, N, geom, residual=None, stats=None):
+    """can gather_gemm(pool=True) serve this launch?  (the 4-channel input layers and the 2-D Winograd path, plain inference
+    epilogue)"""
+    if not (POOL_FUSED and residual is None and stats is None and geom is not None and geom[1] >= 2 and geom[2] >= 2):
+        return False
+    if thin_eligible(mode, C, N, len(geom[7])):
+        return False
+    if c4_eligible(mode, C, N, geom):                    # (gather_gemm's order of preference)
+        return geom[5] == 1 and geom[6] == 1
+    if sc_eligible(mode, C, N, geom):
+        return False
+    return bool(wino2d_eligible(mode, C, N, geom))
+
+
+def _wino2d_forward(d, A, a_off, lda, C, N, geom, Wp, pool=False):
     """input transform -> 36 batched GEMMs -> output transform with the layer's epilogue (descriptor d)"""
     B, H, W = geom[0], geom[1], geom[2]
     T = _L().efgh_wino2d_tiles(c_int32(B), c_int32(H), c_int32(W))
@@ -664,7 +689,10 @@ def _wino2d_forward(d, A, a_off, lda, C, N, geom, Wp):
                 W2V_CACHE.clear()
             W2V_CACHE[(A.data_ptr(), lda, C, B, H, W)] = (V, A._version, threading.get_ident())
     _batched_plain_gemm(V, wino2d_weight(Wp, N, C), Mb, T, C, N)
-    _C.check(_L().efgh_wino2d_output(ptr(Mb), ctypes.byref(d), _st()))
+    if pool:
+        _C.check(_L().efgh_wino2d_output_pooled(ptr(Mb), ctypes.byref(d), _st()))
+    else:
+        _C.check(_L().efgh_wino2d_output(ptr(Mb), ctypes.byref(d), _st()))
 
 
 # ----------------------------------------------------------------------------------------------

@@ -398,6 +398,9 @@ typedef struct efgh_wino_pack_job {
 int efgh_wino_pack_batched(const efgh_wino_pack_job *jobs_dev, int32_t njobs, int64_t nblocks, void *stream);
 int efgh_wino2d_input(const float *A, int64_t lda, int32_t C, int32_t B, int32_t H, int32_t W, float *V, void *stream);
 int efgh_wino2d_output(const float *M, const efgh_gemm_desc *d, void *stream);
+/* the same output transform for a layer that is followed by nn.MaxPool2d(2,2) (nets/vgg.py:69-83, inference): d->out is the POOLED map
+ * [B][Hin/2][Win/2][ldo] = max over each 2x2 window of act((v + bias)*scale + shift); no residual, no statistics */
+int efgh_wino2d_output_pooled(const float *M, const efgh_gemm_desc *d, void *stream);
 int efgh_wino2d_dy(const float *G, int64_t ldg, int32_t N, int32_t B, int32_t H, int32_t W, float *Gy, void *stream);
 int efgh_wino2d_wfinish(const float *S, float *dWp, int32_t N, int32_t C, void *stream);       /* dWp [N][9][C] = A3^T S A3 */
 
@@ -502,6 +505,10 @@ int efgh_sc_wgrad(const efgh_gemm_desc *d, const float *G, int64_t ldg, float *d
 int efgh_c4_supported(const efgh_gemm_desc *d);
 int32_t efgh_c4_stats_rows(int32_t B, int32_t Ho, int32_t Wo);
 int efgh_c4_conv3x3(const efgh_gemm_desc *d, void *stream);
+/* the same layer followed by nn.MaxPool2d(2,2) (nets/vgg.py:69-83, inference): stride 1, no residual / statistics; d->out is the
+ * POOLED map [B][Ho/2][Wo/2][ldo]; bit-identical to efgh_c4_conv3x3 + efgh_maxpool2 */
+int efgh_c4_pooled_supported(const efgh_gemm_desc *d);
+int efgh_c4_conv3x3_pooled(const efgh_gemm_desc *d, void *stream);
 int efgh_c4_wgrad_supported(const efgh_gemm_desc *d);
 int64_t efgh_c4_wgrad_workspace(const efgh_gemm_desc *d);
 int efgh_c4_wgrad(const efgh_gemm_desc *d, const float *G, int64_t ldg, float *dWp, float *workspace, void *stream);

@@ -900,3 +900,69 @@ def test_batched_winograd_weight_transforms_follow_the_batched_repack():
             U1, U2 = V1, V2
         finally:
             ops.BATCH_WINO = True
+
+
+@pytest.mark.parametrize('cin,cout,hw,B', [(128, 256, (9, 13), 2), (256, 256, (8, 12), 1), (512, 512, (10, 14), 3), (128, 128, (17, 262), 1),
+                                           (256, 512, (2, 3), 2)])
+def test_inference_maxpool_rides_in_the_winograd2d_output_transform(L, cin, cout, hw, B):
+    """nets/vgg.py:69-83 in eval mode: [Conv2d 3x3, BatchNorm2d, ReLU, MaxPool2d(2,2)] on the 2-D Winograd path writes the pooled map
+    straight from the output transform (efgh_wino2d_output_pooled) - bit-identical to the unfused layer followed by efgh_maxpool2
+    (the transform's contraction order is written out, so both instantiations round alike), odd heights / widths (floor mode) and
+    ragged tiles included, and equal to torch within the layer's usual tolerance"""
+    from efgh_amd import ops
+    torch.manual_seed(5)
+    feats = nn.Sequential(nn.Conv2d(cin, cout, 3, 1, 1), nn.BatchNorm2d(cout), nn.ReLU(), nn.MaxPool2d(2, 2))
+    with torch.no_grad():
+        feats[1].running_mean.normal_(0, 0.2); feats[1].running_var.uniform_(0.5, 2.0)
+        feats[1].weight.normal_(0, 1.0)                     # (negative scales too: the affine runs before the max)
+    feats.eval()
+    x = torch.randn(B, cin, *hw)
+    with torch.no_grad():
+        ref = feats(x)
+    fg = nn.Sequential(nn.Conv2d(cin, cout, 3, 1, 1), nn.BatchNorm2d(cout), nn.ReLU(), nn.MaxPool2d(2, 2)).cuda()
+    fg.load_state_dict(feats.state_dict())
+    fg.eval()
+    xg = ops.nchw_to_nhwc(x.cuda(), cin)
+    old_min, ops.WINO2D_MIN_C = ops.WINO2D_MIN_C, 128
+    outs = {}
+    try:
+        for fused in (True, False):
+            ops.POOL_FUSED = fused
+            with torch.no_grad():
+                outs[fused] = L.run_vgg(L.Ctx(False), fg, xg)
+    finally:
+        ops.POOL_FUSED, ops.WINO2D_MIN_C = True, old_min
+    assert outs[True].shape == (B, hw[0] // 2, hw[1] // 2, cout)
+    assert torch.equal(outs[True], outs[False])
+    assert _rel(outs[True].permute(0, 3, 1, 2).cpu(), ref) < 2e-5
+
+
+@pytest.mark.parametrize('cin,cout,hw,B', [(4, 64, (9, 70), 2), (3, 64, (8, 33), 1), (4, 32, (6, 130), 2), (4, 128, (5, 31), 1), (3, 64, (2, 2), 3)])
+def test_inference_maxpool_rides_in_the_4_channel_input_layer(L, cin, cout, hw, B):
+    """the first layer of every VGG trunk in eval mode: [Conv2d(3|4 -> N) 3x3, BatchNorm2d, ReLU, MaxPool2d(2,2)] as ONE kernel
+    (efgh_c4_conv3x3_pooled: a wave owns a row pair, the window maximum is taken in its epilogue) - bit-identical to k_c4_conv
+    followed by efgh_maxpool2 (same MFMA order; max is exact), odd sizes and partial 32-pixel blocks included"""
+    from efgh_amd import ops
+    torch.manual_seed(7)
+    feats = nn.Sequential(nn.Conv2d(cin, cout, 3, 1, 1), nn.BatchNorm2d(cout), nn.ReLU(), nn.MaxPool2d(2, 2))
+    with torch.no_grad():
+        feats[1].running_mean.normal_(0, 0.2); feats[1].running_var.uniform_(0.5, 2.0); feats[1].weight.normal_(0, 1.0)
+    feats.eval()
+    x = torch.randn(B, cin, *hw)
+    with torch.no_grad():
+        ref = feats(x)
+    fg = nn.Sequential(nn.Conv2d(cin, cout, 3, 1, 1), nn.BatchNorm2d(cout), nn.ReLU(), nn.MaxPool2d(2, 2)).cuda()
+    fg.load_state_dict(feats.state_dict())
+    fg.eval()
+    xg = ops.nchw_to_nhwc(x.cuda(), 4)
+    outs = {}
+    try:
+        for fused in (True, False):
+            ops.POOL_FUSED = fused
+            with torch.no_grad():
+                outs[fused] = L.run_vgg(L.Ctx(False), fg, xg)
+    finally:
+        ops.POOL_FUSED = True
+    assert outs[True].shape == (B, hw[0] // 2, hw[1] // 2, cout)
+    assert torch.equal(outs[True], outs[False])
+    assert _rel(outs[True].permute(0, 3, 1, 2).cpu(), ref) < 2e-5
