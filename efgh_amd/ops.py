@@ -129,6 +129,7 @@ def _ver(*tensors):
 
 
 BATCH_PACK = True        # every stale packed layout of an owner in ONE launch (tests flip it to compare with per-layout packing)
+PACK_TILED = True        # ... through LDS tiles, coalesced on both sides (False: the flat one-lane-per-element kernel)
 
 
 class _PackJob(ctypes.Structure):
@@ -172,7 +173,7 @@ def _repack_all(device, holder):
         holder.jobs[:] = live
         if not jobs:
             return
-        sig = tuple((w.data_ptr(), buf.data_ptr(), key) for w, key, buf, _ in jobs)
+        sig = (PACK_TILED,) + tuple((w.data_ptr(), buf.data_ptr(), key) for w, key, buf, _ in jobs)
         tab = holder.tables.get(device.index)
         if tab is None or tab[0] != sig:
             arr = (_PackJob * len(jobs))()
@@ -184,12 +185,15 @@ def _repack_all(device, holder):
                 for q in range(16):
                     j.taps[q] = int(taps[q]) if (taps is not None and q < len(taps)) else (q if q < T else 0)
                 prefix.append(total)
-                total += Np * T * Cp
+                total += (Np * T * Cp) if not PACK_TILED else ((Np + 7) // 8) * ((Cp + 31) // 32)
             prefix.append(total)
             raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
             pre = torch.tensor(prefix, dtype=torch.int64).to(device)
             tab = holder.tables[device.index] = (sig, raw, pre, total)
-        _C.check(_L().efgh_pack_weight_batched(ptr(tab[1]), ptr(tab[2]), c_int32(len(jobs)), c_int64(tab[3]), _st()))
+        if PACK_TILED:      # (prefix over LDS tiles of 8 rows x 32 channels)
+            _C.check(_L().efgh_pack_weight_batched_tiled(ptr(tab[1]), ptr(tab[2]), c_int32(len(jobs)), c_int64(tab[3]), _st()))
+        else:
+            _C.check(_L().efgh_pack_weight_batched(ptr(tab[1]), ptr(tab[2]), c_int32(len(jobs)), c_int64(tab[3]), _st()))
         for w, key, buf, cur in jobs:
             buf._efgh_gen = getattr(buf, '_efgh_gen', 0) + 1
             w.__dict__['_efgh_cache'][key] = (cur, buf)

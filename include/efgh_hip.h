@@ -274,6 +274,10 @@ typedef struct {
     int32_t taps[16];
 } efgh_pack_job;
 int efgh_pack_weight_batched(const efgh_pack_job *jobs_dev, const int64_t *prefix_dev, int32_t njobs, int64_t total, void *stream);
+/* the same values through LDS tiles of 8 rows x 32 channels x T taps (coalesced on both sides): tile_prefix_dev [njobs + 1] =
+ * exclusive prefix sums of ceil(Np / 8) * ceil(Cp / 32) (int64), ntiles = tile_prefix_dev[njobs] */
+int efgh_pack_weight_batched_tiled(const efgh_pack_job *jobs_dev, const int64_t *tile_prefix_dev, int32_t njobs, int64_t ntiles,
+                                   void *stream);
 /* out[m][n] = act(sum_z part[z][m][n] + bias[n]), part [S][M][N] contiguous (N % 4 == 0): the planes of a split-K launch */
 int efgh_fold_planes(const float *part, int32_t S, int64_t M, int32_t N, const float *bias, int32_t act, float slope, float *out,
                      int64_t ldo, void *stream);

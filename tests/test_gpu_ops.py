@@ -966,3 +966,38 @@ def test_inference_maxpool_rides_in_the_4_channel_input_layer(L, cin, cout, hw, 
     assert outs[True].shape == (B, hw[0] // 2, hw[1] // 2, cout)
     assert torch.equal(outs[True], outs[False])
     assert _rel(outs[True].permute(0, 3, 1, 2).cpu(), ref) < 2e-5
+
+
+@pytest.mark.parametrize('tiled', [True, False])
+def test_batched_repack_kernels_equal_the_single_pack(tiled):
+    """ops.repack_stale: every registered layout of every stale weight in one launch - the LDS-tiled kernel (coalesced reads along
+    W's contiguous axis, 128-byte rows out) and the flat one - against efgh_pack_weight_padded of the new weights: forward layouts,
+    transposed + tap-reversed data-gradient layouts, zero-padded rows / channels, tap subsets, 1 and 15 taps"""
+    from efgh_amd import ops
+    torch.manual_seed(11)
+    old = ops.PACK_TILED
+    ops.PACK_TILED = tiled
+    try:
+        cases = []
+        for (n, c, k) in [(64, 4, 9), (130, 70, 9), (256, 128, 9), (3, 10, 9), (37, 33, 1), (32, 64, 15), (16, 512, 4)]:
+            w = torch.randn(n, c, k, device='cuda')
+            rev = list(range(k))[::-1]
+            sub = list(range(0, k, 2))
+            lay = [(n, k, c, c * k, k, 1, list(range(k)), None, None, ('fwd',)),                      # Wp[n][t][c]
+                   (c, k, n, k, c * k, 1, rev, None, None, ('dgrad',)),                                # Wp[c][t'][n], taps reversed
+                   (n, k, c, c * k, k, 1, list(range(k)), -(-n // 4) * 4, -(-c // 4) * 4, ('pad',)),   # zero-padded to multiples of 4
+                   (n, len(sub), c, c * k, k, 1, sub, None, None, ('sub',))]                           # a subset of the taps
+            for (N, T, C, sn, sc, st, taps, Np, Cp, key) in lay:
+                if T > 16:
+                    continue
+                buf = ops.pack_weight(w, N, T, C, sn, sc, st, taps, Np=Np, Cp=Cp, key=key + (tiled,))
+                cases.append((w, (N, T, C, sn, sc, st, taps, Np, Cp), buf))
+        with torch.no_grad():
+            for w in {id(c[0]): c[0] for c in cases}.values():
+                w.add_(torch.randn_like(w))
+        ops.repack_stale(torch.device('cuda', torch.cuda.current_device()))
+        for w, (N, T, C, sn, sc, st, taps, Np, Cp), buf in cases:
+            fresh = ops.pack_weight(w, N, T, C, sn, sc, st, taps, Np=Np, Cp=Cp)       # (no key: a fresh single-launch pack)
+            assert torch.equal(buf, fresh), (tuple(w.shape), N, T, C, Np, Cp)
+    finally:
+        ops.PACK_TILED = old
