@@ -31,6 +31,9 @@ EFGH_SIDE_STREAM=0 EFGH_WGRAD_STREAM=0 rocprofv3 --kernel-trace --stats --output
 cp $SCR/s1/*/*kernel_stats.csv $OUT/train_kernel_stats_single_stream.csv
 rocprofv3 --kernel-trace --stats --output-format csv -d $SCR/sf -- python3 $ROOT/bench.py --mode fwd --no-cpu-baseline --no-config-r --no-branch-section > $OUT/bench_fwd_under_rocprof.json 2> $SCR/sf.err
 cp $SCR/sf/*/*kernel_stats.csv $OUT/fwd_kernel_stats.csv
+# the reference's own configuration (batch 1, stock Adam loop): 20 training iterations, per-iteration launch census
+rocprofv3 --kernel-trace --stats --output-format csv -d $SCR/cr -- python3 $ROOT/tools/config_r_loop.py 20 > $OUT/config_r_loop.txt 2> $SCR/cr.err
+cp $SCR/cr/*/*kernel_stats.csv $OUT/config_r_train_kernel_stats.csv
 ls -la $OUT
 tail -n 2 $SCR/*.err | tail -n 30
 rm -rf $SCR

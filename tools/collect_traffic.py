@@ -18,7 +18,7 @@ FAMILIES = {
     'wino2d_transforms': ['k_w2_input', 'k_w2_output', 'k_w2_dy'],
     # the dedicated HBM-bound contraction kernels (thin.hip, c4conv.hip, smallc.hip): reported per STEP, like `bcl`; bench.py sets
     # it against the algorithmic bytes of the launches these kernels served (roofline_hbm_convs.dedicated)
-    'hbm_convs': ['k_thin_', 'k_c4_conv<', 'k_c4_wgrad<', 'k_sc_conv<', 'k_sc_wgrad<', 'k_c4n4_', 'k_n4_conv3x3_c64'],
+    'hbm_convs': ['k_thin_', 'k_c4_conv<', 'k_c4_conv_pool<', 'k_c4_wgrad<', 'k_sc_conv<', 'k_sc_wgrad<', 'k_c4n4_', 'k_n4_conv3x3_c64'],
     'bcl': ['k_lat_keys', 'k_lat_minmax', 'k_lat_scatter', 'k_lat_bucket', 'k_lat_rank', 'k_lat_number', 'k_lat_nbr', 'k_blur_dgrad_alias',
             'k_level_init', 'k_point_keys', 'k_minmax_finalize', 'k_insert', 'k_seg_count', 'k_seg_scan', 'k_seg_assign', 'k_place',
             'k_sortmin', 'k_flag_count', 'k_scan_sums', 'k_assign', 'k_offsets', 'k_neighbors', 'k_splat_gather', 'k_splat_bwd',
