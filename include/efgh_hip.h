@@ -35,7 +35,11 @@ const char *efgh_last_error(void);
  *      against a round-3 header pass their stream as the workspace.
  *   2  round 5: that signature change is recorded here; efgh_plane_gemm / efgh_plane_wgrad (LDS-DMA staged batched plain GEMMs),
  *      the per-sample fused small-level lattice build, the split-precision entry points (efgh_gather_gemm_{bf16x3,bf16x6,f16x3},
- *      efgh_split_{bf16,f16}) removed. */
+ *      efgh_split_{bf16,f16}) removed.
+ *      Added later in round 5 WITHOUT moving the number (no existing signature or struct changed; a caller built against the
+ *      earlier version-2 header keeps working, a caller of the new entry points against an earlier library fails at symbol lookup):
+ *      efgh_wino_pack_batched, efgh_pack_weight_batched_tiled, efgh_wino2d_output_pooled, efgh_c4_pooled_supported,
+ *      efgh_c4_conv3x3_pooled. */
 #define EFGH_ABI_VERSION 2
 int efgh_version(void);
 
