@@ -1,7 +1,7 @@
 """Batched pose-head algebra without host synchronisation (replaces the per-sample python loops
 with .item()/.tolist() of common/torch_utils.py:105-146, 170-233, 256-296): one HIP launch per head
 (csrc/pose.hip), forward and - on the training path - a hand-written backward.  The same formulas as
-device tensor expressions are kept below as the EFGH_POSE_KERNELS=0 path (what the kernels are tested
+device tensor expressions are kept below as the `USE_KERNELS = False` path (what the kernels are tested
 against).  Differentiability mirrors the reference: the skew matrix K is built from detached values,
 only (1-c)/s^2 carries gradient (torch_utils.py:184,194); translation matrices are detached (:229)."""
 import ctypes

@@ -4,7 +4,7 @@
 No host synchronisation (the reference loops over the batch with .item()/int() on every sample).  The pose terms (E/H cosine +
 sign cross-entropy, F mined BCE, G translation) and all ground-truth poses are ONE HIP kernel forward and one backward
 (csrc/pose.hip, PoseLossFn); the image terms are another (csrc/loss.hip, GImageLossFn); the GT depth image goes through the HIP
-rasteriser.  `_compute_loss_expressions` keeps the same loss as batched device tensor expressions (EFGH_POSE_KERNELS=0; what the
+rasteriser.  `_compute_loss_expressions` keeps the same loss as batched device tensor expressions (`common.pose.USE_KERNELS = False`; what the
 kernels are tested against).  Quirks
 reproduced on purpose: `total` sums every dict entry (so e_gn / h_hrzn count twice,
 efghloss.py:33-36), g_mask is scaled by lambda_g_mask AND lambda_g_depth (loss_utils.py:199,204),
