@@ -100,7 +100,37 @@ def cpu_baseline(raw, npts, mode, timed=3):
         one()
         ts.append(time.time() - t0)
     dt = sum(ts) / len(ts)
-    return {'value': 1.0 / dt, 'unit': 'frame-pairs/s', 'cores': cores, 'kind': 'port',
+    # "report the lattice build time separately (C CPU vs HIP)": the five-level pyramid of the same frame
+    # (nets/transforms.py:125-184, nets/generate_data.py:117-193) through oracle/lattice_oracle.c on ONE host thread (a scalar port)
+    # and through efgh_amd.lattice on the GPU (launches + the one read-back of the level sizes, median of 5 after a warm-up)
+    lat = None
+    try:
+        from efgh_amd import lattice as hip_lattice
+        from oracle import lattice as c_lattice
+        scales = [s_ for s_, _ in args['scale_map']]
+        pc1 = b['pc'][0]
+        c_lattice.generate_data(pc1, scales)
+        tl = []
+        for _ in range(3):
+            t0 = time.time()
+            c_lattice.generate_data(pc1, scales)
+            tl.append(time.time() - t0)
+        lat = {'cpu_c_port_ms': round(1e3 * sorted(tl)[1], 2), 'cpu_threads': 1}
+        if torch.cuda.is_available():
+            pcd = torch.from_numpy(b['pc']).cuda()
+            th = []
+            for _ in range(6):
+                torch.cuda.synchronize()
+                t0 = time.time()
+                hip_lattice.build_pyramid_batched(pcd, scales)
+                torch.cuda.synchronize()
+                th.append(time.time() - t0)
+            lat['hip_ms'] = round(1e3 * sorted(th[1:])[2], 3)
+            lat['note'] = ('one frame (%d points), five levels; hip_ms = wall clock of build_pyramid_batched at batch 1 incl. its one host '
+                           'read-back; the same arrays bit for bit (tests/test_gpu_lattice.py)' % npts)
+    except Exception as e:          # noqa: BLE001
+        lat = {'error': repr(e)}
+    return {'value': 1.0 / dt, 'unit': 'frame-pairs/s', 'cores': cores, 'kind': 'port', 'lattice_build': lat,
             'host_cpus': host, 'cpu_model': cpu_model(), 'iterations_s': [round(t, 2) for t in ts], 'warmup_s': round(warm, 2),
             'sample': '%d timed iterations after 1 warm-up, each ONE frame-pair of the same workload (%dx%d RGB, %d points; %s, '
                       'B=1) through oracle/efgh_oracle.py + oracle/lattice_oracle.c, torch CPU fp32, %d of %d host threads, '
