@@ -259,6 +259,9 @@ def test_training_step_vs_oracle_and_golden(golden_dir, manifest, monkeypatch):
     assert worst['G'][0] < 5e-2, worst['G']
     med_f = sorted(e for e, _ in errs['F'])[len(errs['F']) // 2]
     assert med_f < 5e-2, (med_f, worst['F'])
+    # the WORST F parameter as well (round 5; measured 5.9e-3 - the bound is the oracle's own 1- vs 8-thread spread of the terms above, not
+    # the 0.39 of its mined / normalised ones: those flip as a whole or not at all, and on this case they do not)
+    assert worst['F'][0] < 5e-2, worst['F']
     print('grad rel err: ' + ', '.join('%s max %.1e' % (n, worst[n][0]) for n in 'EHFG') + ', F median %.1e' % med_f)
 
 
