@@ -54,6 +54,7 @@ def lib():
             raise EfghError(f'{SO_PATH} has ABI version {got}, this package binds version {ABI_VERSION} of include/efgh_hip.h: '
                             f'rebuild it (`python -m efgh_amd.build`)')
         _lib.efgh_wino2d_tiles.restype = c_int64
+        _lib.efgh_segment_workspace.restype = c_int64
         _lib.efgh_gather_wgrad_workspace.restype = c_int64
         _lib.efgh_plane_wgrad_workspace.restype = c_int64
         _lib.efgh_wino_wgrad_workspace.restype = c_int64

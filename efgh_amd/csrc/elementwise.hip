@@ -238,6 +238,73 @@ k_segment_colmean(const float *__restrict__ x, long long ld, int C, int rows_per
     y[(long long)s * C + c] = (float)(a / rows_per_seg);
 }
 
+// ---- the same two reductions in two stages (round 5): the one-stage kernels above give a segment ONE workgroup per 256 (32)
+// columns - 4-8 workgroups on 256 CUs for the network's shapes (E / H: 128 columns x 31 k vertices per sample; G's translation head:
+// 3 columns x 7 680 positions), each thread walking its whole segment: 224 us for 64 MB.  Stage 1: RS row slices per segment, block =
+// CL column lanes x 256 / CL row lanes, partial (max, first row) / double sums per slice; stage 2 folds the slices IN ORDER
+// (first maximum wins, as torch.max; the sums in a fixed order).  Same results as the one-stage kernels (the mean may differ in
+// its last bit: another summation order of the same doubles).
+__global__ void __launch_bounds__(TPB)
+k_segment_colmax_s1(const float *__restrict__ x, long long ld, int C, const int *__restrict__ seg, int RS, int CL,
+                    float *__restrict__ pmax, int *__restrict__ prow) {
+    __shared__ float sm[TPB]; __shared__ int sr[TPB];
+    const int cl = threadIdx.x % CL, rl = threadIdx.x / CL, RL = TPB / CL;
+    const int c = blockIdx.x * CL + cl, s = blockIdx.y, k = blockIdx.z;
+    const int r0 = seg[s], len = seg[s + 1] - r0;
+    const int a = r0 + (int)((long long)len * k / RS), b = r0 + (int)((long long)len * (k + 1) / RS);
+    float m = -INFINITY; int am = a;
+    if (c < C)
+        for (int r = a + rl; r < b; r += RL) { const float v = x[(long long)r * ld + c]; if (v > m) { m = v; am = r; } }
+    sm[threadIdx.x] = m; sr[threadIdx.x] = am;
+    __syncthreads();
+    if (rl != 0 || c >= C) return;
+    for (int i = 1; i < RL; ++i) {                   // row lanes interleave the rows: a tie goes to the smaller row index
+        const float v = sm[i * CL + cl]; const int r = sr[i * CL + cl];
+        if (v > m || (v == m && r < am)) { m = v; am = r; }
+    }
+    if (b <= a) { m = -INFINITY; am = a; }
+    pmax[((long long)s * RS + k) * C + c] = m; prow[((long long)s * RS + k) * C + c] = am;
+}
+
+__global__ void __launch_bounds__(TPB)
+k_segment_colmax_s2(const float *__restrict__ pmax, const int *__restrict__ prow, int C, int RS, const int *__restrict__ seg,
+                    float *__restrict__ y, int *__restrict__ argrow) {
+    const int s = blockIdx.y, c = blockIdx.x * TPB + threadIdx.x;
+    if (c >= C) return;
+    float m = -INFINITY; int am = seg[s];
+    for (int k = 0; k < RS; ++k) {
+        const float v = pmax[((long long)s * RS + k) * C + c];
+        if (v > m) { m = v; am = prow[((long long)s * RS + k) * C + c]; }
+    }
+    y[(long long)s * C + c] = m;
+    if (argrow) argrow[(long long)s * C + c] = am;
+}
+
+__global__ void __launch_bounds__(TPB)
+k_segment_colmean_s1(const float *__restrict__ x, long long ld, int C, int rows_per_seg, int RS, int CL, double *__restrict__ part) {
+    __shared__ double sm[TPB];
+    const int cl = threadIdx.x % CL, rl = threadIdx.x / CL, RL = TPB / CL;
+    const int c = blockIdx.x * CL + cl, s = blockIdx.y, k = blockIdx.z;
+    const int a = (int)((long long)rows_per_seg * k / RS), b = (int)((long long)rows_per_seg * (k + 1) / RS);
+    double acc = 0.0;
+    if (c < C)
+        for (int r = a + rl; r < b; r += RL) acc += x[((long long)s * rows_per_seg + r) * ld + c];
+    sm[threadIdx.x] = acc;
+    __syncthreads();
+    if (rl != 0 || c >= C) return;
+    for (int i = 1; i < RL; ++i) acc += sm[i * CL + cl];
+    part[((long long)s * RS + k) * C + c] = acc;
+}
+
+__global__ void __launch_bounds__(TPB)
+k_segment_colmean_s2(const double *__restrict__ part, int C, int RS, int rows_per_seg, float *__restrict__ y) {
+    const int s = blockIdx.y, c = blockIdx.x * TPB + threadIdx.x;
+    if (c >= C) return;
+    double a = 0.0;
+    for (int k = 0; k < RS; ++k) a += part[((long long)s * RS + k) * C + c];
+    y[(long long)s * C + c] = (float)(a / rows_per_seg);
+}
+
 // softmax over the first 2 channels of [rows][ld] -> planar (B,2,HW)  (g_mask, gnet.py:124)
 __global__ void __launch_bounds__(TPB)
 k_softmax2_to_nchw(const float *__restrict__ x, long long ld, float *__restrict__ y, int B, long long HW) {
@@ -387,6 +454,44 @@ extern "C" int efgh_segment_colmean(const float *x, int64_t ld, int32_t C, int32
     EFGH_CHECK_ARG(x && y && C > 0 && nseg > 0 && rows_per_seg > 0);
     dim3 grid(cdiv(C, 32), nseg);
     k_segment_colmean<<<grid, TPB, 0, (hipStream_t)stream>>>(x, ld, C, rows_per_seg, y);
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}
+
+// slices per segment of the two-stage forms: enough workgroups to fill the part (~1024), at least ~64 rows per slice
+static int seg_slices(long long rows_per_seg, int nseg, int cblocks) {
+    long long rs = 1024 / ((long long)nseg * cblocks);
+    if (rs > rows_per_seg / 64) rs = rows_per_seg / 64;
+    if (rs > 256) rs = 256;
+    return (int)(rs < 1 ? 1 : rs);
+}
+static int seg_col_lanes(int C) { int cl = 1; while (cl < 32 && cl < C) cl <<= 1; return cl; }
+
+extern "C" int64_t efgh_segment_workspace(int32_t C, int32_t nseg) {      // bytes (either reduction): 256 slices x (8 + 4) bytes at most
+    return (int64_t)nseg * 256 * C * 12;
+}
+
+extern "C" int efgh_segment_colmax_ws(const float *x, int64_t ld, int32_t C, const int32_t *seg, int32_t nseg, int64_t rows_hint,
+                                      float *y, int32_t *argrow, void *workspace, void *stream) {
+    EFGH_CHECK_ARG(x && seg && y && workspace && C > 0 && nseg > 0 && rows_hint > 0);
+    const int CL = seg_col_lanes(C), cb = cdiv(C, CL);
+    const int RS = seg_slices(rows_hint / nseg, nseg, cb);
+    float *pmax = (float *)workspace;
+    int *prow = (int *)(pmax + (long long)nseg * RS * C);
+    k_segment_colmax_s1<<<dim3(cb, nseg, RS), TPB, 0, (hipStream_t)stream>>>(x, ld, C, seg, RS, CL, pmax, prow);
+    k_segment_colmax_s2<<<dim3(cdiv(C, TPB), nseg), TPB, 0, (hipStream_t)stream>>>(pmax, prow, C, RS, seg, y, argrow);
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}
+
+extern "C" int efgh_segment_colmean_ws(const float *x, int64_t ld, int32_t C, int32_t rows_per_seg, int32_t nseg, float *y,
+                                       void *workspace, void *stream) {
+    EFGH_CHECK_ARG(x && y && workspace && C > 0 && nseg > 0 && rows_per_seg > 0 && (((uintptr_t)workspace) & 7) == 0);
+    const int CL = seg_col_lanes(C), cb = cdiv(C, CL);
+    const int RS = seg_slices(rows_per_seg, nseg, cb);
+    double *part = (double *)workspace;
+    k_segment_colmean_s1<<<dim3(cb, nseg, RS), TPB, 0, (hipStream_t)stream>>>(x, ld, C, rows_per_seg, RS, CL, part);
+    k_segment_colmean_s2<<<dim3(cdiv(C, TPB), nseg), TPB, 0, (hipStream_t)stream>>>(part, C, RS, rows_per_seg, y);
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
 }

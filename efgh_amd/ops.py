@@ -789,18 +789,32 @@ def nhwc_to_nchw(x, Cs=None):
     return y
 
 
+SEGMENT_TWO_STAGE = True        # the per-sample reductions of E / H / G's heads spread over ~1024 workgroups (False: one per 256 columns)
+
+
+def _segment_ws(C, nseg, device):
+    return _scratch((_L().efgh_segment_workspace(c_int32(C), c_int32(nseg)) + 3) // 4, device)
+
+
 def segment_colmax(x, ld, C, seg, nseg, want_arg=False):
     y = torch.empty((nseg, C), dtype=torch.float32, device=x.device)
     arg = torch.empty((nseg, C), dtype=torch.int32, device=x.device) if want_arg else None
-    _C.check(_L().efgh_segment_colmax(ptr(x), c_int64(ld), c_int32(C), ptr(seg), c_int32(nseg), ptr(y), ptr(arg),
-                                      _st()))
+    rows = x.numel() // ld
+    if SEGMENT_TWO_STAGE and rows >= 2048:
+        _C.check(_L().efgh_segment_colmax_ws(ptr(x), c_int64(ld), c_int32(C), ptr(seg), c_int32(nseg), c_int64(rows), ptr(y), ptr(arg),
+                                             ptr(_segment_ws(C, nseg, x.device)), _st()))
+    else:
+        _C.check(_L().efgh_segment_colmax(ptr(x), c_int64(ld), c_int32(C), ptr(seg), c_int32(nseg), ptr(y), ptr(arg), _st()))
     return y, arg
 
 
 def segment_colmean(x, ld, C, rows_per_seg, nseg):
     y = torch.empty((nseg, C), dtype=torch.float32, device=x.device)
-    _C.check(_L().efgh_segment_colmean(ptr(x), c_int64(ld), c_int32(C), c_int32(rows_per_seg), c_int32(nseg),
-                                       ptr(y), _st()))
+    if SEGMENT_TWO_STAGE and rows_per_seg >= 512:
+        _C.check(_L().efgh_segment_colmean_ws(ptr(x), c_int64(ld), c_int32(C), c_int32(rows_per_seg), c_int32(nseg), ptr(y),
+                                              ptr(_segment_ws(C, nseg, x.device)), _st()))
+    else:
+        _C.check(_L().efgh_segment_colmean(ptr(x), c_int64(ld), c_int32(C), c_int32(rows_per_seg), c_int32(nseg), ptr(y), _st()))
     return y
 
 

@@ -39,7 +39,7 @@ const char *efgh_last_error(void);
  *      Added later in round 5 WITHOUT moving the number (no existing signature or struct changed; a caller built against the
  *      earlier version-2 header keeps working, a caller of the new entry points against an earlier library fails at symbol lookup):
  *      efgh_wino_pack_batched, efgh_pack_weight_batched_tiled, efgh_wino2d_output_pooled, efgh_c4_pooled_supported,
- *      efgh_c4_conv3x3_pooled. */
+ *      efgh_c4_conv3x3_pooled, efgh_segment_workspace, efgh_segment_colmax_ws, efgh_segment_colmean_ws. */
 #define EFGH_ABI_VERSION 2
 int efgh_version(void);
 
@@ -320,6 +320,14 @@ int efgh_segment_colmax(const float *x, int64_t ld, int32_t C, const int32_t *se
 /* torch.mean(x, 2) over equal segments (gnet.py:165) */
 int efgh_segment_colmean(const float *x, int64_t ld, int32_t C, int32_t rows_per_seg, int32_t nseg,
                          float *y, void *stream);
+/* the same two reductions in two stages (row slices per segment, folded in order: same maxima / first rows, the mean from another
+ * summation order of the same doubles) - the forms the network uses: a segment is spread over ~1024 / nseg workgroups instead of
+ * one per 256 (32) columns.  workspace: efgh_segment_workspace(C, nseg) bytes, 8-byte aligned; rows_hint = total rows (sizes the slices) */
+int64_t efgh_segment_workspace(int32_t C, int32_t nseg);
+int efgh_segment_colmax_ws(const float *x, int64_t ld, int32_t C, const int32_t *seg, int32_t nseg, int64_t rows_hint, float *y,
+                           int32_t *argrow, void *workspace, void *stream);
+int efgh_segment_colmean_ws(const float *x, int64_t ld, int32_t C, int32_t rows_per_seg, int32_t nseg, float *y, void *workspace,
+                            void *stream);
 /* nn.Softmax(dim=1) over 2 channels, written planar (B,2,H,W) (gnet.py:124) */
 int efgh_softmax2_to_nchw(const float *x, int64_t ld, float *y, int32_t B, int64_t HW, void *stream);
 /* G's depth and mask heads carried as ONE map x[B*HW][4] (channel 0 depth, channels 1-2 mask logits): g_depth (B,1,HW) and

@@ -1001,3 +1001,44 @@ def test_batched_repack_kernels_equal_the_single_pack(tiled):
             assert torch.equal(buf, fresh), (tuple(w.shape), N, T, C, Np, Cp)
     finally:
         ops.PACK_TILED = old
+
+
+def test_two_stage_segment_reductions_equal_the_one_stage_kernels():
+    """torch.max over the vertices of a sample (enet.py:154, hnet.py:53) and torch.mean over the positions (gnet.py:165): the
+    two-stage kernels (row slices folded in order) against the one-stage ones and torch - ragged segments, an empty one, repeated
+    maxima (the FIRST row wins, as torch.max), 128 columns and 3; the mean to one ulp (another order of the same float64 sums)"""
+    from efgh_amd import ops
+    torch.manual_seed(2)
+    lens = [31159, 0, 2048, 17, 40000]
+    M, C = sum(lens), 128
+    x = torch.randn(M, C, device='cuda')
+    x[torch.randint(0, M, (20000,), device='cuda'), torch.randint(0, C, (20000,), device='cuda')] = 3.5      # repeated maxima
+    seg = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device='cuda')
+    outs = {}
+    for two in (True, False):
+        ops.SEGMENT_TWO_STAGE = two
+        try:
+            outs[two] = ops.segment_colmax(x, C, C, seg, len(lens), want_arg=True)
+        finally:
+            ops.SEGMENT_TWO_STAGE = True
+    assert torch.equal(outs[True][0], outs[False][0]) and torch.equal(outs[True][1], outs[False][1])
+    for s, n in enumerate(lens):
+        if n:
+            a, b = int(seg[s]), int(seg[s + 1])
+            ref = x[a:b].max(0)
+            assert torch.equal(outs[True][0][s], ref.values)
+            # torch.max's index on ties is unspecified on CUDA: check ours is the first row that attains the maximum
+            first = (x[a:b] == ref.values[None]).float().argmax(0) + a
+            assert torch.equal(outs[True][1][s].long(), first)
+    for C2, P, B in ((3, 7680, 4), (4, 30720, 1), (64, 1000, 8)):
+        t = torch.randn(B * P, 4 if C2 < 4 else C2, device='cuda')
+        ms = {}
+        for two in (True, False):
+            ops.SEGMENT_TWO_STAGE = two
+            try:
+                ms[two] = ops.segment_colmean(t, t.shape[-1], C2, P, B)
+            finally:
+                ops.SEGMENT_TWO_STAGE = True
+        ref = t.view(B, P, -1)[:, :, :C2].double().mean(1).float()
+        assert float((ms[True] - ref).abs().max()) <= 1.2e-7 * float(ref.abs().max()) + 1e-9
+        assert float((ms[True] - ms[False]).abs().max()) <= 1.2e-7 * float(ref.abs().max()) + 1e-9
