@@ -14,8 +14,17 @@ k_minmax_part(const float *__restrict__ x, long long n, int G, float *__restrict
     int b = blockIdx.y, g = blockIdx.x;
     const float *p = x + (long long)b * n;
     float mn = INFINITY, mx = -INFINITY;
-    for (long long i = (long long)g * TPB + threadIdx.x; i < n; i += (long long)G * TPB) {
-        float v = p[i]; mn = fminf(mn, v); mx = fmaxf(mx, v);
+    if ((n & 3) == 0 && (((uintptr_t)p) & 15) == 0) {          // 16-byte loads (min / max do not care about the order)
+        const float4 *p4 = reinterpret_cast<const float4 *>(p);
+        const long long n4 = n >> 2;
+        for (long long i = (long long)g * TPB + threadIdx.x; i < n4; i += (long long)G * TPB) {
+            const float4 v = p4[i];
+            mn = fminf(fminf(mn, v.x), fminf(v.y, fminf(v.z, v.w))); mx = fmaxf(fmaxf(mx, v.x), fmaxf(v.y, fmaxf(v.z, v.w)));
+        }
+    } else {
+        for (long long i = (long long)g * TPB + threadIdx.x; i < n; i += (long long)G * TPB) {
+            float v = p[i]; mn = fminf(mn, v); mx = fmaxf(mx, v);
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { mn = fminf(mn, __shfl_xor(mn, o)); mx = fmaxf(mx, __shfl_xor(mx, o)); }
@@ -38,24 +47,22 @@ __global__ void k_minmax_final(const float *__restrict__ part, int G, float *__r
 
 // ---- normalise + pad: rng [B][h][w][C] -> rp [B][h][w+2*off][C] -----------------------------------
 // rows of y have `wpitch` >= w + 2*off pixels; the pixels past the padded width are zero
+// grid (pixels of a padded row x channel quads, h, B): no 64-bit index divisions per element (the flat version spent 75 us on 20 MB)
 __global__ void __launch_bounds__(TPB)
 k_norm_pad(const float *__restrict__ x, const float *__restrict__ mm, int B, int h, int w, int C, int off, int wpitch,
            float *__restrict__ y) {
     const int wp = w + 2 * off, c4n = C >> 2;
-    long long total = (long long)B * h * wpitch * c4n;
-    for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
-        int cq = (int)(i % c4n); long long r = i / c4n;
-        int xp = (int)(r % wpitch); r /= wpitch;
-        int yy = (int)(r % h); int b = (int)(r / h);
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (xp < wp) {
-            int xs = xp < off ? (w - 1 - xp) : (xp < off + w ? xp - off : xp - off - w);
-            float d = mm[b * 2 + 1] - mm[b * 2];
-            v = *reinterpret_cast<const float4 *>(x + (((long long)b * h + yy) * w + xs) * C + cq * 4);
-            v.x /= d; v.y /= d; v.z /= d; v.w /= d;
-        }
-        reinterpret_cast<float4 *>(y)[i] = v;
+    const int idx = blockIdx.x * TPB + threadIdx.x;
+    if (idx >= wpitch * c4n) return;
+    const int xp = idx / c4n, cq = idx - xp * c4n, yy = blockIdx.y, b = blockIdx.z;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (xp < wp) {
+        const int xs = xp < off ? (w - 1 - xp) : (xp < off + w ? xp - off : xp - off - w);
+        const float d = mm[b * 2 + 1] - mm[b * 2];
+        v = *reinterpret_cast<const float4 *>(x + (((long long)b * h + yy) * w + xs) * C + cq * 4);
+        v.x /= d; v.y /= d; v.z /= d; v.w /= d;
     }
+    reinterpret_cast<float4 *>(y)[((long long)b * h + yy) * wpitch * c4n + idx] = v;
 }
 
 // ---- correlation partials: part[b][y][j] = sum_{x,c} rp[b][y][j+x][c] * cam[b][y][x][c]/(max-min) ----
@@ -156,19 +163,26 @@ k_corr_pack_cam(const float *__restrict__ cam, const float *__restrict__ cam_mm,
     }
 }
 
+// one output (b, j) per 32 lanes: lane s sums its camera segment over the nsplit row groups (nsplit dependent loads instead of
+// nsplit * nseg = 512 per thread - the first version gave every output ONE thread: 40 workgroups, 128 us for 26 MB), then a fixed
+// xor tree over the lanes (deterministic; nseg <= 32)
 __global__ void __launch_bounds__(TPB)
 k_corr_fold(const float *__restrict__ P, int B, int nsplit, long long Mv, int ldp, int nseg, int segw, int nj,
             float invC, float *__restrict__ logit, float *__restrict__ score) {
-    long long total = (long long)B * nj;
-    for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
-        int b = (int)(i / nj), j = (int)(i - (long long)b * nj);
+    const long long total = (long long)B * nj;
+    const int s = threadIdx.x & 31;
+    for (long long i = (long long)blockIdx.x * (TPB / 32) + (threadIdx.x >> 5); i < total; i += (long long)gridDim.x * (TPB / 32)) {
+        const int b = (int)(i / nj), j = (int)(i - (long long)b * nj);
         float a = 0.f;
-        for (int ks = 0; ks < nsplit; ++ks)
-            for (int s = 0; s < nseg; ++s)
+        if (s < nseg)
+            for (int ks = 0; ks < nsplit; ++ks)
                 a += P[(((long long)b * nsplit + ks) * Mv + j + (long long)s * segw) * ldp + s];
-        a *= invC;
-        if (logit) logit[i] = a;
-        score[i] = 1.0f / (1.0f + expf(-a));
+        a += __shfl_xor(a, 16); a += __shfl_xor(a, 8); a += __shfl_xor(a, 4); a += __shfl_xor(a, 2); a += __shfl_xor(a, 1);
+        if (s == 0) {
+            a *= invC;
+            if (logit) logit[i] = a;
+            score[i] = 1.0f / (1.0f + expf(-a));
+        }
     }
 }
 
@@ -315,7 +329,8 @@ extern "C" int efgh_corr_pad(const float *rng, const float *rng_mm, int32_t B, i
                              int32_t off, int32_t wpitch, float *rp, void *stream_) {
     EFGH_CHECK_ARG(rng && rng_mm && rp && B > 0 && h > 0 && w > 0 && C % 4 == 0 && off >= 0 && off <= w);
     EFGH_CHECK_ARG(wpitch >= w + 2 * off);
-    k_norm_pad<<<grid_for((long long)B * h * wpitch * (C / 4)), TPB, 0, (hipStream_t)stream_>>>(
+    EFGH_CHECK_ARG(h <= 65535 && B <= 65535 && (long long)wpitch * (C / 4) < 0x7fffffffLL);
+    k_norm_pad<<<dim3((unsigned)(((long long)wpitch * (C / 4) + TPB - 1) / TPB), h, B), TPB, 0, (hipStream_t)stream_>>>(
         rng, rng_mm, B, h, w, C, off, wpitch, rp);
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
@@ -349,7 +364,8 @@ extern "C" int efgh_corr_fold(const float *P, int32_t B, int32_t nsplit, int64_t
                               int32_t segw, int32_t nj, float *logit, float *score, void *stream_) {
     EFGH_CHECK_ARG(P && score && B > 0 && nsplit >= 1 && Mv > 0 && nseg > 0 && nseg <= ldp && nj > 0);
     EFGH_CHECK_ARG((int64_t)(nj - 1) + (int64_t)(nseg - 1) * segw < Mv);
-    k_corr_fold<<<grid_for((long long)B * nj), TPB, 0, (hipStream_t)stream_>>>(P, B, nsplit, Mv, ldp, nseg, segw, nj,
+    EFGH_CHECK_ARG(nseg <= 32);
+    k_corr_fold<<<grid_for((long long)B * nj * 32), TPB, 0, (hipStream_t)stream_>>>(P, B, nsplit, Mv, ldp, nseg, segw, nj,
                                                                              1.0f / 16.0f, logit, score);
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
