@@ -623,3 +623,62 @@ def test_fused_heads_packed_weights_follow_the_optimizer_when_outputs_are_droppe
             assert torch.equal(fresh, buf), (name, key)
             checked += 1
     assert checked >= 3          # forward layouts of both convolutions + at least one data-gradient layout
+
+
+@pytest.mark.parametrize('optimizer', ['fused', 'stock'])
+def test_every_cached_weight_image_is_current_after_training_steps(manifest, optimizer):
+    """cache invariant over the WHOLE model: after three fused-Adam steps (results discarded, so the allocator re-uses addresses) and
+    the repack a forward starts with, every packed layout whose cache key says "current" equals a fresh pack of the current weight,
+    and every Winograd-domain image (1-D and 2-D) cached on such a layout equals a fresh transform of it - the batched repack through
+    LDS tiles, the batched in-place Winograd transforms and the per-layer lazy paths all have to agree, layer by layer"""
+    from efgh_amd import _C, ops
+    from efgh_amd._C import c_int32, ptr
+    from efgh_amd.losses import EFGHCriterion
+    from efgh_amd.nets import EFGHBackbone
+    from efgh_amd.train import Trainer
+    args = syn.default_args(RAW, 'cuda')
+    m = EFGHBackbone(args)
+    m.load_state_dict(syn.synthetic_state_dict(manifest['state_dict'], 1))
+    m = m.cuda()
+    b = syn.make_batch(RAW, NPTS, 2)
+    inp = [torch.from_numpy(b[k]).cuda() for k in ('pc', 'img', 'calib', 'A')]
+    gt = {k: torch.from_numpy(v) for k, v in b['gt'].items()}
+    if optimizer == 'fused':
+        tr = Trainer(m, EFGHCriterion(args), lr=1e-3)
+        for _ in range(3):
+            tr.step(*inp, gt)
+    else:                                         # the reference's loop: stock Adam moves version counters, not an epoch
+        crit = EFGHCriterion(args)
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+        m.train()
+        for _ in range(3):
+            L, _ = crit.compute_loss(*inp, dict(gt), m(*inp))
+            opt.zero_grad()
+            L['total'].backward()
+            opt.step()
+            del L
+    m.eval()
+    with torch.no_grad():
+        m(*inp)                                   # starts with the batched repack of everything the last Adam step made stale
+    torch.cuda.synchronize()
+    layouts = images = 0
+    for name, w in m.named_parameters():
+        for key, ent in list(w.__dict__.get('_efgh_cache', {}).items()):
+            ver, buf = ent
+            if not torch.is_tensor(buf) or not hasattr(buf, '_efgh_pack') or ver != ops._ver(w):
+                continue                          # (not a packed layout, or a layout nothing has asked for since the last step)
+            N, T, C, Np, Cp, sn, sc, st, taps = buf._efgh_pack
+            fresh = ops.pack_weight(w, N, T, C, sn, sc, st, taps, Np=Np, Cp=Cp)
+            assert torch.equal(buf, fresh), (name, key)
+            layouts += 1
+            for ikey, fn in ((('wino',), 'efgh_wino_pack'), (('wino2d',), 'efgh_wino2d_pack')):
+                ient = buf.__dict__.get('_efgh_cache', {}).get(ikey)
+                if ient is None or ient[0] != ops._ver(buf):
+                    continue
+                U = ient[1]
+                Nn, Cc = (U.shape[2], U.shape[0] // 3 * 16) if ikey == ('wino',) else (U.shape[1], U.shape[2])
+                ref = torch.empty_like(U)
+                _C.check(getattr(_C.lib(), fn)(ptr(buf), ptr(ref), c_int32(Nn), c_int32(Cc), _C.stream_ptr()))
+                assert torch.equal(U, ref), (name, key, ikey)
+                images += 1
+    assert layouts >= 100 and images >= 20, (layouts, images)
