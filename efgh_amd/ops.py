@@ -258,20 +258,28 @@ def repack_stale(device, holder=None):
     _repack_all(device, holder)
 
 
+_SENTINELS = {}          # id(holder) -> (len(jobs), [job indices of a few TRAINABLE weights, spread over the list])
+
+
 def _sentinel_stale(holder, device):
-    """weights without an owner are updated by stock torch optimizers, which move version counters, not the holder's epoch: one
-    registered layout stands for all (an optimizer step rewrites every parameter) - if its key is stale, the whole set is
-    re-packed by the one batched launch instead of layer by layer (145 launches per step of the reference's own loop)"""
+    """weights without an owner are updated by stock torch optimizers, which move version counters, not the holder's epoch: a few
+    registered layouts stand for all (an optimizer step rewrites every TRAINABLE parameter) - if one of their keys is stale, the
+    whole set is re-packed by the one batched launch instead of layer by layer (145 launches per step of the reference's own
+    loop).  The sentinels are chosen among weights with requires_grad (with `grad_false_keys` freezing whole sub-networks, main.py:
+    162-183, a frozen weight never goes stale and must not stand for the rest); the choice is cached per job-list length."""
     jobs = holder.jobs
-    for i in sorted({0, len(jobs) // 3, 2 * len(jobs) // 3, len(jobs) - 1}):      # (a few: frozen sub-networks never go stale)
-        if i < 0 or i >= len(jobs):
-            continue
+    ent = _SENTINELS.get(id(holder))
+    if ent is None or ent[0] != len(jobs) or any(i >= len(jobs) or jobs[i][0]() is None or not jobs[i][0]().requires_grad for i in ent[1]):
+        train = [i for i, (ref, _) in enumerate(jobs) if ref() is not None and ref().requires_grad]
+        pick = sorted({train[0], train[len(train) // 3], train[2 * len(train) // 3], train[-1]}) if train else []
+        ent = _SENTINELS[id(holder)] = (len(jobs), pick)
+    for i in ent[1]:
         ref, key = jobs[i]
         w = ref()
         if w is None or not w.is_cuda or w.device != device or epoch_of(w) is not holder:
             continue
-        ent = w.__dict__.get('_efgh_cache', {}).get(key)
-        if ent is not None and ent[0] != _ver(w):
+        c = w.__dict__.get('_efgh_cache', {}).get(key)
+        if c is not None and c[0] != _ver(w):
             return True
     return False
 

@@ -682,3 +682,45 @@ def test_every_cached_weight_image_is_current_after_training_steps(manifest, opt
                 assert torch.equal(U, ref), (name, key, ikey)
                 images += 1
     assert layouts >= 100 and images >= 20, (layouts, images)
+
+
+def test_stale_detection_with_almost_everything_frozen(manifest):
+    """the reference's stage-wise training freezes whole sub-networks (main.py:162-183) and its stock optimizer moves version
+    counters only: the few registered layouts that stand for "an optimizer step happened" are chosen among the TRAINABLE weights,
+    so a step is seen - and answered by the one batched repack before the streams fork - even when a single late layer trains"""
+    from efgh_amd import ops
+    from efgh_amd.losses import EFGHCriterion
+    from efgh_amd.nets import EFGHBackbone
+    args = syn.default_args(RAW, 'cuda')
+    m = EFGHBackbone(args)
+    m.load_state_dict(syn.synthetic_state_dict(manifest['state_dict'], 1))
+    m = m.cuda()
+    for k, p in m.named_parameters():
+        p.requires_grad_(k.startswith('G.conv_trs_3.'))
+    train = [p for p in m.parameters() if p.requires_grad]
+    assert 1 <= len(train) <= 4
+    b = syn.make_batch(RAW, NPTS, 2)
+    inp = [torch.from_numpy(b[k]).cuda() for k in ('pc', 'img', 'calib', 'A')]
+    gt = {k: torch.from_numpy(v) for k, v in b['gt'].items()}
+    crit = EFGHCriterion(args)
+    opt = torch.optim.Adam(train, lr=1e-2)
+    m.train()
+    dev = inp[0].device
+    for it in range(2):
+        L, _ = crit.compute_loss(*inp, dict(gt), m(*inp))
+        opt.zero_grad()
+        L['total'].backward()
+        opt.step()
+        assert ops._sentinel_stale(ops.GLOBAL_EPOCH, dev), it       # the step is noticed although > 99 % of the layouts never go stale
+    w = dict(m.named_parameters())['G.conv_trs_3.0.weight']
+    m.eval()
+    with torch.no_grad():
+        m(*inp)
+    assert not ops._sentinel_stale(ops.GLOBAL_EPOCH, dev)
+    hit = 0
+    for key, (ver, buf) in w.__dict__['_efgh_cache'].items():
+        if torch.is_tensor(buf) and hasattr(buf, '_efgh_pack') and ver == ops._ver(w):
+            N, T, C, Np, Cp, sn, sc, st, taps = buf._efgh_pack
+            assert torch.equal(buf, ops.pack_weight(w, N, T, C, sn, sc, st, taps, Np=Np, Cp=Cp)), key
+            hit += 1
+    assert hit >= 1
