@@ -161,6 +161,20 @@ k_maxpool2(const float *__restrict__ x, float *__restrict__ y, int B, int H, int
     }
 }
 
+// the vertical half of a 2x2/2 max pool: [B][H][W][C] -> [B][H/2][W][C] (rows 2i, 2i+1; the horizontal half was taken by the producer,
+// k_wino43<.., HPOOL>)
+__global__ void __launch_bounds__(TPB)
+k_maxpool_v2(const float4 *__restrict__ x, float4 *__restrict__ y, int B, int H, long long rowq) {        // rowq = W * C / 4
+    const int Ho = H / 2;
+    const long long total = (long long)B * Ho * rowq;
+    for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
+        const long long q = i % rowq, r = i / rowq;
+        const int oh = (int)(r % Ho); const long long b = r / Ho;
+        const float4 a = x[((b * H + 2 * oh) * rowq) + q], c = x[((b * H + 2 * oh + 1) * rowq) + q];
+        y[i] = make_float4(fmaxf(a.x, c.x), fmaxf(a.y, c.y), fmaxf(a.z, c.z), fmaxf(a.w, c.w));
+    }
+}
+
 // BatchNorm + activation + 2x2/2 max pool in one pass over the raw conv output (training path of the VGG trunks):
 // y[b][oh][ow][c] = max over the window of act(raw*scale[c] + shift[c]); the full-resolution activation is never stored.
 template <bool NT>
@@ -409,6 +423,14 @@ extern "C" int efgh_scale_shift_act_bits(const float *x, int64_t ldx, const floa
 extern "C" int efgh_maxpool2(const float *x, float *y, int32_t B, int32_t H, int32_t W, int32_t C, void *stream) {
     EFGH_CHECK_ARG(x && y && B > 0 && H >= 2 && W >= 2 && C % 4 == 0);
     k_maxpool2<<<grid_for((long long)B * (H / 2) * (W / 2) * (C / 4)), TPB, 0, (hipStream_t)stream>>>(x, y, B, H, W, C);
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}
+
+extern "C" int efgh_maxpool_v2(const float *x, float *y, int32_t B, int32_t H, int32_t W, int32_t C, void *stream) {
+    EFGH_CHECK_ARG(x && y && B > 0 && H >= 2 && W >= 1 && C % 4 == 0 && (((uintptr_t)x) & 15) == 0 && (((uintptr_t)y) & 15) == 0);
+    const long long rowq = (long long)W * (C / 4);
+    k_maxpool_v2<<<grid_for((long long)B * (H / 2) * rowq), TPB, 0, (hipStream_t)stream>>>((const float4 *)x, (float4 *)y, B, H, rowq);
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
 }

@@ -51,7 +51,10 @@ struct WinoArgs {
 
 // BNM: the epilogue also takes the BatchNorm-backward column sums of the written value (stats_mode 1).  A template parameter, not a
 // run-time flag: the flag alone cost the plain kernel 9 % (measured) through the unrolled 16 x 4 epilogue.
-template <bool BNM>
+// HPOOL (inference, a layer followed by MaxPool2d(2,2)): a tile's four pixels are two horizontal halves of pooling windows - the
+// epilogue writes max(v0, v1), max(v2, v3) into a map of HALF the width ([B][H][W/2][N]); the vertical half of the window is a
+// separate pass over that map (a row pair is two workgroups here).  Half the output bytes, half the pooling pass's input.
+template <bool BNM, bool HPOOL = false>
 __global__ void __launch_bounds__(256, 2) k_wino43(const WinoArgs p) {
     __shared__ __attribute__((aligned(16))) float Vs[6 * TM * LD];
     __shared__ __attribute__((aligned(16))) float Us[6 * TN * LD];
@@ -97,6 +100,12 @@ __global__ void __launch_bounds__(256, 2) k_wino43(const WinoArgs p) {
             const int xt = (int)(t % p.TW); const long long r = t / p.TW;
             o = r * p.W + 4 * xt;                       // r = b*H + y
             cnt = p.W - 4 * xt; cnt = cnt > 4 ? 4 : cnt;
+            if (HPOOL) {                                // pooled pixels of the tile in the half-width map (floor: an odd last column has none)
+                const int wp = p.W >> 1;
+                o = r * wp + 2 * xt;
+                cnt = wp - 2 * xt; cnt = cnt > 2 ? 2 : cnt;
+                if (cnt <= 0) { o = -1; cnt = 0; }
+            }
         }
         tpix[tid] = o; tcnt[tid] = cnt;
     }
@@ -241,6 +250,14 @@ __global__ void __launch_bounds__(256, 2) k_wino43(const WinoArgs p) {
             const float m0_ = acc[0][r], m1 = acc[1][r], m2 = acc[2][r], m3 = acc[3][r], m4 = acc[4][r], m5 = acc[5][r];
             const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
             const float yv[4] = {m0_ + s12 + s34, d12 + 2.f * d34, s12 + 4.f * s34, d12 + 8.f * d34 + m5};
+            if (HPOOL) {                     // (no residual, no statistics: an inference epilogue)
+                float w[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { float v = yv[i] + bi; v = v * sc + sf; w[i] = act_neg(v, neg); }
+                st_out(op, fmaxf(w[0], w[1]));
+                if (FULL || cnt > 1) st_out(op + p.ldo, fmaxf(w[2], w[3]));
+                continue;
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 if (!FULL && i >= cnt) continue;
@@ -497,6 +514,26 @@ extern "C" int efgh_wino_conv3x3(const efgh_gemm_desc *d, const float *U, void *
     EFGH_CHECK_ARG(a.nbx * nby < 0x7fffffffLL);
     if (a.smode == 1) k_wino43<true><<<(unsigned)(a.nbx * nby), 256, 0, (hipStream_t)stream_>>>(a);
     else k_wino43<false><<<(unsigned)(a.nbx * nby), 256, 0, (hipStream_t)stream_>>>(a);
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}
+
+extern "C" int efgh_wino_conv3x3_hpool(const efgh_gemm_desc *d, const float *U, void *stream_) {
+    EFGH_CHECK_ARG(supported(d) && U && d->A && d->out && !d->residual && !d->stats && d->Win >= 2);
+    EFGH_CHECK_ARG((((uintptr_t)d->A) & 15) == 0 && (((uintptr_t)U) & 15) == 0);
+    EFGH_CHECK_ARG(d->B > 0 && d->M == (int64_t)d->B * d->Hin * d->Win);
+    WinoArgs a;
+    a.A = d->A; a.lda = d->lda; a.C = d->C;
+    a.B = d->B; a.H = d->Hin; a.W = d->Win; a.TW = (d->Win + 3) / 4;
+    a.U = U; a.N = d->N; a.Mt = (long long)d->B * d->Hin * a.TW;
+    a.bias = d->bias; a.scale = d->scale; a.shift = d->shift; a.residual = nullptr; a.ldr = 0;
+    a.act = d->act; a.slope = d->slope; a.out = d->out; a.ldo = d->ldo; a.stats = nullptr; a.smode = 0;
+    a.bn_raw = nullptr; a.bn_ldraw = 0; a.bn_y = nullptr; a.bn_ldy = 0;
+    a.bn_psc = a.bn_psh = a.bn_mean = a.bn_invstd = nullptr; a.bn_act = 0; a.bn_slope = 0.f;
+    a.nbx = (unsigned)(d->N / TN);
+    const long long nby = (a.Mt + TM - 1) / TM;
+    EFGH_CHECK_ARG(a.nbx * nby < 0x7fffffffLL);
+    k_wino43<false, true><<<(unsigned)(a.nbx * nby), 256, 0, (hipStream_t)stream_>>>(a);
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
 }

@@ -158,10 +158,10 @@ def conv2d(ctx, x, conv, bn=None, act=ACT_NONE, slope=0.0, residual=None, out=No
     if pool:
         # inference: the following MaxPool2d(2,2) rides in the layer's output transform (run_vgg asks pool_fusable first)
         assert out is None and residual is None and not ctx.train
-        out_t, ldo, coff = _alloc_out(x, (B, Ho // 2, Wo // 2), O, None)
+        out_t, ldo, coff = _alloc_out(x, (B, Ho if pool == 'h' else Ho // 2, Wo // 2), O, None)
         _run(ctx, x, ldx, Cp, T, Wp, O, M, 1, [(geom, Wp, M)], out_t, ldo, coff, conv.bias, bn, act, slope, a_off=a_off, c_real=Cw,
-             pool=True)
-        return out_t
+             pool=pool)
+        return ops.maxpool_v2(out_t) if pool == 'h' else out_t
     out_t, ldo, coff = _alloc_out(x, (B, Ho, Wo), O, out)
     res_ld = residual.shape[-1] if residual is not None else 0
     _run(ctx, x, ldx, Cp, T, Wp, O, M, 1, [(geom, Wp, M)], out_t, ldo, coff, conv.bias, bn, act, slope,

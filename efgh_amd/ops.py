@@ -269,10 +269,12 @@ def _sentinel_stale(holder, device):
     162-183, a frozen weight never goes stale and must not stand for the rest); the choice is cached per job-list length."""
     jobs = holder.jobs
     ent = _SENTINELS.get(id(holder))
-    if ent is None or ent[0] != len(jobs) or any(i >= len(jobs) or jobs[i][0]() is None or not jobs[i][0]().requires_grad for i in ent[1]):
+    if ent is None or ent[0] != len(jobs) or any(i >= len(jobs) or jobs[i][0]() is None or jobs[i][0]().requires_grad != ent[2] for i in ent[1]):
         train = [i for i, (ref, _) in enumerate(jobs) if ref() is not None and ref().requires_grad]
+        if not train:                 # (nothing trainable registered: plain tensors updated in place by the caller - any of them may stand)
+            train = [i for i, (ref, _) in enumerate(jobs) if ref() is not None]
         pick = sorted({train[0], train[len(train) // 3], train[2 * len(train) // 3], train[-1]}) if train else []
-        ent = _SENTINELS[id(holder)] = (len(jobs), pick)
+        ent = _SENTINELS[id(holder)] = (len(jobs), pick, bool(pick) and jobs[pick[0]][0]().requires_grad)
     for i in ent[1]:
         ref, key = jobs[i]
         w = ref()
@@ -584,6 +586,10 @@ def gather_gemm(A, lda, C, T, Wp, N, M, out, ldo, mode=0, geom=None, table=None,
         wino = '2d'
         _wino2d_forward(d, A, a_off, lda, C, N, geom, Wp, pool=pool)
         pool = False
+    elif M_dev is None and batch is None and wino_eligible(mode, C, N, geom) and pool == 'h':
+        wino = True
+        pool = False
+        _C.check(_L().efgh_wino_conv3x3_hpool(ctypes.byref(d), ptr(wino_weight(Wp, N, C)), _st()))
     elif M_dev is None and batch is None and wino_eligible(mode, C, N, geom):
         wino = True
         if bn_bwd is not None and stats is None and BN_BWD_FUSED and out_off == 0 and bn_bwd.fits(M, N):
@@ -668,12 +674,13 @@ def w2v_clear():
             del W2V_CACHE[k]
 
 
-POOL_FUSED = True               # inference: MaxPool2d(2,2) behind a 2-D Winograd layer folded into its output transform
+POOL_FUSED = True               # inference: MaxPool2d(2,2) folded into the producing layer (4-channel input layers, 2-D Winograd output transform)
+POOL_HALF = True                # ... and its horizontal half into the 1-D Winograd epilogue (k_wino43<.., HPOOL> + efgh_maxpool_v2)
 
 
 def pool_fusable(mode, C, N, geom, residual=None, stats=None):
-    """can gather_gemm(pool=True) serve this launch?  (the 4-channel input layers and the 2-D Winograd path, plain inference
-    epilogue)"""
+    """can gather_gemm(pool=...) serve this launch?  True: the whole 2x2 window in the producer (4-channel input layers, 2-D Winograd
+    path); 'h': the horizontal half (1-D Winograd path; `out` is [B][Ho][Wo/2][ldo], maxpool_v2 follows); False: no"""
     if not (POOL_FUSED and residual is None and stats is None and geom is not None and geom[1] >= 2 and geom[2] >= 2):
         return False
     if thin_eligible(mode, C, N, len(geom[7])):
@@ -682,7 +689,11 @@ def pool_fusable(mode, C, N, geom, residual=None, stats=None):
         return geom[5] == 1 and geom[6] == 1
     if sc_eligible(mode, C, N, geom):
         return False
-    return bool(wino2d_eligible(mode, C, N, geom))
+    if wino2d_eligible(mode, C, N, geom):
+        return True
+    if POOL_HALF and wino_eligible(mode, C, N, geom) and geom[2] >= 2:
+        return 'h'              # 1-D Winograd: the horizontal half in its epilogue, maxpool_v2 finishes the window
+    return False
 
 
 def _wino2d_forward(d, A, a_off, lda, C, N, geom, Wp, pool=False):
@@ -751,6 +762,14 @@ def maxpool2(x):
     B, H, W, C = x.shape
     y = torch.empty((B, H // 2, W // 2, C), dtype=torch.float32, device=x.device)
     _C.check(_L().efgh_maxpool2(ptr(x), ptr(y), c_int32(B), c_int32(H), c_int32(W), c_int32(C), _st()))
+    return y
+
+
+def maxpool_v2(x):
+    """the vertical half of MaxPool2d(2,2): [B][H][W][C] -> [B][H/2][W][C]"""
+    B, H, W, C = x.shape
+    y = torch.empty((B, H // 2, W, C), dtype=torch.float32, device=x.device)
+    _C.check(_L().efgh_maxpool_v2(ptr(x), ptr(y), c_int32(B), c_int32(H), c_int32(W), c_int32(C), _st()))
     return y
 
 

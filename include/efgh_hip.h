@@ -39,7 +39,8 @@ const char *efgh_last_error(void);
  *      Added later in round 5 WITHOUT moving the number (no existing signature or struct changed; a caller built against the
  *      earlier version-2 header keeps working, a caller of the new entry points against an earlier library fails at symbol lookup):
  *      efgh_wino_pack_batched, efgh_pack_weight_batched_tiled, efgh_wino2d_output_pooled, efgh_c4_pooled_supported,
- *      efgh_c4_conv3x3_pooled, efgh_segment_workspace, efgh_segment_colmax_ws, efgh_segment_colmean_ws. */
+ *      efgh_c4_conv3x3_pooled, efgh_segment_workspace, efgh_segment_colmax_ws, efgh_segment_colmean_ws,
+ *      efgh_wino_conv3x3_hpool, efgh_maxpool_v2. */
 #define EFGH_ABI_VERSION 2
 int efgh_version(void);
 
@@ -311,6 +312,8 @@ int efgh_scale_shift_act_bits(const float *x, int64_t ldx, const float *scale, c
                               const float *res, int64_t ldr, float *y, int64_t ldy, uint32_t *bits, int64_t M, int32_t C,
                               int32_t act, float slope, void *stream);
 int efgh_maxpool2(const float *x, float *y, int32_t B, int32_t H, int32_t W, int32_t C, void *stream);
+/* the vertical half alone, [B][H][W][C] -> [B][H/2][W][C]: behind a producer that took the horizontal half (efgh_wino_conv3x3_hpool) */
+int efgh_maxpool_v2(const float *x, float *y, int32_t B, int32_t H, int32_t W, int32_t C, void *stream);
 /* model-boundary layout changes: (B,Cs,H,W) <-> [B][H][W][Cd] (extra channels zero) */
 int efgh_nchw_to_nhwc(const float *x, float *y, int32_t B, int32_t Cs, int64_t HW, int32_t Cd, void *stream);
 int efgh_nhwc_to_nchw(const float *x, int64_t ld, float *y, int32_t B, int32_t Cs, int64_t HW, void *stream);
@@ -595,6 +598,9 @@ int efgh_corr_toeplitz(const float *dl, int32_t B, int32_t nj, int32_t rows, int
 int efgh_wino_supported(const efgh_gemm_desc *d);
 int32_t efgh_wino_grid_m(int32_t B, int32_t H, int32_t W);
 int efgh_wino_pack(const float *Wp, float *U, int32_t N, int32_t C, void *stream);
+/* inference, a layer followed by nn.MaxPool2d(2,2) (nets/vgg.py:69-83): d->out is the map of HALF the width [B][Hin][Win/2][ldo] =
+ * max over horizontal pixel pairs of act((v + bias)*scale + shift); efgh_maxpool_v2 finishes the window.  No residual / statistics */
+int efgh_wino_conv3x3_hpool(const efgh_gemm_desc *d, const float *U, void *stream);
 int efgh_wino_conv3x3(const efgh_gemm_desc *d, const float *U, void *stream);
 /* weight gradient of the same layers (replaces efgh_gather_wgrad for them; additionally C % 64 == 0): Winograd
  * F(3,4) over 4-pixel gradient tiles, six tile-contracted GEMMs per tile range written as partials [6][N][3C] into the

@@ -865,7 +865,7 @@ def test_batched_winograd_weight_transforms_follow_the_batched_repack():
     from efgh_amd._C import c_int32, ptr
     torch.manual_seed(3)
     shapes = [(64, 64), (128, 64), (256, 128), (16, 32)]
-    ws = [torch.randn(n, c, 3, 3, device='cuda') for n, c in shapes]
+    ws = [torch.randn(n, c, 3, 3, device='cuda').requires_grad_(True) for n, c in shapes]      # (trainable: what an optimizer steps)
 
     def packed(w):
         n, c = w.shape[:2]
@@ -980,7 +980,7 @@ def test_batched_repack_kernels_equal_the_single_pack(tiled):
     try:
         cases = []
         for (n, c, k) in [(64, 4, 9), (130, 70, 9), (256, 128, 9), (3, 10, 9), (37, 33, 1), (32, 64, 15), (16, 512, 4)]:
-            w = torch.randn(n, c, k, device='cuda')
+            w = torch.randn(n, c, k, device='cuda').requires_grad_(True)
             rev = list(range(k))[::-1]
             sub = list(range(0, k, 2))
             lay = [(n, k, c, c * k, k, 1, list(range(k)), None, None, ('fwd',)),                      # Wp[n][t][c]
@@ -1042,3 +1042,37 @@ def test_two_stage_segment_reductions_equal_the_one_stage_kernels():
         ref = t.view(B, P, -1)[:, :, :C2].double().mean(1).float()
         assert float((ms[True] - ref).abs().max()) <= 1.2e-7 * float(ref.abs().max()) + 1e-9
         assert float((ms[True] - ms[False]).abs().max()) <= 1.2e-7 * float(ref.abs().max()) + 1e-9
+
+
+@pytest.mark.parametrize('cin,cout,hw,B', [(64, 128, (9, 70), 2), (64, 64, (8, 13), 1), (64, 128, (17, 262), 1), (64, 128, (6, 256), 3),
+                                           (64, 64, (2, 3), 2)])
+def test_inference_maxpool_half_in_the_winograd43_epilogue(L, cin, cout, hw, B):
+    """the 64-channel pooled layer of the VGG trunks in eval mode: k_wino43<.., HPOOL> writes the maximum over horizontal pixel
+    pairs into a half-width map, efgh_maxpool_v2 takes the vertical half - bit-identical to the plain kernel followed by
+    efgh_maxpool2 (max is exact), ragged widths (W % 4 != 0, odd W: floor mode) and odd heights included"""
+    from efgh_amd import ops
+    torch.manual_seed(9)
+    feats = nn.Sequential(nn.Conv2d(cin, cout, 3, 1, 1), nn.BatchNorm2d(cout), nn.ReLU(), nn.MaxPool2d(2, 2))
+    with torch.no_grad():
+        feats[1].running_mean.normal_(0, 0.2); feats[1].running_var.uniform_(0.5, 2.0); feats[1].weight.normal_(0, 1.0)
+    feats.eval()
+    x = torch.randn(B, cin, *hw)
+    with torch.no_grad():
+        ref = feats(x)
+    fg = nn.Sequential(nn.Conv2d(cin, cout, 3, 1, 1), nn.BatchNorm2d(cout), nn.ReLU(), nn.MaxPool2d(2, 2)).cuda()
+    fg.load_state_dict(feats.state_dict())
+    fg.eval()
+    xg = ops.nchw_to_nhwc(x.cuda(), cin)
+    geom = (B, hw[0], hw[1], hw[0], hw[1], 1, 1, [t // 3 - 1 for t in range(9)], [t % 3 - 1 for t in range(9)], hw[0], hw[1], 1, 1, 0, 0)
+    assert ops.pool_fusable(1, cin, cout, geom) == 'h'
+    outs = {}
+    try:
+        for fused in (True, False):
+            ops.POOL_FUSED = fused
+            with torch.no_grad():
+                outs[fused] = L.run_vgg(L.Ctx(False), fg, xg)
+    finally:
+        ops.POOL_FUSED = True
+    assert outs[True].shape == (B, hw[0] // 2, hw[1] // 2, cout)
+    assert torch.equal(outs[True], outs[False])
+    assert _rel(outs[True].permute(0, 3, 1, 2).cpu(), ref) < 2e-5
