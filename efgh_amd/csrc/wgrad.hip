@@ -196,7 +196,12 @@ k_gather_wgrad(const WArgs p0) {
 // zeroed buffer: run-to-run different sums).  The planes are small (N*K floats) and there can be hundreds of them, so the sum over
 // z is itself spread over 16 lanes per element: lane l adds planes l, l+16, ... in order, an LDS tree (fixed shape) adds the lanes.
 // dst may be plane 0 of `part` (every element is read and written by one workgroup only, reads before the barrier).
-__global__ void __launch_bounds__(256) k_fold_splits(const float4 *part, int zs, long long total4, float4 *dst) {
+// UNPACK (round 5): the folded element goes straight to its place in the reference layout, W.flat[n*sn + c*sc + tap[t]*st] (what
+// k_unpack_weight did in a second launch from the packed [N][T][Cp] plane) - same sums, same order, one launch and one plane less
+struct FoldUnpackArgs { float *W; int N, T, C, Cp; long long sn, sc, st; int taps[16]; int accumulate; };
+
+template <bool UNPACK>
+__global__ void __launch_bounds__(256) k_fold_splits(const float4 *part, int zs, long long total4, float4 *dst, const FoldUnpackArgs u) {
     __shared__ float4 red[256];
     const int e = threadIdx.x & 15, zl = threadIdx.x >> 4;
     const long long i = (long long)blockIdx.x * 16 + e;
@@ -222,7 +227,24 @@ __global__ void __launch_bounds__(256) k_fold_splits(const float4 *part, int zs,
         }
         __syncthreads();
     }
-    if (zl == 0 && i < total4) dst[i] = red[e];
+    if (zl == 0 && i < total4) {
+        if (!UNPACK) { dst[i] = red[e]; return; }
+        const float4 v4 = red[e];
+        const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+        const long long idx = 4 * i;                       // packed index of the quad's first element: (n, t, c), Cp % 4 == 0
+        const int c0 = (int)(idx % u.Cp); const long long r = idx / u.Cp;
+        const int t = (int)(r % u.T), n = (int)(r / u.T);
+        if (n >= u.N) return;
+        int ti = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) if (q == t) ti = u.taps[q];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (c0 + q >= u.C) continue;
+            float *d = &u.W[n * u.sn + (c0 + q) * u.sc + ti * u.st];
+            *d = u.accumulate ? *d + v[q] : v[q];
+        }
+    }
 }
 
 // W.flat[n*sn + c*sc + tap[t]*st] = Wp[n][t][c]   (inverse of k_pack_weight; Wp may be padded to ldn/ldc)
@@ -264,10 +286,42 @@ k_table_scatter_add(const float *__restrict__ src, const int *__restrict__ table
 
 }  // namespace
 
+// A caller that wants the NEXT fold of this host thread to write the reference layout arms a descriptor first
+// (efgh_fold_unpack_arm); the fold consumes it when the plane it folds is that weight's packed [Np][T][Cp] gradient, and
+// efgh_fold_unpack_disarm() tells the caller whether it did (else the caller unpacks dWp itself, as before).
+static thread_local FoldUnpackArgs g_fu;
+static thread_local int g_fu_state = 0;              // 0 idle, 1 armed, 2 consumed
+
+extern "C" int efgh_fold_unpack_arm(float *W, int32_t N, int32_t T, int32_t C, int32_t Cp, int64_t sn, int64_t sc, int64_t stt,
+                                    const int32_t *tapidx, int32_t accumulate) {
+    EFGH_CHECK_ARG(W && N > 0 && T > 0 && T <= 16 && C > 0 && Cp >= C && Cp % 4 == 0);
+    g_fu.W = W; g_fu.N = N; g_fu.T = T; g_fu.C = C; g_fu.Cp = Cp; g_fu.sn = sn; g_fu.sc = sc; g_fu.st = stt;
+    for (int t = 0; t < 16; ++t) g_fu.taps[t] = (tapidx && t < T) ? tapidx[t] : (t < T ? t : 0);
+    g_fu.accumulate = accumulate;
+    g_fu_state = 1;
+    return EFGH_OK;
+}
+
+extern "C" int efgh_fold_unpack_disarm(void) {
+    const int consumed = g_fu_state == 2 ? 1 : 0;
+    g_fu_state = 0;
+    return consumed;
+}
+
 // (also used by efgh_wino_wgrad, wino.hip)
 void efgh_launch_fold_splits(const float *part, int zs, long long total, float *dst, hipStream_t st) {
     const long long total4 = total / 4;
-    k_fold_splits<<<(unsigned)((total4 + 15) / 16), 256, 0, st>>>((const float4 *)part, zs, total4, (float4 *)dst);
+    const unsigned grid = (unsigned)((total4 + 15) / 16);
+    if (g_fu_state == 1) {
+        const long long row = (long long)g_fu.T * g_fu.Cp;
+        if (total % row == 0 && total / row >= g_fu.N && total / row < g_fu.N + 4) {      // (Np = N rounded up to 4 rows)
+            k_fold_splits<true><<<grid, 256, 0, st>>>((const float4 *)part, zs, total4, (float4 *)dst, g_fu);
+            g_fu_state = 2;
+            return;
+        }
+    }
+    FoldUnpackArgs none = {};
+    k_fold_splits<false><<<grid, 256, 0, st>>>((const float4 *)part, zs, total4, (float4 *)dst, none);
 }
 
 static int gather_wgrad_impl(const efgh_gemm_desc *d, const float *G, int64_t ldg, float *dWp, float *workspace, int nbatch,
@@ -355,10 +409,7 @@ static int gather_wgrad_impl(const efgh_gemm_desc *d, const float *G, int64_t ld
         else if (d->mode == 1) k_gather_wgrad<1, 64><<<grid, 256, 0, st>>>(a);
         else k_gather_wgrad<2, 64><<<grid, 256, 0, st>>>(a);
     }
-    if (zs > 1) {
-        const long long total4 = plane / 4;           // N % 4 == 0
-        k_fold_splits<<<(unsigned)((total4 + 15) / 16), 256, 0, st>>>((const float4 *)workspace, (int)zs, total4, (float4 *)dWp);
-    }
+    if (zs > 1) efgh_launch_fold_splits(workspace, (int)zs, plane, dWp, st);       // (N % 4 == 0; nbatch > 1 never matches an armed unpack)
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
 }

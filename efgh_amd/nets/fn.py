@@ -353,9 +353,11 @@ class GemmLayerFn(torch.autograd.Function):
                 for li, (geom, m) in enumerate(spec.launches):
                     T = spec.T if geom is None else len(geom[7])
                     dWp = torch.empty((Np, T, spec.C), dtype=torch.float32, device=dev)
-                    ops.gather_wgrad(x, ld_of(x), spec.C, T, Np, m, draw, Np, dWp, mode=spec.mode, geom=geom,
-                                     table=spec.table)
-                    spec.wgrad_unpack(dWp, li, dW)
+                    ua = getattr(spec.wgrad_unpack, 'args', None)
+                    done = ops.gather_wgrad(x, ld_of(x), spec.C, T, Np, m, draw, Np, dWp, mode=spec.mode, geom=geom,
+                                            table=spec.table, unpack=None if ua is None else (dW,) + tuple(ua(li)))
+                    if not done:             # (a single row chunk, or a path with a transform behind its fold)
+                        spec.wgrad_unpack(dWp, li, dW)
             if side is None:
                 run_wgrad()
             else:

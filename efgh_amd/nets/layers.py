@@ -568,6 +568,7 @@ def _conv2d_grad(ctx, x, conv, bn, act, slope, residual, geom, dims, Cp, passthr
 
     def unpack(dWp, i, dW):
         ops.unpack_weight(dWp, dW, O, T, Cw, Cp, Cw * T, T, 1, list(range(T)))
+    unpack.args = lambda i: (O, T, Cw, Cp, Cw * T, T, 1, list(range(T)), False)       # (ops.gather_wgrad(unpack=...): fold + unpack in one launch)
 
     def dgrad(spec, w, draw, xin, add=None, bnsrc=None):
         """add: a gradient that reached x through ANOTHER consumer (handed over on this layer's passthrough alias); it is folded
@@ -646,6 +647,7 @@ def _convt_grad(ctx, x, convt, bn, act, slope, geoms, dims, passthrough=False):
     def unpack(dWp, i, dW):
         tapidx = geoms[i][3]
         ops.unpack_weight(dWp, dW, O, len(tapidx), Cw, Cw, 9, O * 9, 1, tapidx)
+    unpack.args = lambda i: (O, len(geoms[i][3]), Cw, Cw, 9, O * 9, 1, geoms[i][3], False)
 
     def dgrad(spec, w, draw, xin, add=None):
         # dX[ci][ih][iw] = sum_{co,kh,kw} dY[co][2ih-ph+kh][2iw-pw+kw] * W[ci][co][kh][kw]  (stride-2 conv)
@@ -693,6 +695,7 @@ def _linear_grad(ctx, x, M, C, weight, bias, bn, act, slope):
 
     def unpack(dWp, i, dW):
         ops.unpack_weight(dWp, dW, O, 1, C, Cp, C, 1, 1, [0])
+    unpack.args = lambda i: (O, 1, C, Cp, C, 1, 1, [0], False)
 
     def dgrad(spec, w, draw, xin):
         Wd = ops.pack_weight(w, C, 1, O, 1, C, 1, [0], Np=Cp, Cp=Np, key=('lin_d', Np, Cp))
@@ -714,6 +717,7 @@ def _blur_grad(ctx, splat, H, C, table, conv0, lv=None):
 
     def unpack(dWp, i, dW):
         ops.unpack_weight(dWp, dW, C0, 15, C, C, C * 15, 15, 1, list(range(15)))
+    unpack.args = lambda i: (C0, 15, C, C, C * 15, 15, 1, list(range(15)), False)
 
     def dgrad(spec, w, draw, xin):
         if lv is not None and ops.BLUR_DGRAD_FUSED and C % 4 == 0 and C0 % 4 == 0:

@@ -1133,7 +1133,24 @@ def _scratch(nfloats, device):
     return t
 
 
-def gather_wgrad(A, lda, C, T, N, M, G, ldg, dWp, mode=0, geom=None, table=None):
+FOLD_UNPACK = True       # a split weight gradient's final fold writes the reference layout itself (no packed plane, no unpack launch)
+FOLD_UNPACK_HITS = [0]   # (tests: how many weight gradients took that route)
+
+
+def gather_wgrad(A, lda, C, T, N, M, G, ldg, dWp, mode=0, geom=None, table=None, unpack=None):
+    """unpack: (dW, N_real, T, C_real, Cp, sn, sc, st, taps, accumulate) - where the gradient belongs in the reference layout
+    (ops.unpack_weight's arguments).  -> True when the launch left it there itself (its final fold did the unpack: dWp is then
+    NOT written), False when dWp holds the packed gradient and the caller has to unpack it"""
+    armed = False
+
+    def arm():
+        nonlocal armed
+        if unpack is not None and FOLD_UNPACK and unpack[4] % 4 == 0 and unpack[2] <= 16:
+            dW_, n_, t_, c_, cp_, sn_, sc_, st_, taps_, acc_ = unpack
+            tp_ = (ctypes.c_int32 * 16)(*([int(t) for t in taps_] + [0] * (16 - len(taps_))))
+            _C.check(_L().efgh_fold_unpack_arm(ptr(dW_), c_int32(n_), c_int32(t_), c_int32(c_), c_int32(cp_), c_int64(sn_), c_int64(sc_),
+                                               c_int64(st_), tp_, c_int32(1 if acc_ else 0)))
+            armed = True
     if PROFILE_WGRAD is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -1157,9 +1174,11 @@ def gather_wgrad(A, lda, C, T, N, M, G, ldg, dWp, mode=0, geom=None, table=None)
         # the 1- / 2-channel 3x3 convolutions behind G's transposed heads: column-walking stencil, per-workgroup partial planes folded
         # in a fixed order (also under EFGH_DETERMINISTIC: no atomics)
         thin = True             # (profile lists: an HBM-bound launch)
+        arm()
         _C.check(_L().efgh_c4n4_wgrad(ctypes.byref(d), ptr(G), c_int64(ldg), ptr(dWp),
                                       ptr(_scratch(_L().efgh_c4n4_wgrad_workspace(ctypes.byref(d)), dWp.device)), _st()))
     elif thin:
+        arm()
         _C.check(_L().efgh_thin_wgrad(ctypes.byref(d), ptr(G), c_int64(ldg), ptr(dWp),
                                       ptr(_scratch(_L().efgh_thin_wgrad_workspace(ctypes.byref(d)), dWp.device)), _st()))
     elif (USE_SMALLC and C == 4 and N in (32, 64) and lda % 4 == 0 and ldg % 4 == 0 and d.A % 16 == 0 and G.data_ptr() % 16 == 0
@@ -1167,14 +1186,17 @@ def gather_wgrad(A, lda, C, T, N, M, G, ldg, dWp, mode=0, geom=None, table=None)
         # 4-channel input layers at stride 1: the small-channel weight-gradient kernel (G staged by 16-byte loads, per-wave partial
         # planes folded in a fixed order) instead of k_c4_wgrad (4-byte G loads, fp32 atomics)
         thin = True             # (profile lists: an HBM-bound launch)
+        arm()
         _C.check(_L().efgh_sc_wgrad(ctypes.byref(d), ptr(G), c_int64(ldg), ptr(dWp),
                                     ptr(_scratch(_L().efgh_sc_wgrad_workspace(ctypes.byref(d)), dWp.device)), _st()))
     elif c4_eligible(mode, C, N, geom, wgrad=True):
         thin = True             # (profile lists, as above)
+        arm()
         _C.check(_L().efgh_c4_wgrad(ctypes.byref(d), ptr(G), c_int64(ldg), ptr(dWp),
                                     ptr(_scratch(_L().efgh_c4_wgrad_workspace(ctypes.byref(d)), dWp.device)), _st()))
     elif sc_eligible(mode, C, N, geom, wgrad=True) and lda % 4 == 0 and ldg % 4 == 0 and d.A % 16 == 0 and G.data_ptr() % 16 == 0:
         sc = True
+        arm()
         _C.check(_L().efgh_sc_wgrad(ctypes.byref(d), ptr(G), c_int64(ldg), ptr(dWp),
                                     ptr(_scratch(_L().efgh_sc_wgrad_workspace(ctypes.byref(d)), dWp.device)), _st()))
     elif USE_WINO_WGRAD and wino2d_eligible(mode, C, N, geom, wgrad=True):
@@ -1216,8 +1238,12 @@ def gather_wgrad(A, lda, C, T, N, M, G, ldg, dWp, mode=0, geom=None, table=None)
         S = _scratch(_L().efgh_wino_wgrad_workspace(ctypes.byref(d)), dWp.device)    # per-tile-range partials
         _C.check(_L().efgh_wino_wgrad(ctypes.byref(d), ptr(G), c_int64(ldg), ptr(S), ptr(dWp), _st()))
     else:
+        arm()
         _C.check(_L().efgh_gather_wgrad(ctypes.byref(d), ptr(G), c_int64(ldg), ptr(dWp),
                                         ptr(_scratch(_L().efgh_gather_wgrad_workspace(ctypes.byref(d)), dWp.device)), _st()))
+    done = bool(armed and _L().efgh_fold_unpack_disarm())
+    if done:
+        FOLD_UNPACK_HITS[0] += 1
     if PROFILE_WGRAD is not None and (thin or (not wino and hbm_bound(M, N, T, C))):
         e1.record()
         if PROFILE_THIN is not None:
@@ -1233,6 +1259,7 @@ def gather_wgrad(A, lda, C, T, N, M, G, ldg, dWp, mode=0, geom=None, table=None)
             PROFILE_WINO2D.append(rec)
         else:
             (PROFILE_WINO_WGRAD if (wino and PROFILE_WINO_WGRAD is not None) else PROFILE_WGRAD).append(rec)
+    return done
 
 
 def unpack_weight(Wp, W, N, T, C, Cp, sn, sc, st, taps, accumulate=False):

@@ -40,7 +40,7 @@ const char *efgh_last_error(void);
  *      earlier version-2 header keeps working, a caller of the new entry points against an earlier library fails at symbol lookup):
  *      efgh_wino_pack_batched, efgh_pack_weight_batched_tiled, efgh_wino2d_output_pooled, efgh_c4_pooled_supported,
  *      efgh_c4_conv3x3_pooled, efgh_segment_workspace, efgh_segment_colmax_ws, efgh_segment_colmean_ws,
- *      efgh_wino_conv3x3_hpool, efgh_maxpool_v2. */
+ *      efgh_wino_conv3x3_hpool, efgh_maxpool_v2, efgh_fold_unpack_arm, efgh_fold_unpack_disarm. */
 #define EFGH_ABI_VERSION 2
 int efgh_version(void);
 
@@ -426,6 +426,14 @@ int efgh_wino2d_wfinish(const float *S, float *dWp, int32_t N, int32_t C, void *
 /* W.flat[n*sn + c*sc + tapidx[t]*st] (+)= Wp[n][t][c]  (Wp rows padded to Cp) */
 int efgh_unpack_weight(const float *Wp, float *W, int32_t N, int32_t T, int32_t C, int32_t Cp, int64_t sn,
                        int64_t sc, int64_t st, const int32_t *tapidx_host, int32_t accumulate, void *stream);
+/* fold + unpack in one launch (round 5): efgh_fold_unpack_arm() describes where the NEXT weight-gradient call of this host thread
+ * should leave its result - W.flat[n*sn + c*sc + tapidx[t]*st] (+= when accumulate) instead of the packed dWp[Np][T][Cp]; the
+ * call's final fold of its row-chunk partials honours it when it folds exactly that plane (efgh_gather_wgrad with nbatch <= 1,
+ * efgh_c4_wgrad, efgh_sc_wgrad, efgh_thin_wgrad, efgh_c4n4_wgrad when they split the rows); efgh_fold_unpack_disarm() -> 1 if it
+ * did, 0 if dWp holds the packed gradient as usual (a single row chunk, a path with a transform behind the fold) */
+int efgh_fold_unpack_arm(float *W, int32_t N, int32_t T, int32_t C, int32_t Cp, int64_t sn, int64_t sc, int64_t st,
+                         const int32_t *tapidx_host, int32_t accumulate);
+int efgh_fold_unpack_disarm(void);
 /* dst[table[m*16+t]][c] += src[m][t*C+c]  (adjoint of the neighbour gather, bilateralNN.py:240-242) */
 int efgh_table_scatter_add(const float *src, const int32_t *table, int64_t M, int32_t T, int32_t C,
                            float *dst, void *stream);

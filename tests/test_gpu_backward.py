@@ -373,3 +373,35 @@ def test_vgg_block_with_fused_bn_relu_pool_backward(hw):
         if n.endswith('0.bias') or n.endswith('4.bias'):
             continue                                      # conv bias in front of a train-mode BatchNorm: rounding noise
         assert _relerr(p_.grad.cpu(), q_.grad) < 3e-4, n
+
+
+def test_fold_unpack_in_one_launch_equals_fold_then_unpack():
+    """a split weight gradient's final fold writes the reference (out, in, kh, kw) layout itself (efgh_fold_unpack_arm; k_fold_splits<true>)
+    instead of a packed plane that k_unpack_weight re-reads: bit-identical to the two-launch form for the generic kernel, the
+    small-channel and 4-channel kernels and a padded-channel layer"""
+    from efgh_amd import ops
+    from efgh_amd.nets import layers as L
+    import torch.nn as nn
+    torch.manual_seed(4)
+    hits0 = ops.FOLD_UNPACK_HITS[0]
+    cases = [(nn.Conv2d(64, 128, 3, 2, 1), (2, 64, 40, 56)), (nn.Conv2d(128, 64, 1, 1, 0), (2, 128, 30, 44)),
+             (nn.Conv2d(4, 64, 3, 1, 1), (2, 4, 64, 96)), (nn.Conv2d(32, 32, 3, 1, 1), (2, 32, 64, 96)),
+             (nn.Conv2d(3, 64, 3, 1, 1), (1, 3, 48, 80))]
+    for conv, shp in cases:
+        conv = conv.cuda()
+        x = torch.randn(*shp, device='cuda')
+        cin = shp[1]
+        xg = ops.nchw_to_nhwc(x, -(-cin // 4) * 4).requires_grad_(True)
+        grads = {}
+        for fused in (True, False):
+            ops.FOLD_UNPACK = fused
+            try:
+                conv.zero_grad()
+                y = L.conv2d(L.Ctx(True), xg, conv, None, L.ACT_NONE)
+                (y * torch.linspace(-1, 1, y.numel(), device='cuda').view_as(y)).sum().backward()
+                grads[fused] = conv.weight.grad.clone()
+            finally:
+                ops.FOLD_UNPACK = True
+        assert torch.equal(grads[True], grads[False]), (type(conv), shp)
+        assert float(grads[True].abs().max()) > 0
+    assert ops.FOLD_UNPACK_HITS[0] >= hits0 + 3, (ops.FOLD_UNPACK_HITS[0], hits0)      # (most of these split their rows)
