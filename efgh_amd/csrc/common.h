@@ -155,6 +155,15 @@ static inline int efgh_wg_per_cu(const void *kernel, int threads, size_t dyn_lds
     return n;
 }
 
+// ---- fold / finish + unpack in one launch (wgrad.hip owns the armed descriptor, see efgh_fold_unpack_arm) ----
+struct efgh_fold_unpack_args { float *W; int N, T, C, Cp; long long sn, sc, st; int taps[16]; int accumulate; };
+// takes the armed descriptor of this host thread if it describes a [>= N rows][T][Cp] packed gradient with identity taps
+// (a finish kernel that writes the reference layout itself); marks it consumed
+bool efgh_fold_unpack_take(efgh_fold_unpack_args *out, int rows, int T, int Cp);
+// hides / restores the armed state around an inner fold that must not consume it
+int efgh_fold_unpack_suspend(void);
+void efgh_fold_unpack_resume(int state);
+
 // ---- Winograd weight transforms, one work item per call (k_wino_pack / k_w2_pack and the batched form k_wino_pack_batched) ----
 // float64 with the contraction order WRITTEN OUT (explicit fma): every kernel that inlines these produces the same bits - left to
 // -ffp-contract the two instantiations differed in the last bit of ~0.4 % of the entries, enough to flip near-tie max-pool windows

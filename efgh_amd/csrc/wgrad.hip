@@ -198,7 +198,7 @@ k_gather_wgrad(const WArgs p0) {
 // dst may be plane 0 of `part` (every element is read and written by one workgroup only, reads before the barrier).
 // UNPACK (round 5): the folded element goes straight to its place in the reference layout, W.flat[n*sn + c*sc + tap[t]*st] (what
 // k_unpack_weight did in a second launch from the packed [N][T][Cp] plane) - same sums, same order, one launch and one plane less
-struct FoldUnpackArgs { float *W; int N, T, C, Cp; long long sn, sc, st; int taps[16]; int accumulate; };
+typedef efgh_fold_unpack_args FoldUnpackArgs;
 
 template <bool UNPACK>
 __global__ void __launch_bounds__(256) k_fold_splits(const float4 *part, int zs, long long total4, float4 *dst, const FoldUnpackArgs u) {
@@ -307,6 +307,16 @@ extern "C" int efgh_fold_unpack_disarm(void) {
     g_fu_state = 0;
     return consumed;
 }
+
+bool efgh_fold_unpack_take(efgh_fold_unpack_args *out, int rows, int T, int Cp) {
+    if (g_fu_state != 1 || g_fu.T != T || g_fu.Cp != Cp || rows < g_fu.N || rows >= g_fu.N + 4) return false;
+    for (int t = 0; t < T; ++t) if (g_fu.taps[t] != t) return false;
+    *out = g_fu;
+    g_fu_state = 2;
+    return true;
+}
+int efgh_fold_unpack_suspend(void) { const int s_ = g_fu_state; if (s_ == 1) g_fu_state = 0; return s_; }
+void efgh_fold_unpack_resume(int state) { if (state == 1 && g_fu_state == 0) g_fu_state = 1; }
 
 // (also used by efgh_wino_wgrad, wino.hip)
 void efgh_launch_fold_splits(const float *part, int zs, long long total, float *dst, hipStream_t st) {

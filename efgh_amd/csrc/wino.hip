@@ -458,13 +458,17 @@ __global__ void __launch_bounds__(64 * WR_WAVES, 1) k_wino_wgrad_rows(const Wino
 }
 
 // the folded kw planes [3][N][3C] -> packed [N][9][C]
-__global__ void k_wino_wgrad_finish3(const float *__restrict__ S, float *__restrict__ dWp, int N, int C) {
+// (on, oc, ot): strides of the output - the packed layout (9 C, 1, C) or the reference layout of an armed unpack descriptor
+__global__ void k_wino_wgrad_finish3(const float *__restrict__ S, float *__restrict__ dWp, int N, int C, long long on, long long oc,
+                                     long long ot, int Nr, int Cr, int accumulate) {
     const long long K3 = 3LL * C, total = (long long)N * K3;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int kc = (int)(i % K3); const long long n = i / K3;
         const int kh = kc / C, c = kc - kh * C;
-        float *o = dWp + (n * 9 + kh * 3) * C + c;
-        o[0] = S[i]; o[C] = S[total + i]; o[2 * (long long)C] = S[2 * total + i];
+        if (n >= Nr || c >= Cr) continue;
+        float *o = dWp + n * on + c * oc + (kh * 3) * ot;
+        if (accumulate) { o[0] += S[i]; o[ot] += S[total + i]; o[2 * ot] += S[2 * total + i]; }
+        else { o[0] = S[i]; o[ot] = S[total + i]; o[2 * ot] = S[2 * total + i]; }
     }
 }
 
@@ -585,10 +589,16 @@ extern "C" int efgh_wino_wgrad(const efgh_gemm_desc *d, const float *G, int64_t 
     a.tchunk = 0; a.kt = (unsigned)kt; a.nt = (unsigned)nt;
     k_wino_wgrad_rows<<<dim3((unsigned)zs, (unsigned)((d->C / 64) * nt)), 64 * WR_WAVES, 0, st>>>(a, strips, chunks, rh, d->C / 64);
     EFGH_CHECK_LAUNCH();
+    const int fu = efgh_fold_unpack_suspend();       // (the fold of the S partials below is not the packed gradient)
     if (zs > 1) efgh_launch_fold_splits(S, (int)zs, 3LL * d->N * 3 * d->C, S, st);      // into the first partial, fixed order
+    efgh_fold_unpack_resume(fu);
     const long long total = (long long)d->N * 3 * d->C;
     long long g = (total + 255) / 256;
-    k_wino_wgrad_finish3<<<(int)(g > 4096 ? 4096 : g), 256, 0, st>>>(S, dWp, d->N, d->C);
+    efgh_fold_unpack_args u;
+    if (efgh_fold_unpack_take(&u, d->N, 9, d->C))
+        k_wino_wgrad_finish3<<<(int)(g > 4096 ? 4096 : g), 256, 0, st>>>(S, u.W, d->N, d->C, u.sn, u.sc, u.st, u.N, u.C, u.accumulate);
+    else
+        k_wino_wgrad_finish3<<<(int)(g > 4096 ? 4096 : g), 256, 0, st>>>(S, dWp, d->N, d->C, 9LL * d->C, 1, d->C, d->N, d->C, 0);
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
 }

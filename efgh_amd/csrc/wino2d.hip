@@ -416,7 +416,10 @@ __global__ void __launch_bounds__(256) k_wino_pack_batched(const efgh_wino_pack_
 }
 
 // dWp[n][kh*3 + kw][c] = sum_{i,j} A3T[kh][i] A3T[kw][j] S[6i + j][n][c]
-__global__ void k_w2_wfinish(const float *__restrict__ S, float *__restrict__ dWp, int N, int C) {
+// out: the packed [N][9][C] gradient (on = 9 C, oc = 1, ot = C) or, with an armed unpack descriptor, the reference layout itself
+// (rows < Nr, channels < Cr only)
+__global__ void k_w2_wfinish(const float *__restrict__ S, float *__restrict__ dWp, int N, int C, long long on, long long oc, long long ot,
+                             int Nr, int Cr, int accumulate) {
     const float A3[3][6] = {{1, 1, 1, 1, 1, 0}, {0, W2_A, -W2_A, W2_B, -W2_B, 0}, {0, W2_A2, W2_A2, W2_B2, W2_B2, 1}};
     const long long total = (long long)N * C, plane = total;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -438,7 +441,10 @@ __global__ void k_w2_wfinish(const float *__restrict__ S, float *__restrict__ dW
                 float v = 0.f;
 #pragma unroll
                 for (int a = 0; a < 6; ++a) v += A3[kh][a] * r[a][kw];
-                dWp[(n * 9 + kh * 3 + kw) * C + c] = v;
+                if (n < Nr && c < Cr) {
+                    float *o = dWp + n * on + c * oc + (kh * 3 + kw) * ot;
+                    *o = accumulate ? *o + v : v;
+                }
             }
     }
 }
@@ -547,7 +553,11 @@ extern "C" int efgh_wino2d_wfinish(const float *S, float *dWp, int32_t N, int32_
     EFGH_CHECK_ARG(S && dWp && N > 0 && C > 0);
     const long long total = (long long)N * C;
     long long g = (total + 255) / 256;
-    k_w2_wfinish<<<(int)(g > 4096 ? 4096 : g), 256, 0, (hipStream_t)stream_>>>(S, dWp, N, C);
+    efgh_fold_unpack_args u;
+    if (efgh_fold_unpack_take(&u, N, 9, C))          // straight into the reference layout (no packed plane, no unpack launch)
+        k_w2_wfinish<<<(int)(g > 4096 ? 4096 : g), 256, 0, (hipStream_t)stream_>>>(S, u.W, N, C, u.sn, u.sc, u.st, u.N, u.C, u.accumulate);
+    else
+        k_w2_wfinish<<<(int)(g > 4096 ? 4096 : g), 256, 0, (hipStream_t)stream_>>>(S, dWp, N, C, 9LL * C, 1, C, N, C, 0);
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
 }

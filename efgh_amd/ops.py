@@ -1232,10 +1232,12 @@ def gather_wgrad(A, lda, C, T, N, M, G, ldg, dWp, mode=0, geom=None, table=None,
         if PROFILE_WINO2D_GEMM is not None:
             f1.record()
             PROFILE_WINO2D_GEMM.append((f0, f1, 2.0 * 36 * T2 * C * N, (0, T2, N, 36, C)))
+        arm()                    # (after the batched plane launch: only the finish kernel may write the reference layout)
         _C.check(_L().efgh_wino2d_wfinish(ptr(S), ptr(dWp), c_int32(N), c_int32(C), _st()))
     elif USE_WINO_WGRAD and C % 64 == 0 and wino_eligible(mode, C, N, geom):
         wino = True
         S = _scratch(_L().efgh_wino_wgrad_workspace(ctypes.byref(d)), dWp.device)    # per-tile-range partials
+        arm()                    # (consumed by its finish kernel, not by the fold of the S partials)
         _C.check(_L().efgh_wino_wgrad(ctypes.byref(d), ptr(G), c_int64(ldg), ptr(S), ptr(dWp), _st()))
     else:
         arm()
