@@ -4,9 +4,11 @@ busy = SQ_VALU_MFMA_BUSY_CYCLES / (4 * SQ_BUSY_CU_CYCLES)   (four SIMDs per CU; 
 clock = SQ_BUSY_CU_CYCLES / 256 CUs / kernel time from the same trace."""
 import collections, csv, glob, json, sys
 
-FAMILIES = {'k_wino43': 'k_wino43<', 'k_wino_wgrad_rows': 'k_wino_wgrad_rows(', 'k_gather_gemm<1>': 'k_gather_gemm<1,',
-            'k_gather_gemm<0,128,128> (batched planes of F(4x4,3x3) + plain GEMMs)': 'k_gather_gemm<0, 128, 128',
-            'k_gather_wgrad<0,128> (batched weight-gradient planes of F(4x4,3x3))': 'k_gather_wgrad<0, 128',
+FAMILIES = {'k_wino43': 'k_wino43<', 'k_wino_wgrad_rows': 'k_wino_wgrad_rows(',
+            'k_gather_gemm_dma<1> (LDS-DMA staged implicit GEMM, round 5)': 'k_gather_gemm_dma<1,',
+            'k_gather_gemm<1> (register-staged instances: N <= 32 and ragged channel counts)': 'k_gather_gemm<1,',
+            'k_plane_gemm (batched planes of F(4x4,3x3), round 5)': 'k_plane_gemm<',
+            'k_plane_wgrad (batched weight-gradient planes of F(4x4,3x3), round 5)': 'k_plane_wgrad<',
             'k_gather_wgrad<1>': 'k_gather_wgrad<1,'}
 agg = {k: collections.defaultdict(float) for k in FAMILIES}
 disp = {k: set() for k in FAMILIES}
