@@ -295,272 +295,6 @@ __global__ void __launch_bounds__(256, 2) k_wino43(const WinoArgs p) {
     }
 }
 
-// ---- the same kernel as ONE 8-wave workgroup per CU (round 5, opt-in: efgh_wino_set_w8): 128 tiles x 64 outputs, waves 4 x 2, a
-// two-stage LDS ring (144 KB).  What it changes: half the U staging per MFMA (a U chunk serves 128 tiles), ONE barrier per chunk
-// instead of two, and no barrier between a wave's store phase and its MFMA phase - the transform + LDS stores of chunk ch + 1 go to
-// the other stage while slower waves are still inside the MFMAs of chunk ch.  Same arithmetic per output (same k order, same
-// transforms); the BatchNorm statistics rows cover 128 tiles (efgh_wino_grid_m follows the switch).
-constexpr int TMW = 128;
-template <bool BNM, bool HPOOL = false>
-__global__ void __launch_bounds__(512, 1) k_wino43w(const WinoArgs p) {
-    extern __shared__ __attribute__((aligned(16))) float w8_lds[];           // [2 stages][V 6 x TMW x LD | U 6 x TN x LD]
-    constexpr int STG = 6 * TMW * LD + 6 * TN * LD;
-    float *Vs = w8_lds, *Us = w8_lds + 6 * TMW * LD;                        // stage 0 (stage 1: + STG)
-    __shared__ long long tpix[TMW];      // first output pixel of the tile, -1 = no such tile
-    __shared__ int tcnt[TMW];            // valid pixels in the tile (ragged right edge)
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, lh = lane >> 5;
-    // XCD-aware tile order (see k_gather_gemm): one contiguous band of tiles per XCD
-    const unsigned nbx = p.nbx, nblk = gridDim.x;
-    const unsigned q8 = nblk >> 3, r8 = nblk & 7, xcd = blockIdx.x & 7, within = blockIdx.x >> 3;
-    const unsigned lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + within;
-    const unsigned tile_m = lin / nbx, tile_n = lin - tile_m * nbx;
-    const long long m0 = (long long)tile_m * TMW;
-    const int n0 = tile_n * TN;
-    if (m0 >= p.Mt) return;
-
-    // ---- staging state: thread = (tile st, channel quad cq) ---------------------------------
-    const int st = tid >> 2, cq = (tid & 3) * 4;
-    // LDS image: row = tile (or channel n), four 16-B quads per row stored at quad ^ ((row >> 2) & 3): the eight
-    // lanes of a ds_write_b128 group (2 rows x 4 quads) and the sixteen rows of a ds_read_b128 group (one quad
-    // each) then fall on distinct bank slots without padding
-    const int cqs = ((tid & 3) ^ ((st >> 2) & 3)) * 4;
-    const int stu = st & (TN - 1), ua = 3 * (tid >> 8), cqu = ((tid & 3) ^ ((stu >> 2) & 3)) * 4;      // U: row n, first alpha of this thread
-    long long pix0 = 0;
-    unsigned cmask = 0, rmask = 0;
-    {
-        const long long t = m0 + st;
-        if (t < p.Mt) {
-            const int xt = (int)(t % p.TW); const long long r = t / p.TW;
-            const int y = (int)(r % p.H); const long long b = r / p.H;
-            const int x0 = 4 * xt - 1;
-#pragma unroll
-            for (int q = 0; q < 6; ++q) if ((unsigned)(x0 + q) < (unsigned)p.W) cmask |= 1u << q;
-#pragma unroll
-            for (int kh = 0; kh < 3; ++kh) if ((unsigned)(y + kh - 1) < (unsigned)p.H) rmask |= 1u << kh;
-            pix0 = (b * p.H + y) * p.W + x0;
-        }
-    }
-    if (tid < TMW) {
-        const long long t = m0 + tid;
-        long long o = -1; int cnt = 0;
-        if (t < p.Mt) {
-            const int xt = (int)(t % p.TW); const long long r = t / p.TW;
-            o = r * p.W + 4 * xt;                       // r = b*H + y
-            cnt = p.W - 4 * xt; cnt = cnt > 4 ? 4 : cnt;
-            if (HPOOL) {                                // pooled pixels of the tile in the half-width map (floor: an odd last column has none)
-                const int wp = p.W >> 1;
-                o = r * wp + 2 * xt;
-                cnt = wp - 2 * xt; cnt = cnt > 2 ? 2 : cnt;
-                if (cnt <= 0) { o = -1; cnt = 0; }
-            }
-        }
-        tpix[tid] = o; tcnt[tid] = cnt;
-    }
-    const long long ustride = (long long)p.N * KC;      // one alpha slab of a chunk
-    const float *ubase = p.U + (long long)(n0 + stu) * KC + cq + (long long)ua * ustride;
-
-    // (named registers, not arrays: keeps the prefetched chunk out of scratch memory)
-    float4 ra0, ra1, ra2, ra3, ra4, ra5, ru0, ru1, ru2;
-    // per-thread part of the address once; per chunk only workgroup-uniform offsets (kernel row, channel block)
-    const float *abase = p.A + (pix0 * p.lda + cq);
-    const float *zpage = g_zero_page;
-#define EFGH_LDA(q, dst)                                                                              \
-    {                                                                                                \
-        const float *src = (rok && ((cmask >> q) & 1u)) ? arow + (long long)q * p.lda : zpage;        \
-        dst = *reinterpret_cast<const float4 *>(src);                                                \
-    }
-    // the 12 loads of the next chunk are issued two at a time between the MFMA groups of the current one (a burst of
-    // 12 right after the barrier backs up the address path and delays the first MFMAs of every wave)
-    const float *arow = abase, *urow = ubase;
-    bool rok = false;
-#define EFGH_CHUNK_ADDR(chv)                                                                          \
-    {                                                                                                \
-        const int ch_ = (chv);                                                                       \
-        /* channel block fastest: consecutive chunks use the two 64-B halves of the same 128-B lines */ \
-        const int kh = ch_ / ccn, cc = ch_ - kh * ccn;                                               \
-        rok = (rmask >> kh) & 1u;                                                                    \
-        arow = abase + ((long long)(kh - 1) * p.W * p.lda + cc * KC);                                \
-        urow = ubase + (long long)(cc * 3 + kh) * 6 * ustride;                                       \
-    }
-#define EFGH_LOAD_PAIR(q, da, du)                                                                     \
-    {                                                                                                \
-        EFGH_LDA(q, da)                                                                              \
-        if (q < 3) du = *reinterpret_cast<const float4 *>(urow + q * ustride);                       \
-    }
-
-    f32x16 acc[6];
-#pragma unroll
-    for (int a = 0; a < 6; ++a)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
-
-    const int ccn = p.C / KC, nchunks = 3 * ccn;
-    EFGH_CHUNK_ADDR(0)
-    EFGH_LOAD_PAIR(0, ra0, ru0) EFGH_LOAD_PAIR(1, ra1, ru1) EFGH_LOAD_PAIR(2, ra2, ru2)
-    EFGH_LOAD_PAIR(3, ra3, ru0) EFGH_LOAD_PAIR(4, ra4, ru1) EFGH_LOAD_PAIR(5, ra5, ru2)
-    // stage s of the ring holds chunk s (mod 2): the registers carry chunk ch + 1 while the MFMAs of chunk ch run; its transform +
-    // LDS stores go to the OTHER stage right away (no barrier in front of them: that stage was last read by the MFMAs of chunk ch - 1,
-    // which every wave finished before the barrier that ended iteration ch - 1), so a chunk costs ONE barrier and the store phase
-    // of a wave overlaps the MFMA phases of the others
-    for (int ch = -1; ch < nchunks; ++ch) {
-        float *Vw = Vs + ((ch + 1) & 1) * STG, *Uw = Us + ((ch + 1) & 1) * STG;
-        if (ch + 1 < nchunks) {   // B^T d on the four channels of this thread, then one ds_write_b128 per alpha
-            float4 v0, v1, v2, v3, v4, v5;
-#define EFGH_BT(e)                                                                                   \
-            {                                                                                        \
-                const float d0 = ra0.e, d1 = ra1.e, d2 = ra2.e, d3 = ra3.e, d4 = ra4.e, d5 = ra5.e;    \
-                const float p42 = d4 - 4.f * d2, p31 = d3 - 4.f * d1;                                \
-                const float q42 = d4 - d2, q31 = 2.f * (d3 - d1);                                    \
-                v0.e = 4.f * d0 - 5.f * d2 + d4;                                                     \
-                v1.e = p42 + p31;                                                                    \
-                v2.e = p42 - p31;                                                                    \
-                v3.e = q42 + q31;                                                                    \
-                v4.e = q42 - q31;                                                                    \
-                v5.e = 4.f * d1 - 5.f * d3 + d5;                                                     \
-            }
-            EFGH_BT(x) EFGH_BT(y) EFGH_BT(z) EFGH_BT(w)
-#undef EFGH_BT
-#define EFGH_ST(a, vv)                                                                                \
-            *reinterpret_cast<float4 *>(&Vw[(a * TMW + st) * LD + cqs]) = vv;
-            EFGH_ST(0, v0) EFGH_ST(1, v1) EFGH_ST(2, v2) EFGH_ST(3, v3) EFGH_ST(4, v4) EFGH_ST(5, v5)
-#undef EFGH_ST
-            *reinterpret_cast<float4 *>(&Uw[((ua + 0) * TN + stu) * LD + cqu]) = ru0;
-            *reinterpret_cast<float4 *>(&Uw[((ua + 1) * TN + stu) * LD + cqu]) = ru1;
-            *reinterpret_cast<float4 *>(&Uw[((ua + 2) * TN + stu) * LD + cqu]) = ru2;
-        }
-        if (ch < 0) {             // prologue: chunk 0 is in stage 0; fetch chunk 1 and meet
-            if (nchunks > 1) {
-                EFGH_CHUNK_ADDR(1)
-                EFGH_LOAD_PAIR(0, ra0, ru0) EFGH_LOAD_PAIR(1, ra1, ru1) EFGH_LOAD_PAIR(2, ra2, ru2)
-                EFGH_LOAD_PAIR(3, ra3, ru0) EFGH_LOAD_PAIR(4, ra4, ru1) EFGH_LOAD_PAIR(5, ra5, ru2)
-            }
-            __syncthreads();
-            continue;
-        }
-        const bool more = ch + 2 < nchunks;
-        if (more) EFGH_CHUNK_ADDR(ch + 2)
-        const float *Vr = Vs + (ch & 1) * STG, *Ur = Us + (ch & 1) * STG;
-        {   // fragments of alpha a+1 are fetched while the eight MFMAs of alpha a run (two register sets)
-            const int sw = (l31 >> 2) & 3, q0 = ((2 * lh) ^ sw) * 4, q1 = ((2 * lh + 1) ^ sw) * 4;
-            const float *va = &Vr[(wm * 32 + l31) * LD];
-            const float *ub = &Ur[(wn * 32 + l31) * LD];
-            float4 fa[2][2], fb[2][2];
-            fa[0][0] = *reinterpret_cast<const float4 *>(va + q0); fa[0][1] = *reinterpret_cast<const float4 *>(va + q1);
-            fb[0][0] = *reinterpret_cast<const float4 *>(ub + q0); fb[0][1] = *reinterpret_cast<const float4 *>(ub + q1);
-#pragma unroll
-            for (int a = 0; a < 6; ++a) {
-                const int cur = a & 1, nxt = cur ^ 1;
-                if (a < 5) {
-                    fa[nxt][0] = *reinterpret_cast<const float4 *>(va + (a + 1) * TMW * LD + q0);
-                    fa[nxt][1] = *reinterpret_cast<const float4 *>(va + (a + 1) * TMW * LD + q1);
-                    fb[nxt][0] = *reinterpret_cast<const float4 *>(ub + (a + 1) * TN * LD + q0);
-                    fb[nxt][1] = *reinterpret_cast<const float4 *>(ub + (a + 1) * TN * LD + q1);
-                }
-                if (more) {
-                    if (a == 0) EFGH_LOAD_PAIR(0, ra0, ru0)
-                    if (a == 1) EFGH_LOAD_PAIR(1, ra1, ru1)
-                    if (a == 2) EFGH_LOAD_PAIR(2, ra2, ru2)
-                    if (a == 3) EFGH_LOAD_PAIR(3, ra3, ru0)
-                    if (a == 4) EFGH_LOAD_PAIR(4, ra4, ru1)
-                    if (a == 5) EFGH_LOAD_PAIR(5, ra5, ru2)
-                }
-                __builtin_amdgcn_sched_barrier(0);      // keep the prefetch ahead of the MFMAs (the scheduler would sink it)
-                acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][0].x, fb[cur][0].x, acc[a], 0, 0, 0);
-                acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][0].y, fb[cur][0].y, acc[a], 0, 0, 0);
-                acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][0].z, fb[cur][0].z, acc[a], 0, 0, 0);
-                acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][0].w, fb[cur][0].w, acc[a], 0, 0, 0);
-                acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][1].x, fb[cur][1].x, acc[a], 0, 0, 0);
-                acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][1].y, fb[cur][1].y, acc[a], 0, 0, 0);
-                acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][1].z, fb[cur][1].z, acc[a], 0, 0, 0);
-                acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][1].w, fb[cur][1].w, acc[a], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        __syncthreads();
-    }
-
-    // ---- epilogue: A^T on registers, then the k_gather_gemm epilogue --------------------------
-    float *ssum = Vs, *ssq = Vs + 4 * TN;          // (stage 0 is free: the loop ended on a barrier)
-    const int coll = wn * 32 + l31, col = n0 + coll;
-    const float bi = p.bias ? p.bias[col] : 0.f;
-    const float sc = p.scale ? p.scale[col] : 1.f;
-    const float sf = p.shift ? p.shift[col] : 0.f;
-    float s1 = 0.f, s2 = 0.f;
-    constexpr bool bnm = BNM;
-    float b_psc = 0.f, b_psh = 0.f, b_mu = 0.f, b_is = 0.f;
-    if (bnm) {
-        if (!p.bn_y) { b_psc = p.bn_psc[col]; b_psh = p.bn_psh[col]; }
-        b_mu = p.bn_mean[col]; b_is = p.bn_invstd[col];
-    }
-    // per tile row: the pixel index, the row addresses and the count of valid pixels are formed once; a workgroup-uniform switch picks
-    // the body with / without a residual operand (its four loads of a tile are issued together, ahead of the arithmetic)
-    const float neg = p.act == 1 ? 0.f : (p.act == 2 ? p.slope : 1.f);      // act(v) = max(v, 0) + neg * min(v, 0)
-    auto rows = [&](auto res_c, auto full_c) {
-        constexpr bool RES = decltype(res_c)::value, FULL = decltype(full_c)::value;     // FULL: every tile of the workgroup exists
-#pragma unroll                                                                            // and has its four pixels
-        for (int r = 0; r < 16; ++r) {
-            const int rl = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            const long long opix = tpix[rl];
-            const int cnt = FULL ? 4 : tcnt[rl];
-            if (!FULL && opix < 0) continue;
-            float *op = p.out + opix * p.ldo + col;
-            float rv[4] = {0.f, 0.f, 0.f, 0.f};
-            if (RES) {
-                const float *rp = p.residual + opix * p.ldr + col;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) if (FULL || i < cnt) rv[i] = rp[i * p.ldr];
-            }
-            const float m0_ = acc[0][r], m1 = acc[1][r], m2 = acc[2][r], m3 = acc[3][r], m4 = acc[4][r], m5 = acc[5][r];
-            const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
-            const float yv[4] = {m0_ + s12 + s34, d12 + 2.f * d34, s12 + 4.f * s34, d12 + 8.f * d34 + m5};
-            if (HPOOL) {                     // (no residual, no statistics: an inference epilogue)
-                float w[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) { float v = yv[i] + bi; v = v * sc + sf; w[i] = act_neg(v, neg); }
-                st_out(op, fmaxf(w[0], w[1]));
-                if (FULL || cnt > 1) st_out(op + p.ldo, fmaxf(w[2], w[3]));
-                continue;
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (!FULL && i >= cnt) continue;
-                float v = yv[i] + bi;
-                if (!bnm) { s1 += v; s2 = fmaf(v, v, s2); }
-                v = v * sc + sf;
-                if (RES) v += rv[i];
-                v = act_neg(v, neg);
-                st_out(op + i * p.ldo, v);
-                if (bnm) {
-                    const float rw = p.bn_raw[(opix + i) * p.bn_ldraw + col];
-                    const float yy = p.bn_y ? p.bn_y[(opix + i) * p.bn_ldy + col] : rw * b_psc + b_psh;
-                    const float g = p.bn_act == 1 ? (yy > 0.f ? v : 0.f) : p.bn_act == 2 ? (yy > 0.f ? v : v * p.bn_slope) : v;
-                    s1 += g; s2 += g * ((rw - b_mu) * b_is);
-                }
-            }
-        }
-    };
-    const bool full = m0 + TMW <= p.Mt && (p.W & 3) == 0;
-    if (p.residual) {
-        if (full) rows(std::true_type{}, std::true_type{});
-        else rows(std::true_type{}, std::false_type{});
-    } else {
-        if (full) rows(std::false_type{}, std::true_type{});
-        else rows(std::false_type{}, std::false_type{});
-    }
-    if (p.stats) {
-        s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
-        if (lh == 0) { ssum[wm * TN + coll] = s1; ssq[wm * TN + coll] = s2; }
-        __syncthreads();
-        if (tid < TN) {
-            p.stats[((long long)tile_m * 2 + 0) * p.N + n0 + tid] = (ssum[tid] + ssum[TN + tid]) + (ssum[2 * TN + tid] + ssum[3 * TN + tid]);
-            p.stats[((long long)tile_m * 2 + 1) * p.N + n0 + tid] = (ssq[tid] + ssq[TN + tid]) + (ssq[2 * TN + tid] + ssq[3 * TN + tid]);
-        }
-    }
-}
-
-
 // U[(cc*3 + kh)*6 + a][n][ci] = sum_kw G[a][kw] * Wp[n][kh*3 + kw][cc*16 + ci]      (Wp: packed [N][9][C])
 __global__ void k_wino_pack(const float *__restrict__ Wp, float *__restrict__ U, int N, int C) {
     const long long total = 3LL * C * N;        // (ch, n, ci) triples, six outputs each (wino_pack_item, common.h)
@@ -750,17 +484,9 @@ bool supported(const efgh_gemm_desc *d) {
 
 extern "C" int efgh_wino_supported(const efgh_gemm_desc *d) { return supported(d) ? 1 : 0; }
 
-static std::atomic<int> g_wino_w8{0};
-static std::atomic<unsigned long long> g_w8_raised[3];
-constexpr int W8_LDS = 2 * (6 * TMW * LD + 6 * TN * LD) * 4;
-
-/* process-wide switch: 1 = serve efgh_wino_conv3x3(_hpool) with the 8-wave two-stage kernel (k_wino43w, 128-tile row blocks) */
-extern "C" int efgh_wino_set_w8(int32_t on) { g_wino_w8.store(on ? 1 : 0); return EFGH_OK; }
-
 extern "C" int32_t efgh_wino_grid_m(int32_t B, int32_t H, int32_t W) {
     const long long mt = (long long)B * H * ((W + 3) / 4);
-    const int tm = g_wino_w8.load() ? TMW : TM;
-    return (int32_t)((mt + tm - 1) / tm);
+    return (int32_t)((mt + TM - 1) / TM);
 }
 
 extern "C" int efgh_wino_pack(const float *Wp, float *U, int32_t N, int32_t C, void *stream_) {
@@ -788,19 +514,6 @@ extern "C" int efgh_wino_conv3x3(const efgh_gemm_desc *d, const float *U, void *
     a.bn_psc = d->bn_pscale; a.bn_psh = d->bn_pshift; a.bn_mean = d->bn_mean; a.bn_invstd = d->bn_invstd;
     a.bn_act = d->bn_act; a.bn_slope = d->bn_slope;
     a.nbx = (unsigned)(d->N / TN);
-    if (g_wino_w8.load()) {
-        const long long nby8 = (a.Mt + TMW - 1) / TMW;
-        EFGH_CHECK_ARG(a.nbx * nby8 < 0x7fffffffLL);
-        if (a.smode == 1) {
-            EFGH_CHECK_ARG(efgh_raise_lds_once(g_w8_raised[0], (const void *)k_wino43w<true>, W8_LDS));
-            k_wino43w<true><<<(unsigned)(a.nbx * nby8), 512, W8_LDS, (hipStream_t)stream_>>>(a);
-        } else {
-            EFGH_CHECK_ARG(efgh_raise_lds_once(g_w8_raised[1], (const void *)k_wino43w<false>, W8_LDS));
-            k_wino43w<false><<<(unsigned)(a.nbx * nby8), 512, W8_LDS, (hipStream_t)stream_>>>(a);
-        }
-        EFGH_CHECK_LAUNCH();
-        return EFGH_OK;
-    }
     const long long nby = (a.Mt + TM - 1) / TM;
     EFGH_CHECK_ARG(a.nbx * nby < 0x7fffffffLL);
     if (a.smode == 1) k_wino43<true><<<(unsigned)(a.nbx * nby), 256, 0, (hipStream_t)stream_>>>(a);
@@ -822,14 +535,6 @@ extern "C" int efgh_wino_conv3x3_hpool(const efgh_gemm_desc *d, const float *U, 
     a.bn_raw = nullptr; a.bn_ldraw = 0; a.bn_y = nullptr; a.bn_ldy = 0;
     a.bn_psc = a.bn_psh = a.bn_mean = a.bn_invstd = nullptr; a.bn_act = 0; a.bn_slope = 0.f;
     a.nbx = (unsigned)(d->N / TN);
-    if (g_wino_w8.load()) {
-        const long long nby8 = (a.Mt + TMW - 1) / TMW;
-        EFGH_CHECK_ARG(a.nbx * nby8 < 0x7fffffffLL);
-        EFGH_CHECK_ARG(efgh_raise_lds_once(g_w8_raised[2], (const void *)k_wino43w<false, true>, W8_LDS));
-        k_wino43w<false, true><<<(unsigned)(a.nbx * nby8), 512, W8_LDS, (hipStream_t)stream_>>>(a);
-        EFGH_CHECK_LAUNCH();
-        return EFGH_OK;
-    }
     const long long nby = (a.Mt + TM - 1) / TM;
     EFGH_CHECK_ARG(a.nbx * nby < 0x7fffffffLL);
     k_wino43<false, true><<<(unsigned)(a.nbx * nby), 256, 0, (hipStream_t)stream_>>>(a);

@@ -629,13 +629,9 @@ def gather_gemm(A, lda, C, T, Wp, N, M, out, ldo, mode=0, geom=None, table=None,
 GEMM_DMA = True                 # eligible efgh_gather_gemm launches on the LDS-DMA staged instances (a process-wide switch of the library)
 
 
-WINO_W8 = False                 # k_wino43 as one 8-wave workgroup per CU with a two-stage LDS ring (k_wino43w); a process-wide switch of the library
-
-
 def apply_switches():
-    """push the switches that live inside the library (bench.py --set, tools): call after changing GEMM_DMA / WINO_W8"""
+    """push the switches that live inside the library (bench.py --set, tools): call after changing GEMM_DMA"""
     _L().efgh_gather_gemm_set_dma(c_int32(1 if GEMM_DMA else 0))
-    _L().efgh_wino_set_w8(c_int32(1 if WINO_W8 else 0))
 
 
 PLANE_DMA = True                # the 36 planes of a 2-D Winograd layer on the LDS-DMA staged kernels (planes.hip); False: k_gather_gemm / k_gather_wgrad

@@ -40,7 +40,7 @@ const char *efgh_last_error(void);
  *      earlier version-2 header keeps working, a caller of the new entry points against an earlier library fails at symbol lookup):
  *      efgh_wino_pack_batched, efgh_pack_weight_batched_tiled, efgh_wino2d_output_pooled, efgh_c4_pooled_supported,
  *      efgh_c4_conv3x3_pooled, efgh_segment_workspace, efgh_segment_colmax_ws, efgh_segment_colmean_ws,
- *      efgh_wino_conv3x3_hpool, efgh_maxpool_v2, efgh_fold_unpack_arm, efgh_fold_unpack_disarm, efgh_wino_set_w8. */
+ *      efgh_wino_conv3x3_hpool, efgh_maxpool_v2, efgh_fold_unpack_arm, efgh_fold_unpack_disarm. */
 #define EFGH_ABI_VERSION 2
 int efgh_version(void);
 
@@ -609,8 +609,6 @@ int efgh_wino_pack(const float *Wp, float *U, int32_t N, int32_t C, void *stream
 /* inference, a layer followed by nn.MaxPool2d(2,2) (nets/vgg.py:69-83): d->out is the map of HALF the width [B][Hin][Win/2][ldo] =
  * max over horizontal pixel pairs of act((v + bias)*scale + shift); efgh_maxpool_v2 finishes the window.  No residual / statistics */
 int efgh_wino_conv3x3_hpool(const efgh_gemm_desc *d, const float *U, void *stream);
-/* process-wide: 1 = efgh_wino_conv3x3(_hpool) on the 8-wave / two-stage-LDS kernel (128-tile row blocks: efgh_wino_grid_m follows) */
-int efgh_wino_set_w8(int32_t on);
 int efgh_wino_conv3x3(const efgh_gemm_desc *d, const float *U, void *stream);
 /* weight gradient of the same layers (replaces efgh_gather_wgrad for them; additionally C % 64 == 0): Winograd
  * F(3,4) over 4-pixel gradient tiles, six tile-contracted GEMMs per tile range written as partials [6][N][3C] into the

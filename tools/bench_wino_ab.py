@@ -10,10 +10,7 @@ from efgh_amd.nets import layers as L
 
 torch.set_grad_enabled(False)
 ops.USE_WINO2D = False
-reps = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 8
-if '--w8' in sys.argv:          # the 8-wave / two-stage-LDS kernel (k_wino43w)
-    ops.WINO_W8 = True
-    ops.apply_switches()
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 tot = 0.0
 for (B, H, W, ci, co) in [(8, 384, 1280, 64, 64), (8, 192, 640, 128, 128), (8, 192, 640, 64, 128), (2, 384, 5119, 64, 64), (8, 192, 2559, 64, 128)]:
     torch.manual_seed(0)
