@@ -11,7 +11,8 @@ and rank 0 of the children prints the JSON line.
   (configs[2]); a step = one training step on one batch, inputs resident in HBM.
 * the same run also times the forward-only workload (configs[1], eval, batch 4) and reports it under
   "forward_only" (the north star's 40 frame-pairs/s/GPU target is stated on it).
-Rank 0 prints ONE JSON line.
+Rank 0 prints ONE compact JSON line (< 8 KB, `compact_line`) as the only stdout line; the full object with every per-family
+figure goes to bench_detail.json.
 """
 import argparse
 import json
@@ -44,6 +45,9 @@ def parse():
                     help='cycle this many resident batches of DIFFERENT synthetic frame-pairs through the steps (1 = the same batch '
                          'every step): every sweep has its own lattice sizes, so the speculative sizing of the pyramid (previous '
                          'sizes + 25 %%) and its fallback are part of what is timed, as in a real training loop (iterater.py:26-43)')
+    ap.add_argument('--detail', default=None, metavar='PATH',
+                    help='where the FULL result object goes (default: bench_detail.json next to bench.py, and gpurun_out/ when it '
+                         'exists); stdout carries only the compact line')
     ap.add_argument('--set', action='append', default=[], metavar='MODULE.ATTR=VALUE',
                     help='builder A/B runs: set a switch of efgh_amd (e.g. ops.PLANE_DMA=0) before anything is built; the line '
                          'records it under "switches" (a default run has none)')
@@ -429,6 +433,105 @@ def config_r(iters=10, warm=3):
     return out
 
 
+def _r(x, n=4):
+    return round(x, n) if isinstance(x, float) else x
+
+
+def _rl(o, extra=()):
+    """the contract's roofline object (bound, kernel name, achieved, peak, unit, frac, traffic) + a few small figures"""
+    if not isinstance(o, dict):
+        return None
+    keys = ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic') + tuple(extra)
+    r = {k: _r(o.get(k)) for k in keys if k in o or k == 'traffic'}
+    r['kernel'] = str(o.get('kernel', ''))[:64]
+    return r
+
+
+def compact_line(out):
+    """ONE short JSON object (< 8 KB; in practice ~3 KB) for the driver: the contract keys + the roofline / cpu_baseline objects
+    + the fractions of every kernel family.  The full object (20 KB) goes to bench_detail.json: round 5's line had
+    grown to 20 KB and the driver's record kept only its tail (`BENCH_r05.json: parsed null`)."""
+    c = {k: _r(out.get(k)) for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                                     'vs_baseline', 'dtype', 'data')}
+    cfg = dict(out.get('config') or {})
+    cfg['workload'] = str(cfg.get('workload', ''))[:200]
+    c['config'] = cfg
+    for k in ('rccl_ranks', 'dist_backend', 'visible_gpus', 'replicas_identical', 'compute_streams'):
+        if k in out:
+            c[k] = out[k]
+    c['scale'] = 'unmeasured: the pool has no multi-GPU node' if (out.get('n_gpus') or 1) == 1 else 'this line'
+    c['roofline'] = _rl(out.get('roofline'), ('avg_launch_ms', 'launches_per_step', 'kernel_ms_per_step'))
+    fr = {}
+    for name, key in (('bcl', 'roofline_bcl'), ('gemm', 'roofline_gemm'), ('wgrad', 'roofline_wgrad'), ('wino', 'roofline_wino'),
+                      ('wino_wgrad', 'roofline_wino_wgrad'), ('wino2d_gemm', 'roofline_wino2d_gemm'), ('hbm_convs', 'roofline_hbm_convs'),
+                      ('resnet_branch', 'roofline_resnet_branch'), ('mfma_step', 'mfma_step_utilisation')):
+        o = out.get(key)
+        if isinstance(o, dict) and 'frac' in o:
+            fr[name] = _r(o['frac'])
+    top = out.get('roofline') or {}
+    for name, tag in (('wino2d_gemm', 'k_plane_gemm'), ('wino', 'k_wino43')):
+        if name not in fr and str(top.get('kernel', '')).startswith(tag):
+            fr[name] = _r(top.get('frac'))
+    c['roofline_fracs'] = fr
+    b = out.get('roofline_bcl')
+    if isinstance(b, dict):
+        c['roofline_bcl'] = _rl(b, ('kernel_ms_per_step', 'algorithmic_mb_per_step'))
+        c['roofline_bcl']['kernel'] = 'lattice build + splat gather + splat adjoint (lattice.hip, bcl.hip)'
+        parts = b.get('parts') or {}
+        c['roofline_bcl']['parts_ms'] = {k: _r(v.get('ms_per_step')) for k, v in parts.items()}
+    rb = out.get('roofline_resnet_branch')
+    if isinstance(rb, dict):
+        c['roofline_resnet_branch'] = {'frac': _r(rb.get('frac')), 'span_ms': _r(rb.get('span_ms'), 2), 'non_mfma_ms': _r(rb.get('non_mfma_ms'), 2),
+                                       'mfma_kernels_alone_frac': _r((rb.get('mfma_kernels_alone') or {}).get('frac'))}
+    cb = out.get('cpu_baseline')
+    if isinstance(cb, dict):
+        c['cpu_baseline'] = {k: _r(cb.get(k), 5) for k in ('value', 'unit', 'cores', 'host_cpus', 'kind')}
+        c['cpu_baseline']['sample'] = str(cb.get('sample', ''))[:240]
+    fo = out.get('forward_only')
+    if isinstance(fo, dict):
+        c['forward_value'] = _r(fo.get('value'), 3)
+        c['forward_ms_per_step'] = _r(fo.get('ms_per_step'), 3)
+        ff = {}
+        for name, key in (('top', 'roofline'), ('bcl', 'roofline_bcl'), ('resnet_branch', 'roofline_resnet_branch'),
+                          ('mfma_step', 'mfma_step_utilisation'), ('hbm_convs', 'roofline_hbm_convs')):
+            o = fo.get(key)
+            if isinstance(o, dict) and 'frac' in o:
+                ff[name] = _r(o['frac'])
+        c['forward_fracs'] = ff
+    cr = out.get('config_r')
+    if isinstance(cr, dict):
+        if 'error' in cr:
+            c['config_r'] = {'error': str(cr['error'])[:200]}
+        else:
+            c['config_r'] = {'train_ms': _r(cr.get('train_ms'), 2), 'fwd_ms': _r(cr.get('fwd_ms'), 2),
+                             'enqueue_ms': _r((cr.get('train') or {}).get('enqueue_ms'), 2), 'gpu_ms': _r((cr.get('train') or {}).get('gpu_ms'), 2),
+                             'host_syncs': cr.get('host_syncs_per_train_iteration')}
+    for k in ('peak_hbm_gb_per_gpu', 'switches'):
+        if k in out:
+            c[k] = _r(out[k], 2)
+    c['detail'] = 'bench_detail.json'
+    return c
+
+
+def emit(out, detail=None):
+    """full object -> bench_detail.json (+ gpurun_out/ when it exists); the compact line is the ONLY stdout line (the full object is
+    not printed anywhere: a 20-KB line on either stream is what the driver's record could not hold)"""
+    full = json.dumps(out)
+    paths = [detail] if detail else [os.path.join(d, 'bench_detail.json') for d in (ROOT, os.path.join(ROOT, 'gpurun_out')) if os.path.isdir(d)]
+    for path in paths:
+        try:
+            with open(path, 'w') as fh:
+                fh.write(full + '\n')
+        except OSError as e:
+            sys.stderr.write('bench.py: could not write %s (%s)\n' % (path, e))
+    sys.stderr.write('bench.py: full object (%d bytes) written to bench_detail.json\n' % len(full))
+    sys.stderr.flush()
+    line = json.dumps(compact_line(out), separators=(',', ':'))
+    assert len(line) < 8192, len(line)
+    sys.stdout.flush()
+    print(line, flush=True)
+
+
 def spawn_ranks(a):
     """`python bench.py --gpus N` outside a launcher: start `torch.distributed.run` with N ranks as a CHILD process and hand its
     exit code on.  Nothing in this process has touched the GPU (no torch import yet), so no initialised process is replaced."""
@@ -750,7 +853,7 @@ def main():
             out['forward_mfma_frac'] = fwd['mfma_step_utilisation']['frac']
             out['forward_roofline_frac'] = fwd.get('roofline', {}).get('frac')
             out['forward_roofline_bcl_frac'] = fwd.get('roofline_bcl', {}).get('frac')
-        print(json.dumps(out))
+        emit(out, a.detail)
     if world > 1:
         dist.destroy_process_group()
 

@@ -411,3 +411,31 @@ def test_launcher_refuses_gpus_n_for_a_test_configuration(tmp_path):
     r = subprocess.run([sys.executable, '-m', 'efgh_amd.run', '--gpus', '2', str(tmp_path / 'main.py'), str(tmp_path / 'cfg.yaml'), 'x'],
                        env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and 'single process' in r.stderr
+
+
+def test_bench_line_is_compact(capsys, tmp_path):
+    """the driver keeps a bounded tail of bench.py's stdout (round 5's 20-KB line was recorded as `parsed: null`): the ONE stdout line
+    is a short object built by `bench.compact_line` from the full result, which goes to a file.  Run on a committed full object."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location('bench_under_test', os.path.join(ROOT, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    full = json.load(open(os.path.join(ROOT, 'profiles', 'r05_bench_default.json')))
+    detail = tmp_path / 'detail.json'
+    bench.emit(full, str(detail))
+    lines = [l for l in capsys.readouterr().out.splitlines() if l.strip()]
+    assert len(lines) == 1 and len(lines[0]) < 8192
+    c = json.loads(lines[0])
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype',
+              'data', 'config', 'roofline', 'cpu_baseline', 'roofline_fracs', 'forward_value', 'config_r'):
+        assert k in c, k
+    assert c['config']['workload'].startswith('BASELINE.json configs[2]') and 'model' not in c['config']
+    r = c['roofline']
+    assert r['bound'] in ('hbm', 'mfma') and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3 and 'traffic' in r and r['unit'] == 'TFLOP/s'
+    cb = c['cpu_baseline']
+    assert cb['kind'] == 'port' and cb['cores'] == 32 and cb['value'] > 0 and cb['sample']
+    assert abs(c['value'] - full['value']) < 1e-3 and abs(c['ms_per_step'] - full['ms_per_step']) < 1e-3
+    for k in ('bcl', 'gemm', 'wgrad', 'wino', 'wino_wgrad', 'wino2d_gemm', 'hbm_convs', 'resnet_branch', 'mfma_step'):
+        assert 0 < c['roofline_fracs'][k] <= 1, k
+    assert json.load(open(detail)) == full

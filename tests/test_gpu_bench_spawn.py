@@ -28,9 +28,9 @@ def test_bench_spawns_its_own_ranks():
     # after the timed steps every rank holds bit-identical weights (same start, same all-reduced gradients, same Adam), and the
     # communication stream has its hardware queue: three compute streams under world > 1
     assert out['replicas_identical'] is True and out['compute_streams'] == 3
-    for k in ('roofline', 'forward_only'):
+    for k in ('roofline', 'forward_value', 'roofline_fracs'):
         assert k in out
-    assert out['roofline']['frac'] <= 1.0
+    assert out['roofline']['frac'] <= 1.0 and len(lines[0]) < 8192
 
 
 def test_bench_rejects_a_mismatched_launcher():
