@@ -7,7 +7,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get('EFGH_LIB') or os.path.join(_HERE, 'lib', 'libefgh_hip.so')      # EFGH_LIB: A/B runs of two builds
 _lib = None
-ABI_VERSION = 2          # EFGH_ABI_VERSION of include/efgh_hip.h this binding was written against
+ABI_VERSION = 3          # EFGH_ABI_VERSION of include/efgh_hip.h this binding was written against
 
 c_void_p, c_int, c_int32, c_int64, c_float = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int32,
                                               ctypes.c_int64, ctypes.c_float)
@@ -37,6 +37,23 @@ class GemmDesc(ctypes.Structure):
         ('bn_pscale', c_void_p), ('bn_pshift', c_void_p), ('bn_mean', c_void_p), ('bn_invstd', c_void_p),
         ('bn_act', c_int32), ('bn_slope', c_float),
     ]
+
+
+class WgradOutDesc(ctypes.Structure):
+    """mirror of efgh_wgrad_out_desc (include/efgh_hip.h): where a weight gradient belongs in the caller's own layout"""
+    _fields_ = [('W', c_void_p), ('N', c_int32), ('T', c_int32), ('C', c_int32), ('Cp', c_int32),
+                ('sn', c_int64), ('sc', c_int64), ('st', c_int64), ('taps', c_int32 * 16), ('accumulate', c_int32)]
+
+
+WROTE_OUT = 1            # EFGH_WROTE_OUT
+
+
+def check_wrote(rc):
+    """return code of a weight-gradient entry point -> True when the launch wrote the caller's layout itself (EFGH_WROTE_OUT)"""
+    if rc == WROTE_OUT:
+        return True
+    check(rc)
+    return False
 
 
 def lib():

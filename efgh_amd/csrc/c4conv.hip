@@ -13,7 +13,6 @@
 // combined with fp32 atomics.
 #include "common.h"
 
-void efgh_launch_fold_splits(const float *part, int zs, long long total, float *dst, hipStream_t st);   // wgrad.hip
 
 namespace {
 
@@ -511,7 +510,8 @@ extern "C" int64_t efgh_c4_wgrad_workspace(const efgh_gemm_desc *d) {
     return (int64_t)grid_of(a.units) * WAVES * d->N * 36;
 }
 
-extern "C" int efgh_c4_wgrad(const efgh_gemm_desc *d, const float *G, int64_t ldg, float *dWp, float *workspace, void *stream_) {
+extern "C" int efgh_c4_wgrad(const efgh_gemm_desc *d, const float *G, int64_t ldg, float *dWp, float *workspace,
+                             const efgh_wgrad_out_desc *out, void *stream_) {
     hipStream_t st = (hipStream_t)stream_;
     EFGH_CHECK_ARG(efgh_c4_wgrad_supported(d) && G && dWp && ldg >= d->N);
     EFGH_CHECK_ARG(workspace && (((uintptr_t)workspace) & 15) == 0 && (((uintptr_t)dWp) & 15) == 0);
@@ -528,7 +528,7 @@ extern "C" int efgh_c4_wgrad(const efgh_gemm_desc *d, const float *G, int64_t ld
     case 7: k_c4_wgrad<7><<<grid, 256, 0, st>>>(a); break;
     default: k_c4_wgrad<8><<<grid, 256, 0, st>>>(a); break;
     }
-    efgh_launch_fold_splits(workspace, grid * WAVES, (long long)d->N * 36, dWp, st);
+    const bool wrote = efgh_launch_fold_splits(workspace, grid * WAVES, (long long)d->N * 36, dWp, st, out);
     EFGH_CHECK_LAUNCH();
-    return EFGH_OK;
+    return wrote ? EFGH_WROTE_OUT : EFGH_OK;
 }

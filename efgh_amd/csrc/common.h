@@ -155,14 +155,17 @@ static inline int efgh_wg_per_cu(const void *kernel, int threads, size_t dyn_lds
     return n;
 }
 
-// ---- fold / finish + unpack in one launch (wgrad.hip owns the armed descriptor, see efgh_fold_unpack_arm) ----
-struct efgh_fold_unpack_args { float *W; int N, T, C, Cp; long long sn, sc, st; int taps[16]; int accumulate; };
-// takes the armed descriptor of this host thread if it describes a [>= N rows][T][Cp] packed gradient with identity taps
-// (a finish kernel that writes the reference layout itself); marks it consumed
-bool efgh_fold_unpack_take(efgh_fold_unpack_args *out, int rows, int T, int Cp);
-// hides / restores the armed state around an inner fold that must not consume it
-int efgh_fold_unpack_suspend(void);
-void efgh_fold_unpack_resume(int state);
+// ---- fold / finish + unpack in one launch: every weight-gradient entry point takes an optional `const efgh_wgrad_out_desc *out`
+// (include/efgh_hip.h; ABI 3 - rounds 5's thread-local arm / disarm hand-off is gone: no state outlives a call) ----
+// the fold of `zs` partial planes (wgrad.hip); with `out` describing exactly the folded [>= N rows][T][Cp] plane it writes the
+// caller's layout itself and returns true, else the packed plane goes to dst and it returns false
+bool efgh_launch_fold_splits(const float *part, int zs, long long total, float *dst, hipStream_t st, const efgh_wgrad_out_desc *out = nullptr);
+// does `out` describe a [rows][T][Cp] packed gradient with identity taps (what a FINISH kernel can write through plain strides)?
+static inline bool efgh_wgrad_out_fits(const efgh_wgrad_out_desc *out, int rows, int T, int Cp) {
+    if (!out || !out->W || out->T != T || out->Cp != Cp || rows < out->N || rows >= out->N + 4) return false;
+    for (int t = 0; t < T; ++t) if (out->taps[t] != t) return false;
+    return true;
+}
 
 // ---- Winograd weight transforms, one work item per call (k_wino_pack / k_w2_pack and the batched form k_wino_pack_batched) ----
 // float64 with the contraction order WRITTEN OUT (explicit fma): every kernel that inlines these produces the same bits - left to

@@ -291,7 +291,6 @@ bool gemm_ok(const efgh_gemm_desc *d) {
 
 }  // namespace
 
-void efgh_launch_fold_splits(const float *part, int zs, long long total, float *dst, hipStream_t st);      // wgrad.hip
 
 extern "C" int efgh_plane_gemm_supported(const efgh_gemm_desc *d) { return gemm_ok(d) ? 1 : 0; }
 

@@ -23,7 +23,6 @@
 // once, as 16-byte accesses, with the next unit's loads in flight during the MFMAs.
 #include "common.h"
 
-void efgh_launch_fold_splits(const float *part, int zs, long long total, float *dst, hipStream_t st);   // wgrad.hip
 
 namespace {
 
@@ -405,7 +404,8 @@ extern "C" int64_t efgh_sc_wgrad_workspace(const efgh_gemm_desc *d) {
     return (int64_t)grid_of(a.units) * WAVES * d->N * d->T * d->C;
 }
 
-extern "C" int efgh_sc_wgrad(const efgh_gemm_desc *d, const float *G, int64_t ldg, float *dWp, float *workspace, void *stream_) {
+extern "C" int efgh_sc_wgrad(const efgh_gemm_desc *d, const float *G, int64_t ldg, float *dWp, float *workspace,
+                             const efgh_wgrad_out_desc *out, void *stream_) {
     hipStream_t st = (hipStream_t)stream_;
     EFGH_CHECK_ARG(efgh_sc_wgrad_supported(d) && G && dWp && workspace && ldg >= d->N && ldg % 4 == 0 && (((uintptr_t)G) & 15) == 0);
     SCArgs a;
@@ -423,7 +423,7 @@ extern "C" int efgh_sc_wgrad(const efgh_gemm_desc *d, const float *G, int64_t ld
     // waves without a unit never ran: their planes are garbage - only the planes of waves that had work are folded
     const long long nw = (long long)grid * WAVES;
     const long long used = a.units < nw ? a.units : nw;
-    efgh_launch_fold_splits(workspace, (int)used, (long long)d->N * d->T * d->C, dWp, st);
+    const bool wrote = efgh_launch_fold_splits(workspace, (int)used, (long long)d->N * d->T * d->C, dWp, st, out);
     EFGH_CHECK_LAUNCH();
-    return EFGH_OK;
+    return wrote ? EFGH_WROTE_OUT : EFGH_OK;
 }

@@ -9,7 +9,6 @@
 // (bias, scale/shift, residual, activation) as k_gather_gemm; packed weights [N][T][C].
 #include "common.h"
 
-void efgh_launch_fold_splits(const float *part, int zs, long long total, float *dst, hipStream_t st);   // wgrad.hip
 
 namespace {
 constexpr int TPB = 256;
@@ -658,7 +657,8 @@ extern "C" int64_t efgh_thin_wgrad_workspace(const efgh_gemm_desc *d) {
     return (int64_t)thin_wgrad_grid(d, nullptr) * d->N * d->T * d->C;
 }
 
-extern "C" int efgh_thin_wgrad(const efgh_gemm_desc *d, const float *G, int64_t ldg, float *dWp, float *workspace, void *stream_) {
+extern "C" int efgh_thin_wgrad(const efgh_gemm_desc *d, const float *G, int64_t ldg, float *dWp, float *workspace,
+                               const efgh_wgrad_out_desc *out, void *stream_) {
     hipStream_t st = (hipStream_t)stream_;
     EFGH_CHECK_ARG(d && G && dWp && d->mode == 1 && d->N % 4 == 0 && d->C % 4 == 0 && ldg % 4 == 0);
     EFGH_CHECK_ARG(d->M == (int64_t)d->B * d->Hv * d->Wv);
@@ -681,9 +681,9 @@ extern "C" int efgh_thin_wgrad(const efgh_gemm_desc *d, const float *G, int64_t 
         efgh_set_error("thin wgrad: unsupported shape C=%d N=%d T=%d", d->C, d->N, d->T);
         return EFGH_E_INVALID;
     }
-    efgh_launch_fold_splits(workspace, grid, (long long)a.N * a.K, dWp, st);
+    const bool wrote = efgh_launch_fold_splits(workspace, grid, (long long)a.N * a.K, dWp, st, out);
     EFGH_CHECK_LAUNCH();
-    return EFGH_OK;
+    return wrote ? EFGH_WROTE_OUT : EFGH_OK;
 }
 
 /* 4 -> 4 channels, 3x3, stride 1, pad 1: deterministic weight gradient (k_c4n4_wgrad3x3); workspace in floats */
@@ -694,7 +694,8 @@ extern "C" int64_t efgh_c4n4_wgrad_workspace(const efgh_gemm_desc *d) {
     return (int64_t)((d->Win + 255) / 256) * ((d->Hin + CN_RPW - 1) / CN_RPW) * d->B * 144;
 }
 
-extern "C" int efgh_c4n4_wgrad(const efgh_gemm_desc *d, const float *G, int64_t ldg, float *dWp, float *workspace, void *stream_) {
+extern "C" int efgh_c4n4_wgrad(const efgh_gemm_desc *d, const float *G, int64_t ldg, float *dWp, float *workspace,
+                               const efgh_wgrad_out_desc *out, void *stream_) {
     hipStream_t st = (hipStream_t)stream_;
     EFGH_CHECK_ARG(c4n4_ok(d) && G && dWp && workspace && ldg % 4 == 0 && (((uintptr_t)G) & 15) == 0 &&
                    (int64_t)(d->Win + 512) * ldg * 4 < (1ll << 31));
@@ -703,9 +704,9 @@ extern "C" int efgh_c4n4_wgrad(const efgh_gemm_desc *d, const float *G, int64_t 
     a.G = G; a.ldg = ldg;
     const dim3 grid((a.Win + 255) / 256, (a.Hin + CN_RPW - 1) / CN_RPW, d->B);
     k_c4n4_wgrad3x3<<<grid, 256, 0, st>>>(a, workspace);
-    efgh_launch_fold_splits(workspace, (int)(grid.x * grid.y * grid.z), 144, dWp, st);
+    const bool wrote = efgh_launch_fold_splits(workspace, (int)(grid.x * grid.y * grid.z), 144, dWp, st, out);
     EFGH_CHECK_LAUNCH();
-    return EFGH_OK;
+    return wrote ? EFGH_WROTE_OUT : EFGH_OK;
 }
 
 // ---- stride-2 transposed conv with <= 2 output channels as GEMM + col2im ------------------------------

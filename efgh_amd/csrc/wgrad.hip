@@ -198,7 +198,7 @@ k_gather_wgrad(const WArgs p0) {
 // dst may be plane 0 of `part` (every element is read and written by one workgroup only, reads before the barrier).
 // UNPACK (round 5): the folded element goes straight to its place in the reference layout, W.flat[n*sn + c*sc + tap[t]*st] (what
 // k_unpack_weight did in a second launch from the packed [N][T][Cp] plane) - same sums, same order, one launch and one plane less
-typedef efgh_fold_unpack_args FoldUnpackArgs;
+typedef efgh_wgrad_out_desc FoldUnpackArgs;
 
 template <bool UNPACK>
 __global__ void __launch_bounds__(256) k_fold_splits(const float4 *part, int zs, long long total4, float4 *dst, const FoldUnpackArgs u) {
@@ -286,56 +286,25 @@ k_table_scatter_add(const float *__restrict__ src, const int *__restrict__ table
 
 }  // namespace
 
-// A caller that wants the NEXT fold of this host thread to write the reference layout arms a descriptor first
-// (efgh_fold_unpack_arm); the fold consumes it when the plane it folds is that weight's packed [Np][T][Cp] gradient, and
-// efgh_fold_unpack_disarm() tells the caller whether it did (else the caller unpacks dWp itself, as before).
-static thread_local FoldUnpackArgs g_fu;
-static thread_local int g_fu_state = 0;              // 0 idle, 1 armed, 2 consumed
-
-extern "C" int efgh_fold_unpack_arm(float *W, int32_t N, int32_t T, int32_t C, int32_t Cp, int64_t sn, int64_t sc, int64_t stt,
-                                    const int32_t *tapidx, int32_t accumulate) {
-    EFGH_CHECK_ARG(W && N > 0 && T > 0 && T <= 16 && C > 0 && Cp >= C && Cp % 4 == 0);
-    g_fu.W = W; g_fu.N = N; g_fu.T = T; g_fu.C = C; g_fu.Cp = Cp; g_fu.sn = sn; g_fu.sc = sc; g_fu.st = stt;
-    for (int t = 0; t < 16; ++t) g_fu.taps[t] = (tapidx && t < T) ? tapidx[t] : (t < T ? t : 0);
-    g_fu.accumulate = accumulate;
-    g_fu_state = 1;
-    return EFGH_OK;
-}
-
-extern "C" int efgh_fold_unpack_disarm(void) {
-    const int consumed = g_fu_state == 2 ? 1 : 0;
-    g_fu_state = 0;
-    return consumed;
-}
-
-bool efgh_fold_unpack_take(efgh_fold_unpack_args *out, int rows, int T, int Cp) {
-    if (g_fu_state != 1 || g_fu.T != T || g_fu.Cp != Cp || rows < g_fu.N || rows >= g_fu.N + 4) return false;
-    for (int t = 0; t < T; ++t) if (g_fu.taps[t] != t) return false;
-    *out = g_fu;
-    g_fu_state = 2;
-    return true;
-}
-int efgh_fold_unpack_suspend(void) { const int s_ = g_fu_state; if (s_ == 1) g_fu_state = 0; return s_; }
-void efgh_fold_unpack_resume(int state) { if (state == 1 && g_fu_state == 0) g_fu_state = 1; }
-
-// (also used by efgh_wino_wgrad, wino.hip)
-void efgh_launch_fold_splits(const float *part, int zs, long long total, float *dst, hipStream_t st) {
+// (also used by efgh_wino_wgrad, wino.hip, and the dedicated kernels' weight gradients)
+bool efgh_launch_fold_splits(const float *part, int zs, long long total, float *dst, hipStream_t st, const efgh_wgrad_out_desc *out) {
     const long long total4 = total / 4;
     const unsigned grid = (unsigned)((total4 + 15) / 16);
-    if (g_fu_state == 1) {
-        const long long row = (long long)g_fu.T * g_fu.Cp;
-        if (total % row == 0 && total / row >= g_fu.N && total / row < g_fu.N + 4) {      // (Np = N rounded up to 4 rows)
-            k_fold_splits<true><<<grid, 256, 0, st>>>((const float4 *)part, zs, total4, (float4 *)dst, g_fu);
-            g_fu_state = 2;
-            return;
+    if (out && out->W && out->T >= 1 && out->T <= 16 && out->Cp >= out->C && out->Cp % 4 == 0) {
+        const long long row = (long long)out->T * out->Cp;
+        if (total % row == 0 && total / row >= out->N && total / row < out->N + 4) {      // (Np = N rounded up to 4 rows)
+            k_fold_splits<true><<<grid, 256, 0, st>>>((const float4 *)part, zs, total4, (float4 *)dst, *out);
+            return true;
         }
     }
     FoldUnpackArgs none = {};
     k_fold_splits<false><<<grid, 256, 0, st>>>((const float4 *)part, zs, total4, (float4 *)dst, none);
+    return false;
 }
 
 static int gather_wgrad_impl(const efgh_gemm_desc *d, const float *G, int64_t ldg, float *dWp, float *workspace, int nbatch,
-                             int64_t bsG, int64_t bsD, void *stream_);
+                             int64_t bsG, int64_t bsD, const efgh_wgrad_out_desc *out, void *stream_);
+
 
 // the rows m are cut into `zs` chunks that fill whole rounds of resident workgroups (efgh_round_chunks, common.h; round 5 - rounds
 // 1-4 aimed at ~1024 workgroups whatever the layer).  The occupancy is asked of the runtime.  Chunks are multiples of TM.
@@ -360,8 +329,8 @@ extern "C" int64_t efgh_gather_wgrad_workspace(const efgh_gemm_desc *d) {
 }
 
 extern "C" int efgh_gather_wgrad(const efgh_gemm_desc *d, const float *G, int64_t ldg, float *dWp, float *workspace,
-                                 void *stream_) {
-    return gather_wgrad_impl(d, G, ldg, dWp, workspace, 1, 0, 0, stream_);
+                                 const efgh_wgrad_out_desc *out, void *stream_) {
+    return gather_wgrad_impl(d, G, ldg, dWp, workspace, 1, 0, 0, out, stream_);
 }
 
 /* the same contraction for d->nbatch independent problems in ONE launch (mode 0): problem b reads A + b*d->batch_stride_a and
@@ -370,11 +339,11 @@ extern "C" int efgh_gather_wgrad_batched(const efgh_gemm_desc *d, const float *G
                                          float *dWp, int64_t batch_stride_dw, float *workspace, void *stream_) {
     EFGH_CHECK_ARG(d && d->mode == 0 && d->nbatch >= 1 && d->nbatch <= 65535);
     EFGH_CHECK_ARG(d->batch_stride_a % 4 == 0 && batch_stride_g % 4 == 0 && batch_stride_dw == (int64_t)d->N * d->C);
-    return gather_wgrad_impl(d, G, ldg, dWp, workspace, d->nbatch, batch_stride_g, batch_stride_dw, stream_);
+    return gather_wgrad_impl(d, G, ldg, dWp, workspace, d->nbatch, batch_stride_g, batch_stride_dw, nullptr, stream_);
 }
 
 static int gather_wgrad_impl(const efgh_gemm_desc *d, const float *G, int64_t ldg, float *dWp, float *workspace, int nbatch,
-                             int64_t bsG, int64_t bsD, void *stream_) {
+                             int64_t bsG, int64_t bsD, const efgh_wgrad_out_desc *out, void *stream_) {
     hipStream_t st = (hipStream_t)stream_;
     EFGH_CHECK_ARG(d && d->A && G && dWp);
     EFGH_CHECK_ARG(d->C > 0 && d->C % 4 == 0 && d->T >= 1 && d->T <= 16 && d->N >= 1 && d->M >= 1);
@@ -419,9 +388,10 @@ static int gather_wgrad_impl(const efgh_gemm_desc *d, const float *G, int64_t ld
         else if (d->mode == 1) k_gather_wgrad<1, 64><<<grid, 256, 0, st>>>(a);
         else k_gather_wgrad<2, 64><<<grid, 256, 0, st>>>(a);
     }
-    if (zs > 1) efgh_launch_fold_splits(workspace, (int)zs, plane, dWp, st);       // (N % 4 == 0; nbatch > 1 never matches an armed unpack)
+    bool wrote = false;
+    if (zs > 1) wrote = efgh_launch_fold_splits(workspace, (int)zs, plane, dWp, st, nbatch == 1 ? out : nullptr);       // (N % 4 == 0)
     EFGH_CHECK_LAUNCH();
-    return EFGH_OK;
+    return wrote ? EFGH_WROTE_OUT : EFGH_OK;
 }
 
 extern "C" int efgh_unpack_weight(const float *Wp, float *W, int32_t N, int32_t T, int32_t C, int32_t Cp,

@@ -20,7 +20,6 @@
 #include "common.h"
 #include <type_traits>
 
-void efgh_launch_fold_splits(const float *part, int zs, long long total, float *dst, hipStream_t st);   // wgrad.hip
 
 namespace {
 
@@ -572,7 +571,7 @@ extern "C" int64_t efgh_wino_wgrad_workspace(const efgh_gemm_desc *d) {
 }
 
 extern "C" int efgh_wino_wgrad(const efgh_gemm_desc *d, const float *G, int64_t ldg, float *S, float *dWp,
-                               void *stream_) {
+                               const efgh_wgrad_out_desc *out, void *stream_) {
     hipStream_t st = (hipStream_t)stream_;
     EFGH_CHECK_ARG(supported(d) && d->C % 64 == 0 && d->A && G && S && dWp && ldg % 4 == 0);
     EFGH_CHECK_ARG((((uintptr_t)d->A) & 15) == 0 && (((uintptr_t)G) & 15) == 0);
@@ -589,16 +588,14 @@ extern "C" int efgh_wino_wgrad(const efgh_gemm_desc *d, const float *G, int64_t 
     a.tchunk = 0; a.kt = (unsigned)kt; a.nt = (unsigned)nt;
     k_wino_wgrad_rows<<<dim3((unsigned)zs, (unsigned)((d->C / 64) * nt)), 64 * WR_WAVES, 0, st>>>(a, strips, chunks, rh, d->C / 64);
     EFGH_CHECK_LAUNCH();
-    const int fu = efgh_fold_unpack_suspend();       // (the fold of the S partials below is not the packed gradient)
-    if (zs > 1) efgh_launch_fold_splits(S, (int)zs, 3LL * d->N * 3 * d->C, S, st);      // into the first partial, fixed order
-    efgh_fold_unpack_resume(fu);
+    if (zs > 1) efgh_launch_fold_splits(S, (int)zs, 3LL * d->N * 3 * d->C, S, st);      // into the first partial, fixed order (not the packed gradient: no `out`)
     const long long total = (long long)d->N * 3 * d->C;
     long long g = (total + 255) / 256;
-    efgh_fold_unpack_args u;
-    if (efgh_fold_unpack_take(&u, d->N, 9, d->C))
-        k_wino_wgrad_finish3<<<(int)(g > 4096 ? 4096 : g), 256, 0, st>>>(S, u.W, d->N, d->C, u.sn, u.sc, u.st, u.N, u.C, u.accumulate);
+    const bool direct = efgh_wgrad_out_fits(out, d->N, 9, d->C);      // the finish kernel writes the caller's layout itself
+    if (direct)
+        k_wino_wgrad_finish3<<<(int)(g > 4096 ? 4096 : g), 256, 0, st>>>(S, out->W, d->N, d->C, out->sn, out->sc, out->st, out->N, out->C, out->accumulate);
     else
         k_wino_wgrad_finish3<<<(int)(g > 4096 ? 4096 : g), 256, 0, st>>>(S, dWp, d->N, d->C, 9LL * d->C, 1, d->C, d->N, d->C, 0);
     EFGH_CHECK_LAUNCH();
-    return EFGH_OK;
+    return direct ? EFGH_WROTE_OUT : EFGH_OK;
 }

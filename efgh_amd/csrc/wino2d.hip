@@ -31,8 +31,9 @@ __device__ __forceinline__ int ilog2(int v) { return 31 - __builtin_clz(v); }
 // four waves per SIMD resident; with 16-byte quads the kernels needed 256 registers (+ spills) and ran at 1.1 TB/s
 typedef float2 vec_t;
 constexpr int VW = 2;
+struct vec1_t { float x; };          // one channel per lane (k_w2_bwd: twice the tensors of the plain transforms live per tile)
 #define F4OP(dst, expr)                                                                              \
-    { dst.x = expr(x); dst.y = expr(y); }
+    { dst.x = expr(x); if constexpr (sizeof(dst) == 8) dst.y = expr(y); }
 
 // Interpolation points 0, +-3/4, +-3/2, inf (Toom-Cook F(4,3)).  Lavin & Gray's 0, +-1, +-2, inf put factors of 4, 5 and 8 into
 // the transforms; in fp32 the 2-D form then carries 1.5e-6 rms / 3.6e-6 max relative error on a 256-channel layer, this set
@@ -52,6 +53,7 @@ constexpr int VW = 2;
 #define W2_B3 3.375f           /* b^3 */
 
 // B^T (6 -> 6)
+template <class vec_t>
 __device__ __forceinline__ void bt6(const vec_t d[6], vec_t v[6]) {
 #define E0(e) (W2_A2B2 * d[0].e - W2_SUM * d[2].e + d[4].e)
 #define E1(e) ((d[4].e - W2_B2 * d[2].e) + W2_A * (d[3].e - W2_B2 * d[1].e))
@@ -87,6 +89,7 @@ __device__ __forceinline__ void at4(const vec_t m[6], vec_t y[4]) {
 #define W2_F0 (1.0f / 1.265625f)                  /* 1 / f(0)    = 64/81   */
 #define W2_FA (-128.0f / 243.0f)                  /* 1 / f(+-a)             */
 #define W2_FB (32.0f / 243.0f)                    /* 1 / f(+-b)             */
+template <class vec_t>
 __device__ __forceinline__ void g46(const vec_t g[4], vec_t u[6]) {
 #define E0(e) (W2_F0 * g[0].e)
 #define E1(e) (((g[0].e + W2_A2 * g[2].e) + (W2_A * g[1].e + W2_A3 * g[3].e)) * W2_FA)
@@ -129,9 +132,14 @@ __device__ __forceinline__ void axpy4(vec_t &a, float s, const vec_t &v) {
 }
 
 // ---- input transform: thread = (tile, channel pair); 36 x 8-byte loads (pixels outside the image are zero), 36 stores
-template <bool NT>
+// AFF (round 6): A is the RAW output of a train-mode BatchNorm layer whose normalise + activate pass was not run - the transform
+// applies act(raw * scale[c] + shift[c]) on the way in (the producer's activation has this layer as its only consumer, so it is
+// never written or re-read: one write + one read of the activation less per such pair of layers, nets/resnet.py:55-71 conv1 -> conv2,
+// nets/vgg.py:69-83 un-pooled pairs, nets/net_utils.py:66-98 convT -> conv).  Same expression as k_scale_shift_act (one fma, act_f).
+template <bool NT, bool AFF>
 __global__ void __launch_bounds__(TPB)
-k_w2_input(const float *__restrict__ A, long long lda, int C, const TileGeo g, float *__restrict__ V) {
+k_w2_input(const float *__restrict__ A, long long lda, int C, const TileGeo g, float *__restrict__ V,
+           const float *__restrict__ scale, const float *__restrict__ shift, int act, float slope) {
     const int q4n = C / VW, sh = ilog2(q4n);
     const int idx = blockIdx.x * TPB + threadIdx.x;
     const int tx = idx >> sh, q = idx & (q4n - 1);
@@ -144,6 +152,11 @@ k_w2_input(const float *__restrict__ A, long long lda, int C, const TileGeo g, f
     // 1-D transforms in place.  No branch around a load: out-of-image taps read a clamped (valid) address and are zeroed by a
     // select (36 exec-masked branches, one per load, kept the loads from being issued together)
     const vec_t zero = make_float2(0.f, 0.f);
+    vec_t sc = make_float2(1.f, 1.f), sf = zero;
+    if (AFF) {
+        sc = *reinterpret_cast<const vec_t *>(scale + q * VW);
+        sf = *reinterpret_cast<const vec_t *>(shift + q * VW);
+    }
     vec_t d[6][6];
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
@@ -156,7 +169,12 @@ k_w2_input(const float *__restrict__ A, long long lda, int C, const TileGeo g, f
             const int x = x0 - 1 + c;
             const bool ok = rok && (unsigned)x < (unsigned)g.W;
             const int xc = min(max(x, 0), g.W - 1);
-            const vec_t v = *reinterpret_cast<const vec_t *>(__builtin_assume_aligned(row + (long long)xc * lda, 8));
+            vec_t v = *reinterpret_cast<const vec_t *>(__builtin_assume_aligned(row + (long long)xc * lda, 8));
+            if (AFF) {
+                v.x = fmaf(v.x, sc.x, sf.x); v.y = fmaf(v.y, sc.y, sf.y);
+                if (act == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); }
+                else if (act == 2) { v.x = v.x > 0.f ? v.x : v.x * slope; v.y = v.y > 0.f ? v.y : v.y * slope; }
+            }
             d[r][c] = ok ? v : zero;
         }
     }
@@ -229,6 +247,151 @@ k_w2_dy(const float *__restrict__ G, long long ldg, int N, const TileGeo g, floa
     for (int i = 0; i < 6; ++i)
 #pragma unroll
         for (int j = 0; j < 6; ++j) st2<NT>(vp + (long long)(6 * i + j) * as, acc[i][j]);
+}
+
+// ---- BatchNorm backward "apply" inside the two gradient-side transforms (round 6).  A 2-D Winograd layer with a train-mode BatchNorm
+// ran its backward as  reduce (dy, raw -> column sums) -> apply (dy, raw -> draw) -> k_w2_input(draw) for the data gradient +
+// k_w2_dy(draw) for the weight gradient: draw was written once and read twice.  This kernel computes
+//     dpre = dy * act'(y),   draw = coef * (dpre - m1 - xhat * m2),   xhat = (raw - mean) * invstd        (float64, as k_act_bn_bwd_apply)
+// on the fly for the 6x6 window of its tile and leaves BOTH transforms - Vd = B^T draw B over the window, Gy = G4 draw G4^T over the
+// window's inner 4x4 (the tile itself) - and, for a residual layer, dres = dpre of the tile: 2 reads + 4.5 (5.5) writes instead
+// of 5 + 4.5 (6.5).  The activation mask comes from the sign bits the forward pass left (BITS: residual layers) or is re-derived
+// from raw * pscale + pshift, exactly as in the two-pass form.
+struct W2BwdArgs {
+    const float *dy; long long lddy; const float *raw; long long ldraw; const unsigned *ybits;
+    const float *mean, *invstd, *coef, *pscale, *pshift; const double *m1, *m2;
+    int N, act; float slope; TileGeo g;
+    float *Vd, *Gy, *dres; long long lddres;
+};
+
+template <bool NT>
+__device__ __forceinline__ float ld1(const float *p) { return NT ? __builtin_nontemporal_load(p) : *p; }
+template <bool NT>
+__device__ __forceinline__ void st1(float *p, float v) { if (NT) __builtin_nontemporal_store(v, p); else *p = v; }
+
+// thread = (tile, ONE channel): a wave covers 64 consecutive channels of a pixel (256-byte rows).  With channel pairs the window
+// of dy AND raw plus both transforms held 213-256 VGPRs (1-2 waves per SIMD; k_w2_output ran at a third of its rate like that)
+template <bool NT, bool BITS>
+__global__ void __launch_bounds__(TPB, 4)          // (<= 128 VGPRs: an HBM-bound pass lives on bytes in flight)
+k_w2_bwd(const W2BwdArgs p) {
+    const int sh = ilog2(p.N);
+    const int idx = blockIdx.x * TPB + threadIdx.x;
+    // N >= 64 (a power of two): the 64 lanes of a wave are 64 consecutive channels of ONE tile - the tile index is wave-uniform and
+    // is told to the compiler as such: every pixel address is then a scalar base + the lane's channel (no 64-bit address VGPRs),
+    // and the mask words come in through the scalar cache
+    const int tx = __builtin_amdgcn_readfirstlane(idx >> sh), c0 = idx & (p.N - 1);
+    if (tx >= p.g.TW) return;
+    const int rowt = blockIdx.y, ty = rowt % p.g.TH;
+    const long long b = rowt / p.g.TH;
+    const long long t = (long long)rowt * p.g.TW + tx;
+    const int y0 = 4 * ty, x0 = 4 * tx;
+    const float mu = p.mean[c0], is = p.invstd[c0], cf = p.coef[c0];
+    const double m1 = p.m1[c0], m2 = p.m2[c0];
+    float psc = 0.f, psh = 0.f;
+    if (!BITS) { psc = p.pscale[c0]; psh = p.pshift[c0]; }
+    // addresses: one scalar base per window row and tensor + a 32-bit lane offset per window column (clamped; out-of-image taps
+    // are zeroed after the arithmetic).  72 independent 64-bit addresses cost 144 SGPRs / VGPRs and spilled.
+    int xcs[6];
+    unsigned offd[6], offr[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        xcs[c] = min(max(x0 - 1 + c, 0), p.g.W - 1);
+        offd[c] = 4u * (unsigned)(xcs[c] * (int)p.lddy + c0);          // BYTE offsets: base (SGPR pair) + zext(32-bit VGPR) is the
+        offr[c] = 4u * (unsigned)(xcs[c] * (int)p.ldraw + c0);         // addressing mode; an element offset would be shifted in 64 bits
+    }
+    // BITS: the 36 mask bits first, packed into one 64-bit register.  The 64 mask bits of a wave's 64 channels of a pixel are one
+    // aligned 8-byte word at a wave-uniform address: scalar loads, in two halves of 18 (36 SGPRs each)
+    unsigned long long mk = 0ULL;
+    if (BITS) {
+        const int cb = __builtin_amdgcn_readfirstlane(c0) & ~63;
+        const unsigned cl = (unsigned)(c0 & 63);
+        const int wpp = p.N >> 5;                                            // mask words per pixel
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+            for (int rr = 0; rr < 3; ++rr) {
+                const int r = 3 * half + rr;
+                const int yc = min(max(y0 - 1 + r, 0), p.g.H - 1);
+                const unsigned *bw = p.ybits + ((b * p.g.H + yc) * p.g.W) * wpp + (cb >> 5);
+#pragma unroll
+                for (int c = 0; c < 6; ++c) {
+                    const unsigned long long w2 = *reinterpret_cast<const unsigned long long *>(bw + xcs[c] * wpp);
+                    mk |= ((w2 >> cl) & 1ULL) << (6 * r + c);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    vec1_t d[6][6];
+    float rw[6][6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        const int yc = min(max(y0 - 1 + r, 0), p.g.H - 1);
+        const long long prow = (b * p.g.H + yc) * p.g.W;
+        const float *dr = p.dy + prow * p.lddy, *rr = p.raw + prow * p.ldraw;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            d[r][c].x = ld1<NT>(reinterpret_cast<const float *>(reinterpret_cast<const char *>(dr) + offd[c]));
+            rw[r][c] = ld1<NT>(reinterpret_cast<const float *>(reinterpret_cast<const char *>(rr) + offr[c]));
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        const int y = y0 - 1 + r;
+        const bool rok = (unsigned)y < (unsigned)p.g.H;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            const int x = x0 - 1 + c;
+            const bool ok = rok && (unsigned)x < (unsigned)p.g.W;
+            const float yy = BITS ? (((mk >> (6 * r + c)) & 1ULL) ? 1.f : -1.f) : fmaf(rw[r][c], psc, psh);
+            float da = 1.f;
+            if (p.act == 1) da = yy > 0.f ? 1.f : 0.f;
+            else if (p.act == 2) da = yy > 0.f ? 1.f : p.slope;
+            const float gv = d[r][c].x * da;
+            if (p.dres && ok && r >= 1 && r <= 4 && c >= 1 && c <= 4)
+                st1<NT>(p.dres + ((b * p.g.H + y) * p.g.W + x) * p.lddres + c0, gv);
+            const double xh = ((double)rw[r][c] - (double)mu) * (double)is;
+            const float o = (float)((double)cf * (((double)gv - m1) - xh * m2));
+            d[r][c].x = ok ? o : 0.f;
+        }
+    }
+    // Gy = G4 draw G4^T over the tile itself (rows / columns 1..4 of the window), stored column by column
+    {
+        vec1_t wx[4][6];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const vec1_t in4[4] = {d[r + 1][1], d[r + 1][2], d[r + 1][3], d[r + 1][4]};
+            g46(in4, wx[r]);
+        }
+        float *gp = p.Gy + t * 36 * p.N + c0;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            vec1_t col[4], w[6];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) col[r] = wx[r][j];
+            g46(col, w);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) st1<NT>(gp + (long long)(6 * i + j) * p.N, w[i].x);
+        }
+    }
+    // Vd = B^T draw B over the window
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        vec1_t w[6];
+        bt6(d[r], w);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) d[r][j] = w[j];
+    }
+    float *vp = p.Vd + t * 36 * p.N + c0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        vec1_t col[6], w[6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) col[r] = d[r][j];
+        bt6(col, w);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) st1<NT>(vp + (long long)(6 * i + j) * p.N, w[i].x);
+    }
 }
 
 // ---- output transform + the k_gather_gemm epilogue.  Thread = (tile column, channel pair); a workgroup walks ROWS_PER_BLOCK
@@ -503,8 +666,21 @@ extern "C" int efgh_wino2d_input(const float *A, int64_t lda, int32_t C, int32_t
     EFGH_CHECK_ARG((((uintptr_t)A) & 15) == 0 && (((uintptr_t)V) & 15) == 0);
     const TileGeo g = geo(B, H, W);
     EFGH_CHECK_ARG(pow2(C / VW) && (long long)B * g.TH < 65536);
-    if (efgh_stream_nt(g.T * 36ll * C * 4)) k_w2_input<true><<<row_grid(g, C / VW, 1), TPB, 0, (hipStream_t)stream_>>>(A, lda, C, g, V);
-    else k_w2_input<false><<<row_grid(g, C / VW, 1), TPB, 0, (hipStream_t)stream_>>>(A, lda, C, g, V);
+    if (efgh_stream_nt(g.T * 36ll * C * 4)) k_w2_input<true, false><<<row_grid(g, C / VW, 1), TPB, 0, (hipStream_t)stream_>>>(A, lda, C, g, V, nullptr, nullptr, 0, 0.f);
+    else k_w2_input<false, false><<<row_grid(g, C / VW, 1), TPB, 0, (hipStream_t)stream_>>>(A, lda, C, g, V, nullptr, nullptr, 0, 0.f);
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}
+
+/* the same transform of act(A * scale[c] + shift[c]): A = the raw output of a train-mode BatchNorm layer (see k_w2_input<.., AFF>) */
+extern "C" int efgh_wino2d_input_act(const float *A, int64_t lda, int32_t C, int32_t B, int32_t H, int32_t W, const float *scale,
+                                     const float *shift, int32_t act, float slope, float *V, void *stream_) {
+    EFGH_CHECK_ARG(A && V && scale && shift && C > 0 && C % 4 == 0 && lda % 4 == 0 && B > 0 && H > 0 && W > 0 && act >= 0 && act <= 2);
+    EFGH_CHECK_ARG((((uintptr_t)A) & 15) == 0 && (((uintptr_t)V) & 15) == 0 && (((uintptr_t)scale) & 7) == 0 && (((uintptr_t)shift) & 7) == 0);
+    const TileGeo g = geo(B, H, W);
+    EFGH_CHECK_ARG(pow2(C / VW) && (long long)B * g.TH < 65536);
+    if (efgh_stream_nt(g.T * 36ll * C * 4)) k_w2_input<true, true><<<row_grid(g, C / VW, 1), TPB, 0, (hipStream_t)stream_>>>(A, lda, C, g, V, scale, shift, act, slope);
+    else k_w2_input<false, true><<<row_grid(g, C / VW, 1), TPB, 0, (hipStream_t)stream_>>>(A, lda, C, g, V, scale, shift, act, slope);
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
 }
@@ -517,6 +693,30 @@ extern "C" int efgh_wino2d_dy(const float *G, int64_t ldg, int32_t N, int32_t B,
     EFGH_CHECK_ARG(pow2(N / VW) && (long long)B * g.TH < 65536);
     if (efgh_stream_nt(g.T * 36ll * N * 4)) k_w2_dy<true><<<row_grid(g, N / VW, 1), TPB, 0, (hipStream_t)stream_>>>(G, ldg, N, g, Gy);
     else k_w2_dy<false><<<row_grid(g, N / VW, 1), TPB, 0, (hipStream_t)stream_>>>(G, ldg, N, g, Gy);
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}
+
+extern "C" int efgh_wino2d_bwd_transforms(const float *dy, int64_t lddy, const float *raw, int64_t ldraw, const uint32_t *ybits,
+                                          const float *pscale, const float *pshift, const float *mean, const float *invstd,
+                                          const float *coef, const double *m1, const double *m2, int32_t N, int32_t B, int32_t H,
+                                          int32_t W, int32_t act, float slope, float *Vd, float *Gy, float *dres, int64_t lddres,
+                                          void *stream_) {
+    EFGH_CHECK_ARG(dy && raw && mean && invstd && coef && m1 && m2 && Vd && Gy && N > 0 && N % 4 == 0 && B > 0 && H > 0 && W > 0);
+    EFGH_CHECK_ARG((ybits != nullptr) != (pscale != nullptr && pshift != nullptr) && act >= 0 && act <= 2);
+    EFGH_CHECK_ARG(lddy % 4 == 0 && ldraw % 4 == 0 && (!dres || lddres % 4 == 0) && (!ybits || N % 32 == 0));
+    EFGH_CHECK_ARG(((((uintptr_t)dy) | ((uintptr_t)raw) | ((uintptr_t)Vd) | ((uintptr_t)Gy) | ((uintptr_t)dres)) & 15) == 0);
+    W2BwdArgs a;
+    a.dy = dy; a.lddy = lddy; a.raw = raw; a.ldraw = ldraw; a.ybits = ybits;
+    a.mean = mean; a.invstd = invstd; a.coef = coef; a.pscale = pscale; a.pshift = pshift; a.m1 = m1; a.m2 = m2;
+    a.N = N; a.act = act; a.slope = slope; a.g = geo(B, H, W);
+    a.Vd = Vd; a.Gy = Gy; a.dres = dres; a.lddres = lddres;
+    EFGH_CHECK_ARG(pow2(N) && N >= 64 && (long long)B * a.g.TH < 65536 && (((uintptr_t)ybits) & 7) == 0);
+    EFGH_CHECK_ARG((long long)W * lddy < (1ll << 30) && (long long)W * ldraw < (1ll << 30));        // (32-bit lane offsets inside a row)
+    const dim3 grid = row_grid(a.g, N, 1);             // (one channel per lane)
+    const bool nt = efgh_stream_nt(a.g.T * 36ll * N * 4);
+    if (ybits) { if (nt) k_w2_bwd<true, true><<<grid, TPB, 0, (hipStream_t)stream_>>>(a); else k_w2_bwd<false, true><<<grid, TPB, 0, (hipStream_t)stream_>>>(a); }
+    else { if (nt) k_w2_bwd<true, false><<<grid, TPB, 0, (hipStream_t)stream_>>>(a); else k_w2_bwd<false, false><<<grid, TPB, 0, (hipStream_t)stream_>>>(a); }
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
 }
@@ -549,15 +749,15 @@ extern "C" int efgh_wino2d_output_pooled(const float *M, const efgh_gemm_desc *d
     return EFGH_OK;
 }
 
-extern "C" int efgh_wino2d_wfinish(const float *S, float *dWp, int32_t N, int32_t C, void *stream_) {
+extern "C" int efgh_wino2d_wfinish(const float *S, float *dWp, int32_t N, int32_t C, const efgh_wgrad_out_desc *out, void *stream_) {
     EFGH_CHECK_ARG(S && dWp && N > 0 && C > 0);
     const long long total = (long long)N * C;
     long long g = (total + 255) / 256;
-    efgh_fold_unpack_args u;
-    if (efgh_fold_unpack_take(&u, N, 9, C))          // straight into the reference layout (no packed plane, no unpack launch)
-        k_w2_wfinish<<<(int)(g > 4096 ? 4096 : g), 256, 0, (hipStream_t)stream_>>>(S, u.W, N, C, u.sn, u.sc, u.st, u.N, u.C, u.accumulate);
+    const bool direct = efgh_wgrad_out_fits(out, N, 9, C);          // straight into the caller's layout (no packed plane, no unpack launch)
+    if (direct)
+        k_w2_wfinish<<<(int)(g > 4096 ? 4096 : g), 256, 0, (hipStream_t)stream_>>>(S, out->W, N, C, out->sn, out->sc, out->st, out->N, out->C, out->accumulate);
     else
         k_w2_wfinish<<<(int)(g > 4096 ? 4096 : g), 256, 0, (hipStream_t)stream_>>>(S, dWp, N, C, 9LL * C, 1, C, N, C, 0);
     EFGH_CHECK_LAUNCH();
-    return EFGH_OK;
+    return direct ? EFGH_WROTE_OUT : EFGH_OK;
 }

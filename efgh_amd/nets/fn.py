@@ -41,7 +41,7 @@ class LayerSpec:
 
     def __init__(self, N, C, T, mode, launches, M, out_shape, pack_fwd, dgrad, wgrad_unpack, bn=None,
                  train=False, act=ACT_NONE, slope=0.0, table=None, c_real=None, custom_forward=None,
-                 custom_wgrad=None, passthrough=False, pool=False):
+                 custom_wgrad=None, passthrough=False, pool=False, defer_act=False, bwd_fusable=False):
         self.N, self.C, self.T, self.mode, self.M = N, C, T, mode, M
         self.launches, self.out_shape = launches, out_shape
         self.pack_fwd, self.dgrad, self.wgrad_unpack = pack_fwd, dgrad, wgrad_unpack
@@ -55,6 +55,20 @@ class LayerSpec:
         # pool: the layer is followed by MaxPool2d(2,2); BatchNorm + activation + pooling run as one pass over the raw output and
         # the full-resolution activation is never stored (backward recomputes the window from raw)
         self.pool = pool
+        # defer_act: the caller guarantees that this layer's activation has ONE consumer and that it is a 2-D Winograd layer
+        # (ops.lazy_capable): the normalise + activate pass is not run, the raw output is returned carrying an ops.LazyAct
+        self.defer_act = defer_act
+        # bwd_fusable: the layer's data AND weight gradient both run on the 2-D Winograd path, so the BatchNorm backward's apply
+        # pass can ride in their gradient-side transforms (ops.wino2d_bwd_transforms); its dgrad takes pre_v=
+        self.bwd_fusable = bwd_fusable
+
+
+def materialize(x, lazy):
+    """act(x*scale + shift) of a raw BatchNorm output with a pending activation, for a consumer that cannot apply it itself"""
+    M = x.numel() // x.shape[-1]
+    y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    ops.scale_shift_act(x, ld_of(x), lazy.scale, lazy.shift, y, x.shape[-1], M, x.shape[-1], lazy.act, lazy.slope)
+    return y
 
 
 def claim_grad(p):
@@ -91,7 +105,7 @@ def _bias_grad_behind_bn(ctx, p_bias, draw, M, Np, N, train_bn, delivered):
     if g is not None:                      # the flat gradient slice is already zero (FlatParams.zero_grad)
         delivered.append(done)
         return None
-    return torch.zeros(N, dtype=torch.float32, device=draw.device)
+    return torch.zeros(N, dtype=torch.float32, device=ctx.saved_tensors[0].device)
 
 
 class BnSrc:
@@ -120,7 +134,13 @@ class GemmLayerFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias, gamma, beta, residual, spec, out_target=None):
         ctx.set_materialize_grads(False)      # an unused passthrough alias must arrive as None, not as a zero tensor to add
         ctx.xsrc = getattr(x, '_efgh_bnsrc', None)           # the BatchNorm layer that produced x (BnSrc), if any
+        lazy = getattr(x, '_efgh_lazy', None)                # x is a RAW BatchNorm output whose activation this layer applies itself
         x = as_rows(x)
+        if lazy is not None and not (spec.custom_forward is None and len(spec.launches) == 1 and not spec.passthrough
+                                     and x.shape[-1] == spec.C
+                                     and ops.lazy_capable(spec.mode, spec.C, ceil4(spec.N), spec.launches[0][0])):
+            x, lazy = materialize(x, lazy), None              # (a consumer the producer was not told about: never wrong, only slower)
+        ctx.lazy = lazy
         dev = x.device
         N, Np = spec.N, ceil4(spec.N)
         M = spec.M
@@ -149,14 +169,14 @@ class GemmLayerFn(torch.autograd.Function):
             if fused_plain:
                 ops.gather_gemm(x, ld_of(x), spec.C, T, wp, Np, m, out, Np, mode=spec.mode, geom=geom,
                                 table=spec.table, bias=b, residual=res, ldr=0 if res is None else ld_of(res),
-                                act=spec.act, slope=spec.slope, flops=fl)
+                                act=spec.act, slope=spec.slope, flops=fl, lazy=lazy)
             else:
                 st = None
                 if need_stats and not thin:
                     st = stats[g0:g0 + gs[li]]
                     g0 += gs[li]
                 ops.gather_gemm(x, ld_of(x), spec.C, T, wp, Np, m, out, Np, mode=spec.mode, geom=geom,
-                                table=spec.table, bias=b, act=ACT_NONE, stats=st, flops=fl)
+                                table=spec.table, bias=b, act=ACT_NONE, stats=st, flops=fl, lazy=lazy)
         ops.TLS.w2v_wanted = False
         y = out
         if bn is not None:
@@ -185,6 +205,12 @@ class GemmLayerFn(torch.autograd.Function):
             if spec.pool:
                 assert res is None
                 y = ops.maxpool2_affine(raw, scale, shift, spec.act, spec.slope)
+            elif (spec.defer_act and ops.LAZY_ACT and need_stats and res is None and Np == N and out_target is None
+                  and spec.custom_forward is None):
+                # the single consumer (a 2-D Winograd layer) normalises and activates inside its input transform: no pass here,
+                # no activation tensor; this layer's own backward re-derives the mask from raw*scale + shift as it always did
+                y = raw
+                y._efgh_lazy = ops.LazyAct(scale, shift, spec.act, spec.slope)
             else:
                 # out_target = (buffer [..][Ct], channel offset): the activation is written straight into that channel slice (the
                 # training-path form of the decoder's torch.cat, see ConcatFn); the returned tensor is a view of the buffer
@@ -280,6 +306,12 @@ class GemmLayerFn(torch.autograd.Function):
             gs1, d1 = claim_grad(p_bias)
             if gs1 is not None:
                 delivered.append(d1)
+        own_wgrad = ctx.needs_input_grad[1] and spec.custom_wgrad is None
+        pre_v = pre_gy = None
+        # the apply pass of the BatchNorm backward inside the gradient-side transforms of a 2-D Winograd layer (draw is never stored)
+        fuse_bwd = (ops.W2_BWD_FUSED and spec.bwd_fusable and has_bn and spec.train and not spec.pool and Np == N
+                    and ctx.needs_input_grad[0] and own_wgrad and (ybits is not None or (psc is not None and not has_res))
+                    and len(spec.out_shape) == 3)
         if fused_pool:
             # BatchNorm backward straight from the pooled gradient (no full-resolution dy is ever written)
             draw, s1, s2 = ops.pool_bn_bwd(dy.contiguous(), raw, mean, invstd, coef, psc, psh, spec.act, spec.slope,
@@ -317,12 +349,19 @@ class GemmLayerFn(torch.autograd.Function):
                 dbeta, dgamma = (s1, s2) if Np == N else (s1[:N].clone(), s2[:N].clone())
             if has_bias and not has_bn and gs1 is None:
                 dbias = s1 if Np == N else s1[:N].clone()
-            draw = torch.empty(tuple(spec.out_shape) + (Np,), dtype=torch.float32, device=dev)
-            if has_res:
-                dres = torch.empty(tuple(spec.out_shape) + (Np,), dtype=torch.float32, device=dev)
-            ops.act_bn_bwd_apply(dy, ld_of(dy), ymask, ldy, raw, Np, mean if train_bn else None,
-                                 invstd if train_bn else None, coef, m1, m2, M, Np, spec.act, spec.slope, draw, Np,
-                                 dres, Np, pscale=psc, pshift=psh)
+            if fuse_bwd:
+                Bo, Ho, Wo = spec.out_shape
+                pre_v, pre_gy, dres = ops.wino2d_bwd_transforms(dy, ld_of(dy), raw, Np, ybits, None if ybits is not None else psc,
+                                                                None if ybits is not None else psh, mean, invstd, coef, m1, m2, Np,
+                                                                Bo, Ho, Wo, spec.act, spec.slope, has_res)
+                draw = None
+            else:
+                draw = torch.empty(tuple(spec.out_shape) + (Np,), dtype=torch.float32, device=dev)
+                if has_res:
+                    dres = torch.empty(tuple(spec.out_shape) + (Np,), dtype=torch.float32, device=dev)
+                ops.act_bn_bwd_apply(dy, ld_of(dy), ymask, ldy, raw, Np, mean if train_bn else None,
+                                     invstd if train_bn else None, coef, m1, m2, M, Np, spec.act, spec.slope, draw, Np,
+                                     dres, Np, pscale=psc, pshift=psh)
             if has_bias and has_bn:          # bias in front of BatchNorm: d/dbias = column sums of draw
                 dbias = _bias_grad_behind_bn(ctx, p_bias, draw, M, Np, N, train_bn, delivered)
         # ---- dgrad is on the critical path of backward and is enqueued first; the weight gradient only needs draw and x, and
@@ -330,7 +369,6 @@ class GemmLayerFn(torch.autograd.Function):
         # weight-gradient stream BEHIND this layer's dgrad, so that it runs underneath the HBM-bound BatchNorm passes of the next
         # layer instead of competing with the dgrad for the matrix pipes (measured: waiting only for draw costs 3 ms per step)
         gW = dw_done = side = None
-        own_wgrad = ctx.needs_input_grad[1] and spec.custom_wgrad is None
         if own_wgrad:
             gW, dw_done = claim_grad(p_w)
             side = ops.wgrad_stream(dev) if (gW is not None and ops.WGRAD_SIDE) else None
@@ -341,6 +379,8 @@ class GemmLayerFn(torch.autograd.Function):
                 kw['add'] = as_rows(dskip)
             if ctx.xsrc is not None and getattr(spec.dgrad, 'takes_bnsrc', False):
                 kw['bnsrc'] = ctx.xsrc
+            if pre_v is not None:
+                kw['pre_v'] = pre_v
             dx = spec.dgrad(spec, weight, draw, x, **kw)
         # ---- wgrad
         dW = None
@@ -349,13 +389,19 @@ class GemmLayerFn(torch.autograd.Function):
         elif own_wgrad:
             dW = gW if gW is not None else torch.empty_like(weight)
 
+            xw, lazy_w = x, ctx.lazy
+            if lazy_w is not None and not ops.wgrad_lazy_capable(spec.mode, spec.C, Np, spec.launches[0][0]):
+                xw, lazy_w = materialize(x, lazy_w), None      # (a switch flipped between forward and backward: never wrong, only slower)
+
             def run_wgrad():
+                x = xw
                 for li, (geom, m) in enumerate(spec.launches):
                     T = spec.T if geom is None else len(geom[7])
                     dWp = torch.empty((Np, T, spec.C), dtype=torch.float32, device=dev)
                     ua = getattr(spec.wgrad_unpack, 'args', None)
                     done = ops.gather_wgrad(x, ld_of(x), spec.C, T, Np, m, draw, Np, dWp, mode=spec.mode, geom=geom,
-                                            table=spec.table, unpack=None if ua is None else (dW,) + tuple(ua(li)))
+                                            table=spec.table, unpack=None if ua is None else (dW,) + tuple(ua(li)),
+                                            lazy=lazy_w, pre_gy=pre_gy)
                     if not done:             # (a single row chunk, or a path with a transform behind its fold)
                         spec.wgrad_unpack(dWp, li, dW)
             if side is None:
@@ -363,7 +409,7 @@ class GemmLayerFn(torch.autograd.Function):
             else:
                 side.wait_stream(torch.cuda.current_stream())
                 x.record_stream(side)
-                draw.record_stream(side)
+                (draw if draw is not None else pre_gy).record_stream(side)
                 with torch.cuda.stream(side):
                     run_wgrad()
             if gW is not None:

@@ -131,8 +131,21 @@ def _run(ctx, x, lda, C, T, Wp, N, M, mode, geoms, out_t, ldo, coff, bias, bn, a
                         x_off=coff, y_off=coff, res_off=res_off)
 
 
+def _same3x3_geom(B, H, W):
+    return (B, H, W, H, W, 1, 1, [t // 3 - 1 for t in range(9)], [t % 3 - 1 for t in range(9)], H, W, 1, 1, 0, 0)
+
+
+def lazy_consumer_ok(ctx, conv, B, H, W):
+    """training step: will `conv` (applied to a [B][H][W][in_channels] map) run on the 2-D Winograd path, whose input transform can
+    apply its producer's pending BatchNorm + activation (ops.LazyAct)?  The producer then skips its normalise pass (defer_act)."""
+    return bool(ctx.grad and ctx.train and ops.LAZY_ACT and isinstance(conv, nn.Conv2d) and conv.kernel_size == (3, 3)
+                and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.in_channels % 4 == 0
+                and ops.lazy_capable(1, conv.in_channels, ceil4(conv.out_channels), _same3x3_geom(B, H, W)))
+
+
 # ----------------------------------------------------------------------------------------------
-def conv2d(ctx, x, conv, bn=None, act=ACT_NONE, slope=0.0, residual=None, out=None, in_ch=None, skip_out=False, pool=False):
+def conv2d(ctx, x, conv, bn=None, act=ACT_NONE, slope=0.0, residual=None, out=None, in_ch=None, skip_out=False, pool=False,
+           defer_act=False):
     """nn.Conv2d (+BatchNorm2d) (+residual) (+activation) on [B][H][W][Cx].
     in_ch: (coff, C) selects a channel slice of x.  Returns the output buffer [B][Ho][Wo][ld]."""
     B, H, W, ldx = x.shape
@@ -152,9 +165,11 @@ def conv2d(ctx, x, conv, bn=None, act=ACT_NONE, slope=0.0, residual=None, out=No
     geom = (B, H, W, Ho, Wo, sh, sw, dh, dw, Ho, Wo, 1, 1, 0, 0)
     M = B * Ho * Wo
     if ctx.grad:
+        assert in_ch is None or getattr(x, '_efgh_lazy', None) is None       # (a slice view would lose the pending activation)
         xs = x if in_ch is None else x[..., a_off:a_off + Cx]
         return _conv2d_grad(ctx, xs, conv, bn, act, slope, residual, geom, (B, H, W, Ho, Wo), Cp, passthrough=skip_out, pool=pool,
-                            out=out)
+                            out=out, defer_act=defer_act)
+    assert not defer_act
     if pool:
         # inference: the following MaxPool2d(2,2) rides in the layer's output transform (run_vgg asks pool_fusable first)
         assert out is None and residual is None and not ctx.train
@@ -194,7 +209,7 @@ def _convt_small_forward(x, convt, out_raw, scale=None, shift=None, act=ACT_NONE
     ops.convt_col2im(Y, B, H, W, Ho, Wo, O, convt.padding[0], scale, shift, act, slope, out_raw)
 
 
-def conv_transpose2d(ctx, x, convt, bn=None, act=ACT_NONE, slope=0.0, out=None, skip_out=False):
+def conv_transpose2d(ctx, x, convt, bn=None, act=ACT_NONE, slope=0.0, out=None, skip_out=False, defer_for=None):
     """nn.ConvTranspose2d(k=3, s=2) as four stride-1 sub-convolutions, one per output parity class
     (or, for <= 3 output channels, as ONE GEMM over the input pixels + a col2im fold)."""
     B, H, W, ldx = x.shape
@@ -235,7 +250,9 @@ def conv_transpose2d(ctx, x, convt, bn=None, act=ACT_NONE, slope=0.0, out=None, 
             geoms.append((geom, Wp, B * Hv * Wv, tapidx, (cy, cx)))
     if ctx.grad:
         assert out is None
-        return _convt_grad(ctx, x, convt, bn, act, slope, geoms, (B, H, W, Ho, Wo), passthrough=skip_out)
+        # defer_for: the Conv2d that is the ONLY consumer of this layer's activation (net_utils.py:66-98)
+        return _convt_grad(ctx, x, convt, bn, act, slope, geoms, (B, H, W, Ho, Wo), passthrough=skip_out,
+                           defer_act=defer_for is not None and lazy_consumer_ok(ctx, defer_for, B, Ho, Wo))
     _run(ctx, x, ldx, Cw, 0, None, O, B * Ho * Wo, 1, [g[:3] for g in geoms], out_t, ldo, coff, convt.bias, bn,
          act, slope)
     return out_t
@@ -316,7 +333,12 @@ def run_vgg(ctx, features, x):
             # inference: into the output transform of the 2-D Winograd layers (the pooled map is all that is ever written)
             pooled = i + 3 < len(mods) and isinstance(mods[i + 3], nn.MaxPool2d) and m.out_channels % 4 == 0
             fuse = pooled and (ctx.grad or (not ctx.train and _pool_fusable_eval(x, m)))
-            x = conv2d(ctx, x, m, mods[i + 1], ACT_RELU, pool=fuse)
+            # an un-pooled layer's activation goes to the next convolution only: when that one runs on the 2-D Winograd path it
+            # normalises + activates inside its input transform and this layer writes no activation at all (training step)
+            nxt = mods[i + 3] if i + 3 < len(mods) else None
+            defer = (not pooled and m.kernel_size == (3, 3) and m.stride == (1, 1) and m.padding == (1, 1)
+                     and lazy_consumer_ok(ctx, nxt, x.shape[0], x.shape[1], x.shape[2]))
+            x = conv2d(ctx, x, m, mods[i + 1], ACT_RELU, pool=fuse, defer_act=defer)
             i += 4 if fuse else 3
     return x
 
@@ -333,9 +355,9 @@ def run_convt_bn_relu(ctx, seq, x, out=None, skip_out=False):
     skip_out (training path): also returns an alias of x for x's NEXT consumer; the gradient that consumer sends back is added
     in this layer's dgrad epilogue (see _conv2d_grad.dgrad)."""
     if skip_out and ctx.grad:
-        y, alias = conv_transpose2d(ctx, x, seq[0], seq[1], ACT_LEAKY, 0.2, skip_out=True)
+        y, alias = conv_transpose2d(ctx, x, seq[0], seq[1], ACT_LEAKY, 0.2, skip_out=True, defer_for=seq[3])
         return conv2d(ctx, y, seq[3], seq[4], ACT_LEAKY, 0.2, out=out), alias
-    y = conv_transpose2d(ctx, x, seq[0], seq[1], ACT_LEAKY, 0.2)
+    y = conv_transpose2d(ctx, x, seq[0], seq[1], ACT_LEAKY, 0.2, defer_for=seq[3] if ctx.grad else None)
     y = conv2d(ctx, y, seq[3], seq[4], ACT_LEAKY, 0.2, out=out)
     return (y, x) if skip_out else y
 
@@ -515,17 +537,23 @@ def run_convt_heads(ctx, seq_d, seq_m, x):
 
 def run_basic_block(ctx, blk, x, out=None, alias_in=False):
     """nets/resnet.py:55-71."""
+    def defer1(xin):
+        # conv1's activation feeds conv2 only: a 2-D Winograd conv2 applies bn1 + ReLU inside its input transform (ops.LazyAct)
+        c1 = blk.conv1
+        Ho = (xin.shape[1] + 2 * c1.padding[0] - c1.kernel_size[0]) // c1.stride[0] + 1
+        Wo = (xin.shape[2] + 2 * c1.padding[1] - c1.kernel_size[1]) // c1.stride[1] + 1
+        return lazy_consumer_ok(ctx, blk.conv2, xin.shape[0], Ho, Wo)
     if ctx.grad and blk.downsample is None:
         # the identity branch takes an alias of x handed out by conv1's Function: its gradient is added in conv1's dgrad
         # epilogue instead of by autograd's elementwise accumulation (one read-read-write pass over the activation)
-        y, idt = conv2d(ctx, x, blk.conv1, blk.bn1, ACT_RELU, skip_out=True)
+        y, idt = conv2d(ctx, x, blk.conv1, blk.bn1, ACT_RELU, skip_out=True, defer_act=defer1(x))
     elif ctx.grad:
         # x has two consumers here (conv1, downsample) and possibly a third outside (a decoder concatenation, alias_in): they are
         # chained through passthrough aliases, so the gradients of x are accumulated in dgrad epilogues, not by autograd
         # (the 1x1 / stride-2 downsample is first in the chain: in backward it is the last to run and adds its one parity class
         # IN PLACE to the gradient conv1 has already produced)
         idt, a1 = conv2d(ctx, x, blk.downsample[0], blk.downsample[1], ACT_NONE, skip_out=True)
-        y, a2 = conv2d(ctx, a1, blk.conv1, blk.bn1, ACT_RELU, skip_out=True)
+        y, a2 = conv2d(ctx, a1, blk.conv1, blk.bn1, ACT_RELU, skip_out=True, defer_act=defer1(a1))
         y = conv2d(ctx, y, blk.conv2, blk.bn2, ACT_RELU, residual=idt, out=out)
         return (y, a2) if alias_in else y
     else:
@@ -555,7 +583,7 @@ def _bn_args(bn):
     return (None, None) if bn is None else (bn.weight, bn.bias)
 
 
-def _conv2d_grad(ctx, x, conv, bn, act, slope, residual, geom, dims, Cp, passthrough=False, pool=False, out=None):
+def _conv2d_grad(ctx, x, conv, bn, act, slope, residual, geom, dims, Cp, passthrough=False, pool=False, out=None, defer_act=False):
     B, H, W, Ho, Wo = dims
     Cw, O = conv.in_channels, conv.out_channels
     kh, kw = conv.kernel_size
@@ -570,12 +598,14 @@ def _conv2d_grad(ctx, x, conv, bn, act, slope, residual, geom, dims, Cp, passthr
         ops.unpack_weight(dWp, dW, O, T, Cw, Cp, Cw * T, T, 1, list(range(T)))
     unpack.args = lambda i: (O, T, Cw, Cp, Cw * T, T, 1, list(range(T)), False)       # (ops.gather_wgrad(unpack=...): fold + unpack in one launch)
 
-    def dgrad(spec, w, draw, xin, add=None, bnsrc=None):
-        """add: a gradient that reached x through ANOTHER consumer (handed over on this layer's passthrough alias); it is folded
+    def dgrad(spec, w, draw, xin, add=None, bnsrc=None, pre_v=None):
+        """pre_v: B^T draw B, already made by ops.wino2d_bwd_transforms (draw itself is None then: it was never stored).
+        add: a gradient that reached x through ANOTHER consumer (handed over on this layer's passthrough alias); it is folded
         into the result in the kernels' epilogues instead of by a separate elementwise pass of autograd.
         bnsrc: the BatchNorm layer that produced x (fn.BnSrc): its backward column sums are taken in this launch's epilogue when
         the kernel supports it, and the returned gradient is tagged with them"""
-        dev = draw.device
+        dev = (draw if draw is not None else pre_v).device
+        assert pre_v is None or (sh == 1 and sw == 1)
         if sh == 1 and sw == 1:
             # taps in ascending (dh, dw) order = the canonical 3x3 order the Winograd kernel recognises
             order = sorted(range(T), key=lambda i: (ph - i // kw, pw - i % kw))
@@ -586,7 +616,7 @@ def _conv2d_grad(ctx, x, conv, bn, act, slope, residual, geom, dims, Cp, passthr
             g = (B, Ho, Wo, H, W, 1, 1, dhs, dws, H, W, 1, 1, 0, 0)
             st = ops.gather_gemm(draw, Np, Np, T, Wd, Cp, B * H * W, dx, Cp, mode=1, geom=g,
                                  residual=add, ldr=0 if add is None else FN.ld_of(add), flops=2.0 * B * H * W * Cw * T * O,
-                                 bn_bwd=bnsrc)
+                                 bn_bwd=bnsrc, pre_v=pre_v)
             if st is not None:
                 dx._efgh_bnsums = (st, bnsrc, dx._version)      # (an in-place accumulation by autograd moves the version on)
             return dx
@@ -625,9 +655,13 @@ def _conv2d_grad(ctx, x, conv, bn, act, slope, residual, geom, dims, Cp, passthr
         return dx
 
     dgrad.takes_bnsrc = True
+    # data AND weight gradient on the 2-D Winograd path: the BatchNorm backward's apply pass rides in their transforms
+    fus = bool((kh, kw, sh, sw, ph, pw) == (3, 3, 1, 1, 1, 1) and bn is not None and ctx.train and not pool
+               and ops.lazy_capable(1, Np, Cp, _same3x3_geom(B, H, W)) and ops.wgrad_lazy_capable(1, Cp, Np, geom))
     spec = FN.LayerSpec(O, Cp, T, 1, [(geom, B * Ho * Wo)], B * Ho * Wo, (B, Ho, Wo), pack_fwd, dgrad, unpack,
                         bn=bn, train=ctx.train, act=act, slope=slope, c_real=Cw,
-                        passthrough=passthrough and x.requires_grad and x.shape[-1] == Cp, pool=pool)
+                        passthrough=passthrough and x.requires_grad and x.shape[-1] == Cp, pool=pool,
+                        defer_act=defer_act, bwd_fusable=fus)
     g_, b_ = _bn_args(bn)
     out = FN.GemmLayerFn.apply(x, conv.weight, conv.bias, g_, b_, residual, spec, out)
     if passthrough and not spec.passthrough:
@@ -635,7 +669,7 @@ def _conv2d_grad(ctx, x, conv, bn, act, slope, residual, geom, dims, Cp, passthr
     return out
 
 
-def _convt_grad(ctx, x, convt, bn, act, slope, geoms, dims, passthrough=False):
+def _convt_grad(ctx, x, convt, bn, act, slope, geoms, dims, passthrough=False, defer_act=False):
     B, H, W, Ho, Wo = dims
     Cw, O = convt.in_channels, convt.out_channels
     ph, pw = convt.padding
@@ -678,7 +712,7 @@ def _convt_grad(ctx, x, convt, bn, act, slope, geoms, dims, passthrough=False):
     spec = FN.LayerSpec(O, Cw, 0, 1, [(g[0], g[2]) for g in geoms], B * Ho * Wo, (B, Ho, Wo), pack_fwd, dgrad,
                         unpack, bn=bn, train=ctx.train, act=act, slope=slope, c_real=Cw,
                         custom_forward=custom_fwd, custom_wgrad=custom_wgrad,
-                        passthrough=passthrough and x.requires_grad)
+                        passthrough=passthrough and x.requires_grad, defer_act=defer_act and custom_fwd is None)
     g_, b_ = _bn_args(bn)
     out = FN.GemmLayerFn.apply(x, convt.weight, convt.bias, g_, b_, None, spec)
     if passthrough and not spec.passthrough:

@@ -528,12 +528,17 @@ def _blur_gemm_ksplit(A, lda, C, Wp, N, M, out, ldo, table, bias, act, slope, a_
 
 def gather_gemm(A, lda, C, T, Wp, N, M, out, ldo, mode=0, geom=None, table=None, bias=None, scale=None,
                 shift=None, residual=None, ldr=0, act=ACT_NONE, slope=0.0, stats=None, a_off=0, out_off=0,
-                res_off=0, M_dev=None, flops=None, batch=None, alias_mask=False, bn_bwd=None, pool=False):
+                res_off=0, M_dev=None, flops=None, batch=None, alias_mask=False, bn_bwd=None, pool=False, lazy=None, pre_v=None):
     """See efgh_gemm_desc.  A/out/residual may be addressed with an element offset (channel slices).
     pool: `out` is the 2x2 max-pooled map [B][Ho/2][Wo/2][ldo] (only for launches pool_fusable() accepts: the 2-D Winograd path).
     bn_bwd: a BnSrc (nets/fn.py) - the BatchNorm layer that produced the tensor whose GRADIENT this launch writes; when the
     kernel serving the launch supports it (Winograd F(4,3)) the column sums of that layer's BatchNorm backward are taken in the
-    epilogue and the [rows][2][N] partials are RETURNED (else None: the layer runs its own reduction pass)."""
+    epilogue and the [rows][2][N] partials are RETURNED (else None: the layer runs its own reduction pass).
+    lazy: a LazyAct - A is the RAW output of a train-mode BatchNorm layer and act(A*scale + shift) is applied by the consumer (only the
+    2-D Winograd input transform can: the caller asks lazy_capable() first).  pre_v: the input transform of the launch, already
+    made (wino2d_bwd_transforms: the data gradient of a layer whose draw is never stored); A may then be None."""
+    if (lazy is not None or pre_v is not None) and not (M_dev is None and batch is None and lazy_capable(mode, C, N, geom)):
+        raise _C.EfghError('gather_gemm(lazy= / pre_v=) on a launch the 2-D Winograd path does not serve (ask lazy_capable() first)')
     if (KSPLIT_MAX_ROWS and mode == 2 and M <= KSPLIT_MAX_ROWS and T == 15 and N % 4 == 0 and T * C >= 1024 and batch is None
             and scale is None and shift is None and residual is None and stats is None and M_dev is None
             and (bias is None or bias.numel() == N)):
@@ -544,7 +549,7 @@ def gather_gemm(A, lda, C, T, Wp, N, M, out, ldo, mode=0, geom=None, table=None,
     bn_stats = None
     d = _C.GemmDesc()
     es = 4
-    d.A = A.data_ptr() + a_off * es
+    d.A = (A.data_ptr() + a_off * es) if A is not None else 0
     d.lda, d.C, d.T, d.mode = lda, C, T, mode
     if geom is not None:
         (d.B, d.Hin, d.Win, d.Hv, d.Wv, d.sh, d.sw, dh, dw, d.Ho, d.Wo, d.osh, d.osw, d.oh0, d.ow0) = geom
@@ -584,7 +589,7 @@ def gather_gemm(A, lda, C, T, Wp, N, M, out, ldo, mode=0, geom=None, table=None,
         _C.check(_L().efgh_sc_conv3x3(ctypes.byref(d), _st()))
     elif M_dev is None and batch is None and wino2d_eligible(mode, C, N, geom):
         wino = '2d'
-        _wino2d_forward(d, A, a_off, lda, C, N, geom, Wp, pool=pool)
+        _wino2d_forward(d, A, a_off, lda, C, N, geom, Wp, pool=pool, lazy=lazy, pre_v=pre_v)
         pool = False
     elif M_dev is None and batch is None and wino_eligible(mode, C, N, geom) and pool == 'h':
         wino = True
@@ -696,16 +701,65 @@ def pool_fusable(mode, C, N, geom, residual=None, stats=None):
     return False
 
 
-def _wino2d_forward(d, A, a_off, lda, C, N, geom, Wp, pool=False):
+class LazyAct:
+    """a train-mode BatchNorm layer's normalise + activate pass that was NOT run: the tensor carrying this (`_efgh_lazy`) is the layer's
+    RAW output, and its single consumer - a 2-D Winograd layer - applies act(raw*scale + shift) inside its input transform
+    (efgh_wino2d_input_act): the activation is never written or re-read"""
+    __slots__ = ('scale', 'shift', 'act', 'slope')
+
+    def __init__(self, scale, shift, act, slope):
+        self.scale, self.shift, self.act, self.slope = scale, shift, act, slope
+
+
+LAZY_ACT = True                 # producers defer, 2-D Winograd consumers apply (nets/fn.py, nets/layers.py); False: every activation is materialised
+W2_BWD_FUSED = True             # BatchNorm backward 'apply' inside the gradient-side transforms of the 2-D Winograd layers (efgh_wino2d_bwd_transforms)
+LAZY_HITS = [0, 0]              # (tests: deferred activations consumed, fused backward transforms run)
+
+
+def lazy_capable(mode, C, N, geom):
+    """does gather_gemm serve this launch on the 2-D Winograd path (whose input transform can apply a pending BatchNorm + activation)?
+    (>= 128 channels on both sides: none of the kernels gather_gemm prefers - thin, 4-channel, small-channel - overlaps)"""
+    return geom is not None and wino2d_eligible(mode, C, N, geom) and min(C, N) >= 64
+
+
+def wino2d_input(A, a_off, lda, C, B, H, W, V, lazy=None):
+    if lazy is None:
+        _C.check(_L().efgh_wino2d_input(_C.c_void_p(A.data_ptr() + 4 * a_off), c_int64(lda), c_int32(C), c_int32(B), c_int32(H),
+                                        c_int32(W), ptr(V), _st()))
+    else:
+        LAZY_HITS[0] += 1
+        _C.check(_L().efgh_wino2d_input_act(_C.c_void_p(A.data_ptr() + 4 * a_off), c_int64(lda), c_int32(C), c_int32(B), c_int32(H),
+                                            c_int32(W), ptr(lazy.scale), ptr(lazy.shift), c_int32(lazy.act), c_float(lazy.slope),
+                                            ptr(V), _st()))
+
+
+def wino2d_bwd_transforms(dy, lddy, raw, ldraw, ybits, psc, psh, mean, invstd, coef, m1, m2, N, B, H, W, act, slope, want_dres):
+    """-> (Vd, Gy, dres | None): see efgh_wino2d_bwd_transforms (include/efgh_hip.h)"""
+    T2 = _L().efgh_wino2d_tiles(c_int32(B), c_int32(H), c_int32(W))
+    dev = raw.device
+    Vd = torch.empty((T2, 36, N), dtype=torch.float32, device=dev)
+    Gy = torch.empty((T2, 36, N), dtype=torch.float32, device=dev)
+    dres = torch.empty((B, H, W, N), dtype=torch.float32, device=dev) if want_dres else None
+    LAZY_HITS[1] += 1
+    _C.check(_L().efgh_wino2d_bwd_transforms(ptr(dy), c_int64(lddy), ptr(raw), c_int64(ldraw), ptr(ybits), ptr(psc), ptr(psh), ptr(mean),
+                                             ptr(invstd), ptr(coef), ptr(m1), ptr(m2), c_int32(N), c_int32(B), c_int32(H), c_int32(W),
+                                             c_int32(act), c_float(slope), ptr(Vd), ptr(Gy), ptr(dres), c_int64(N), _st()))
+    return Vd, Gy, dres
+
+
+def _wino2d_forward(d, A, a_off, lda, C, N, geom, Wp, pool=False, lazy=None, pre_v=None):
     """input transform -> 36 batched GEMMs -> output transform with the layer's epilogue (descriptor d)"""
     B, H, W = geom[0], geom[1], geom[2]
     T = _L().efgh_wino2d_tiles(c_int32(B), c_int32(H), c_int32(W))
-    dev = A.device
-    V = torch.empty((T, 36, C), dtype=torch.float32, device=dev)
+    dev = A.device if A is not None else pre_v.device
     Mb = torch.empty((T, 36, N), dtype=torch.float32, device=dev)
-    _C.check(_L().efgh_wino2d_input(_C.c_void_p(A.data_ptr() + 4 * a_off), c_int64(lda), c_int32(C), c_int32(B), c_int32(H),
-                                    c_int32(W), ptr(V), _st()))
-    if W2V_KEEP and TLS.w2v_wanted and a_off == 0:
+    if pre_v is not None:
+        assert tuple(pre_v.shape) == (T, 36, C)
+        V = pre_v
+    else:
+        V = torch.empty((T, 36, C), dtype=torch.float32, device=dev)
+        wino2d_input(A, a_off, lda, C, B, H, W, V, lazy)
+    if pre_v is None and W2V_KEEP and TLS.w2v_wanted and a_off == 0:
         # 2.25x the activation, ~10 GB over the eligible layers at batch 8 (of 288 GB): saves one transform pass per layer and step
         with _LOCK:
             if len(W2V_CACHE) > 512:
@@ -1137,20 +1191,29 @@ FOLD_UNPACK = True       # a split weight gradient's final fold writes the refer
 FOLD_UNPACK_HITS = [0]   # (tests: how many weight gradients took that route)
 
 
-def gather_wgrad(A, lda, C, T, N, M, G, ldg, dWp, mode=0, geom=None, table=None, unpack=None):
+def wgrad_lazy_capable(mode, C, N, geom):
+    """does gather_wgrad serve this launch on the 2-D Winograd path?"""
+    return bool(USE_WINO_WGRAD and geom is not None and wino2d_eligible(mode, C, N, geom, wgrad=True) and min(C, N) >= 64)
+
+
+def gather_wgrad(A, lda, C, T, N, M, G, ldg, dWp, mode=0, geom=None, table=None, unpack=None, lazy=None, pre_gy=None):
     """unpack: (dW, N_real, T, C_real, Cp, sn, sc, st, taps, accumulate) - where the gradient belongs in the reference layout
     (ops.unpack_weight's arguments).  -> True when the launch left it there itself (its final fold did the unpack: dWp is then
-    NOT written), False when dWp holds the packed gradient and the caller has to unpack it"""
-    armed = False
-
-    def arm():
-        nonlocal armed
-        if unpack is not None and FOLD_UNPACK and unpack[4] % 4 == 0 and unpack[2] <= 16:
-            dW_, n_, t_, c_, cp_, sn_, sc_, st_, taps_, acc_ = unpack
-            tp_ = (ctypes.c_int32 * 16)(*([int(t) for t in taps_] + [0] * (16 - len(taps_))))
-            _C.check(_L().efgh_fold_unpack_arm(ptr(dW_), c_int32(n_), c_int32(t_), c_int32(c_), c_int32(cp_), c_int64(sn_), c_int64(sc_),
-                                               c_int64(st_), tp_, c_int32(1 if acc_ else 0)))
-            armed = True
+    NOT written), False when dWp holds the packed gradient and the caller has to unpack it.
+    lazy: A is a raw BatchNorm output with a pending activation (LazyAct; 2-D Winograd path only: the kept forward transform already has
+    it applied, a re-transform applies it again).  pre_gy: the gradient-side transform, already made (wino2d_bwd_transforms); G may be None"""
+    if (lazy is not None or pre_gy is not None) and not wgrad_lazy_capable(mode, C, N, geom):
+        raise _C.EfghError('gather_wgrad(lazy= / pre_gy=) on a launch the 2-D Winograd weight gradient does not serve')
+    od = None                # efgh_wgrad_out_desc: the entry points that can leave the reference layout themselves take it explicitly
+    if unpack is not None and FOLD_UNPACK and unpack[4] % 4 == 0 and unpack[2] <= 16:
+        dW_, n_, t_, c_, cp_, sn_, sc_, st_, taps_, acc_ = unpack
+        od = _C.WgradOutDesc()
+        od.W, od.N, od.T, od.C, od.Cp, od.sn, od.sc, od.st = dW_.data_ptr(), n_, t_, c_, cp_, sn_, sc_, st_
+        for i_, t__ in enumerate(taps_):
+            od.taps[i_] = int(t__)
+        od.accumulate = 1 if acc_ else 0
+    odp = None if od is None else ctypes.byref(od)
+    done = False
     if PROFILE_WGRAD is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -1174,31 +1237,26 @@ def gather_wgrad(A, lda, C, T, N, M, G, ldg, dWp, mode=0, geom=None, table=None,
         # the 1- / 2-channel 3x3 convolutions behind G's transposed heads: column-walking stencil, per-workgroup partial planes folded
         # in a fixed order (also under EFGH_DETERMINISTIC: no atomics)
         thin = True             # (profile lists: an HBM-bound launch)
-        arm()
-        _C.check(_L().efgh_c4n4_wgrad(ctypes.byref(d), ptr(G), c_int64(ldg), ptr(dWp),
-                                      ptr(_scratch(_L().efgh_c4n4_wgrad_workspace(ctypes.byref(d)), dWp.device)), _st()))
+        done = _C.check_wrote(_L().efgh_c4n4_wgrad(ctypes.byref(d), ptr(G), c_int64(ldg), ptr(dWp),
+                                                   ptr(_scratch(_L().efgh_c4n4_wgrad_workspace(ctypes.byref(d)), dWp.device)), odp, _st()))
     elif thin:
-        arm()
-        _C.check(_L().efgh_thin_wgrad(ctypes.byref(d), ptr(G), c_int64(ldg), ptr(dWp),
-                                      ptr(_scratch(_L().efgh_thin_wgrad_workspace(ctypes.byref(d)), dWp.device)), _st()))
+        done = _C.check_wrote(_L().efgh_thin_wgrad(ctypes.byref(d), ptr(G), c_int64(ldg), ptr(dWp),
+                                                   ptr(_scratch(_L().efgh_thin_wgrad_workspace(ctypes.byref(d)), dWp.device)), odp, _st()))
     elif (USE_SMALLC and C == 4 and N in (32, 64) and lda % 4 == 0 and ldg % 4 == 0 and d.A % 16 == 0 and G.data_ptr() % 16 == 0
           and geom is not None and geom[5] == 1 and sc_eligible(mode, 16, 16, geom, wgrad=True)):
         # 4-channel input layers at stride 1: the small-channel weight-gradient kernel (G staged by 16-byte loads, per-wave partial
         # planes folded in a fixed order) instead of k_c4_wgrad (4-byte G loads, fp32 atomics)
         thin = True             # (profile lists: an HBM-bound launch)
-        arm()
-        _C.check(_L().efgh_sc_wgrad(ctypes.byref(d), ptr(G), c_int64(ldg), ptr(dWp),
-                                    ptr(_scratch(_L().efgh_sc_wgrad_workspace(ctypes.byref(d)), dWp.device)), _st()))
+        done = _C.check_wrote(_L().efgh_sc_wgrad(ctypes.byref(d), ptr(G), c_int64(ldg), ptr(dWp),
+                                                 ptr(_scratch(_L().efgh_sc_wgrad_workspace(ctypes.byref(d)), dWp.device)), odp, _st()))
     elif c4_eligible(mode, C, N, geom, wgrad=True):
         thin = True             # (profile lists, as above)
-        arm()
-        _C.check(_L().efgh_c4_wgrad(ctypes.byref(d), ptr(G), c_int64(ldg), ptr(dWp),
-                                    ptr(_scratch(_L().efgh_c4_wgrad_workspace(ctypes.byref(d)), dWp.device)), _st()))
+        done = _C.check_wrote(_L().efgh_c4_wgrad(ctypes.byref(d), ptr(G), c_int64(ldg), ptr(dWp),
+                                                 ptr(_scratch(_L().efgh_c4_wgrad_workspace(ctypes.byref(d)), dWp.device)), odp, _st()))
     elif sc_eligible(mode, C, N, geom, wgrad=True) and lda % 4 == 0 and ldg % 4 == 0 and d.A % 16 == 0 and G.data_ptr() % 16 == 0:
         sc = True
-        arm()
-        _C.check(_L().efgh_sc_wgrad(ctypes.byref(d), ptr(G), c_int64(ldg), ptr(dWp),
-                                    ptr(_scratch(_L().efgh_sc_wgrad_workspace(ctypes.byref(d)), dWp.device)), _st()))
+        done = _C.check_wrote(_L().efgh_sc_wgrad(ctypes.byref(d), ptr(G), c_int64(ldg), ptr(dWp),
+                                                 ptr(_scratch(_L().efgh_sc_wgrad_workspace(ctypes.byref(d)), dWp.device)), odp, _st()))
     elif USE_WINO_WGRAD and wino2d_eligible(mode, C, N, geom, wgrad=True):
         wino = '2d'
         B, H, W = geom[0], geom[1], geom[2]
@@ -1208,14 +1266,18 @@ def gather_wgrad(A, lda, C, T, N, M, G, ldg, dWp, mode=0, geom=None, table=None,
             kept = W2V_CACHE.pop((A.data_ptr(), lda, C, B, H, W), None)
         if kept is not None:
             kept[0].record_stream(torch.cuda.current_stream())          # (made on the forward's stream, maybe read on another)
-        Gy = torch.empty((T2, 36, N), dtype=torch.float32, device=dev)
         S = torch.empty((36, N, C), dtype=torch.float32, device=dev)
         if kept is not None and kept[1] == A._version and kept[0].shape == (T2, 36, C):
             V = kept[0]                                                            # B^T x B from the forward pass
         else:
             V = torch.empty((T2, 36, C), dtype=torch.float32, device=dev)
-            _C.check(_L().efgh_wino2d_input(ptr(A), c_int64(lda), c_int32(C), c_int32(B), c_int32(H), c_int32(W), ptr(V), _st()))
-        _C.check(_L().efgh_wino2d_dy(ptr(G), c_int64(ldg), c_int32(N), c_int32(B), c_int32(H), c_int32(W), ptr(Gy), _st()))
+            wino2d_input(A, 0, lda, C, B, H, W, V, lazy)
+        if pre_gy is not None:
+            assert tuple(pre_gy.shape) == (T2, 36, N)
+            Gy = pre_gy
+        else:
+            Gy = torch.empty((T2, 36, N), dtype=torch.float32, device=dev)
+            _C.check(_L().efgh_wino2d_dy(ptr(G), c_int64(ldg), c_int32(N), c_int32(B), c_int32(H), c_int32(W), ptr(Gy), _st()))
         g = _C.GemmDesc()
         g.A, g.lda, g.C, g.T, g.mode, g.N, g.M = V.data_ptr(), 36 * C, C, 1, 0, N, T2
         g.nbatch, g.batch_stride_a = 36, C
@@ -1232,18 +1294,14 @@ def gather_wgrad(A, lda, C, T, N, M, G, ldg, dWp, mode=0, geom=None, table=None,
         if PROFILE_WINO2D_GEMM is not None:
             f1.record()
             PROFILE_WINO2D_GEMM.append((f0, f1, 2.0 * 36 * T2 * C * N, (0, T2, N, 36, C)))
-        arm()                    # (after the batched plane launch: only the finish kernel may write the reference layout)
-        _C.check(_L().efgh_wino2d_wfinish(ptr(S), ptr(dWp), c_int32(N), c_int32(C), _st()))
+        done = _C.check_wrote(_L().efgh_wino2d_wfinish(ptr(S), ptr(dWp), c_int32(N), c_int32(C), odp, _st()))      # (only the finish kernel may write the reference layout)
     elif USE_WINO_WGRAD and C % 64 == 0 and wino_eligible(mode, C, N, geom):
         wino = True
         S = _scratch(_L().efgh_wino_wgrad_workspace(ctypes.byref(d)), dWp.device)    # per-tile-range partials
-        arm()                    # (consumed by its finish kernel, not by the fold of the S partials)
-        _C.check(_L().efgh_wino_wgrad(ctypes.byref(d), ptr(G), c_int64(ldg), ptr(S), ptr(dWp), _st()))
+        done = _C.check_wrote(_L().efgh_wino_wgrad(ctypes.byref(d), ptr(G), c_int64(ldg), ptr(S), ptr(dWp), odp, _st()))
     else:
-        arm()
-        _C.check(_L().efgh_gather_wgrad(ctypes.byref(d), ptr(G), c_int64(ldg), ptr(dWp),
-                                        ptr(_scratch(_L().efgh_gather_wgrad_workspace(ctypes.byref(d)), dWp.device)), _st()))
-    done = bool(armed and _L().efgh_fold_unpack_disarm())
+        done = _C.check_wrote(_L().efgh_gather_wgrad(ctypes.byref(d), ptr(G), c_int64(ldg), ptr(dWp),
+                                                     ptr(_scratch(_L().efgh_gather_wgrad_workspace(ctypes.byref(d)), dWp.device)), odp, _st()))
     if done:
         FOLD_UNPACK_HITS[0] += 1
     if PROFILE_WGRAD is not None and (thin or (not wino and hbm_bound(M, N, T, C))):

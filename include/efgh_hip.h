@@ -25,6 +25,7 @@ extern "C" {
 #define EFGH_OK 0
 #define EFGH_E_INVALID (-1)   /* bad argument / unsupported shape */
 #define EFGH_E_LAUNCH (-2)    /* hip launch error */
+#define EFGH_WROTE_OUT 1      /* weight-gradient entry points only: the launch wrote `out`'s layout itself, dWp is untouched */
 
 const char *efgh_last_error(void);
 
@@ -41,7 +42,12 @@ const char *efgh_last_error(void);
  *      efgh_wino_pack_batched, efgh_pack_weight_batched_tiled, efgh_wino2d_output_pooled, efgh_c4_pooled_supported,
  *      efgh_c4_conv3x3_pooled, efgh_segment_workspace, efgh_segment_colmax_ws, efgh_segment_colmean_ws,
  *      efgh_wino_conv3x3_hpool, efgh_maxpool_v2, efgh_fold_unpack_arm, efgh_fold_unpack_disarm. */
-#define EFGH_ABI_VERSION 2
+/*   3  round 6: the weight-gradient entry points (efgh_gather_wgrad, efgh_thin_wgrad, efgh_c4n4_wgrad, efgh_c4_wgrad, efgh_sc_wgrad,
+ *      efgh_wino_wgrad, efgh_wino2d_wfinish) take an explicit `const efgh_wgrad_out_desc *out` in front of the stream and return
+ *      EFGH_WROTE_OUT when they left the gradient in the caller's layout themselves; efgh_fold_unpack_arm / _disarm (a thread-local
+ *      descriptor consumed by the NEXT call: hidden state in an interface that promises none) are removed.  New:
+ *      efgh_wino2d_input_act, efgh_wino2d_bwd_transforms (BatchNorm apply / backward apply inside the 2-D Winograd transforms). */
+#define EFGH_ABI_VERSION 3
 int efgh_version(void);
 
 /* ------------------------------------------------------------------ lattice (K1, K2) ------
@@ -387,8 +393,21 @@ int efgh_corr1d(const float *rp, const float *cam, const float *cam_mm, int32_t 
  * `workspace` with plain stores and the planes are then added in chunk order: no atomics, no memset, the result is
  * bit-reproducible run to run.  efgh_gather_wgrad_workspace(d) = floats of `workspace` needed (0: a single chunk writes dWp
  * directly and `workspace` may be NULL); for the batched form set d->nbatch before asking.                               */
+/* `out` (may be NULL): where the gradient belongs in the CALLER's own layout - W[n*sn + c*sc + taps[t]*st] (+= when accumulate) for
+ * rows n < N, channels c < C of the packed [Np][T][Cp] gradient (Np = N rounded up to 4).  When the call's last launch can write
+ * that layout itself (the fold of its row-chunk partials, or the finish kernel of a Winograd weight gradient) it does and the call
+ * returns EFGH_WROTE_OUT with dWp untouched; otherwise (a single row chunk, taps the finish kernel cannot express) it returns EFGH_OK
+ * with the packed gradient in dWp and the caller runs efgh_unpack_weight.  Nothing is remembered between calls. */
+typedef struct efgh_wgrad_out_desc {
+    float *W;
+    int32_t N, T, C, Cp;
+    int64_t sn, sc, st;
+    int32_t taps[16];
+    int32_t accumulate;
+} efgh_wgrad_out_desc;
 int64_t efgh_gather_wgrad_workspace(const efgh_gemm_desc *d);
-int efgh_gather_wgrad(const efgh_gemm_desc *d, const float *G, int64_t ldg, float *dWp, float *workspace, void *stream);
+int efgh_gather_wgrad(const efgh_gemm_desc *d, const float *G, int64_t ldg, float *dWp, float *workspace,
+                      const efgh_wgrad_out_desc *out, void *stream);
 /* the same contraction for d->nbatch independent problems in ONE launch (mode 0 only): problem b reads A + b*d->batch_stride_a
  * and G + b*batch_stride_g and writes dWp + b*batch_stride_dw (= N*C) */
 int efgh_gather_wgrad_batched(const efgh_gemm_desc *d, const float *G, int64_t ldg, int64_t batch_stride_g, float *dWp,
@@ -416,24 +435,31 @@ typedef struct efgh_wino_pack_job {
 } efgh_wino_pack_job;
 int efgh_wino_pack_batched(const efgh_wino_pack_job *jobs_dev, int32_t njobs, int64_t nblocks, void *stream);
 int efgh_wino2d_input(const float *A, int64_t lda, int32_t C, int32_t B, int32_t H, int32_t W, float *V, void *stream);
+/* round 6: the same transform of act(A*scale[c] + shift[c]) - A is the RAW output of a train-mode BatchNorm layer whose normalise +
+ * activate pass (efgh_scale_shift_act) was not run because this layer is the activation's only consumer (nets/resnet.py:55-71
+ * conv1 -> conv2; nets/vgg.py:69-83 un-pooled pairs; nets/net_utils.py:66-98 convT -> conv): one write + one read of it less */
+int efgh_wino2d_input_act(const float *A, int64_t lda, int32_t C, int32_t B, int32_t H, int32_t W, const float *scale,
+                          const float *shift, int32_t act, float slope, float *V, void *stream);
+/* round 6: the "apply" pass of the BatchNorm backward (efgh_act_bn_bwd_apply) inside the two gradient-side transforms of a 2-D Winograd
+ * layer: from dy, raw, the activation mask (ybits: the sign bits efgh_scale_shift_act_bits left, N % 32 == 0; or pscale / pshift: the
+ * mask is re-derived from raw*pscale + pshift - exactly one of the two), mean / invstd / coef [N] and the finalised float64 means m1 / m2
+ * of efgh_act_bn_bwd_reduce it computes draw = coef*(dy*act' - m1 - xhat*m2) on the fly and leaves Vd = B^T draw B [T][36][N] (what
+ * efgh_wino2d_input(draw) writes: the data gradient's operand), Gy = G4 draw G4^T [T][36][N] (efgh_wino2d_dy(draw): the weight
+ * gradient's) and - when dres != NULL - dres = dy*act' (the gradient of the residual branch).  draw itself is never stored. */
+int efgh_wino2d_bwd_transforms(const float *dy, int64_t lddy, const float *raw, int64_t ldraw, const uint32_t *ybits,
+                               const float *pscale, const float *pshift, const float *mean, const float *invstd, const float *coef,
+                               const double *m1, const double *m2, int32_t N, int32_t B, int32_t H, int32_t W, int32_t act,
+                               float slope, float *Vd, float *Gy, float *dres, int64_t lddres, void *stream);
 int efgh_wino2d_output(const float *M, const efgh_gemm_desc *d, void *stream);
 /* the same output transform for a layer that is followed by nn.MaxPool2d(2,2) (nets/vgg.py:69-83, inference): d->out is the POOLED map
  * [B][Hin/2][Win/2][ldo] = max over each 2x2 window of act((v + bias)*scale + shift); no residual, no statistics */
 int efgh_wino2d_output_pooled(const float *M, const efgh_gemm_desc *d, void *stream);
 int efgh_wino2d_dy(const float *G, int64_t ldg, int32_t N, int32_t B, int32_t H, int32_t W, float *Gy, void *stream);
-int efgh_wino2d_wfinish(const float *S, float *dWp, int32_t N, int32_t C, void *stream);       /* dWp [N][9][C] = A3^T S A3 */
+int efgh_wino2d_wfinish(const float *S, float *dWp, int32_t N, int32_t C, const efgh_wgrad_out_desc *out, void *stream);   /* dWp [N][9][C] = A3^T S A3 */
 
 /* W.flat[n*sn + c*sc + tapidx[t]*st] (+)= Wp[n][t][c]  (Wp rows padded to Cp) */
 int efgh_unpack_weight(const float *Wp, float *W, int32_t N, int32_t T, int32_t C, int32_t Cp, int64_t sn,
                        int64_t sc, int64_t st, const int32_t *tapidx_host, int32_t accumulate, void *stream);
-/* fold + unpack in one launch (round 5): efgh_fold_unpack_arm() describes where the NEXT weight-gradient call of this host thread
- * should leave its result - W.flat[n*sn + c*sc + tapidx[t]*st] (+= when accumulate) instead of the packed dWp[Np][T][Cp]; the
- * call's final fold of its row-chunk partials honours it when it folds exactly that plane (efgh_gather_wgrad with nbatch <= 1,
- * efgh_c4_wgrad, efgh_sc_wgrad, efgh_thin_wgrad, efgh_c4n4_wgrad when they split the rows); efgh_fold_unpack_disarm() -> 1 if it
- * did, 0 if dWp holds the packed gradient as usual (a single row chunk, a path with a transform behind the fold) */
-int efgh_fold_unpack_arm(float *W, int32_t N, int32_t T, int32_t C, int32_t Cp, int64_t sn, int64_t sc, int64_t st,
-                         const int32_t *tapidx_host, int32_t accumulate);
-int efgh_fold_unpack_disarm(void);
 /* dst[table[m*16+t]][c] += src[m][t*C+c]  (adjoint of the neighbour gather, bilateralNN.py:240-242) */
 int efgh_table_scatter_add(const float *src, const int32_t *table, int64_t M, int32_t T, int32_t C,
                            float *dst, void *stream);
@@ -505,13 +531,15 @@ int efgh_thin_gemm(const efgh_gemm_desc *d, void *stream);
 /* weight gradient of the same thin layers (C == 4 with N/4 a power of two and T in {1, 2, 4, 9}; or N == 4): no atomics - every
  * workgroup leaves a partial [N][T*C] plane in `workspace` (efgh_thin_wgrad_workspace floats), folded in a fixed order into dWp. */
 int64_t efgh_thin_wgrad_workspace(const efgh_gemm_desc *d);
-int efgh_thin_wgrad(const efgh_gemm_desc *d, const float *G, int64_t ldg, float *dWp, float *workspace, void *stream);
+int efgh_thin_wgrad(const efgh_gemm_desc *d, const float *G, int64_t ldg, float *dWp, float *workspace,
+                    const efgh_wgrad_out_desc *out, void *stream);
 /* 4 -> 4 channels (the 1- / 2-channel convolutions behind G's transposed heads, gnet.py:56-68), 3x3, stride 1, pad 1: weight gradient
  * without atomics - one partial [4][9][4] plane per workgroup in `workspace` (efgh_c4n4_wgrad_workspace floats), folded in a fixed
  * order into dWp. */
 int efgh_c4n4_supported(const efgh_gemm_desc *d);
 int64_t efgh_c4n4_wgrad_workspace(const efgh_gemm_desc *d);
-int efgh_c4n4_wgrad(const efgh_gemm_desc *d, const float *G, int64_t ldg, float *dWp, float *workspace, void *stream);
+int efgh_c4n4_wgrad(const efgh_gemm_desc *d, const float *G, int64_t ldg, float *dWp, float *workspace,
+                    const efgh_wgrad_out_desc *out, void *stream);
 
 /* 3x3 convolutions with C == 4 input channels per tap, stride 1 or 2, pad 1, N in {32, 64, 128} on fp32 MFMA (the RGB / range /
  * depth input layers: nets/vgg.py:77 first conv, nets/gnet.py:21,80; and the data gradient of G's transposed heads): the three
@@ -528,7 +556,8 @@ int32_t efgh_sc_stats_rows(int32_t B, int32_t H, int32_t W);
 int efgh_sc_conv3x3(const efgh_gemm_desc *d, void *stream);
 int efgh_sc_wgrad_supported(const efgh_gemm_desc *d);      /* also C == 4 with N in {32, 64} at stride 1 (the RGB / range / depth input layers) */
 int64_t efgh_sc_wgrad_workspace(const efgh_gemm_desc *d);
-int efgh_sc_wgrad(const efgh_gemm_desc *d, const float *G, int64_t ldg, float *dWp, float *workspace, void *stream);
+int efgh_sc_wgrad(const efgh_gemm_desc *d, const float *G, int64_t ldg, float *dWp, float *workspace,
+                  const efgh_wgrad_out_desc *out, void *stream);
 int efgh_c4_supported(const efgh_gemm_desc *d);
 int32_t efgh_c4_stats_rows(int32_t B, int32_t Ho, int32_t Wo);
 int efgh_c4_conv3x3(const efgh_gemm_desc *d, void *stream);
@@ -538,7 +567,8 @@ int efgh_c4_pooled_supported(const efgh_gemm_desc *d);
 int efgh_c4_conv3x3_pooled(const efgh_gemm_desc *d, void *stream);
 int efgh_c4_wgrad_supported(const efgh_gemm_desc *d);
 int64_t efgh_c4_wgrad_workspace(const efgh_gemm_desc *d);
-int efgh_c4_wgrad(const efgh_gemm_desc *d, const float *G, int64_t ldg, float *dWp, float *workspace, void *stream);
+int efgh_c4_wgrad(const efgh_gemm_desc *d, const float *G, int64_t ldg, float *dWp, float *workspace,
+                  const efgh_wgrad_out_desc *out, void *stream);
 
 /* debugging aid: the resident-workgroups-per-CU figures the weight-gradient chunking uses, as text */
 int efgh_debug_occupancy(char *out, int32_t cap);
@@ -616,7 +646,8 @@ int efgh_wino_conv3x3(const efgh_gemm_desc *d, const float *U, void *stream);
  * dWp [N][9][C]: bit-reproducible.                                                                          */
 int efgh_wino_wgrad_supported(const efgh_gemm_desc *d);
 int64_t efgh_wino_wgrad_workspace(const efgh_gemm_desc *d);
-int efgh_wino_wgrad(const efgh_gemm_desc *d, const float *G, int64_t ldg, float *S, float *dWp, void *stream);
+int efgh_wino_wgrad(const efgh_gemm_desc *d, const float *G, int64_t ldg, float *S, float *dWp, const efgh_wgrad_out_desc *out,
+                    void *stream);
 
 /* ------------------------------------------------------------------ sample preparation --
  * GPU form of the reference's per-sample CPU transforms, data_loader/loader_utils.py:104-202 (called from

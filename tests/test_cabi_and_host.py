@@ -25,7 +25,13 @@ def test_header_symbols_exported(so_path):
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
     lib.efgh_version.restype = ctypes.c_int
-    assert lib.efgh_version() == 2          # EFGH_ABI_VERSION (include/efgh_hip.h)
+    want = int(re.search(r'#define\s+EFGH_ABI_VERSION\s+(\d+)', hdr).group(1))
+    assert lib.efgh_version() == want == 3  # EFGH_ABI_VERSION (include/efgh_hip.h); the Python binding refuses any other (efgh_amd/_C.py)
+    # ABI 3: no hidden hand-off between calls - the round-5 arm / disarm pair is gone, the weight-gradient entry points take `out`
+    assert not hasattr(lib, 'efgh_fold_unpack_arm') and not hasattr(lib, 'efgh_fold_unpack_disarm')
+    for n in ('efgh_gather_wgrad', 'efgh_thin_wgrad', 'efgh_c4n4_wgrad', 'efgh_c4_wgrad', 'efgh_sc_wgrad', 'efgh_wino_wgrad', 'efgh_wino2d_wfinish'):
+        decl = re.search(r'int ' + n + r'\(([^;]*)\);', hdr).group(1)
+        assert 'const efgh_wgrad_out_desc *out' in decl, n
     lib.efgh_lattice_hash_capacity.restype = ctypes.c_int64
     assert lib.efgh_lattice_hash_capacity(ctypes.c_int32(131072)) == 1 << 20
     # argument validation happens before any device work: a NULL descriptor is rejected with a message

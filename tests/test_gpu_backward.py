@@ -376,7 +376,7 @@ def test_vgg_block_with_fused_bn_relu_pool_backward(hw):
 
 
 def test_fold_unpack_in_one_launch_equals_fold_then_unpack():
-    """a split weight gradient's final fold writes the reference (out, in, kh, kw) layout itself (efgh_fold_unpack_arm; k_fold_splits<true>)
+    """a split weight gradient's final fold writes the reference (out, in, kh, kw) layout itself (the explicit `efgh_wgrad_out_desc *out` argument of the weight-gradient entry points, ABI 3; k_fold_splits<true>)
     instead of a packed plane that k_unpack_weight re-reads: bit-identical to the two-launch form for the generic kernel, the
     small-channel and 4-channel kernels and a padded-channel layer"""
     from efgh_amd import ops
