@@ -209,7 +209,9 @@ class GemmLayerFn(torch.autograd.Function):
                   and spec.custom_forward is None):
                 # the single consumer (a 2-D Winograd layer) normalises and activates inside its input transform: no pass here,
                 # no activation tensor; this layer's own backward re-derives the mask from raw*scale + shift as it always did
-                y = raw
+                # (an ALIAS object of raw, not raw itself: the BnSrc tag below refers to raw, and y referring to something that refers to
+                # y would be a cycle - a step's activations would wait for the garbage collector instead of their reference counts)
+                y = raw.detach()
                 y._efgh_lazy = ops.LazyAct(scale, shift, spec.act, spec.slope)
             else:
                 # out_target = (buffer [..][Ct], channel offset): the activation is written straight into that channel slice (the
