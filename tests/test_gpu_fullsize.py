@@ -176,6 +176,21 @@ def test_fullsize_training_step_vs_oracle(manifest, monkeypatch):
     assert relg < 2e-2
 
 
+def test_fullsize_training_step_batch2_vs_batched_oracle(manifest, monkeypatch):
+    """config S (the bench's sizes), train mode, BATCH 2 against the batched oracle (iterater.py:35-43 with the per-GPU batch of
+    SURVEY 8a-0: per-sample lattices / rasters / correlation, BatchNorm statistics over both samples): every loss term and the E / H / F
+    gradients through the whole pipeline, G's on teacher-forced inputs - the batch-statistics backward (the fused transforms of round 6
+    included) held to the oracle at full size, not only by the batch-8 property checks of tests/test_gpu_bench_workloads.py.  The
+    small-size twin is tests/test_gpu_backward.py::test_training_step_batch2_vs_batched_oracle."""
+    from efgh_amd import ops
+    h0 = list(ops.LAZY_HITS)
+    rel, relg = _training_step(manifest, monkeypatch, RAW, NPTS, batch=syn.make_batch(RAW, NPTS, 2))
+    assert rel['E'] < 2e-3 and rel['H'] < 1e-2 and (rel['F'] == 0.0 or rel['F'] < 2e-2), rel
+    assert relg < 2e-2
+    # (the step really ran on the round-6 paths: deferred activations consumed, backward transforms fused)
+    assert ops.LAZY_HITS[0] > h0[0] and ops.LAZY_HITS[1] > h0[1]
+
+
 def test_fullsize_g_gradient_vs_float64_oracle(manifest, monkeypatch):
     """config S, G's gradient with frozen upstream inputs against the oracle's G evaluated in FLOAT64 - what the distance to the
     float32 oracle (pass B: 1.4e-2) is made of.  Measured (round 5, MI355X): the float32 ORACLE itself is 8.0e-3 from the float64
