@@ -416,6 +416,11 @@ struct W2OutArgs {
     int act; float slope;
     float *out; long long ldo;
     float *stats;
+    // BNM (efgh_gemm_desc.stats_mode 1): `stats` receives the BatchNorm-BACKWARD column sums of the written value instead of the
+    // forward statistics - sum g and sum g * xhat, g = out * act'(raw*pscale + pshift), xhat = (raw - mean) * invstd - where raw is
+    // the raw output of the layer whose activation this launch's `out` is the gradient of (that layer's reduction pass is then skipped)
+    const float *bn_raw; long long bn_ldraw;
+    const float *bn_psc, *bn_psh, *bn_mean, *bn_invstd; int bn_act; float bn_slope;
 };
 
 constexpr int ROWS_PER_BLOCK = 1;              // rows of tiles per workgroup of k_w2_output (one statistics row per workgroup)
@@ -423,7 +428,7 @@ constexpr int ROWS_PER_BLOCK = 1;              // rows of tiles per workgroup of
 // POOL: the layer is followed by MaxPool2d(2,2) (inference path of the VGG trunks, nets/vgg.py:69-83): a 4x4 output tile holds four
 // whole pooling windows (tiles start at multiples of 4), so the epilogue writes max over each window of act(v*scale + shift) into
 // the POOLED map [B][H/2][W/2][N] - the full-resolution activation is neither written nor read back by a pooling pass.
-template <bool NT, bool POOL>
+template <bool NT, bool POOL, bool BNM = false>
 __global__ void __launch_bounds__(TPB, 4)          // (four workgroups per CU: <= 128 VGPRs - the pass is bound by bytes in flight)
 k_w2_output(const W2OutArgs p) {
     __shared__ float red[2][TPB][VW];
@@ -436,6 +441,13 @@ k_w2_output(const W2OutArgs p) {
     const vec_t sc = p.scale ? *reinterpret_cast<const vec_t *>(p.scale + col) : one;
     const vec_t sf = p.shift ? *reinterpret_cast<const vec_t *>(p.shift + col) : zero;
     vec_t s1 = zero, s2 = zero;
+    vec_t b_psc = zero, b_psh = zero, b_mu = zero, b_is = zero;
+    float b_neg = 1.f;
+    if (BNM) {
+        b_psc = *reinterpret_cast<const vec_t *>(p.bn_psc + col); b_psh = *reinterpret_cast<const vec_t *>(p.bn_psh + col);
+        b_mu = *reinterpret_cast<const vec_t *>(p.bn_mean + col); b_is = *reinterpret_cast<const vec_t *>(p.bn_invstd + col);
+        b_neg = p.bn_act == 1 ? 0.f : (p.bn_act == 2 ? p.bn_slope : 1.f);
+    }
     const long long as = p.N;                      // M [T][36][N]
     const int nrows = p.g.B * p.g.TH;
     for (int k = 0; k < ROWS_PER_BLOCK; ++k) {
@@ -526,18 +538,27 @@ k_w2_output(const W2OutArgs p) {
         const long long pix0 = (b * p.g.H + y0) * p.g.W + x0;
         float *ob = p.out + pix0 * p.ldo + col;
         const float *rb = p.residual ? p.residual + pix0 * p.ldr + col : nullptr;
-        const int ldo_i = (int)p.ldo, ldr_i = (int)p.ldr;
+        const float *bnr = BNM ? p.bn_raw + pix0 * p.bn_ldraw + col : nullptr;
+        const int ldo_i = (int)p.ldo, ldr_i = (int)p.ldr, ldb_i = (int)p.bn_ldraw;
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
             if (y0 + a >= p.g.H) continue;
+            vec_t rwv[4];
+            if (BNM) {       // the row's four raw values first (clamped column: one round trip per row, not one per element)
+#pragma unroll
+                for (int x = 0; x < 4; ++x)
+                    rwv[x] = *reinterpret_cast<const vec_t *>(bnr + (a * p.g.W + min(x, p.g.W - 1 - x0)) * ldb_i);
+            }
 #pragma unroll
             for (int x = 0; x < 4; ++x) {
                 if (x0 + x >= p.g.W) continue;
                 const int po = a * p.g.W + x;
                 vec_t v = Y[a][x];
                 v.x += bi.x; v.y += bi.y;
-                s1.x += v.x; s1.y += v.y;
-                s2.x = fmaf(v.x, v.x, s2.x); s2.y = fmaf(v.y, v.y, s2.y);
+                if (!BNM) {
+                    s1.x += v.x; s1.y += v.y;
+                    s2.x = fmaf(v.x, v.x, s2.x); s2.y = fmaf(v.y, v.y, s2.y);
+                }
                 v.x = v.x * sc.x + sf.x; v.y = v.y * sc.y + sf.y;
                 if (rb) {
                     const vec_t r = *reinterpret_cast<const vec_t *>(rb + po * ldr_i);
@@ -546,6 +567,13 @@ k_w2_output(const W2OutArgs p) {
                 if (p.act == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); }
                 else if (p.act == 2) { v.x = v.x > 0.f ? v.x : v.x * p.slope; v.y = v.y > 0.f ? v.y : v.y * p.slope; }
                 st2<NT>(ob + po * ldo_i, v);
+                if (BNM) {
+                    const vec_t rw = rwv[x];
+                    const float gx = v.x * (fmaf(rw.x, b_psc.x, b_psh.x) > 0.f ? 1.f : b_neg);
+                    const float gy = v.y * (fmaf(rw.y, b_psc.y, b_psh.y) > 0.f ? 1.f : b_neg);
+                    s1.x += gx; s1.y += gy;
+                    s2.x = fmaf(gx, (rw.x - b_mu.x) * b_is.x, s2.x); s2.y = fmaf(gy, (rw.y - b_mu.y) * b_is.y, s2.y);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -743,8 +771,19 @@ extern "C" int efgh_wino2d_output(const float *M, const efgh_gemm_desc *d, void 
     a.M = M; a.N = d->N; a.g = geo(d->B, d->Hin, d->Win);
     a.bias = d->bias; a.scale = d->scale; a.shift = d->shift; a.residual = d->residual; a.ldr = d->ldr;
     a.act = d->act; a.slope = d->slope; a.out = d->out; a.ldo = d->ldo; a.stats = d->stats;
-    if (efgh_stream_nt(a.g.T * 36ll * d->N * 4)) k_w2_output<true, false><<<row_grid(a.g, d->N / VW, ROWS_PER_BLOCK), TPB, 0, (hipStream_t)stream_>>>(a);
-    else k_w2_output<false, false><<<row_grid(a.g, d->N / VW, ROWS_PER_BLOCK), TPB, 0, (hipStream_t)stream_>>>(a);
+    a.bn_raw = nullptr; a.bn_ldraw = 0; a.bn_psc = a.bn_psh = a.bn_mean = a.bn_invstd = nullptr; a.bn_act = 0; a.bn_slope = 0.f;
+    const dim3 grid = row_grid(a.g, d->N / VW, ROWS_PER_BLOCK);
+    const bool nt = efgh_stream_nt(a.g.T * 36ll * d->N * 4);
+    if (d->stats && d->stats_mode == 1) {
+        // the BatchNorm-backward sums of the layer this launch writes the gradient of (mask re-derived from raw: layers without a residual)
+        EFGH_CHECK_ARG(d->bn_raw && d->bn_mean && d->bn_invstd && d->bn_pscale && d->bn_pshift && !d->bn_y && d->bn_ldraw % 4 == 0);
+        EFGH_CHECK_ARG((long long)4 * d->Win * d->bn_ldraw < (1ll << 31) && (((uintptr_t)d->bn_raw) & 7) == 0);
+        a.bn_raw = d->bn_raw; a.bn_ldraw = d->bn_ldraw; a.bn_psc = d->bn_pscale; a.bn_psh = d->bn_pshift;
+        a.bn_mean = d->bn_mean; a.bn_invstd = d->bn_invstd; a.bn_act = d->bn_act; a.bn_slope = d->bn_slope;
+        if (nt) k_w2_output<true, false, true><<<grid, TPB, 0, (hipStream_t)stream_>>>(a);
+        else k_w2_output<false, false, true><<<grid, TPB, 0, (hipStream_t)stream_>>>(a);
+    } else if (nt) k_w2_output<true, false><<<grid, TPB, 0, (hipStream_t)stream_>>>(a);
+    else k_w2_output<false, false><<<grid, TPB, 0, (hipStream_t)stream_>>>(a);
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
 }
@@ -757,6 +796,7 @@ extern "C" int efgh_wino2d_output_pooled(const float *M, const efgh_gemm_desc *d
     a.M = M; a.N = d->N; a.g = geo(d->B, d->Hin, d->Win);
     a.bias = d->bias; a.scale = d->scale; a.shift = d->shift; a.residual = nullptr; a.ldr = 0;
     a.act = d->act; a.slope = d->slope; a.out = d->out; a.ldo = d->ldo; a.stats = nullptr;
+    a.bn_raw = nullptr; a.bn_ldraw = 0; a.bn_psc = a.bn_psh = a.bn_mean = a.bn_invstd = nullptr; a.bn_act = 0; a.bn_slope = 0.f;
     if (efgh_stream_nt(a.g.T * 36ll * d->N * 4)) k_w2_output<true, true><<<row_grid(a.g, d->N / VW, ROWS_PER_BLOCK), TPB, 0, (hipStream_t)stream_>>>(a);
     else k_w2_output<false, true><<<row_grid(a.g, d->N / VW, ROWS_PER_BLOCK), TPB, 0, (hipStream_t)stream_>>>(a);
     EFGH_CHECK_LAUNCH();

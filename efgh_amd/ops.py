@@ -589,6 +589,17 @@ def gather_gemm(A, lda, C, T, Wp, N, M, out, ldo, mode=0, geom=None, table=None,
         _C.check(_L().efgh_sc_conv3x3(ctypes.byref(d), _st()))
     elif M_dev is None and batch is None and wino2d_eligible(mode, C, N, geom):
         wino = '2d'
+        if (bn_bwd is not None and stats is None and BN_BWD_FUSED_2D and out_off == 0 and not pool and bn_bwd.fits(M, N)
+                and bn_bwd.y is None and bn_bwd.raw.stride(-2) % 4 == 0):
+            # the BatchNorm-backward sums of the layer whose activation gradient this launch writes, in its output transform: that
+            # layer's reduction pass (a read of dy and of raw) is not run (efgh_gemm_desc.stats_mode 1)
+            rows = _L().efgh_wino2d_stats_rows(c_int32(geom[0]), c_int32(geom[1]), c_int32(geom[2]), c_int32(N))
+            bn_stats = torch.empty((rows, 2, N), dtype=torch.float32, device=out.device)
+            d.stats, d.stats_mode = bn_stats.data_ptr(), 1
+            d.bn_raw, d.bn_ldraw = bn_bwd.raw.data_ptr(), bn_bwd.raw.stride(-2)
+            d.bn_pscale, d.bn_pshift = bn_bwd.psc.data_ptr(), bn_bwd.psh.data_ptr()
+            d.bn_mean, d.bn_invstd = bn_bwd.mean.data_ptr(), bn_bwd.invstd.data_ptr()
+            d.bn_act, d.bn_slope = bn_bwd.act, bn_bwd.slope
         _wino2d_forward(d, A, a_off, lda, C, N, geom, Wp, pool=pool, lazy=lazy, pre_v=pre_v)
         pool = False
     elif M_dev is None and batch is None and wino_eligible(mode, C, N, geom) and pool == 'h':
@@ -986,6 +997,7 @@ def neighbor_gather_adjoint(lv, src, C):
 # extra 4-byte loads per thread of the producer's raw output sit at the end of the kernel, behind the MFMA loop, and cost
 # k_wino43<true> more than the 1-GB read the reduction pass no longer does.
 BN_BWD_FUSED = False
+BN_BWD_FUSED_2D = True     # ... in the OUTPUT TRANSFORM of a 2-D Winograd data gradient (an HBM-bound pass that has the gradient tile in registers anyway)
 
 
 def bwd_finalize_f32(stats, C, count):

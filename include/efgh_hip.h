@@ -250,7 +250,7 @@ typedef struct {
      * + convolution is this same gather-GEMM on the gradient with tap-mirrored weights (no [H][15 C] intermediate); the aliased
      * hits are added by efgh_blur_dgrad_alias. */
     int32_t table_alias_mask;
-    /* stats_mode 1 (honoured by efgh_wino_conv3x3): `stats` [rows][2][N] receives, instead of the forward statistics, the two
+    /* stats_mode 1 (honoured by efgh_wino_conv3x3 and - round 6, bn_y == NULL only - efgh_wino2d_output): `stats` [rows][2][N] receives, instead of the forward statistics, the two
      * column sums the BatchNorm backward of the PRODUCER of A's gradient needs of the value this launch writes (a data gradient,
      * after the residual add):   sum g   and   sum g * (bn_raw - bn_mean) * bn_invstd,
      *     g = out * act'(bn_y ? bn_y : bn_raw * bn_pscale + bn_pshift)

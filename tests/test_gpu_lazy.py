@@ -43,10 +43,10 @@ class _Block(nn.Module):          # nets/resnet.py:38-71 BasicBlock (parameter c
         return F.relu(self.bn2(self.conv2(y)) + idt)
 
 
-def _run(model_fn, params_of, x_nchw, gy_nchw, lazy, fused, cin_pad=None):
+def _run(model_fn, params_of, x_nchw, gy_nchw, lazy, fused, sums2d=False):
     from efgh_amd import ops
-    old = (ops.LAZY_ACT, ops.W2_BWD_FUSED)
-    ops.LAZY_ACT, ops.W2_BWD_FUSED = lazy, fused
+    old = (ops.LAZY_ACT, ops.W2_BWD_FUSED, ops.BN_BWD_FUSED_2D)
+    ops.LAZY_ACT, ops.W2_BWD_FUSED, ops.BN_BWD_FUSED_2D = lazy, fused, sums2d
     try:
         h0 = list(ops.LAZY_HITS)
         ops.TLS.train_step = True
@@ -58,7 +58,7 @@ def _run(model_fn, params_of, x_nchw, gy_nchw, lazy, fused, cin_pad=None):
                 (ops.LAZY_HITS[0] - h0[0], ops.LAZY_HITS[1] - h0[1]))
     finally:
         ops.TLS.train_step = False
-        ops.LAZY_ACT, ops.W2_BWD_FUSED = old
+        ops.LAZY_ACT, ops.W2_BWD_FUSED, ops.BN_BWD_FUSED_2D = old
         for p in params_of():
             p.grad = None
 
@@ -133,6 +133,24 @@ def test_vgg_pairs_and_convt_pair_lazy():
         return L.run_convt_bn_relu(c, ug, L.run_vgg(c, fg, xg))
     base = _run(fn, prm, x, gy, False, False)
     both = _run(fn, prm, x, gy, True, True)
+    # + the BatchNorm-backward column sums of a layer taken in the output transform of its consumer's 2-D data gradient (no reduction
+    # pass over dy and raw for the un-pooled, residual-free layers in front of a 2-D Winograd layer)
+    import efgh_amd.ops as ops_
+    calls = []
+    orig = ops_.act_bn_bwd_reduce
+    ops_.act_bn_bwd_reduce = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        n0 = len(calls)
+        allf = _run(fn, prm, x, gy, True, True, sums2d=True)
+        n_all = len(calls) - n0
+        _run(fn, prm, x, gy, True, True, sums2d=False)
+        n_wo = len(calls) - n0 - n_all
+    finally:
+        ops_.act_bn_bwd_reduce = orig
+    assert n_all <= n_wo - 3, (n_all, n_wo)                 # 128->256 (behind 256->256), 256->512 (behind 512->512), the convT (behind its conv)
+    assert torch.equal(allf[0], base[0]) and _relerr(allf[1], base[1]) < 3e-5
+    for a, b in zip(allf[2], base[2]):
+        assert _relerr(a, b) < 3e-5
     assert both[3][0] >= 3 and both[3][1] >= 3, both[3]      # 256->256, 512->512, the convT's conv; fused backward in the >= 128-channel un-pooled layers
     assert torch.equal(base[0], both[0])
     assert _relerr(both[1], base[1]) < 3e-5
