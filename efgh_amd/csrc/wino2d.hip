@@ -269,6 +269,47 @@ k_w2_dy(const float *__restrict__ G, long long ldg, int N, const TileGeo g, floa
 // window's inner 4x4 (the tile itself) - and, for a residual layer, dres = dpre of the tile: 2 reads + 4.5 (5.5) writes instead
 // of 5 + 4.5 (6.5).  The activation mask comes from the sign bits the forward pass left (BITS: residual layers) or is re-derived
 // from raw * pscale + pshift, exactly as in the two-pass form.
+// both gradient-side transforms of one (tile, channel) from the 6x6 window of draw: Gy = G4 draw G4^T over the tile itself (rows /
+// columns 1..4 of the window) and Vd = B^T draw B over the window, each stored column by column
+template <bool NT>
+__device__ __forceinline__ void st1_(float *p, float v) { if (NT) __builtin_nontemporal_store(v, p); else *p = v; }
+template <bool NT>
+__device__ __forceinline__ void w2_bwd_store(vec1_t d[6][6], float *gp, float *vp, int N) {
+    {
+        vec1_t wx[4][6];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const vec1_t in4[4] = {d[r + 1][1], d[r + 1][2], d[r + 1][3], d[r + 1][4]};
+            g46(in4, wx[r]);
+        }
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            vec1_t col[4], w[6];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) col[r] = wx[r][j];
+            g46(col, w);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) st1_<NT>(gp + (long long)(6 * i + j) * N, w[i].x);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        vec1_t w[6];
+        bt6(d[r], w);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) d[r][j] = w[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        vec1_t col[6], w[6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) col[r] = d[r][j];
+        bt6(col, w);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) st1_<NT>(vp + (long long)(6 * i + j) * N, w[i].x);
+    }
+}
+
 struct W2BwdArgs {
     const float *dy; long long lddy; const float *raw; long long ldraw; const unsigned *ybits;
     const float *mean, *invstd, *coef, *pscale, *pshift; const double *m1, *m2;
@@ -369,43 +410,82 @@ k_w2_bwd(const W2BwdArgs p) {
             d[r][c].x = ok ? o : 0.f;
         }
     }
-    // Gy = G4 draw G4^T over the tile itself (rows / columns 1..4 of the window), stored column by column
-    {
-        vec1_t wx[4][6];
+    w2_bwd_store<NT>(d, p.Gy + t * 36 * p.N + c0, p.Vd + t * 36 * p.N + c0, p.N);
+}
+
+// ---- the same for a layer whose activation went straight into MaxPool2d(2,2) (vgg.py:69-83; k_maxpool2_affine forward): dy is the
+// POOLED gradient [B][H/2][W/2][N]; dpre is dy * act' at the first maximum (scan order) of every 2x2 window of act(raw*pscale +
+// pshift) and 0 elsewhere - exactly pool_cell_dpre() of backward.hip, which the two-pass form (k_pool_bn_bwd_apply -> draw ->
+// k_w2_input + k_w2_dy) evaluates.  The 6x6 window of a tile (origin a multiple of 4) is covered by 4x4 whole pooling cells = the
+// 8x8 raw region [y0-2, y0+5] x [x0-2, x0+5]: 64 raw + 16 pooled-gradient loads per (tile, channel).
+template <bool NT>
+__global__ void __launch_bounds__(TPB, 3)
+k_w2_bwd_pool(const W2BwdArgs p) {
+    const int sh = ilog2(p.N);
+    const int idx = blockIdx.x * TPB + threadIdx.x;
+    const int tx = __builtin_amdgcn_readfirstlane(idx >> sh), c0 = idx & (p.N - 1);
+    if (tx >= p.g.TW) return;
+    const int rowt = blockIdx.y, ty = rowt % p.g.TH;
+    const long long b = rowt / p.g.TH;
+    const long long t = (long long)rowt * p.g.TW + tx;
+    const int y0 = 4 * ty, x0 = 4 * tx;
+    const int Ho = p.g.H >> 1, Wo = p.g.W >> 1;
+    const float mu = p.mean[c0], is = p.invstd[c0], cf = p.coef[c0];
+    const double m1 = p.m1[c0], m2 = p.m2[c0];
+    const float negd = p.act == 1 ? 0.f : (p.act == 2 ? p.slope : 1.f), nega = negd;      // act(t) = max(t,0) + nega*min(t,0); act'(t <= 0) = negd
+    const double Ad = (double)cf * (double)is * m2, Bd = (double)cf * m1 - Ad * (double)mu;
+    const float psc = p.pscale[c0], psh = p.pshift[c0];
+    unsigned offr[8], offg[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const vec1_t in4[4] = {d[r + 1][1], d[r + 1][2], d[r + 1][3], d[r + 1][4]};
-            g46(in4, wx[r]);
+    for (int c = 0; c < 8; ++c) offr[c] = 4u * (unsigned)(min(max(x0 - 2 + c, 0), p.g.W - 1) * (int)p.ldraw + c0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) offg[j] = 4u * (unsigned)(min(max((x0 >> 1) - 1 + j, 0), max(Wo - 1, 0)) * (int)p.lddy + c0);
+    float rw[8][8], gp_[4][4];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int yc = min(max(y0 - 2 + r, 0), p.g.H - 1);
+        const float *rr = p.raw + ((b * p.g.H + yc) * p.g.W) * p.ldraw;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) rw[r][c] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(rr) + offr[c]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ic = min(max((y0 >> 1) - 1 + i, 0), max(Ho - 1, 0));
+        const float *gr = p.dy + ((b * Ho + ic) * Wo) * p.lddy;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) gp_[i][j] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(gr) + offg[j]);
+    }
+    vec1_t d[6][6];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ci = (y0 >> 1) - 1 + i;                       // pooling cell row (may be -1 or beyond the pooled map)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int cj = (x0 >> 1) - 1 + j;
+            const bool pooled = (unsigned)ci < (unsigned)Ho && (unsigned)cj < (unsigned)Wo;
+            // the four activated values of the cell, first maximum in scan order (pool_cell_dpre)
+            float e[4], tt[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                tt[q] = fmaf(rw[2 * i + (q >> 1)][2 * j + (q & 1)], psc, psh);
+                e[q] = fmaxf(tt[q], 0.f) + nega * fminf(tt[q], 0.f);
+            }
+            int best = 0;
+#pragma unroll
+            for (int q = 1; q < 4; ++q) if (e[q] > e[best]) best = q;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = 2 * i + (q >> 1) - 1, c = 2 * j + (q & 1) - 1;          // window coordinates of the element
+                if (r < 0 || r > 5 || c < 0 || c > 5) continue;                           // (compile-time: the region's outer ring)
+                const int y = y0 - 1 + r, x = x0 - 1 + c;
+                const bool ok = (unsigned)y < (unsigned)p.g.H && (unsigned)x < (unsigned)p.g.W;
+                const float gv = (pooled && q == best) ? gp_[i][j] * (tt[q] > 0.f ? 1.f : negd) : 0.f;
+                const float o = (float)fma(-(double)rw[2 * i + (q >> 1)][2 * j + (q & 1)], Ad, fma((double)cf, (double)gv, -Bd));
+                d[r][c].x = ok ? o : 0.f;
+            }
         }
-        float *gp = p.Gy + t * 36 * p.N + c0;
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            vec1_t col[4], w[6];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) col[r] = wx[r][j];
-            g46(col, w);
-#pragma unroll
-            for (int i = 0; i < 6; ++i) st1<NT>(gp + (long long)(6 * i + j) * p.N, w[i].x);
-        }
     }
-    // Vd = B^T draw B over the window
-#pragma unroll
-    for (int r = 0; r < 6; ++r) {
-        vec1_t w[6];
-        bt6(d[r], w);
-#pragma unroll
-        for (int j = 0; j < 6; ++j) d[r][j] = w[j];
-    }
-    float *vp = p.Vd + t * 36 * p.N + c0;
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-        vec1_t col[6], w[6];
-#pragma unroll
-        for (int r = 0; r < 6; ++r) col[r] = d[r][j];
-        bt6(col, w);
-#pragma unroll
-        for (int i = 0; i < 6; ++i) st1<NT>(vp + (long long)(6 * i + j) * p.N, w[i].x);
-    }
+    w2_bwd_store<NT>(d, p.Gy + t * 36 * p.N + c0, p.Vd + t * 36 * p.N + c0, p.N);
 }
 
 // ---- output transform + the k_gather_gemm epilogue.  Thread = (tile column, channel pair); a workgroup walks ROWS_PER_BLOCK
@@ -759,6 +839,27 @@ extern "C" int efgh_wino2d_bwd_transforms(const float *dy, int64_t lddy, const f
     const bool nt = efgh_stream_nt(a.g.T * 36ll * N * 4);
     if (ybits) { if (nt) k_w2_bwd<true, true><<<grid, TPB, 0, (hipStream_t)stream_>>>(a); else k_w2_bwd<false, true><<<grid, TPB, 0, (hipStream_t)stream_>>>(a); }
     else { if (nt) k_w2_bwd<true, false><<<grid, TPB, 0, (hipStream_t)stream_>>>(a); else k_w2_bwd<false, false><<<grid, TPB, 0, (hipStream_t)stream_>>>(a); }
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}
+
+extern "C" int efgh_wino2d_bwd_transforms_pooled(const float *dy_pool, int64_t lddy, const float *raw, int64_t ldraw, const float *pscale,
+                                                 const float *pshift, const float *mean, const float *invstd, const float *coef,
+                                                 const double *m1, const double *m2, int32_t N, int32_t B, int32_t H, int32_t W,
+                                                 int32_t act, float slope, float *Vd, float *Gy, void *stream_) {
+    EFGH_CHECK_ARG(dy_pool && raw && pscale && pshift && mean && invstd && coef && m1 && m2 && Vd && Gy && N > 0 && B > 0 && H >= 2 && W >= 2);
+    EFGH_CHECK_ARG(lddy % 4 == 0 && ldraw % 4 == 0 && act >= 0 && act <= 2);
+    EFGH_CHECK_ARG(((((uintptr_t)dy_pool) | ((uintptr_t)raw) | ((uintptr_t)Vd) | ((uintptr_t)Gy)) & 15) == 0);
+    W2BwdArgs a;
+    a.dy = dy_pool; a.lddy = lddy; a.raw = raw; a.ldraw = ldraw; a.ybits = nullptr;
+    a.mean = mean; a.invstd = invstd; a.coef = coef; a.pscale = pscale; a.pshift = pshift; a.m1 = m1; a.m2 = m2;
+    a.N = N; a.act = act; a.slope = slope; a.g = geo(B, H, W);
+    a.Vd = Vd; a.Gy = Gy; a.dres = nullptr; a.lddres = 0;
+    EFGH_CHECK_ARG(pow2(N) && N >= 64 && (long long)B * a.g.TH < 65536);
+    EFGH_CHECK_ARG((long long)W * lddy < (1ll << 30) && (long long)W * ldraw < (1ll << 30));
+    const dim3 grid = row_grid(a.g, N, 1);
+    if (efgh_stream_nt(a.g.T * 36ll * N * 4)) k_w2_bwd_pool<true><<<grid, TPB, 0, (hipStream_t)stream_>>>(a);
+    else k_w2_bwd_pool<false><<<grid, TPB, 0, (hipStream_t)stream_>>>(a);
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
 }

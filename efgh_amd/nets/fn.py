@@ -311,13 +311,15 @@ class GemmLayerFn(torch.autograd.Function):
         own_wgrad = ctx.needs_input_grad[1] and spec.custom_wgrad is None
         pre_v = pre_gy = None
         # the apply pass of the BatchNorm backward inside the gradient-side transforms of a 2-D Winograd layer (draw is never stored)
-        fuse_bwd = (ops.W2_BWD_FUSED and spec.bwd_fusable and has_bn and spec.train and not spec.pool and Np == N
+        fuse_bwd = (ops.W2_BWD_FUSED and spec.bwd_fusable and has_bn and spec.train and Np == N
                     and ctx.needs_input_grad[0] and own_wgrad and (ybits is not None or (psc is not None and not has_res))
-                    and len(spec.out_shape) == 3)
+                    and len(spec.out_shape) == 3 and ((fused_pool and ops.W2_BWD_FUSED_POOL) or not spec.pool))
         if fused_pool:
             # BatchNorm backward straight from the pooled gradient (no full-resolution dy is ever written)
             draw, s1, s2 = ops.pool_bn_bwd(dy.contiguous(), raw, mean, invstd, coef, psc, psh, spec.act, spec.slope,
-                                           s1=gs1, s2=gs2)
+                                           s1=gs1, s2=gs2, transforms=fuse_bwd)
+            if fuse_bwd:
+                (pre_v, pre_gy), draw = draw, None
             if gs1 is None:
                 dbeta, dgamma = s1, s2
             if has_bias:

@@ -656,7 +656,7 @@ def _conv2d_grad(ctx, x, conv, bn, act, slope, residual, geom, dims, Cp, passthr
 
     dgrad.takes_bnsrc = True
     # data AND weight gradient on the 2-D Winograd path: the BatchNorm backward's apply pass rides in their transforms
-    fus = bool((kh, kw, sh, sw, ph, pw) == (3, 3, 1, 1, 1, 1) and bn is not None and ctx.train and not pool
+    fus = bool((kh, kw, sh, sw, ph, pw) == (3, 3, 1, 1, 1, 1) and bn is not None and ctx.train
                and ops.lazy_capable(1, Np, Cp, _same3x3_geom(B, H, W)) and ops.wgrad_lazy_capable(1, Cp, Np, geom))
     spec = FN.LayerSpec(O, Cp, T, 1, [(geom, B * Ho * Wo)], B * Ho * Wo, (B, Ho, Wo), pack_fwd, dgrad, unpack,
                         bn=bn, train=ctx.train, act=act, slope=slope, c_real=Cw,

@@ -724,6 +724,7 @@ class LazyAct:
 
 LAZY_ACT = True                 # producers defer, 2-D Winograd consumers apply (nets/fn.py, nets/layers.py); False: every activation is materialised
 W2_BWD_FUSED = True             # BatchNorm backward 'apply' inside the gradient-side transforms of the 2-D Winograd layers (efgh_wino2d_bwd_transforms)
+W2_BWD_FUSED_POOL = True        # ... also for the layers whose activation goes straight into MaxPool2d(2,2) (efgh_wino2d_bwd_transforms_pooled)
 LAZY_HITS = [0, 0]              # (tests: deferred activations consumed, fused backward transforms run)
 
 
@@ -1357,9 +1358,10 @@ def act_bn_bwd_reduce(dy, lddy, y, ldy, raw, ldraw, mean, invstd, M, C, act, slo
                                          c_float(slope), ptr(part), ptr(s1), ptr(s2), ptr(m1), ptr(m2), _st()))
 
 
-def pool_bn_bwd(dy_pool, raw, mean, invstd, coef, pscale, pshift, act, slope, s1=None, s2=None):
+def pool_bn_bwd(dy_pool, raw, mean, invstd, coef, pscale, pshift, act, slope, s1=None, s2=None, transforms=False):
     """BatchNorm backward of a conv+BN+act layer fused with MaxPool2d(2,2), from the pooled gradient; raw [B][H][W][C].
-    -> (draw [B][H][W][C], dbeta [C], dgamma [C])"""
+    -> (draw [B][H][W][C], dbeta [C], dgamma [C]); transforms=True (a 2-D Winograd layer, round 6): draw is not stored - the apply pass
+    runs inside the layer's two gradient-side transforms (efgh_wino2d_bwd_transforms_pooled) -> ((Vd, Gy), dbeta, dgamma)"""
     B, H, W, C = raw.shape
     dev = raw.device
     G = _L().efgh_pool_bwd_groups(c_int32(B), c_int32(H), c_int32(W))
@@ -1371,6 +1373,15 @@ def pool_bn_bwd(dy_pool, raw, mean, invstd, coef, pscale, pshift, act, slope, s1
     _C.check(_L().efgh_pool_bn_bwd_reduce(ptr(dy_pool), ptr(raw), ptr(mean), ptr(invstd), ptr(pscale), ptr(pshift), c_int32(B),
                                           c_int32(H), c_int32(W), c_int32(C), c_int32(act), c_float(slope), ptr(part), ptr(s1),
                                           ptr(s2), ptr(m1), ptr(m2), _st()))
+    if transforms:
+        T2 = _L().efgh_wino2d_tiles(c_int32(B), c_int32(H), c_int32(W))
+        Vd = torch.empty((T2, 36, C), dtype=torch.float32, device=dev)
+        Gy = torch.empty((T2, 36, C), dtype=torch.float32, device=dev)
+        LAZY_HITS[1] += 1
+        _C.check(_L().efgh_wino2d_bwd_transforms_pooled(ptr(dy_pool), c_int64(C), ptr(raw), c_int64(C), ptr(pscale), ptr(pshift), ptr(mean),
+                                                        ptr(invstd), ptr(coef), ptr(m1), ptr(m2), c_int32(C), c_int32(B), c_int32(H),
+                                                        c_int32(W), c_int32(act), c_float(slope), ptr(Vd), ptr(Gy), _st()))
+        return (Vd, Gy), s1, s2
     draw = torch.empty_like(raw)
     _C.check(_L().efgh_pool_bn_bwd_apply(ptr(dy_pool), ptr(raw), ptr(mean), ptr(invstd), ptr(coef), ptr(m1), ptr(m2), ptr(pscale),
                                          ptr(pshift), c_int32(B), c_int32(H), c_int32(W), c_int32(C), c_int32(act),

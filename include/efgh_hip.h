@@ -450,6 +450,13 @@ int efgh_wino2d_bwd_transforms(const float *dy, int64_t lddy, const float *raw, 
                                const float *pscale, const float *pshift, const float *mean, const float *invstd, const float *coef,
                                const double *m1, const double *m2, int32_t N, int32_t B, int32_t H, int32_t W, int32_t act,
                                float slope, float *Vd, float *Gy, float *dres, int64_t lddres, void *stream);
+/* the same for a layer whose activation went straight into MaxPool2d(2,2) (nets/vgg.py:69-83; efgh_maxpool2_affine in the forward pass):
+ * dy_pool [B][H/2][W/2][N] is the POOLED gradient; dpre = dy_pool * act' at the first maximum (scan order) of every 2x2 window of
+ * act(raw*pscale + pshift), 0 elsewhere (what efgh_pool_bn_bwd_apply evaluates); m1 / m2 from efgh_pool_bn_bwd_reduce */
+int efgh_wino2d_bwd_transforms_pooled(const float *dy_pool, int64_t lddy, const float *raw, int64_t ldraw, const float *pscale,
+                                      const float *pshift, const float *mean, const float *invstd, const float *coef,
+                                      const double *m1, const double *m2, int32_t N, int32_t B, int32_t H, int32_t W, int32_t act,
+                                      float slope, float *Vd, float *Gy, void *stream);
 int efgh_wino2d_output(const float *M, const efgh_gemm_desc *d, void *stream);
 /* the same output transform for a layer that is followed by nn.MaxPool2d(2,2) (nets/vgg.py:69-83, inference): d->out is the POOLED map
  * [B][Hin/2][Win/2][ldo] = max over each 2x2 window of act((v + bias)*scale + shift); no residual, no statistics */

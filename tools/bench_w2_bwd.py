@@ -55,7 +55,13 @@ for B, H, W, C in [(8, 96, 320, 256), (8, 48, 160, 512), (8, 96, 1280, 256), (8,
                                               ptr(None if b else sf), ptr(mean), ptr(invstd), ptr(coef), ptr(m1), ptr(m2), c_int32(C), c_int32(B),
                                               c_int32(H), c_int32(W), c_int32(1), c_float(0.0), ptr(V), ptr(G), ptr(dres if b else None), c_int64(C), st))
     t_f, t_fb = timeit(lambda: fused(False)), timeit(lambda: fused(True))
+    # pooled layer (vgg.py:69-83): reduce stays; apply + input + dy vs the pooled fused transforms
+    dyp = torch.randn(B, H // 2, W // 2, C, device='cuda')
+    t_pool3 = timeit(lambda: ops.pool_bn_bwd(dyp, raw, mean, invstd, coef, sc, sf, 1, 0.0))
+    t_poolf = timeit(lambda: ops.pool_bn_bwd(dyp, raw, mean, invstd, coef, sc, sf, 1, 0.0, transforms=True))
     gb = raw.numel() * 4 / 1e9
+    print('   pooled: reduce + apply %.0f us (+ input %.0f + dy %.0f = %.0f us)  vs  reduce + fused transforms %.0f us'
+          % (t_pool3 * 1e3, t_in * 1e3, t_dy * 1e3, (t_pool3 + t_in + t_dy) * 1e3, t_poolf * 1e3))
     print('B=%d %dx%d C=%d (%.3f GB) fwd: act %.0f + input %.0f = %.0f us  vs input_act %.0f us (%.2f TB/s) | bwd: apply %.0f + input %.0f + dy %.0f = %.0f us vs '
           'fused %.0f us (%.2f TB/s) | residual: apply %.0f + .. = %.0f us vs fused %.0f us (%.2f TB/s)'
           % (B, H, W, C, gb, t_ssa * 1e3, t_in * 1e3, (t_ssa + t_in) * 1e3, t_ina * 1e3, 3.25 * gb / t_ina, t_app * 1e3, t_in * 1e3, t_dy * 1e3,
