@@ -191,7 +191,7 @@ def traffic_source(workload):
 
 
 # the PMC passes the `traffic` fields are read from (tools/collect_round_evidence.sh writes them, profiles/README.md)
-TRAFFIC_FILE = {'train': 'r05_hbm_traffic_train.json', 'fwd': 'r05_hbm_traffic_fwd.json'}
+TRAFFIC_FILE = {'train': 'r06_hbm_traffic_train.json', 'fwd': 'r06_hbm_traffic_fwd.json'}
 
 
 def mfma_step_utilisation(prof, steps, ms_per_step):
@@ -219,7 +219,7 @@ def gemm_roofline(prof, steps, kernel):
     ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     return {'bound': 'mfma', 'kernel': kernel, 'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
             'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
-            'traffic_unit': 'HBM-side bytes per launch (committed rocprofv3 PMC passes of this bench command, profiles/r05_hbm_traffic_*.json)',
+            'traffic_unit': 'HBM-side bytes per launch (committed rocprofv3 PMC passes of this bench command, profiles/r06_hbm_traffic_*.json)',
             'launches_per_step': n / max(1, steps),
             'avg_launch_ms': ms / max(1, n), 'algorithmic_gflop_per_launch': fl / max(1, n) / 1e9,
             'kernel_ms_per_step': ms / max(1, steps)}
@@ -280,7 +280,7 @@ def rooflines(prof, steps, workload='train'):
                                + (' + splat adjoint' if any(k.endswith('bwd') for k in parts) else ''),
                                'achieved': ach, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': ach / PEAK_HBM_GBS,
                                'traffic': None,
-                               'traffic_unit': 'HBM-side bytes per STEP, all lattice.hip + bcl.hip launches (profiles/r05_hbm_traffic_*.json)',
+                               'traffic_unit': 'HBM-side bytes per STEP, all lattice.hip + bcl.hip launches (profiles/r06_hbm_traffic_*.json)',
                                'launches_per_step': len(bcl) / max(1, steps), 'kernel_ms_per_step': ms / max(1, steps),
                                'algorithmic_mb_per_step': by / max(1, steps) / 1e6,
                                'parts': {k: {'ms_per_step': v[0] / max(1, steps), 'algorithmic_mb_per_step': v[1] / max(1, steps) / 1e6,

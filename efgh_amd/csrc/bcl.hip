@@ -34,7 +34,7 @@ template <int LPV>
 __global__ void __launch_bounds__(TPB)
 k_splat_gather(const float4 *__restrict__ emg, const float4 *__restrict__ feat, int64_t ldf4, int cf4,
                const float *__restrict__ bary, const int *__restrict__ list, const int2 *__restrict__ vseg, int H,
-               float4 *__restrict__ splat, float *__restrict__ wsum) {
+               float4 *__restrict__ splat, float *__restrict__ wsum, int normalize) {
     constexpr int VPB = TPB / LPV;                             // vertices per block
     const int64_t nblocks = ((int64_t)H + VPB - 1) / VPB;
     const int64_t blk = xcd_band_block(blockIdx.x, nblocks);
@@ -93,7 +93,7 @@ k_splat_gather(const float4 *__restrict__ emg, const float4 *__restrict__ feat, 
     }
     if (e != 0 || !have) return;
     // w of slot 0 was accumulated by every lane of the slot identically
-    const float nrm = 1.0f / (w + 1e-5f);
+    const float nrm = normalize ? 1.0f / (w + 1e-5f) : 1.0f;          // (use_norm = False, bilateralNN.py:196: the plain sparse sum)
     float4 *dst = splat + (int64_t)h * CH;
     dst[c] = make_float4(a0.x * nrm, a0.y * nrm, a0.z * nrm, a0.w * nrm);
     if (LPV == 64 && c + 64 < CH) dst[c + 64] = make_float4(a1.x * nrm, a1.y * nrm, a1.z * nrm, a1.w * nrm);
@@ -104,7 +104,7 @@ k_splat_gather(const float4 *__restrict__ emg, const float4 *__restrict__ feat, 
 //   gfeat[p][c] = sum_r bary[p][r] / (wsum[off[p][r]] + 1e-5) * gsplat[off[p][r]][coff + c]
 __global__ void __launch_bounds__(TPB)
 k_splat_bwd(const float4 *__restrict__ gsplat, int c4, int coff4, const float *__restrict__ wsum, int cf4,
-            const float4 *__restrict__ bary, const int4 *__restrict__ off, int n, float4 *__restrict__ gfeat, int64_t ldg4) {
+            const float4 *__restrict__ bary, const int4 *__restrict__ off, int n, float4 *__restrict__ gfeat, int64_t ldg4, int normalize) {
     const int64_t total = (int64_t)n * cf4;
     const int64_t nblocks = (total + TPB - 1) / TPB;
     const int64_t blk = xcd_band_block(blockIdx.x, nblocks);
@@ -119,7 +119,7 @@ k_splat_bwd(const float4 *__restrict__ gsplat, int c4, int coff4, const float *_
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const float w = bb[r] * (1.0f / (wsum[oo[r]] + 1e-5f));
+        const float w = normalize ? bb[r] * (1.0f / (wsum[oo[r]] + 1e-5f)) : bb[r];
         fma4(a, w, gsplat[(int64_t)oo[r] * c4 + coff4 + c]);
     }
     gfeat[(int64_t)p * ldg4 + c] = a;
@@ -227,7 +227,7 @@ k_blur_dgrad_alias(const float *__restrict__ dy, int64_t ldy, int N, const float
 
 extern "C" int efgh_splat_gather(const float *emg, const float *feat, int64_t ldf, int32_t Cf, const float *bary,
                                  const int32_t *list, const int32_t *vseg, int32_t H, int32_t avg_len,
-                                 int32_t lanes_per_vertex, float *splat, float *wsum, void *stream_) {
+                                 int32_t lanes_per_vertex, int32_t normalize, float *splat, float *wsum, void *stream_) {
     hipStream_t st = (hipStream_t)stream_;
     EFGH_CHECK_ARG(feat && bary && list && vseg && splat && wsum && H > 0 && Cf > 0 && Cf % 4 == 0 && Cf <= 508 && ldf % 4 == 0);
     const int CH = (emg ? 1 : 0) + Cf / 4;
@@ -242,26 +242,26 @@ extern "C" int efgh_splat_gather(const float *emg, const float *feat, int64_t ld
     const int64_t grid = (nblocks + 7) / 8 * 8;
     if (lpv == 16)
         k_splat_gather<16><<<(unsigned)grid, TPB, 0, st>>>((const float4 *)emg, (const float4 *)feat, ldf / 4, Cf / 4, bary, list,
-                                                           (const int2 *)vseg, H, (float4 *)splat, wsum);
+                                                           (const int2 *)vseg, H, (float4 *)splat, wsum, normalize);
     else if (lpv == 32)
         k_splat_gather<32><<<(unsigned)grid, TPB, 0, st>>>((const float4 *)emg, (const float4 *)feat, ldf / 4, Cf / 4, bary, list,
-                                                           (const int2 *)vseg, H, (float4 *)splat, wsum);
+                                                           (const int2 *)vseg, H, (float4 *)splat, wsum, normalize);
     else
         k_splat_gather<64><<<(unsigned)grid, TPB, 0, st>>>((const float4 *)emg, (const float4 *)feat, ldf / 4, Cf / 4, bary, list,
-                                                           (const int2 *)vseg, H, (float4 *)splat, wsum);
+                                                           (const int2 *)vseg, H, (float4 *)splat, wsum, normalize);
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
 }
 
 extern "C" int efgh_splat_bwd(const float *gsplat, int32_t C, int32_t coff, const float *wsum, int32_t Cf, const float *bary,
-                              const int32_t *off, int32_t n, float *gfeat, int64_t ldg, void *stream_) {
+                              const int32_t *off, int32_t n, float *gfeat, int64_t ldg, int32_t normalize, void *stream_) {
     hipStream_t st = (hipStream_t)stream_;
     EFGH_CHECK_ARG(gsplat && wsum && bary && off && gfeat && n > 0 && C % 4 == 0 && coff % 4 == 0 && Cf % 4 == 0 && Cf > 0 &&
                    coff + Cf <= C && ldg % 4 == 0);
     const int64_t nblocks = ((int64_t)n * (Cf / 4) + TPB - 1) / TPB;
     const int64_t grid = (nblocks + 7) / 8 * 8;
     k_splat_bwd<<<(unsigned)grid, TPB, 0, st>>>((const float4 *)gsplat, C / 4, coff / 4, wsum, Cf / 4, (const float4 *)bary,
-                                                (const int4 *)off, n, (float4 *)gfeat, ldg / 4);
+                                                (const int4 *)off, n, (float4 *)gfeat, ldg / 4, normalize);
     EFGH_CHECK_LAUNCH();
     return EFGH_OK;
 }

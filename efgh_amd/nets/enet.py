@@ -16,7 +16,12 @@ class Enet(nn.Module):
         dim = args['dim']
         self.scale_map = args['scale_map']
         assert dim == 3 and all(int(r) == 1 for _, r in self.scale_map), 'd=3, radius-1 BCL only'
-        assert args['use_leaky'] and args['bcn_use_norm'] and not args['last_relu']
+        # the reference's E-net switches (enet.py:25-83 -> net_utils.py:6-11, bilateralNN.py:121-135,196): the shipped configurations
+        # set use_leaky / bcn_use_norm and clear last_relu (configs/train_rellis.yaml:8-12); the other values are honoured as well
+        self.use_leaky, self.use_norm, self.last_relu = bool(args['use_leaky']), bool(args['bcn_use_norm']), bool(args['last_relu'])
+        if not args.get('bcn_use_bias', True):
+            # (use_bias only adds a parameter behind the SLICE step, which enet.py:37-81 never enables: do_slice=False)
+            pass
         self.device = args['DEVICE']
         self.conv_in = nn.Sequential(conv_1x1(dim, 32, True), conv_1x1(32, 32, True), conv_1x1(32, 32, True))
         self.bcn1 = BilateralConvFlex(32 + dim + 1, [32, 32])          # enet.py:30-83
@@ -54,17 +59,21 @@ class Enet(nn.Module):
         x = ops.nchw_to_nhwc(pc, 4).view(B * N, 4)
         for i in range(3):
             conv = self.conv_in[i][0]
-            x = L.linear_rows(ctx, x, B * N, conv.in_channels, conv.weight, conv.bias, act=ACT_LEAKY, slope=0.1)
+            x = L.linear_rows(ctx, x, B * N, conv.in_channels, conv.weight, conv.bias, act=ACT_LEAKY if self.use_leaky else ACT_RELU,
+                              slope=0.1 if self.use_leaky else 0.0)                 # net_utils.py:11: LEAKY_RATE 0.1
         # level-l input rows = [el_minus_gr (4, in the lattice's own array) | previous features]: read in place by the splat
         cur = x
         for l in range(5):
             d = lv[l]
             cf = cins[l] - 4
             if ctx.grad:
-                splat = FN.SplatFn.apply(cur, d, cf)
+                splat = FN.SplatFn.apply(cur, d, cf, True, self.use_norm)
             else:
-                splat, _ = ops.splat_fwd(d, cur, cf)
-            cur = L.blur_conv(ctx, splat, d.H, cins[l], d, bcns[l].blur_conv[0], bcns[l].blur_conv[2])
+                splat, _ = ops.splat_fwd(d, cur, cf, normalize=self.use_norm)
+            # last_relu (bilateralNN.py:121-135): an activation behind the second convolution - LeakyReLU(0.1) / ReLU by use_leaky
+            la = (ACT_LEAKY if self.use_leaky else ACT_RELU) if self.last_relu else ops.ACT_NONE
+            cur = L.blur_conv(ctx, splat, d.H, cins[l], d, bcns[l].blur_conv[0], bcns[l].blur_conv[2], last_act=la,
+                              last_slope=0.1 if (self.last_relu and self.use_leaky) else 0.0)
         x = cur                                                          # (sum_b H5_b, 256)
         segs = lv[4].seg
         M = x.shape[0]

@@ -511,21 +511,21 @@ class SplatFn(torch.autograd.Function):
     arrays carry no gradient (generate_data.py:119)."""
 
     @staticmethod
-    def forward(ctx, feat, lv, Cf, use_emg=True):
+    def forward(ctx, feat, lv, Cf, use_emg=True, normalize=True):
         feat = as_rows(feat)
-        splat, wsum = ops.splat_fwd(lv, feat, Cf, use_emg)
+        splat, wsum = ops.splat_fwd(lv, feat, Cf, use_emg, normalize)
         ctx.save_for_backward(wsum)
-        ctx.meta = (lv, Cf, feat.shape[-1], use_emg)
+        ctx.meta = (lv, Cf, feat.shape[-1], use_emg, normalize)
         return splat
 
     @staticmethod
     def backward(ctx, g):
         (wsum,) = ctx.saved_tensors
-        lv, Cf, ldf, use_emg = ctx.meta
+        lv, Cf, ldf, use_emg, normalize = ctx.meta
         gfeat = torch.zeros((lv.n_in, ldf), dtype=torch.float32, device=g.device) if ldf != Cf else \
             torch.empty((lv.n_in, Cf), dtype=torch.float32, device=g.device)
-        ops.splat_bwd(lv, g.contiguous(), wsum, Cf, gfeat, use_emg)
-        return gfeat, None, None, None
+        ops.splat_bwd(lv, g.contiguous(), wsum, Cf, gfeat, use_emg, normalize)
+        return gfeat, None, None, None, None
 
 
 class Softmax2ToNchwFn(torch.autograd.Function):

@@ -281,7 +281,7 @@ def linear_rows(ctx, x, M, C, weight, bias, bn=None, act=ACT_NONE, slope=0.0, ou
     return out_t
 
 
-def blur_conv(ctx, splat, H, C, table, conv0, conv1, out=None):
+def blur_conv(ctx, splat, H, C, table, conv0, conv1, out=None, last_act=ACT_NONE, last_slope=0.0):
     """BCL blur: gather 15 neighbour rows + Conv2d(C,C0,(15,1)) + ReLU + Conv2d(C0,C1,1)
     (nets/bilateralNN.py:240-246).  splat [H][C]; `table` = the lattice level (efgh_amd.lattice.LatticeLevel: its neighbour
     table also serves the adjoint of the gather) or a bare [H][16] neighbour table -> [H][ld]."""
@@ -292,12 +292,12 @@ def blur_conv(ctx, splat, H, C, table, conv0, conv1, out=None):
     if ctx.grad:
         assert out is None
         mid = _blur_grad(ctx, splat, H, C, table, conv0, lv)
-        return linear_rows(ctx, mid, H, C0, conv1.weight, conv1.bias)
+        return linear_rows(ctx, mid, H, C0, conv1.weight, conv1.bias, act=last_act, slope=last_slope)
     Wp0 = ops.pack_weight(conv0.weight, C0, 15, C, C * 15, 15, 1, list(range(15)), key=('blur0',))
     mid = torch.empty((H, C0), dtype=torch.float32, device=splat.device)
     ops.gather_gemm(splat, C, C, 15, Wp0, C0, H, mid, C0, mode=2, table=table, bias=conv0.bias.detach(),
                     act=ACT_RELU)
-    return linear_rows(ctx, mid, H, C0, conv1.weight, conv1.bias, out=out)
+    return linear_rows(ctx, mid, H, C0, conv1.weight, conv1.bias, out=out, act=last_act, slope=last_slope)   # (last_relu, bilateralNN.py:121-135)
 
 
 def maxpool2(ctx, x):

@@ -958,9 +958,10 @@ def _bcl_prof(what, nbytes):
     return _P()
 
 
-def splat_fwd(lv, feat, Cf, use_emg=True):
+def splat_fwd(lv, feat, Cf, use_emg=True, normalize=True):
     """BCL splat of one lattice level (efgh_amd.lattice.LatticeLevel): rows [el_minus_gr (4, from the lattice) | feat[:, :Cf]]
-    of the level's n_in points -> splat [H][4 + Cf] (use_emg=False: feat rows only, [H][Cf]), wsum [H]."""
+    of the level's n_in points -> splat [H][4 + Cf] (use_emg=False: feat rows only, [H][Cf]), wsum [H].
+    normalize=False: args['bcn_use_norm'] = False of the reference (bilateralNN.py:196: no density normalisation)"""
     _C.require_cuda(feat)
     n, H = lv.n_in, lv.H
     assert feat.shape[0] >= n and feat.stride(1) == 1 and feat.stride(0) % 4 == 0 and Cf % 4 == 0
@@ -969,17 +970,17 @@ def splat_fwd(lv, feat, Cf, use_emg=True):
     wsum = torch.empty((H,), dtype=torch.float32, device=feat.device)
     with _bcl_prof('splat', float(n) * (4 * C + 48) + float(H) * (4 * C + 4)):                 # SURVEY 8d bytes
         _C.check(_L().efgh_splat_gather(ptr(lv.emg_pm if use_emg else None), ptr(feat), c_int64(feat.stride(0)), c_int32(Cf),
-                                        ptr(lv.bary_pm), ptr(lv.list), ptr(lv.vseg), c_int32(H), c_int32(max(1, 4 * n // max(H, 1))), c_int32(SPLAT_LANES), ptr(splat),
+                                        ptr(lv.bary_pm), ptr(lv.list), ptr(lv.vseg), c_int32(H), c_int32(max(1, 4 * n // max(H, 1))), c_int32(SPLAT_LANES), c_int32(1 if normalize else 0), ptr(splat),
                                         ptr(wsum), _st()))
     return splat, wsum
 
 
-def splat_bwd(lv, gsplat, wsum, Cf, gfeat, use_emg=True):
+def splat_bwd(lv, gsplat, wsum, Cf, gfeat, use_emg=True, normalize=True):
     """gradient of splat_fwd w.r.t. feat[:, :Cf] (el_minus_gr carries none) -> gfeat [n][ld]"""
     C = gsplat.shape[1]
     with _bcl_prof('splat bwd', float(lv.n_in) * (4 * C + 48) + float(lv.H) * (4 * C + 4)):
         _C.check(_L().efgh_splat_bwd(ptr(gsplat), c_int32(C), c_int32(4 if use_emg else 0), ptr(wsum), c_int32(Cf), ptr(lv.bary_pm),
-                                     ptr(lv.off_pm), c_int32(lv.n_in), ptr(gfeat), c_int64(gfeat.stride(0)), _st()))
+                                     ptr(lv.off_pm), c_int32(lv.n_in), ptr(gfeat), c_int64(gfeat.stride(0)), c_int32(1 if normalize else 0), _st()))
 
 
 def neighbor_gather_adjoint(lv, src, C):

@@ -46,7 +46,8 @@ const char *efgh_last_error(void);
  *      efgh_wino_wgrad, efgh_wino2d_wfinish) take an explicit `const efgh_wgrad_out_desc *out` in front of the stream and return
  *      EFGH_WROTE_OUT when they left the gradient in the caller's layout themselves; efgh_fold_unpack_arm / _disarm (a thread-local
  *      descriptor consumed by the NEXT call: hidden state in an interface that promises none) are removed.  New:
- *      efgh_wino2d_input_act, efgh_wino2d_bwd_transforms (BatchNorm apply / backward apply inside the 2-D Winograd transforms). */
+ *      efgh_wino2d_input_act, efgh_wino2d_bwd_transforms(_pooled) (BatchNorm apply / backward apply inside the 2-D Winograd
+ *      transforms); efgh_splat_gather / efgh_splat_bwd take `normalize` (args['bcn_use_norm'] of the reference's E net). */
 #define EFGH_ABI_VERSION 3
 int efgh_version(void);
 
@@ -181,16 +182,17 @@ int efgh_lattice_part_neighbors(const void *workspace, const float *pts, int64_t
  * lattice build (no floating-point atomics, fixed summation order).  The input row of point p is
  * [emg[p] (4 channels; emg may be NULL: no such channels) | feat[p*ldf .. +Cf)]  ->
  * splat [H][C], C = (emg ? 4 : 0) + Cf  (row h = reference row h+1; the reference's all-zero row 0 is represented by
- * neighbour index -1), already multiplied by 1/(sum_bary + 1e-5).  wsum [H] holds the density (kept for backward).
+ * neighbour index -1), already multiplied by 1/(sum_bary + 1e-5) when `normalize` != 0 (args['bcn_use_norm'], bilateralNN.py:196-211;
+ * 0: the plain sparse sum).  wsum [H] holds the density (kept for backward).
  * lanes_per_vertex: 64, 32 (two vertices per wave; needs C/4 <= 32) or 0 = chosen from avg_len (entries per vertex,
  * 4*n_in / H).  The mappings differ in the fp32 summation order only; a given mapping is bit-reproducible.                */
 int efgh_splat_gather(const float *emg, const float *feat, int64_t ldf, int32_t Cf, const float *bary,
                       const int32_t *list, const int32_t *vseg, int32_t H, int32_t avg_len, int32_t lanes_per_vertex,
-                      float *splat, float *wsum, void *stream);
-/* backward w.r.t. feat: gfeat[p][c] = sum_r bary[p][r] / (wsum[off[p][r]] + 1e-5) * gsplat[off[p][r]][coff + c], c < Cf;
- * gsplat [H][C] */
+                      int32_t normalize, float *splat, float *wsum, void *stream);
+/* backward w.r.t. feat: gfeat[p][c] = sum_r bary[p][r] / (wsum[off[p][r]] + 1e-5) * gsplat[off[p][r]][coff + c], c < Cf
+ * (normalize == 0: without the density factor); gsplat [H][C] */
 int efgh_splat_bwd(const float *gsplat, int32_t C, int32_t coff, const float *wsum, int32_t Cf, const float *bary,
-                   const int32_t *off, int32_t n, float *gfeat, int64_t ldg, void *stream);
+                   const int32_t *off, int32_t n, float *gfeat, int64_t ldg, int32_t normalize, void *stream);
 /* adjoint of the blur's neighbour gather (autograd of bilateralNN.py:240-242) through the lattice's own table:
  * dst[h][c] = sum over (m, t < 15) with nbr[m][t] == h of src[m][t*C + c]; src [H][15*C], dst [H][C] (overwritten).
  * n_alias = info + EFGH_LATTICE_INFO_ALIAS (device).                                                                */

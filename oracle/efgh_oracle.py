@@ -256,42 +256,51 @@ def depth_image(pc, cam_T_velo, size):
 # =========================================================================================
 # E-net (nets/enet.py) with BCL (nets/bilateralNN.py)
 # =========================================================================================
-def bcl(P, pre, feat, bary, off, nbr):
-    """BilateralConvFlex.forward, nets/bilateralNN.py:148-249 (do_splat, use_norm, no slice).
+def bcl(P, pre, feat, bary, off, nbr, use_norm=True, last_relu=False, use_leaky=True):
+    """BilateralConvFlex.forward, nets/bilateralNN.py:148-249 (do_splat, no slice).  use_norm: density normalisation (:196-211);
+    last_relu: an activation behind the last convolution, LeakyReLU(0.1) / ReLU by use_leaky (:121-135).
     feat (C,N) f32; bary (4,N) f32; off (4,N) i64; nbr (15,H) i64  ->  (C_out, H)."""
     C, N = feat.shape
     H = nbr.size(1)
     idx = (off + 1).reshape(-1)                                   # :186
     tmp = (bary[None, :, :] * feat[:, None, :]).reshape(C, -1).t()  # :182-184  (4N, C)
     splat = torch.zeros((H + 1, C)).index_add(0, idx, tmp)        # SparseSum :6-27
-    ones = torch.zeros((H + 1,)).index_add(0, idx, bary.reshape(-1))  # :193-206
-    splat = splat * (1.0 / (ones + 1e-5))[:, None]                # :209-211
+    if use_norm:
+        ones = torch.zeros((H + 1,)).index_add(0, idx, bary.reshape(-1))  # :193-206
+        splat = splat * (1.0 / (ones + 1e-5))[:, None]                # :209-211
     spread = splat[(nbr + 1)]                                     # (15,H,C)  :240-242
     x = spread.permute(2, 0, 1)[None]                             # (1,C,15,H)
     x = F.conv2d(x, P[pre + '.blur_conv.0.weight'], P[pre + '.blur_conv.0.bias'])   # :103-114
     x = F.relu(x)
     x = F.conv2d(x, P[pre + '.blur_conv.2.weight'], P[pre + '.blur_conv.2.bias'])   # :123
+    if last_relu:
+        x = F.leaky_relu(x, 0.1) if use_leaky else F.relu(x)      # :131-134
     return x[0, :, 0, :]
 
 
-def enet(P, pc, train, lattice=None):
+def enet(P, pc, train, lattice=None, args=None):
     """nets/enet.py:103-187.  The reference uses batch element 0 only (:107) and is hard-wired to batch 1; for
     B > 1 every sample gets its own lattice and BCL chain (B independent evaluations) and the only coupling is train-mode
     BatchNorm1d of the head, whose statistics run over the vertices of ALL samples - the (1, C, sum_b H5_b) tensor the head's
     Conv1d / BatchNorm1d see when the samples' vertex rows are laid end to end (B = 1: exactly the reference)."""
     B = pc.size(0)
     feats = []
+    # the E-net switches of the configuration (enet.py:25-83; the shipped yamls: use_leaky, bcn_use_norm set, last_relu clear)
+    use_leaky = True if args is None else bool(args.get('use_leaky', True))
+    use_norm = True if args is None else bool(args.get('bcn_use_norm', True))
+    last_relu = False if args is None else bool(args.get('last_relu', False))
     for b in range(B):
         lat = lattice if (lattice is not None and B == 1) else _lattice.generate_data(pc[b].detach().numpy())
         x = pc[b:b + 1, :3, :]
-        for i in range(3):                                        # conv_in :24-28, LeakyReLU(0.1)
-            x = F.leaky_relu(F.conv1d(x, P[f'E.conv_in.{i}.0.weight'], P[f'E.conv_in.{i}.0.bias']), 0.1)
+        for i in range(3):                                        # conv_in :24-28, LeakyReLU(0.1) / ReLU (net_utils.py:11)
+            x = F.conv1d(x, P[f'E.conv_in.{i}.0.weight'], P[f'E.conv_in.{i}.0.bias'])
+            x = F.leaky_relu(x, 0.1) if use_leaky else F.relu(x)
         feat = x[0]
         for l in range(5):                                        # :113-141
             g = lat[l]
             emg = torch.from_numpy(g['emg'])
             feat = bcl(P, f'E.bcn{l + 1}', torch.cat((emg, feat), 0), torch.from_numpy(g['bary']),
-                       torch.from_numpy(g['off']), torch.from_numpy(g['nbr']))
+                       torch.from_numpy(g['off']), torch.from_numpy(g['nbr']), use_norm, last_relu, use_leaky)
         feats.append(feat)
     seg = [0]
     for f_ in feats:
@@ -440,7 +449,7 @@ def gnet(P, pc, img, ret, args, train, keep=None):
 # backbone (nets/efghbackbone.py:23-43)
 # =========================================================================================
 def forward(P, pc, img, calib, A, args, train=False, keep=None, lattice=None):
-    rete = enet(P, pc, train, lattice)
+    rete = enet(P, pc, train, lattice, args)
     reth = hnet(P, img, train)
     ret = {}
     ret.update(rete)
