@@ -233,6 +233,71 @@ k_pool_bn_bwd_reduce(const float *__restrict__ dyp, const float *__restrict__ ra
     }
 }
 
+// ---- the same two sums from POOLED tensors only (round 6).  With a ReLU, dpre is non-zero only at the window's first maximum and only
+// where the pooled activation y is positive, and there y = gamma*xhat + beta of that very element: xhat = (y - beta) / gamma with
+// beta = mean*pscale + pshift, 1/gamma = invstd/pscale.  So  sum dpre = sum_{y>0} dy_pool  and  sum dpre*xhat = sum_{y>0} dy_pool *
+// (y - beta)/gamma  need the pooled gradient and the pooled activation (which the next layer's backward keeps alive anyway) - a
+// quarter of a read each - instead of dy_pool + the full-resolution raw map: 0.5 units of traffic against 1.25.  A channel with
+// gamma == 0 (pscale == 0: y is constant, every window's first element wins) takes xhat from raw at that element, as before.
+template <bool NT>
+__global__ void __launch_bounds__(TPB)
+k_pool_bn_bwd_reduce_y(const float *__restrict__ dyp, const float *__restrict__ y, const float *__restrict__ raw,
+                       const float *__restrict__ mean, const float *__restrict__ invstd, const float *__restrict__ pscale,
+                       const float *__restrict__ pshift, int H, int W, int C, long long Mp, int rows_per_block, int CL,
+                       double *__restrict__ part) {
+    __shared__ double s1s[TPB][4], s2s[TPB][4];
+    const int cl = threadIdx.x % CL, rl = threadIdx.x / CL, RL = TPB / CL;
+    const int c = (blockIdx.x * CL + cl) * 4;
+    const int Ho = H >> 1, Wo = W >> 1;
+    long long r0 = (long long)blockIdx.y * rows_per_block, r1 = r0 + rows_per_block;
+    if (r1 > Mp) r1 = Mp;
+    double s1[4] = {0., 0., 0., 0.}, s2[4] = {0., 0., 0., 0.};
+    if (c < C) {
+        const float4 mu = *reinterpret_cast<const float4 *>(mean + c), is = *reinterpret_cast<const float4 *>(invstd + c);
+        const float4 psc = *reinterpret_cast<const float4 *>(pscale + c), psh = *reinterpret_cast<const float4 *>(pshift + c);
+        const float muv[4] = {mu.x, mu.y, mu.z, mu.w}, isv[4] = {is.x, is.y, is.z, is.w};
+        const float scv[4] = {psc.x, psc.y, psc.z, psc.w}, shv[4] = {psh.x, psh.y, psh.z, psh.w};
+        float bet[4], rg[4];
+        bool flat = false;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            bet[q] = fmaf(muv[q], scv[q], shv[q]);
+            rg[q] = scv[q] != 0.f ? isv[q] / scv[q] : 0.f;
+            flat |= scv[q] == 0.f;
+        }
+        for (long long r = r0 + rl; r < r1; r += RL) {
+            const float4 g4 = ld_stream<NT>(dyp + r * C + c), y4 = ld_stream<NT>(y + r * C + c);
+            const float gv[4] = {g4.x, g4.y, g4.z, g4.w}, yv[4] = {y4.x, y4.y, y4.z, y4.w};
+            float rw0[4] = {0.f, 0.f, 0.f, 0.f};
+            if (flat) {                              // (a channel of this quad has gamma == 0: xhat of the window's first element from raw)
+                const int j = (int)(r % Wo); const long long t = r / Wo;
+                const int i = (int)(t % Ho); const long long b = t / Ho;
+                const float4 w4 = *reinterpret_cast<const float4 *>(raw + (((b * H + 2 * i) * W) + 2 * j) * (long long)C + c);
+                rw0[0] = w4.x; rw0[1] = w4.y; rw0[2] = w4.z; rw0[3] = w4.w;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float d = yv[q] > 0.f ? gv[q] : 0.f;
+                const float xh = scv[q] != 0.f ? (yv[q] - bet[q]) * rg[q] : (rw0[q] - muv[q]) * isv[q];
+                s1[q] += (double)d;
+                s2[q] += (double)d * (double)xh;
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { s1s[threadIdx.x][q] = s1[q]; s2s[threadIdx.x][q] = s2[q]; }
+    __syncthreads();
+    if (rl != 0 || c >= C) return;
+    for (int k = 1; k < RL; ++k)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { s1[q] += s1s[k * CL + cl][q]; s2[q] += s2s[k * CL + cl][q]; }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        part[((long long)blockIdx.y * 2) * C + c + q] = s1[q];
+        part[((long long)blockIdx.y * 2 + 1) * C + c + q] = s2[q];
+    }
+}
+
 template <bool NT>
 __global__ void __launch_bounds__(TPB)
 k_pool_bn_bwd_apply(const float *__restrict__ dyp, const float *__restrict__ raw, const float *__restrict__ mean,
@@ -680,6 +745,30 @@ extern "C" int efgh_pool_bn_bwd_reduce(const float *dy_pool, const float *raw, c
                                                                   slope, (int)bwd_rows_per_block(ncell), CL, part);
     else k_pool_bn_bwd_reduce<false><<<dim3(cdiv(C / 4, CL), G), TPB, 0, st>>>(dy_pool, raw, mean, invstd, pscale, pshift, B, H, W, C, act,
                                                                   slope, (int)bwd_rows_per_block(ncell), CL, part);
+    k_bwd_finalize<<<cdiv(C, 32), dim3(32, 32), 0, st>>>(part, G, C, (double)B * H * W, sum_dpre, sum_dpre_xhat, mean_dpre,
+                                                         mean_dpre_xhat);
+    EFGH_CHECK_LAUNCH();
+    return EFGH_OK;
+}
+
+/* the same sums from the POOLED gradient and the POOLED activation y [B][H/2][W/2][C] (ReLU layers; see k_pool_bn_bwd_reduce_y);
+ * `part` has efgh_bwd_groups(B * (H/2) * (W/2)) rows */
+extern "C" int efgh_pool_bn_bwd_reduce_pooled(const float *dy_pool, const float *y_pool, const float *raw, const float *mean,
+                                              const float *invstd, const float *pscale, const float *pshift, int32_t B, int32_t H,
+                                              int32_t W, int32_t C, double *part, float *sum_dpre, float *sum_dpre_xhat,
+                                              double *mean_dpre, double *mean_dpre_xhat, void *stream_) {
+    hipStream_t st = (hipStream_t)stream_;
+    EFGH_CHECK_ARG(dy_pool && y_pool && raw && mean && invstd && pscale && pshift && part && sum_dpre && sum_dpre_xhat && mean_dpre &&
+                   mean_dpre_xhat);
+    EFGH_CHECK_ARG(B > 0 && H >= 2 && W >= 2 && C > 0 && C % 4 == 0);
+    const long long Mp = (long long)B * (H / 2) * (W / 2);
+    const int G = efgh_bwd_groups(Mp);
+    int CL = 1;
+    while (CL < 64 && CL * 4 < C) CL <<= 1;
+    if (efgh_stream_nt(Mp * C * 4)) k_pool_bn_bwd_reduce_y<true><<<dim3(cdiv(C / 4, CL), G), TPB, 0, st>>>(dy_pool, y_pool, raw, mean, invstd, pscale, pshift, H, W, C, Mp,
+                                                                  (int)bwd_rows_per_block(Mp), CL, part);
+    else k_pool_bn_bwd_reduce_y<false><<<dim3(cdiv(C / 4, CL), G), TPB, 0, st>>>(dy_pool, y_pool, raw, mean, invstd, pscale, pshift, H, W, C, Mp,
+                                                                  (int)bwd_rows_per_block(Mp), CL, part);
     k_bwd_finalize<<<cdiv(C, 32), dim3(32, 32), 0, st>>>(part, G, C, (double)B * H * W, sum_dpre, sum_dpre_xhat, mean_dpre,
                                                          mean_dpre_xhat);
     EFGH_CHECK_LAUNCH();

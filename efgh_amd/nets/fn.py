@@ -317,7 +317,7 @@ class GemmLayerFn(torch.autograd.Function):
         if fused_pool:
             # BatchNorm backward straight from the pooled gradient (no full-resolution dy is ever written)
             draw, s1, s2 = ops.pool_bn_bwd(dy.contiguous(), raw, mean, invstd, coef, psc, psh, spec.act, spec.slope,
-                                           s1=gs1, s2=gs2, transforms=fuse_bwd)
+                                           s1=gs1, s2=gs2, transforms=fuse_bwd, y_pool=y)
             if fuse_bwd:
                 (pre_v, pre_gy), draw = draw, None
             if gs1 is None:

@@ -1359,21 +1359,33 @@ def act_bn_bwd_reduce(dy, lddy, y, ldy, raw, ldraw, mean, invstd, M, C, act, slo
                                          c_float(slope), ptr(part), ptr(s1), ptr(s2), ptr(m1), ptr(m2), _st()))
 
 
-def pool_bn_bwd(dy_pool, raw, mean, invstd, coef, pscale, pshift, act, slope, s1=None, s2=None, transforms=False):
+POOL_REDUCE_FROM_Y = True       # ReLU layers: the pooled BatchNorm-backward sums from the pooled gradient and the pooled activation only
+
+
+def pool_bn_bwd(dy_pool, raw, mean, invstd, coef, pscale, pshift, act, slope, s1=None, s2=None, transforms=False, y_pool=None):
     """BatchNorm backward of a conv+BN+act layer fused with MaxPool2d(2,2), from the pooled gradient; raw [B][H][W][C].
     -> (draw [B][H][W][C], dbeta [C], dgamma [C]); transforms=True (a 2-D Winograd layer, round 6): draw is not stored - the apply pass
     runs inside the layer's two gradient-side transforms (efgh_wino2d_bwd_transforms_pooled) -> ((Vd, Gy), dbeta, dgamma)"""
     B, H, W, C = raw.shape
     dev = raw.device
-    G = _L().efgh_pool_bwd_groups(c_int32(B), c_int32(H), c_int32(W))
-    part = torch.empty((G, 2, C), dtype=torch.float64, device=dev)
     s1 = s1 if s1 is not None else torch.empty(C, dtype=torch.float32, device=dev)
     s2 = s2 if s2 is not None else torch.empty(C, dtype=torch.float32, device=dev)
     m1 = torch.empty(C, dtype=torch.float64, device=dev)
     m2 = torch.empty(C, dtype=torch.float64, device=dev)
-    _C.check(_L().efgh_pool_bn_bwd_reduce(ptr(dy_pool), ptr(raw), ptr(mean), ptr(invstd), ptr(pscale), ptr(pshift), c_int32(B),
-                                          c_int32(H), c_int32(W), c_int32(C), c_int32(act), c_float(slope), ptr(part), ptr(s1),
-                                          ptr(s2), ptr(m1), ptr(m2), _st()))
+    if (POOL_REDUCE_FROM_Y and y_pool is not None and act == ACT_RELU and y_pool.is_contiguous()
+            and tuple(y_pool.shape) == (B, H // 2, W // 2, C)):
+        # (y_pool: the layer's own output - the next layer's backward keeps it alive; the full-resolution raw map is not read)
+        G = _L().efgh_bwd_groups(c_int64(B * (H // 2) * (W // 2)))
+        part = torch.empty((G, 2, C), dtype=torch.float64, device=dev)
+        _C.check(_L().efgh_pool_bn_bwd_reduce_pooled(ptr(dy_pool), ptr(y_pool), ptr(raw), ptr(mean), ptr(invstd), ptr(pscale), ptr(pshift),
+                                                     c_int32(B), c_int32(H), c_int32(W), c_int32(C), ptr(part), ptr(s1), ptr(s2), ptr(m1),
+                                                     ptr(m2), _st()))
+    else:
+        G = _L().efgh_pool_bwd_groups(c_int32(B), c_int32(H), c_int32(W))
+        part = torch.empty((G, 2, C), dtype=torch.float64, device=dev)
+        _C.check(_L().efgh_pool_bn_bwd_reduce(ptr(dy_pool), ptr(raw), ptr(mean), ptr(invstd), ptr(pscale), ptr(pshift), c_int32(B),
+                                              c_int32(H), c_int32(W), c_int32(C), c_int32(act), c_float(slope), ptr(part), ptr(s1),
+                                              ptr(s2), ptr(m1), ptr(m2), _st()))
     if transforms:
         T2 = _L().efgh_wino2d_tiles(c_int32(B), c_int32(H), c_int32(W))
         Vd = torch.empty((T2, 36, C), dtype=torch.float32, device=dev)

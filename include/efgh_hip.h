@@ -508,6 +508,13 @@ int efgh_pool_bn_bwd_reduce(const float *dy_pool, const float *raw, const float 
                             const float *pshift, int32_t B, int32_t H, int32_t W, int32_t C, int32_t act, float slope,
                             double *part, float *sum_dpre, float *sum_dpre_xhat, double *mean_dpre, double *mean_dpre_xhat,
                             void *stream);
+/* round 6: the same sums for a ReLU layer from POOLED tensors only - the pooled gradient and the pooled activation y_pool
+ * [B][H/2][W/2][C] (dpre is non-zero only where y_pool > 0, and there xhat = (y_pool - beta) / gamma of the winning element): half a
+ * unit of traffic instead of 1.25.  raw is read only for channels with pscale == 0.  part: [efgh_bwd_groups(B*(H/2)*(W/2))][2][C] */
+int efgh_pool_bn_bwd_reduce_pooled(const float *dy_pool, const float *y_pool, const float *raw, const float *mean,
+                                   const float *invstd, const float *pscale, const float *pshift, int32_t B, int32_t H, int32_t W,
+                                   int32_t C, double *part, float *sum_dpre, float *sum_dpre_xhat, double *mean_dpre,
+                                   double *mean_dpre_xhat, void *stream);
 int efgh_pool_bn_bwd_apply(const float *dy_pool, const float *raw, const float *mean, const float *invstd, const float *coef,
                            const double *m1, const double *m2, const float *pscale, const float *pshift, int32_t B, int32_t H,
                            int32_t W, int32_t C, int32_t act, float slope, float *draw, void *stream);

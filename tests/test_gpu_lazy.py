@@ -184,3 +184,41 @@ def test_lazy_tensor_reaching_an_unaware_consumer_is_materialised():
         assert torch.equal(out, ref)
     finally:
         ops.TLS.train_step = False
+
+
+@pytest.mark.parametrize('cin,cout,hw', [(4, 64, (36, 52)), (64, 128, (24, 40)), (256, 256, (16, 24)), (64, 64, (11, 15))])
+def test_pooled_bn_backward_sums_from_pooled_tensors(cin, cout, hw):
+    """conv + BatchNorm + ReLU + MaxPool2d(2,2) (vgg.py:69-83), training backward: the two column sums taken from the pooled gradient and
+    the pooled ACTIVATION alone (efgh_pool_bn_bwd_reduce_pooled: xhat = (y - beta) / gamma at the winning element) against the pass
+    that re-reads the full-resolution raw map - same gradients to rounding, also with a gamma that is exactly zero (that channel
+    falls back to raw inside the kernel) and on odd map sizes"""
+    from efgh_amd import ops
+    from efgh_amd.nets import layers as L
+    torch.manual_seed(11)
+    conv, bn = nn.Conv2d(cin, cout, 3, 1, 1).cuda(), _mk_bn(cout).cuda()
+    with torch.no_grad():
+        bn.weight[3] = 0.0                       # gamma == 0: y is constant in that channel
+        bn.weight[5] = -0.7                      # a negative gamma: the window's maximum is the raw minimum
+    x = torch.randn(2, hw[0], hw[1], (cin + 3) // 4 * 4, device='cuda')
+    if cin < 4:
+        x[..., cin:] = 0
+    res = {}
+    for flag in (True, False):
+        ops.POOL_REDUCE_FROM_Y = flag
+        ops.TLS.train_step = True
+        try:
+            for p in list(conv.parameters()) + list(bn.parameters()):
+                p.grad = None
+            xg = x.clone().requires_grad_(True)
+            y = L.conv2d(L.Ctx(True), xg, conv, bn, L.ACT_RELU, pool=True)
+            g = torch.linspace(-1, 1, y.numel(), device='cuda').view_as(y)
+            (y * g).sum().backward()
+            res[flag] = (y.detach().clone(), xg.grad.clone(), conv.weight.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone())
+        finally:
+            ops.POOL_REDUCE_FROM_Y = True
+            ops.TLS.train_step = False
+    assert torch.equal(res[True][0], res[False][0])
+    for a, b, n in zip(res[True][1:], res[False][1:], ('dx', 'dW', 'dgamma', 'dbeta')):
+        assert _relerr(a, b) < 5e-6, (n, _relerr(a, b))
+    assert torch.equal(res[True][4], res[False][4]) or _relerr(res[True][4], res[False][4]) < 1e-6       # (dbeta = sum dpre: the same terms)
+    assert abs(float(res[True][3][3]) - float(res[False][3][3])) <= 2e-6 * float(res[False][3].abs().max())   # the gamma == 0 channel
